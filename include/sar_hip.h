@@ -1,0 +1,220 @@
+/*
+ * sar_hip.h -- C ABI of libsar_hip.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the
+ * skeleton-action-recognition hot path (ST-GCN training, VirtualRadar spectrograms).
+ *
+ * The reference (itskalvik/skeleton-action-recognition) is pure Python and has no FFI of its own:
+ * every entry point below replaces the framework op(s) the reference invokes at the cited
+ * file:line.  Conventions shared by every function:
+ *   - extern "C", plain C types; every pointer is a DEVICE pointer owned by the caller unless the
+ *     parameter is documented as host memory.  The library never allocates or frees device memory.
+ *   - the last argument is the hipStream_t (passed as void*) the work is enqueued on; calls are
+ *     asynchronous with respect to the host and re-entrant on distinct streams.
+ *   - return value: 0 = OK, negative = argument error (SAR_E_*), positive = hipError_t.
+ *     sar_last_error_string() returns a thread-local description of the last failure.
+ *
+ * Activation layout ("CN"): an activation with C channels over B sequences of T frames x V joints
+ * is a row-major matrix [C][ld], ld >= B*T*V, column n = (b*T + t)*V + v.  (The reference's NCHW
+ * tensor (B,C,T,V) is this matrix with the batch axis moved inside the row.)
+ * Weight layouts are the reference's Keras HWIO layouts: graph conv (Cin, K*F) -- channel k*F+f as
+ * in models/gcn.py:207 --, temporal conv (Kt, Cin, F), residual conv (Cin, F), logits (Cin, classes).
+ */
+#ifndef SAR_HIP_H
+#define SAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAR_E_ARG (-1)      /* invalid argument (null pointer, bad size, unsupported shape) */
+#define SAR_E_UNSUP (-2)    /* valid but unsupported configuration (e.g. adjacency denser than 4 nnz/column) */
+
+typedef void* sar_stream_t;
+
+int sar_version(void);
+const char* sar_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused conv-GEMM on the CN layout (fp32 MFMA, v_mfma_f32_32x32x2_f32).
+ *
+ *   out[m, n] = sum_tap sum_c W[tap][c][m] * OP_tap(pro(src))[c, n]  (+ bias term) ; epilogue
+ *
+ * mode SAR_CONV_GRAPH    : OP_k(x)[c,(b,t,w)] = sum_v x[c,(b,t,v)] * A[k,v,w]  (A given as <=4-nnz
+ *                          column gather lists).  With W = the GraphConvTD kernel this is
+ *                          models/gcn.py:199-209 (1x1 Conv2D + reshape + einsum 'nkctv,kvw->nctw')
+ *                          in the reordered form  sum_k W_k (x A_k) + sum_k b_k colsum(A_k);
+ *                          with A^T lists and W^T it is that layer's data gradient.
+ * mode SAR_CONV_TEMPORAL : OP_tap(x)[c,(b,to,v)] = x[c,(b, to*stride + tap - pad, v)] (zero outside
+ *                          [0,T_src)): Conv2D(F,[Kt,1],strides=[s,1],'same'), models/stgcn.py:29-36
+ *                          (pad = TF-SAME begin pad), and with taps=1,pad=0 the strided 1x1
+ *                          residual conv, models/stgcn.py:47-54.
+ *                          transposed=1 gives the data gradient of that conv: out frame t gathers
+ *                          src frame (t + pad - tap)/stride when divisible.
+ * pro(x) = x                                   if pro_scale == NULL
+ *        = relu?(x * pro_scale[c] + pro_shift[c])  (BatchNormalization+ReLU of models/stgcn.py:27-28
+ *          folded into the operand load; padding stays exactly 0 as in the reference)
+ * epilogue (epi):
+ *   SAR_EPI_NONE   store
+ *   SAR_EPI_STATS  store + per-row partial (sum, sum of squares) -> partials (train-mode BN statistics)
+ *   SAR_EPI_MASK   val = (aux*aux_scale[m]+aux_shift[m] > 0) ? val : 0 ; store ;
+ *                  partial (sum val, sum val*aux)   (ReLU+BN backward reductions)
+ *   SAR_EPI_ADD    val += aux ; store               (residual gradient accumulation)
+ * partials layout: [M][nparts][2] with nparts = sar_conv_gemm_nparts(desc).
+ * ------------------------------------------------------------------------------------------------ */
+enum { SAR_CONV_GRAPH = 0, SAR_CONV_TEMPORAL = 1 };
+enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3 };
+
+typedef struct sar_conv_desc {
+  int32_t mode;        /* SAR_CONV_* */
+  int32_t transposed;  /* TEMPORAL only */
+  int32_t B, V;        /* sequences (N*M), joints */
+  int32_t T_src, T_out;/* frames of src / out */
+  int32_t Kc, M;       /* src channels (reduction), out channels */
+  int32_t taps, stride, pad;
+  int32_t pro_relu;
+  int32_t epi;
+  int32_t nz[3];       /* GRAPH: gather-list length per adjacency slice (<=4) */
+  const float* src; int64_t ld_src;
+  float* out; int64_t ld_out;
+  const float* W;          /* element (tap, c, m) at tap*w_stride_tap + c*w_stride_c + m (m contiguous) */
+  int64_t w_stride_tap, w_stride_c;
+  const float* bias;       /* TEMPORAL: [M]; GRAPH: [taps][M] (scaled by colsum(A_k)[w]); may be NULL */
+  const float* pro_scale; const float* pro_shift;   /* [Kc] or NULL */
+  const int32_t* g_idx;    /* GRAPH: [taps][V][4] source joint of each gather entry */
+  const float* g_wt;       /* GRAPH: [taps][V][4] weight of each gather entry */
+  const float* g_colsum;   /* GRAPH: [taps][V] column sums of A_k (bias term) */
+  const float* aux; int64_t ld_aux;                  /* epilogue operand [M][ld_aux] */
+  const float* aux_scale; const float* aux_shift;    /* [M] (SAR_EPI_MASK) */
+  float* partials;         /* [M][nparts][2] (SAR_EPI_STATS / SAR_EPI_MASK) */
+} sar_conv_desc;
+
+int sar_conv_gemm_nparts(const sar_conv_desc* d);                 /* host query, no GPU work */
+int sar_conv_gemm_f32(const sar_conv_desc* d, sar_stream_t s);
+
+/* Weight gradient of the same operator (reduction over all positions n):
+ *   dW[tap][c][m] = sum_n dout[m, n] * OP_tap(pro(src))[c, n]        (tf.GradientTape of the conv,
+ *   dbias                                                             main_gnn.py:233)
+ * Written as per-split partial slabs slab[split][wsize + bsize] (deterministic; no atomics), element
+ * (tap,c,m) at tap*w_stride_tap + c*w_stride_c + m, bias partials at wsize + [..]; reduce with
+ * sar_slab_reduce_f32.  bias slab: TEMPORAL [M]; GRAPH [taps][M] (= sum_n dout*colsum(A_k)[w(n)]). */
+typedef struct sar_wgrad_desc {
+  int32_t mode;
+  int32_t B, V;
+  int32_t T_src, T_out;     /* frames of src / dout */
+  int32_t Kc, M;
+  int32_t taps, stride, pad;
+  int32_t pro_relu;
+  int32_t nz[3];
+  int32_t nsplit;           /* number of slabs (grid.x) */
+  const float* src; int64_t ld_src;
+  const float* dout; int64_t ld_dout;
+  const float* pro_scale; const float* pro_shift;
+  const int32_t* g_idx; const float* g_wt; const float* g_colsum;
+  int64_t w_stride_tap, w_stride_c;  /* element strides inside the weight tensor */
+  int64_t wsize, bsize;              /* floats per slab = wsize + bsize */
+  float* slab;                       /* [nsplit][wsize + bsize] */
+} sar_wgrad_desc;
+
+int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s);
+/* out[i] = sum_s slab[s*slab_stride + i] (i < n), summed in split order. */
+int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch-norm plumbing (Keras BatchNormalization(axis=1), models/stgcn.py:27,37,56,111).
+ * partials: [C][nparts][2] (sum, sum of squares); statistics reduced in fp64.
+ *   mean = S1/count ; var = S2/count - mean^2 (biased) ; rstd = 1/sqrt(var+eps)
+ *   scale = gamma*rstd ; shift = beta - mean*scale
+ *   running_mean = momentum*rm + (1-momentum)*mean ; running_var likewise with var*count/(count-1)
+ *   when unbiased_running != 0 (fused NCHW path) -- skipped when running_mean == NULL.
+ * ------------------------------------------------------------------------------------------------ */
+int sar_bn_finalize_f32(const float* partials, int nparts, int C, double count, float eps, float momentum,
+                        int unbiased_running, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var,
+                        float* mean, float* rstd, float* scale, float* shift, sar_stream_t s);
+/* inference affine from the moving statistics (training=False path, main_gnn.py:207). */
+int sar_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, int C, float* scale, float* shift, sar_stream_t s);
+/* Backward reductions -> coefficients.  partials [C][nparts][2] = (sum dz, sum dz*x).
+ *   dgamma = rstd*(S2 - mean*S1) ; dbeta = S1 ; and  dx = k1*dz + k2*x + k3  with
+ *   k1 = gamma*rstd, k2 = -gamma*rstd^2*b, k3 = gamma*rstd*(mean*rstd*b - a), a = S1/count, b = dgamma/count.
+ * partial_stride: floats between consecutive channels; partial_step: floats between consecutive parts. */
+int sar_bn_bwd_finalize_f32(const float* partials, int nparts, int64_t chan_stride, int64_t part_stride,
+                            int off1, int off2, int C, double count,
+                            const float* gamma, const float* mean, const float* rstd,
+                            float* dgamma, float* dbeta, float* k1, float* k2, float* k3, sar_stream_t s);
+
+/* data_bn, models/stgcn.py:142-147: x (N,C,T,V,M) contiguous -> CN activation [C][ld] with
+ * b = n*M+m; BN channel = v*C+c, statistics over (n,m,t).  Optional fused joint->bone transform
+ * (data_gen/gen_bone_data.py:36-41): bone_parent[v] = v2 (or -1 for none) subtracts joint v2. */
+int sar_data_bn_stats_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+                          float* partials /* [V*C][N][2] */, sar_stream_t s);
+int sar_data_bn_apply_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+                          const float* scale, const float* shift, float* out, int64_t ld_out, sar_stream_t s);
+/* backward: partials [V*C][N][2] = (sum dy, sum dy*x_raw) from dy in CN layout. */
+int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+                               const float* dy, int64_t ld_dy, float* partials, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Block tail, models/stgcn.py:37,62-63:  y = relu(u*sc[c]+sh[c] + res)
+ *   res_kind 0: none ; 1: identity (res = r) ; 2: conv residual (res = r*rsc[c]+rsh[c])
+ * ------------------------------------------------------------------------------------------------ */
+int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
+                            const float* rsc, const float* rsh, float* y, int C, int64_t n, int64_t ld, sar_stream_t s);
+/* backward pass 1: dz = (y>0)?dy:0 ; partials[C][nparts][4] = (sum dz, sum dz*u, sum dz*r, 0) */
+int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
+                                   float* partials, int nparts, int C, int64_t n, int64_t ld, sar_stream_t s);
+/* backward pass 2: du = k1*dz+k2*u+k3 ; dr = rk1*dz+rk2*r+rk3 (if dr != NULL) ; dz_out = dz (if != NULL) */
+int sar_bn_add_relu_bwd_apply_f32(const float* dy, const float* y, const float* u, const float* r,
+                                  const float* k1, const float* k2, const float* k3,
+                                  const float* rk1, const float* rk2, const float* rk3,
+                                  float* du, float* dr, float* dz_out, int C, int64_t n, int64_t ld, sar_stream_t s);
+/* generic row-affine: out = k1[c]*a + k2[c]*b + k3[c]  (BN backward apply: dg from dz1 and g) */
+int sar_affine2_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
+                    float* out, int C, int64_t n, int64_t ld, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Head, models/stgcn.py:153-158: GlobalAveragePooling2D over (T,V), mean over the M persons,
+ * 1x1 Conv2D logits.  y: CN [C][ld], B = N*Mp sequences of TV positions.
+ * ------------------------------------------------------------------------------------------------ */
+int sar_pool_fwd_f32(const float* y, int64_t ld, int C, int B, int TV, int Mp, float* feat /* [N][C] */, sar_stream_t s);
+int sar_fc_fwd_f32(const float* feat, const float* W /* [C][K] */, const float* bias, int N, int C, int K,
+                   float* logits /* [N][K] */, sar_stream_t s);
+/* main_gnn.py:224-226: loss_i = CE(logits_i, label_i); dlogits = (softmax - onehot)*inv_global_batch.
+ * loss_sum[0] receives sum_i loss_i * inv_global_batch (written, not accumulated). */
+int sar_softmax_ce_f32(const float* logits, const int64_t* labels, int N, int K, float inv_global_batch,
+                       float* loss_sum, float* dlogits, float* probs /* may be NULL */, sar_stream_t s);
+int sar_fc_bwd_f32(const float* feat, const float* W, const float* dlogits, int N, int C, int K,
+                   float* dW, float* dbias, float* dfeat, sar_stream_t s);
+/* dy[c,(b,tv)] = dfeat[b/Mp][c] / (Mp*TV) */
+int sar_pool_bwd_f32(const float* dfeat, int64_t ld, int C, int B, int TV, int Mp, float* dy, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer, main_gnn.py:312-314 (tf.keras SGD momentum 0.9 nesterov):
+ *   v <- momentum*v - lr*g ; w <- w + momentum*v - lr*g      over a flat parameter buffer.
+ * lr is read from device memory (lr_dev[0]) so a captured graph can be replayed across LR changes.
+ * ------------------------------------------------------------------------------------------------ */
+int sar_sgd_nesterov_f32(float* w, float* v, const float* g, int64_t n, const float* lr_dev, float momentum,
+                         sar_stream_t s);
+/* batched 2-D transpose: in [batch][R][Cc] -> out [batch][Cc][R] (weight re-layout for data gradients) */
+int sar_transpose_f32(const float* in, float* out, int batch, int R, int Cc, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * VirtualRadar, layers/virtual_radar.py:79-134.
+ * sar_vr_signal_f32  (:93-123): x (B,3,T,V,M) contiguous -> complex baseband z[b][t] (re, im planes).
+ *   edges given as src/dst joint index arrays (E entries); loc = radar_location (3 floats, device),
+ *   wavelength (1 float, device).  fp32 arithmetic in the reference's op order; accurate sin/cos.
+ * sar_stft_logmag_f32 (:124-133 + nnAudio 0.1.1 STFT): reflect-pad n_fft/2, periodic-Hann windowed
+ *   DFT of length n_fft every hop samples, out[b][(k + n_fft/2) % n_fft][f] = log(|Z[k,f]| + 1e-6).
+ *   If out_cols > 0 only the frames  f = floor(j*F/out_cols), j < out_cols  are produced (nearest
+ *   F.interpolate of models/resnet.py:26 fused as a column select) and out is [B][n_fft][out_cols].
+ * ------------------------------------------------------------------------------------------------ */
+int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, const int32_t* e_src, const int32_t* e_dst, int E,
+                      const float* loc, const float* wavelength, float* z_re, float* z_im, sar_stream_t s);
+int sar_stft_logmag_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
+                        const float* window /* [n_fft] */, int out_cols, float* out, sar_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAR_HIP_H */

@@ -31,7 +31,6 @@ by (i) an independent float64 numpy re-derivation on small shapes
 bit-exact adjacency (oracle/graph.py, pinned).
 """
 import math
-import re
 
 import numpy as np
 import torch
@@ -75,7 +74,7 @@ def block_residual_kind(cin, f, s, residual):
     return "conv"
 
 
-def init_params(num_classes=60, in_channels=3, num_node=25, seed=0, dtype=torch.float32):
+def init_params(num_classes=60, in_channels=3, num_node=25, seed=0, dtype=torch.float32, blocks=None):
     """models/stgcn.py:101-133 (+ lazy residual build :41-56).  Returns a flat
     ordered dict name -> tensor in Keras layouts, plus BN moving statistics."""
     g = torch.Generator().manual_seed(seed)
@@ -87,7 +86,7 @@ def init_params(num_classes=60, in_channels=3, num_node=25, seed=0, dtype=torch.
     p["data_bn.moving_mean"] = torch.zeros(nch, dtype=dtype)
     p["data_bn.moving_var"] = torch.ones(nch, dtype=dtype)
     cin = in_channels
-    for i, (f, s, res) in enumerate(BLOCKS):
+    for i, (f, s, res) in enumerate(blocks or BLOCKS):
         pre = "l%d." % i
         p[pre + "gcn.kernel"] = _trunc_normal((1, 1, cin, KS * f), 1 * 1 * KS * f, g, dtype)
         p[pre + "gcn.bias"] = torch.zeros(KS * f, dtype=dtype)
@@ -185,9 +184,9 @@ def data_bn(x, p, training, new_stats=None):
     return h
 
 
-def st_block(x, p, i, A, training, new_stats=None, taps=None):
+def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None):
     """models/stgcn.py:58-64 for block i.  x (B,Cin,T,V)."""
-    f, s, res = BLOCKS[i]
+    f, s, res = (blocks or BLOCKS)[i]
     pre = "l%d." % i
     kind = block_residual_kind(x.shape[1], f, s, res)
     if kind == "none":
@@ -215,15 +214,15 @@ def st_block(x, p, i, A, training, new_stats=None, taps=None):
     return y
 
 
-def forward(p, x, training, new_stats=None, taps=None, n_blocks=len(BLOCKS)):
+def forward(p, x, training, new_stats=None, taps=None, blocks=None):
     """models/stgcn.py:135-160.  x (N,C,T,V,M) -> logits (N, classes)."""
     N, C, T, V, M = x.shape
     h = data_bn(x, p, training, new_stats)
     if taps is not None:
         taps["x0"] = h
     A = p["A"]
-    for i in range(n_blocks):
-        h = st_block(h, p, i, A, training, new_stats, taps)
+    for i in range(len(blocks or BLOCKS)):
+        h = st_block(h, p, i, A, training, new_stats, taps, blocks)
     pooled = h.mean(dim=(2, 3))                    # GlobalAveragePooling2D, stgcn.py:154
     feat = pooled.reshape(N, M, -1).mean(dim=1)    # stgcn.py:155-156
     if taps is not None:
@@ -238,24 +237,19 @@ def loss_fn(logits, labels, global_batch_size):
     return ce * (1.0 / global_batch_size)
 
 
-def loss_and_grads(p, x, labels, global_batch_size=None, n_blocks=len(BLOCKS)):
+def loss_and_grads(p, x, labels, global_batch_size=None, blocks=None):
     """One train_step's differentiable part (main_gnn.py:221-233)."""
     names = trainable_names(p)
     leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
     q = dict(p)
     q.update(leaves)
     new_stats, taps = {}, {}
-    logits = forward(q, x, True, new_stats, taps, n_blocks)
+    logits = forward(q, x, True, new_stats, taps, blocks)
     gbs = global_batch_size or x.shape[0]
     loss = loss_fn(logits, labels, gbs)
-    used = [k for k in names if _used(k, n_blocks)]
+    used = names
     grads = torch.autograd.grad(loss, [leaves[k] for k in used])
     return logits.detach(), loss.detach(), dict(zip(used, grads)), new_stats, {k: v.detach() for k, v in taps.items()}
-
-
-def _used(name, n_blocks):
-    m = re.match(r"l(\d+)\.", name)
-    return int(m.group(1)) < n_blocks if m else True
 
 
 def lr_schedule(iteration, base_lr=0.1, steps=(10, 50), batch_size=64):

@@ -49,7 +49,7 @@ def _tconv(x, kernel, bias, stride):
     return out
 
 
-def forward_np(p, x, n_blocks=len(BLOCKS)):
+def forward_np(p, x, blocks=None):
     """train-mode forward; p: dict name -> numpy float64; x (N,C,T,V,M)."""
     N, C, T, V, M = x.shape
     h = np.zeros((N * M, C, T, V))
@@ -65,8 +65,8 @@ def forward_np(p, x, n_blocks=len(BLOCKS)):
             ch = v * C + c
             h[:, c, :, v] = (s - mean) / np.sqrt(var + BN_EPS) * p["data_bn.gamma"][ch] + p["data_bn.beta"][ch]
     A = p["A"]
-    for i in range(n_blocks):
-        f, s, res = BLOCKS[i]
+    for i in range(len(blocks or BLOCKS)):
+        f, s, res = (blocks or BLOCKS)[i]
         pre = "l%d." % i
         kind = block_residual_kind(h.shape[1], f, s, res)
         if kind == "none":

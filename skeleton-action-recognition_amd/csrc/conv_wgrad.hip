@@ -1,0 +1,266 @@
+// conv_wgrad.hip -- weight gradients of the fused graph / temporal convolutions (fp32 MFMA, gfx950).
+//
+//   dW[tap][c][m] = sum_n dout[m, n] * OP_tap(pro(src))[c, n]        (reduction over ALL positions)
+//
+// Replaces tape.gradient (main_gnn.py:233) for the GraphConvTD kernel (models/gcn.py:192-196), the
+// 9x1 temporal conv (models/stgcn.py:29-36) and the strided 1x1 residual conv (models/stgcn.py:47-54).
+//
+// Design (MI355X): the MFMA reduction axis is the position axis.  A workgroup owns a (32*WF) x
+// (32*WC) x taps block of the weight tensor and walks its share of the sequence-aligned position
+// tiles (FT whole frames, same tiling as conv_gemm): per tile it stages the dout rows and the src
+// rows (+ temporal halo, BN+ReLU folded, zero padding materialised) in LDS with ODD row strides so
+// that the per-lane-row operand reads are bank-conflict free, then issues one
+// v_mfma_f32_32x32x2_f32 per tap per two positions.  The graph operand (x.A_k) is gathered on the
+// fly from the staged x rows through a <=4-entry list per adjacency slice.  Partial results go to
+// per-split slabs (plain coalesced stores; summed in split order by sar_slab_reduce_f32), so the
+// result is deterministic -- no float atomics.  MFMA orientation: A = src operand (rows c),
+// B = dout (cols m), so the accumulator columns are m and slab stores are 128-B contiguous.
+#include "sar_common.h"
+
+namespace {
+
+struct WgradK {
+  sar_wgrad_desc d;
+  int FT, TPS, NT, NF, RW, SP, NPOS, NP, DP;
+  float invRW, invNP;
+};
+
+template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
+  static_assert(WF * WC * WT == 4, "4 waves per workgroup");
+  static_assert(WT * TPW >= TAPS, "taps must be covered");
+  constexpr int BF = 32 * WF, CT = 32 * WC;
+  constexpr int NZMAX = 4;
+  constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const sar_wgrad_desc& d = k.d;
+  const int V = d.V;
+  float* D = smem;                          // [BF][DP]
+  float* S = D + BF * k.DP;                 // [CT][SP]
+  int* PT = (int*)(S + CT * k.SP);          // [NP][2] : (src column offset of position p, joint v)
+  int* GI = PT + 2 * k.NP;                  // GRAPH [3][V][4] gather joint
+  float* GW = (float*)(GI + 3 * V * NZMAX); // GRAPH [3][V][4] gather weight
+  float* GC = GW + 3 * V * NZMAX;           // GRAPH [3][V] colsum
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wf = wave % WF, wc = (wave / WF) % WC, wt = wave / (WF * WC);
+  const int f0 = blockIdx.y * BF, c0 = blockIdx.z * CT;
+
+  // ---- tile-independent tables
+  for (int p = tid; p < k.NP; p += 256) {
+    int fo = p / V, v = p - (p / V) * V;
+    if (p >= k.NPOS) { fo = 0; v = 0; }
+    PT[2 * p] = (MODE == SAR_CONV_GRAPH) ? fo * V : fo * d.stride * V + v;
+    PT[2 * p + 1] = v;
+  }
+  if (MODE == SAR_CONV_GRAPH) {
+    for (int i = tid; i < 3 * V * NZMAX; i += 256) {
+      GI[i] = d.g_idx[i];
+      GW[i] = d.g_wt[i];
+    }
+    for (int i = tid; i < 3 * V; i += 256) GC[i] = d.g_colsum ? d.g_colsum[i] : 0.f;
+  }
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float bsum[3] = {0.f, 0.f, 0.f};
+
+  const int seq_src = d.T_src * V, seq_out = d.T_out * V;
+  const bool has_pro = d.pro_scale != nullptr;
+  const bool do_bias = (wc == 0) && (MODE == SAR_CONV_GRAPH || wt == 0) && blockIdx.z == 0;
+
+  for (int tile = blockIdx.x; tile < k.NT; tile += gridDim.x) {
+    const int b = tile / k.TPS;
+    const int t0 = (tile - b * k.TPS) * k.FT;
+    const int t_lo = (MODE == SAR_CONV_GRAPH) ? t0 : t0 * d.stride - d.pad;
+    __syncthreads();  // previous tile's reads done (also orders the table writes before first use)
+    // ---- stage dout rows f0..f0+BF over the tile's positions (zero outside the sequence / tile)
+    const float* dout_b = d.dout + (int64_t)b * seq_out;
+    for (int idx = tid; idx < BF * k.NP; idx += 256) {
+      const int f = (int)(((float)idx + 0.5f) * k.invNP);
+      const int p = idx - f * k.NP;
+      const int pabs = t0 * V + p;
+      float val = 0.f;
+      if (p < k.NPOS && pabs < seq_out && f0 + f < d.M) val = dout_b[(int64_t)(f0 + f) * d.ld_dout + pabs];
+      D[f * k.DP + p] = val;
+    }
+    // ---- stage src rows c0..c0+CT (folded BN+ReLU, exact zero padding)
+    const float* src_b = d.src + (int64_t)b * seq_src;
+    for (int idx = tid; idx < CT * k.RW; idx += 256) {
+      const int c = (int)(((float)idx + 0.5f) * k.invRW);
+      const int r = idx - c * k.RW;
+      const int rabs = t_lo * V + r;
+      const int cg = c0 + c;
+      float val = 0.f;
+      if (cg < d.Kc && (unsigned)rabs < (unsigned)seq_src) {
+        val = src_b[(int64_t)cg * d.ld_src + rabs];
+        if (has_pro) {
+          val = fmaf(val, d.pro_scale[cg], d.pro_shift[cg]);
+          if (d.pro_relu) val = fmaxf(val, 0.f);
+        }
+      }
+      S[c * k.SP + r] = val;
+    }
+    __syncthreads();
+
+    const float* Drow = D + (wf * 32 + l31) * k.DP;
+    const float* Srow = S + (wc * 32 + l31) * k.SP;
+    for (int step = 0; step < k.NP / 2; ++step) {
+      const int p = 2 * step + hi;
+      const int poff = PT[2 * p];
+      const int v = PT[2 * p + 1];
+      const float dval = Drow[p];
+      if (MODE == SAR_CONV_TEMPORAL) {
+        bsum[0] += dval;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int tp = wt * TPW + i;
+          if (tp < TAPS) {
+            const float sval = Srow[poff + tp * V];
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sval, dval, acc[i], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int tp = i;  // WT == 1 in graph mode
+          const int* gi = GI + (tp * V + v) * NZMAX;
+          const float* gwp = GW + (tp * V + v) * NZMAX;
+          float sval = gwp[0] * Srow[poff + gi[0]];
+#pragma unroll
+          for (int j = 1; j < NZMAX; ++j)
+            if (j < NZ[tp]) sval = fmaf(gwp[j], Srow[poff + gi[j]], sval);
+          bsum[i] = fmaf(dval, GC[tp * V + v], bsum[i]);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sval, dval, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- write this split's slab
+  float* slab = d.slab + (int64_t)blockIdx.x * (d.wsize + d.bsize);
+  const int f = f0 + wf * 32 + l31;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tp = wt * TPW + i;
+    if (tp < TAPS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wc * 32 + mfma_row(r, hi);
+        if (c < d.Kc && f < d.M) slab[(int64_t)tp * d.w_stride_tap + (int64_t)c * d.w_stride_c + f] = acc[i][r];
+      }
+    }
+  }
+  if (d.bsize > 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float t = bsum[i] + __shfl_xor(bsum[i], 32);
+      const bool mine = (MODE == SAR_CONV_TEMPORAL) ? (i == 0) : (i < TAPS);
+      if (mine && do_bias && hi == 0 && f < d.M) slab[d.wsize + (int64_t)i * d.M + f] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit,
+                                                          int64_t slab_stride, int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * slab_stride + i];
+    out[i] = s;
+  }
+}
+
+int geometry(const sar_wgrad_desc& d, WgradK& k) {
+  k.FT = 128 / d.V;
+  if (k.FT < 1) return -1;
+  if (k.FT > d.T_out) k.FT = d.T_out;
+  k.TPS = (d.T_out + k.FT - 1) / k.FT;
+  k.NT = d.B * k.TPS;
+  k.NPOS = k.FT * d.V;
+  k.NP = (k.NPOS + 1) & ~1;
+  k.DP = k.NP | 1;
+  k.NF = (d.mode == SAR_CONV_GRAPH) ? k.FT : (k.FT - 1) * d.stride + d.taps;
+  k.RW = k.NF * d.V;
+  k.SP = k.RW | 1;
+  k.invRW = 1.0f / (float)k.RW;
+  k.invNP = 1.0f / (float)k.NP;
+  return 0;
+}
+
+template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2>
+int launch(const sar_wgrad_desc& d, hipStream_t st) {
+  WgradK k;
+  k.d = d;
+  if (geometry(d, k)) return SAR_E_ARG;
+  constexpr int BF = 32 * WF, CT = 32 * WC;
+  size_t lds = sizeof(float) * ((size_t)BF * k.DP + (size_t)CT * k.SP) + sizeof(int) * 2 * k.NP;
+  if (MODE == SAR_CONV_GRAPH) lds += (sizeof(int) + sizeof(float)) * 3 * d.V * 4 + sizeof(float) * 3 * d.V;
+  auto kern = conv_wgrad_kernel<MODE, TAPS, WF, WC, WT, TPW, NZ0, NZ1, NZ2>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      sar_set_error("sar_conv_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  dim3 grid(d.nsplit, (d.M + BF - 1) / BF, (d.Kc + CT - 1) / CT);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s) {
+  SAR_REQUIRE(d != nullptr, "sar_conv_wgrad: null descriptor");
+  SAR_REQUIRE(d->mode == SAR_CONV_GRAPH || d->mode == SAR_CONV_TEMPORAL, "sar_conv_wgrad: bad mode %d", d->mode);
+  SAR_REQUIRE(d->B > 0 && d->V > 0 && d->V <= 64 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0,
+              "sar_conv_wgrad: bad sizes");
+  SAR_REQUIRE(d->src && d->dout && d->slab, "sar_conv_wgrad: null src/dout/slab");
+  SAR_REQUIRE(d->nsplit >= 1 && d->nsplit <= 65535, "sar_conv_wgrad: nsplit %d out of range", d->nsplit);
+  SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_dout >= (int64_t)d->B * d->T_out * d->V,
+              "sar_conv_wgrad: leading dimension smaller than B*T*V");
+  SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_wgrad: pro_scale/pro_shift mismatch");
+  SAR_REQUIRE(d->wsize > 0 && d->bsize >= 0, "sar_conv_wgrad: bad slab sizes");
+  int rc = 0;
+  hipStream_t st = as_stream(s);
+  if (d->mode == SAR_CONV_GRAPH) {
+    SAR_REQUIRE(d->taps == 3 && d->T_src == d->T_out, "sar_conv_wgrad: graph mode needs 3 slices and equal T");
+    SAR_REQUIRE(d->g_idx && d->g_wt, "sar_conv_wgrad: graph gather tables required");
+    SAR_REQUIRE(d->bsize == 0 || (d->bsize == 3 * (int64_t)d->M && d->g_colsum), "sar_conv_wgrad: graph bias slab is [3][M]");
+    for (int i = 0; i < 3; ++i)
+      if (d->nz[i] < 1 || d->nz[i] > 4) {
+        sar_set_error("sar_conv_wgrad: adjacency slice %d needs %d gather entries per column (max 4)", i, d->nz[i]);
+        return SAR_E_UNSUP;
+      }
+    if (d->nz[0] == 1 && d->nz[1] == 1) rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 1, 1, 4>(*d, st);
+    else if (d->nz[0] == 1 && d->nz[2] == 1) rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 1, 4, 1>(*d, st);
+    else rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 4, 4, 4>(*d, st);
+  } else {
+    SAR_REQUIRE(d->stride >= 1 && d->pad >= 0, "sar_conv_wgrad: bad stride/pad");
+    SAR_REQUIRE(d->bsize == 0 || d->bsize == d->M, "sar_conv_wgrad: temporal bias slab is [M]");
+    if (d->taps == 9) rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1>(*d, st);
+    else if (d->taps == 1) rc = launch<SAR_CONV_TEMPORAL, 1, 2, 2, 1, 1, 1, 1, 1>(*d, st);
+    else {
+      sar_set_error("sar_conv_wgrad: temporal kernel size %d not built (1 and 9 are)", d->taps);
+      return SAR_E_UNSUP;
+    }
+  }
+  if (rc) return rc;
+  SAR_LAUNCH_CHECK("sar_conv_wgrad_f32");
+  return 0;
+}
+
+extern "C" int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out,
+                                   sar_stream_t s) {
+  SAR_REQUIRE(slab && out && nsplit >= 1 && n > 0 && slab_stride >= n, "sar_slab_reduce: bad arguments");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), slab, nsplit, slab_stride, n, out);
+  SAR_LAUNCH_CHECK("sar_slab_reduce_f32");
+  return 0;
+}

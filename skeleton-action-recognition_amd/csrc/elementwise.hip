@@ -1,0 +1,637 @@
+// elementwise.hip -- HBM-bound kernels of the ST-GCN step on the CN layout (gfx950):
+// batch-norm finalisation, the block tail (BN + residual + ReLU) forward/backward, data_bn with the
+// (N,C,T,V,M) -> CN re-layout, the classifier head, softmax cross-entropy, Nesterov SGD.
+// All row-wise kernels move 16 B per lane when the row stride allows it (float4), are grid-strided
+// inside a row and reduce through wave shuffles -> LDS -> one partial per workgroup (no atomics, so
+// every reduction is deterministic).  Reference call sites are cited in include/sar_hip.h.
+#include <stdarg.h>
+#include "sar_common.h"
+
+// ------------------------------------------------------------------------------------ error state
+static thread_local char g_err[512] = "no error";
+void sar_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* sar_last_error_string(void) { return g_err; }
+extern "C" int sar_version(void) { return 100; }
+
+namespace {
+
+constexpr int TPB = 256;
+
+// block-wide sum of NV values; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red /* [4][NV] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = red[i] + red[NV + i] + red[2 * NV + i] + red[3 * NV + i];
+}
+
+// ------------------------------------------------------------------------------------ BN finalize
+__global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
+                                                          float eps, float momentum, int unbiased_running,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float* mean_o,
+                                                          float* rstd_o, float* scale_o, float* shift_o) {
+  const int c = blockIdx.x;
+  const float* p = partials + (int64_t)c * nparts * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += TPB) {
+    s1 += (double)p[2 * i];
+    s2 += (double)p[2 * i + 1];
+  }
+  __shared__ double red[2][4];
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    if (mean_o) mean_o[c] = (float)mean;
+    if (rstd_o) rstd_o[c] = (float)rstd;
+    scale_o[c] = (float)(g * rstd);
+    shift_o[c] = (float)(b - mean * g * rstd);
+    if (running_mean) {
+      const double vr = (unbiased_running && count > 1.0) ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((double)momentum * running_mean[c] + (1.0 - (double)momentum) * mean);
+      running_var[c] = (float)((double)momentum * running_var[c] + (1.0 - (double)momentum) * vr);
+    }
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.0f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * rstd;
+  shift[c] = b - rm[c] * g * rstd;
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts,
+                                                              int64_t chan_stride, int64_t part_stride, int off1, int off2,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* dgamma, float* dbeta, float* k1, float* k2, float* k3) {
+  const int c = blockIdx.x;
+  const float* p = partials + (int64_t)c * chan_stride;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += TPB) {
+    s1 += (double)p[(int64_t)i * part_stride + off1];
+    s2 += (double)p[(int64_t)i * part_stride + off2];
+  }
+  __shared__ double red[2][4];
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double m = mean[c], rs = rstd[c], g = gamma ? (double)gamma[c] : 1.0;
+    const double dg = rs * (s2 - m * s1);  // sum dz * xhat
+    if (dgamma) dgamma[c] = (float)dg;
+    if (dbeta) dbeta[c] = (float)s1;
+    const double a = s1 / count, b = dg / count;
+    if (k1) {
+      k1[c] = (float)(g * rs);
+      k2[c] = (float)(-g * rs * rs * b);
+      k3[c] = (float)(g * rs * (m * rs * b - a));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ data_bn
+// One workgroup per (n, c) slab x[n][c][T][V][M] (contiguous, M fastest).
+__device__ __forceinline__ float load_joint(const float* slab, int t, int v, int m, int V, int M, const int* bone_parent) {
+  float val = slab[(t * V + v) * M + m];
+  if (bone_parent) {
+    const int v2 = bone_parent[v];
+    if (v2 >= 0) val -= slab[(t * V + v2) * M + m];
+  }
+  return val;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __restrict__ x, int N, int C, int T, int V, int M,
+                                                             const int* __restrict__ bone_parent,
+                                                             const float* __restrict__ dy, int64_t ld_dy,
+                                                             float* __restrict__ partials) {
+  const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+  const float* slab = x + (int64_t)blockIdx.x * T * V * M;
+  const int VM = V * M;
+  const int groups = TPB / VM;  // row groups working in parallel
+  const int col = threadIdx.x % VM, rg = threadIdx.x / VM;
+  const int v = col / M, m = col - v * M;
+  float s1 = 0.f, s2 = 0.f;
+  if (rg < groups) {
+    for (int t = rg; t < T; t += groups) {
+      const float val = load_joint(slab, t, v, m, V, M, bone_parent);
+      if (BWD) {
+        const float g = dy[(int64_t)c * ld_dy + ((int64_t)(n * M + m) * T + t) * V + v];
+        s1 += g;
+        s2 = fmaf(g, val, s2);
+      } else {
+        s1 += val;
+        s2 = fmaf(val, val, s2);
+      }
+    }
+  }
+  __shared__ float r1[TPB], r2[TPB];
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < V) {
+    float a = 0.f, b = 0.f;
+    for (int g = 0; g < groups; ++g)
+      for (int mm = 0; mm < M; ++mm) {
+        a += r1[g * VM + threadIdx.x * M + mm];
+        b += r2[g * VM + threadIdx.x * M + mm];
+      }
+    float* pp = partials + ((int64_t)(threadIdx.x * C + c) * N + n) * 2;
+    pp[0] = a;
+    pp[1] = b;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void data_bn_apply_kernel(const float* __restrict__ x, int N, int C, int T, int V, int M,
+                                                            const int* __restrict__ bone_parent,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ out, int64_t ld_out) {
+  const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+  const float* slab = x + (int64_t)blockIdx.x * T * V * M;
+  const int VM = V * M, total = T * VM;
+  for (int e = threadIdx.x; e < total; e += TPB) {
+    const int t = e / VM, r = e - t * VM;
+    const int v = r / M, m = r - v * M;
+    const float val = load_joint(slab, t, v, m, V, M, bone_parent);
+    const int ch = v * C + c;
+    out[(int64_t)c * ld_out + ((int64_t)(n * M + m) * T + t) * V + v] = fmaf(val, scale[ch], shift[ch]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ row-wise kernels
+template <int VEC> struct VecT;
+template <> struct VecT<4> { typedef float4 T; };
+template <> struct VecT<1> { typedef float T; };
+template <int VEC> __device__ __forceinline__ void ld(const float* p, float (&r)[VEC]) {
+  if (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(p); r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w; }
+  else r[0] = *p;
+}
+template <int VEC> __device__ __forceinline__ void st(float* p, const float (&r)[VEC]) {
+  if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  else *p = r[0];
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __restrict__ u, const float* __restrict__ sc,
+                                                              const float* __restrict__ sh, int res_kind,
+                                                              const float* __restrict__ r, const float* __restrict__ rsc,
+                                                              const float* __restrict__ rsh, float* __restrict__ y,
+                                                              int64_t n, int64_t ldm) {
+  const int c = blockIdx.y;
+  const float a = sc[c], b = sh[c];
+  const float ra = (res_kind == 2) ? rsc[c] : 1.f, rb = (res_kind == 2) ? rsh[c] : 0.f;
+  const int64_t base = (int64_t)c * ldm;
+  for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
+    float uv[VEC], rv[VEC], o[VEC];
+    ld<VEC>(u + base + i, uv);
+    if (res_kind) ld<VEC>(r + base + i, rv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float z = fmaf(uv[j], a, b);
+      if (res_kind) z += fmaf(rv[j], ra, rb);
+      o[j] = fmaxf(z, 0.f);
+    }
+    st<VEC>(y + base + i, o);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                     const float* __restrict__ u, const float* __restrict__ r,
+                                                                     float* __restrict__ partials, int64_t n, int64_t ldm) {
+  const int c = blockIdx.y;
+  const int64_t base = (int64_t)c * ldm;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
+    float g[VEC], yv[VEC], uv[VEC], rv[VEC];
+    ld<VEC>(dy + base + i, g);
+    ld<VEC>(y + base + i, yv);
+    ld<VEC>(u + base + i, uv);
+    if (r) ld<VEC>(r + base + i, rv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float dz = yv[j] > 0.f ? g[j] : 0.f;
+      acc[0] += dz;
+      acc[1] = fmaf(dz, uv[j], acc[1]);
+      if (r) acc[2] = fmaf(dz, rv[j], acc[2]);
+    }
+  }
+  __shared__ float red[4 * 3];
+  block_sum<3>(acc, red);
+  if (threadIdx.x == 0) {
+    float* pp = partials + ((int64_t)c * gridDim.x + blockIdx.x) * 4;
+    pp[0] = acc[0];
+    pp[1] = acc[1];
+    pp[2] = acc[2];
+    pp[3] = 0.f;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ u, const float* __restrict__ r,
+    const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3, const float* __restrict__ rk1,
+    const float* __restrict__ rk2, const float* __restrict__ rk3, float* du, float* dr, float* dz_out, int64_t n,
+    int64_t ldm) {
+  const int c = blockIdx.y;
+  const int64_t base = (int64_t)c * ldm;
+  const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
+  const float b1 = dr ? rk1[c] : 0.f, b2 = dr ? rk2[c] : 0.f, b3 = dr ? rk3[c] : 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
+    float g[VEC], yv[VEC], uv[VEC], rv[VEC], o1[VEC], o2[VEC], o3[VEC];
+    ld<VEC>(dy + base + i, g);
+    ld<VEC>(y + base + i, yv);
+    ld<VEC>(u + base + i, uv);
+    if (dr) ld<VEC>(r + base + i, rv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float dz = yv[j] > 0.f ? g[j] : 0.f;
+      o3[j] = dz;
+      o1[j] = fmaf(a1, dz, fmaf(a2, uv[j], a3));
+      if (dr) o2[j] = fmaf(b1, dz, fmaf(b2, rv[j], b3));
+    }
+    st<VEC>(du + base + i, o1);
+    if (dr) st<VEC>(dr + base + i, o2);
+    if (dz_out) st<VEC>(dz_out + base + i, o3);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void affine2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ k1, const float* __restrict__ k2,
+                                                      const float* __restrict__ k3, float* out, int64_t n, int64_t ldm) {
+  const int c = blockIdx.y;
+  const int64_t base = (int64_t)c * ldm;
+  const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
+  for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
+    float av[VEC], bv[VEC], o[VEC];
+    ld<VEC>(a + base + i, av);
+    ld<VEC>(b + base + i, bv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = fmaf(a1, av[j], fmaf(a2, bv[j], a3));
+    st<VEC>(out + base + i, o);
+  }
+}
+
+inline bool vec4_ok(int64_t n, int64_t ldm, std::initializer_list<const void*> ptrs) {
+  if ((n & 3) || (ldm & 3)) return false;
+  for (const void* p : ptrs)
+    if (p && ((uintptr_t)p & 15)) return false;
+  return true;
+}
+
+inline int row_blocks(int64_t n, int vec) {
+  int64_t per = (int64_t)TPB * vec * 8;  // ~8 iterations per thread
+  int64_t b = (n + per - 1) / per;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------ head
+__global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__ y, int64_t ldm, int span, float inv,
+                                                       int C, float* __restrict__ feat) {
+  const int n = blockIdx.x, c = blockIdx.y;
+  const float* p = y + (int64_t)c * ldm + (int64_t)n * span;
+  float acc[1] = {0.f};
+  for (int i = threadIdx.x; i < span; i += TPB) acc[0] += p[i];
+  __shared__ float red[4];
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) feat[(int64_t)n * C + c] = acc[0] * inv;
+}
+
+__global__ void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W, const float* __restrict__ bias,
+                              int C, int K, float* __restrict__ logits) {
+  const int n = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float s = bias ? bias[k] : 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(feat[(int64_t)n * C + c], W[(int64_t)c * K + k], s);
+    logits[(int64_t)n * K + k] = s;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         int N, int K, float inv_gbs, float* loss_sum,
+                                                         float* __restrict__ dlogits, float* __restrict__ probs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float lsum = 0.f;
+  for (int n = wave; n < N; n += 4) {
+    const float* row = logits + (int64_t)n * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, row[k]);
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) se += expf(row[k] - mx);
+    se = wave_sum(se);
+    const int lab = (int)labels[n];
+    const float lse = logf(se) + mx;
+    if (lane == 0) lsum += (lse - row[lab]);
+    const float inv = 1.f / se;
+    for (int k = lane; k < K; k += 64) {
+      const float p = expf(row[k] - mx) * inv;
+      if (probs) probs[(int64_t)n * K + k] = p;
+      if (dlogits) dlogits[(int64_t)n * K + k] = (p - (k == lab ? 1.f : 0.f)) * inv_gbs;
+    }
+  }
+  __shared__ float red[4];
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss_sum) loss_sum[0] = (red[0] + red[1] + red[2] + red[3]) * inv_gbs;
+}
+
+__global__ void fc_bwd_w_kernel(const float* __restrict__ feat, const float* __restrict__ dl, int N, int C, int K,
+                                float* __restrict__ dW, float* __restrict__ dbias) {
+  const int c = blockIdx.x;  // blockIdx.x == C handles the bias
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float s = 0.f;
+    if (c < C) {
+      for (int n = 0; n < N; ++n) s = fmaf(feat[(int64_t)n * C + c], dl[(int64_t)n * K + k], s);
+      dW[(int64_t)c * K + k] = s;
+    } else {
+      for (int n = 0; n < N; ++n) s += dl[(int64_t)n * K + k];
+      dbias[k] = s;
+    }
+  }
+}
+
+__global__ void fc_bwd_x_kernel(const float* __restrict__ W, const float* __restrict__ dl, int C, int K,
+                                float* __restrict__ dfeat) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(dl[(int64_t)n * K + k], W[(int64_t)c * K + k], s);
+    dfeat[(int64_t)n * C + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__ dfeat, int64_t ldm, int span, float inv,
+                                                       int C, float* __restrict__ dy) {
+  const int n = blockIdx.x, c = blockIdx.y;
+  const float val = dfeat[(int64_t)n * C + c] * inv;
+  float* p = dy + (int64_t)c * ldm + (int64_t)n * span;
+  for (int i = threadIdx.x; i < span; i += TPB) p[i] = val;
+}
+
+// ------------------------------------------------------------------------------------ optimizer / misc
+__global__ __launch_bounds__(TPB) void sgd_nesterov_kernel(float* __restrict__ w, float* __restrict__ v,
+                                                           const float* __restrict__ g, int64_t n,
+                                                           const float* __restrict__ lr_dev, float momentum) {
+  const float lr = lr_dev[0];
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float gi = g[i];
+    const float vn = momentum * v[i] - lr * gi;
+    v[i] = vn;
+    w[i] = w[i] + momentum * vn - lr * gi;
+  }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int64_t boff = (int64_t)blockIdx.z * R * Cc;
+  int r = blockIdx.y * 32 + threadIdx.y, c = blockIdx.x * 32 + threadIdx.x;
+  for (int j = 0; j < 32; j += 8)
+    if (r + j < R && c < Cc) tile[threadIdx.y + j][threadIdx.x] = in[boff + (int64_t)(r + j) * Cc + c];
+  __syncthreads();
+  c = blockIdx.x * 32 + threadIdx.y;
+  r = blockIdx.y * 32 + threadIdx.x;
+  for (int j = 0; j < 32; j += 8)
+    if (c + j < Cc && r < R) out[boff + (int64_t)(c + j) * R + r] = tile[threadIdx.x][threadIdx.y + j];
+}
+
+}  // namespace
+
+// ====================================================================================== C ABI
+extern "C" int sar_bn_finalize_f32(const float* partials, int nparts, int C, double count, float eps, float momentum,
+                                   int unbiased_running, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                                   sar_stream_t s) {
+  SAR_REQUIRE(partials && nparts > 0 && C > 0 && count > 0 && scale && shift, "sar_bn_finalize: bad arguments");
+  SAR_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sar_bn_finalize: running stats mismatch");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(TPB), 0, as_stream(s), partials, nparts, count, eps, momentum,
+                     unbiased_running, gamma, beta, running_mean, running_var, mean, rstd, scale, shift);
+  SAR_LAUNCH_CHECK("sar_bn_finalize_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, int C, float* scale, float* shift,
+                                      sar_stream_t s) {
+  SAR_REQUIRE(running_mean && running_var && scale && shift && C > 0, "sar_bn_eval_affine: bad arguments");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), gamma, beta, running_mean,
+                     running_var, eps, C, scale, shift);
+  SAR_LAUNCH_CHECK("sar_bn_eval_affine_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_bwd_finalize_f32(const float* partials, int nparts, int64_t chan_stride, int64_t part_stride,
+                                       int off1, int off2, int C, double count, const float* gamma, const float* mean,
+                                       const float* rstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                                       sar_stream_t s) {
+  SAR_REQUIRE(partials && nparts > 0 && C > 0 && count > 0 && mean && rstd, "sar_bn_bwd_finalize: bad arguments");
+  SAR_REQUIRE((k1 == nullptr) == (k2 == nullptr) && (k1 == nullptr) == (k3 == nullptr), "sar_bn_bwd_finalize: k1/k2/k3");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(TPB), 0, as_stream(s), partials, nparts, chan_stride,
+                     part_stride, off1, off2, count, gamma, mean, rstd, dgamma, dbeta, k1, k2, k3);
+  SAR_LAUNCH_CHECK("sar_bn_bwd_finalize_f32");
+  return 0;
+}
+
+static int data_bn_check(const float* x, int N, int C, int T, int V, int M) {
+  SAR_REQUIRE(x && N > 0 && C > 0 && T > 0 && V > 0 && M > 0, "sar_data_bn: bad sizes");
+  SAR_REQUIRE(V * M <= TPB, "sar_data_bn: V*M = %d exceeds %d", V * M, TPB);
+  return 0;
+}
+
+extern "C" int sar_data_bn_stats_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+                                     float* partials, sar_stream_t s) {
+  int rc = data_bn_check(x, N, C, T, V, M);
+  if (rc) return rc;
+  SAR_REQUIRE(partials, "sar_data_bn_stats: null partials");
+  hipLaunchKernelGGL(data_bn_reduce_kernel<false>, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M,
+                     bone_parent, (const float*)nullptr, (int64_t)0, partials);
+  SAR_LAUNCH_CHECK("sar_data_bn_stats_f32");
+  return 0;
+}
+
+extern "C" int sar_data_bn_apply_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+                                     const float* scale, const float* shift, float* out, int64_t ld_out, sar_stream_t s) {
+  int rc = data_bn_check(x, N, C, T, V, M);
+  if (rc) return rc;
+  SAR_REQUIRE(scale && shift && out && ld_out >= (int64_t)N * M * T * V, "sar_data_bn_apply: bad arguments");
+  hipLaunchKernelGGL(data_bn_apply_kernel, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent, scale,
+                     shift, out, ld_out);
+  SAR_LAUNCH_CHECK("sar_data_bn_apply_f32");
+  return 0;
+}
+
+extern "C" int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+                                          const float* dy, int64_t ld_dy, float* partials, sar_stream_t s) {
+  int rc = data_bn_check(x, N, C, T, V, M);
+  if (rc) return rc;
+  SAR_REQUIRE(dy && partials && ld_dy >= (int64_t)N * M * T * V, "sar_data_bn_bwd_reduce: bad arguments");
+  hipLaunchKernelGGL(data_bn_reduce_kernel<true>, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent,
+                     dy, ld_dy, partials);
+  SAR_LAUNCH_CHECK("sar_data_bn_bwd_reduce_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
+                                       const float* rsc, const float* rsh, float* y, int C, int64_t n, int64_t ldm,
+                                       sar_stream_t s) {
+  SAR_REQUIRE(u && sc && sh && y && C > 0 && n > 0 && ldm >= n, "sar_bn_add_relu_fwd: bad arguments");
+  SAR_REQUIRE(res_kind >= 0 && res_kind <= 2 && (res_kind == 0 || r) && (res_kind != 2 || (rsc && rsh)),
+              "sar_bn_add_relu_fwd: residual arguments");
+  if (vec4_ok(n, ldm, {u, r, y})) {
+    hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), u, sc, sh,
+                       res_kind, r, rsc, rsh, y, n, ldm);
+  } else {
+    hipLaunchKernelGGL(bn_add_relu_fwd_kernel<1>, dim3(row_blocks(n, 1), C), dim3(TPB), 0, as_stream(s), u, sc, sh,
+                       res_kind, r, rsc, rsh, y, n, ldm);
+  }
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_fwd_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
+                                              float* partials, int nparts, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(dy && y && u && partials && nparts > 0 && nparts <= 65535 && C > 0 && n > 0 && ldm >= n,
+              "sar_bn_add_relu_bwd_reduce: bad arguments");
+  if (vec4_ok(n, ldm, {dy, y, u, r})) {
+    hipLaunchKernelGGL(bn_add_relu_bwd_reduce_kernel<4>, dim3(nparts, C), dim3(TPB), 0, as_stream(s), dy, y, u, r,
+                       partials, n, ldm);
+  } else {
+    hipLaunchKernelGGL(bn_add_relu_bwd_reduce_kernel<1>, dim3(nparts, C), dim3(TPB), 0, as_stream(s), dy, y, u, r,
+                       partials, n, ldm);
+  }
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_apply_f32(const float* dy, const float* y, const float* u, const float* r,
+                                             const float* k1, const float* k2, const float* k3, const float* rk1,
+                                             const float* rk2, const float* rk3, float* du, float* dr, float* dz_out,
+                                             int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(dy && y && u && k1 && k2 && k3 && du && C > 0 && n > 0 && ldm >= n, "sar_bn_add_relu_bwd_apply: bad arguments");
+  SAR_REQUIRE(!dr || (r && rk1 && rk2 && rk3), "sar_bn_add_relu_bwd_apply: residual arguments");
+  if (vec4_ok(n, ldm, {dy, y, u, r, du, dr, dz_out})) {
+    hipLaunchKernelGGL(bn_add_relu_bwd_apply_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), dy, y, u,
+                       r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, n, ldm);
+  } else {
+    hipLaunchKernelGGL(bn_add_relu_bwd_apply_kernel<1>, dim3(row_blocks(n, 1), C), dim3(TPB), 0, as_stream(s), dy, y, u,
+                       r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, n, ldm);
+  }
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_f32");
+  return 0;
+}
+
+extern "C" int sar_affine2_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
+                               float* out, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(a && b && k1 && k2 && k3 && out && C > 0 && n > 0 && ldm >= n, "sar_affine2: bad arguments");
+  if (vec4_ok(n, ldm, {a, b, out})) {
+    hipLaunchKernelGGL(affine2_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), a, b, k1, k2, k3, out, n,
+                       ldm);
+  } else {
+    hipLaunchKernelGGL(affine2_kernel<1>, dim3(row_blocks(n, 1), C), dim3(TPB), 0, as_stream(s), a, b, k1, k2, k3, out, n,
+                       ldm);
+  }
+  SAR_LAUNCH_CHECK("sar_affine2_f32");
+  return 0;
+}
+
+extern "C" int sar_pool_fwd_f32(const float* y, int64_t ldm, int C, int B, int TV, int Mp, float* feat, sar_stream_t s) {
+  SAR_REQUIRE(y && feat && C > 0 && B > 0 && TV > 0 && Mp > 0 && B % Mp == 0 && ldm >= (int64_t)B * TV,
+              "sar_pool_fwd: bad arguments");
+  const int span = Mp * TV;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B / Mp, C), dim3(TPB), 0, as_stream(s), y, ldm, span, 1.0f / (float)span, C,
+                     feat);
+  SAR_LAUNCH_CHECK("sar_pool_fwd_f32");
+  return 0;
+}
+
+extern "C" int sar_fc_fwd_f32(const float* feat, const float* W, const float* bias, int N, int C, int K, float* logits,
+                              sar_stream_t s) {
+  SAR_REQUIRE(feat && W && logits && N > 0 && C > 0 && K > 0, "sar_fc_fwd: bad arguments");
+  hipLaunchKernelGGL(fc_fwd_kernel, dim3(N), dim3(128), 0, as_stream(s), feat, W, bias, C, K, logits);
+  SAR_LAUNCH_CHECK("sar_fc_fwd_f32");
+  return 0;
+}
+
+extern "C" int sar_softmax_ce_f32(const float* logits, const int64_t* labels, int N, int K, float inv_global_batch,
+                                  float* loss_sum, float* dlogits, float* probs, sar_stream_t s) {
+  SAR_REQUIRE(logits && labels && N > 0 && K > 0, "sar_softmax_ce: bad arguments");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(TPB), 0, as_stream(s), logits, labels, N, K, inv_global_batch,
+                     loss_sum, dlogits, probs);
+  SAR_LAUNCH_CHECK("sar_softmax_ce_f32");
+  return 0;
+}
+
+extern "C" int sar_fc_bwd_f32(const float* feat, const float* W, const float* dlogits, int N, int C, int K, float* dW,
+                              float* dbias, float* dfeat, sar_stream_t s) {
+  SAR_REQUIRE(feat && W && dlogits && dW && dbias && dfeat && N > 0 && C > 0 && K > 0, "sar_fc_bwd: bad arguments");
+  hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(C + 1), dim3(128), 0, as_stream(s), feat, dlogits, N, C, K, dW, dbias);
+  hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(N), dim3(256), 0, as_stream(s), W, dlogits, C, K, dfeat);
+  SAR_LAUNCH_CHECK("sar_fc_bwd_f32");
+  return 0;
+}
+
+extern "C" int sar_pool_bwd_f32(const float* dfeat, int64_t ldm, int C, int B, int TV, int Mp, float* dy, sar_stream_t s) {
+  SAR_REQUIRE(dfeat && dy && C > 0 && B > 0 && TV > 0 && Mp > 0 && B % Mp == 0 && ldm >= (int64_t)B * TV,
+              "sar_pool_bwd: bad arguments");
+  const int span = Mp * TV;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B / Mp, C), dim3(TPB), 0, as_stream(s), dfeat, ldm, span, 1.0f / (float)span,
+                     C, dy);
+  SAR_LAUNCH_CHECK("sar_pool_bwd_f32");
+  return 0;
+}
+
+extern "C" int sar_sgd_nesterov_f32(float* w, float* v, const float* g, int64_t n, const float* lr_dev, float momentum,
+                                    sar_stream_t s) {
+  SAR_REQUIRE(w && v && g && lr_dev && n > 0, "sar_sgd_nesterov: bad arguments");
+  int blocks = (int)((n + TPB - 1) / TPB);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(blocks), dim3(TPB), 0, as_stream(s), w, v, g, n, lr_dev, momentum);
+  SAR_LAUNCH_CHECK("sar_sgd_nesterov_f32");
+  return 0;
+}
+
+extern "C" int sar_transpose_f32(const float* in, float* out, int batch, int R, int Cc, sar_stream_t s) {
+  SAR_REQUIRE(in && out && batch > 0 && R > 0 && Cc > 0, "sar_transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, batch), dim3(32, 8), 0, as_stream(s), in, out,
+                     R, Cc);
+  SAR_LAUNCH_CHECK("sar_transpose_f32");
+  return 0;
+}

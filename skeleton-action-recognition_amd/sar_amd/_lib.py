@@ -1,0 +1,114 @@
+"""ctypes binding of libsar_hip.so (the C ABI declared in include/sar_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails,
+an exception is raised.  Nothing here imports the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsar_hip.so")
+
+SAR_CONV_GRAPH, SAR_CONV_TEMPORAL = 0, 1
+SAR_EPI_NONE, SAR_EPI_STATS, SAR_EPI_MASK, SAR_EPI_ADD = 0, 1, 2, 3
+
+_fp = C.c_void_p  # every device pointer crosses the ABI as void*
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("transposed", C.c_int32), ("B", C.c_int32), ("V", C.c_int32),
+        ("T_src", C.c_int32), ("T_out", C.c_int32), ("Kc", C.c_int32), ("M", C.c_int32),
+        ("taps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("pro_relu", C.c_int32),
+        ("epi", C.c_int32), ("nz", C.c_int32 * 3),
+        ("src", _fp), ("ld_src", C.c_int64), ("out", _fp), ("ld_out", C.c_int64),
+        ("W", _fp), ("w_stride_tap", C.c_int64), ("w_stride_c", C.c_int64), ("bias", _fp),
+        ("pro_scale", _fp), ("pro_shift", _fp),
+        ("g_idx", _fp), ("g_wt", _fp), ("g_colsum", _fp),
+        ("aux", _fp), ("ld_aux", C.c_int64), ("aux_scale", _fp), ("aux_shift", _fp),
+        ("partials", _fp),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("B", C.c_int32), ("V", C.c_int32), ("T_src", C.c_int32), ("T_out", C.c_int32),
+        ("Kc", C.c_int32), ("M", C.c_int32), ("taps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("pro_relu", C.c_int32), ("nz", C.c_int32 * 3), ("nsplit", C.c_int32),
+        ("src", _fp), ("ld_src", C.c_int64), ("dout", _fp), ("ld_dout", C.c_int64),
+        ("pro_scale", _fp), ("pro_shift", _fp),
+        ("g_idx", _fp), ("g_wt", _fp), ("g_colsum", _fp),
+        ("w_stride_tap", C.c_int64), ("w_stride_c", C.c_int64), ("wsize", C.c_int64), ("bsize", C.c_int64),
+        ("slab", _fp),
+    ]
+
+
+# name -> (restype, argtypes); every name must also be declared in include/sar_hip.h
+_i, _i64, _f, _d = C.c_int, C.c_int64, C.c_float, C.c_double
+SIGNATURES = {
+    "sar_version": (_i, []),
+    "sar_last_error_string": (C.c_char_p, []),
+    "sar_conv_gemm_nparts": (_i, [C.POINTER(ConvDesc)]),
+    "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),
+    "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
+    "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),
+    "sar_bn_finalize_f32": (_i, [_fp, _i, _i, _d, _f, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "sar_bn_eval_affine_f32": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _fp]),
+    "sar_bn_bwd_finalize_f32": (_i, [_fp, _i, _i64, _i64, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "sar_data_bn_stats_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp]),
+    "sar_data_bn_apply_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i64, _fp]),
+    "sar_data_bn_bwd_reduce_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i64, _fp, _fp]),
+    "sar_bn_add_relu_fwd_f32": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_reduce_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_apply_f32": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),
+    "sar_affine2_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
+    "sar_pool_fwd_f32": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
+    "sar_fc_fwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
+    "sar_softmax_ce_f32": (_i, [_fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),
+    "sar_fc_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    "sar_pool_bwd_f32": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
+    "sar_sgd_nesterov_f32": (_i, [_fp, _fp, _fp, _i64, _fp, _f, _fp]),
+    "sar_transpose_f32": (_i, [_fp, _fp, _i, _i, _i, _fp]),
+    "sar_vr_signal_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
+    "sar_stft_logmag_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _fp]),
+}
+
+_lib = None
+
+
+class SarError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsar_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SarError(
+            "libsar_hip.so not found at %s -- build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sar_last_error_string().decode("utf-8", "replace")
+        raise SarError("%s failed (rc=%d): %s" % (what or "libsar_hip call", rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

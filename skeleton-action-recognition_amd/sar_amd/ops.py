@@ -1,0 +1,200 @@
+"""Thin tensor-level wrappers over the C ABI (include/sar_hip.h).  torch is used only for device
+memory and the current HIP stream; all arithmetic happens in libsar_hip.so.
+
+Activations use the CN layout: a 2-D float32 tensor [C][B*T*V] (see include/sar_hip.h).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, WgradDesc, check, ptr, stream_ptr
+
+
+def _f32(t):
+    assert t is None or (t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()), "need contiguous cuda float32"
+    return t
+
+
+class GraphTables:
+    """Device copies of the gather lists (graph_tables.gather_lists)."""
+
+    def __init__(self, A, device, transpose=False):
+        from .graph_tables import gather_lists
+        idx, wt, nz, colsum = gather_lists(A, transpose)
+        self.idx = torch.from_numpy(idx).to(device)
+        self.wt = torch.from_numpy(wt).to(device)
+        self.colsum = torch.from_numpy(colsum).to(device)
+        self.nz = nz
+        self.K, self.V = idx.shape[0], idx.shape[1]
+
+
+def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
+              transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
+              aux_affine=None, want_partials=False):
+    """Launch sar_conv_gemm_f32.  Returns (partials, nparts) when the epilogue reduces, else None."""
+    lib = L.load()
+    d = ConvDesc()
+    d.mode, d.transposed, d.B, d.V = mode, int(transposed), B, V
+    d.T_src, d.T_out, d.Kc, d.M = T_src, T_out, Kc, M
+    d.taps, d.stride, d.pad, d.pro_relu, d.epi = taps, stride, pad, int(pro_relu), epi
+    _f32(src), _f32(out), _f32(W)
+    d.src, d.ld_src = ptr(src), src.stride(0)
+    d.out, d.ld_out = ptr(out), out.stride(0)
+    d.W, d.w_stride_tap, d.w_stride_c = ptr(W), w_stride_tap, w_stride_c
+    d.bias = ptr(_f32(bias))
+    if pro is not None:
+        d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
+    if tables is not None:
+        d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
+        for i in range(3):
+            d.nz[i] = tables.nz[i]
+    if aux is not None:
+        d.aux, d.ld_aux = ptr(_f32(aux)), aux.stride(0)
+    if aux_affine is not None:
+        d.aux_scale, d.aux_shift = ptr(_f32(aux_affine[0])), ptr(_f32(aux_affine[1]))
+    partials = None
+    nparts = 0
+    if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
+        nparts = lib.sar_conv_gemm_nparts(C.byref(d))
+        if nparts <= 0:
+            check(nparts or -1, "sar_conv_gemm_nparts")
+        partials = torch.empty((M, nparts, 2), dtype=torch.float32, device=src.device)
+        d.partials = ptr(partials)
+    check(lib.sar_conv_gemm_f32(C.byref(d), stream_ptr()), "sar_conv_gemm_f32")
+    return (partials, nparts) if partials is not None else None
+
+
+def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
+               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None):
+    """dW (and dbias, stored right behind it) -> dW_out[0 : wsize+bsize] (flat float32 view)."""
+    lib = L.load()
+    d = WgradDesc()
+    d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
+    d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
+    ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
+    if nsplit is None:
+        ft = max(1, min(128 // V, T_out))
+        ntiles = B * ((T_out + ft - 1) // ft)
+        wgs = ((M + 63) // 64) * ((Kc + ct - 1) // ct)
+        nsplit = max(1, min(ntiles, (1024 + wgs - 1) // wgs))
+    d.nsplit = nsplit
+    _f32(src), _f32(dout)
+    d.src, d.ld_src, d.dout, d.ld_dout = ptr(src), src.stride(0), ptr(dout), dout.stride(0)
+    if pro is not None:
+        d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
+    if tables is not None:
+        d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
+        for i in range(3):
+            d.nz[i] = tables.nz[i]
+    d.w_stride_tap, d.w_stride_c, d.wsize, d.bsize = w_stride_tap, w_stride_c, wsize, bsize
+    slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
+    d.slab = ptr(slab)
+    check(lib.sar_conv_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv_wgrad_f32")
+    assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
+    check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, wsize + bsize, wsize + bsize, ptr(dW_out), stream_ptr()),
+          "sar_slab_reduce_f32")
+
+
+def bn_finalize(partials, nparts, C_, count, eps, momentum, unbiased_running, gamma, beta, running_mean, running_var,
+                mean, rstd, scale, shift):
+    check(L.load().sar_bn_finalize_f32(ptr(partials), nparts, C_, float(count), eps, momentum, int(unbiased_running),
+                                       ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(mean), ptr(rstd),
+                                       ptr(scale), ptr(shift), stream_ptr()), "sar_bn_finalize_f32")
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
+    check(L.load().sar_bn_eval_affine_f32(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps,
+                                          running_mean.numel(), ptr(scale), ptr(shift), stream_ptr()),
+          "sar_bn_eval_affine_f32")
+
+
+def bn_bwd_finalize(partials, nparts, chan_stride, part_stride, off1, off2, C_, count, gamma, mean, rstd, dgamma, dbeta,
+                    k1=None, k2=None, k3=None):
+    check(L.load().sar_bn_bwd_finalize_f32(ptr(partials), nparts, chan_stride, part_stride, off1, off2, C_, float(count),
+                                           ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(k1), ptr(k2),
+                                           ptr(k3), stream_ptr()), "sar_bn_bwd_finalize_f32")
+
+
+def data_bn_stats(x, bone_parent, partials):
+    N, C_, T, V, M = x.shape
+    check(L.load().sar_data_bn_stats_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(partials), stream_ptr()),
+          "sar_data_bn_stats_f32")
+
+
+def data_bn_apply(x, bone_parent, scale, shift, out):
+    N, C_, T, V, M = x.shape
+    check(L.load().sar_data_bn_apply_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(scale), ptr(shift), ptr(out),
+                                         out.stride(0), stream_ptr()), "sar_data_bn_apply_f32")
+
+
+def data_bn_bwd_reduce(x, bone_parent, dy, partials):
+    N, C_, T, V, M = x.shape
+    check(L.load().sar_data_bn_bwd_reduce_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(dy), dy.stride(0),
+                                              ptr(partials), stream_ptr()), "sar_data_bn_bwd_reduce_f32")
+
+
+def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y):
+    check(L.load().sar_bn_add_relu_fwd_f32(ptr(u), ptr(sc), ptr(sh), res_kind, ptr(r), ptr(rsc), ptr(rsh), ptr(y),
+                                           u.shape[0], u.shape[1], u.stride(0), stream_ptr()), "sar_bn_add_relu_fwd_f32")
+
+
+def bn_add_relu_bwd_reduce(dy, y, u, r):
+    Cc, n = u.shape
+    nparts = max(1, min(256, (n + 8191) // 8192))
+    partials = torch.empty((Cc, nparts, 4), dtype=torch.float32, device=u.device)
+    check(L.load().sar_bn_add_relu_bwd_reduce_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(partials), nparts, Cc, n,
+                                                  u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_reduce_f32")
+    return partials, nparts
+
+
+def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out):
+    Cc, n = u.shape
+    rk = rk or (None, None, None)
+    check(L.load().sar_bn_add_relu_bwd_apply_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(k[0]), ptr(k[1]), ptr(k[2]),
+                                                 ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(du), ptr(dr), ptr(dz_out), Cc, n,
+                                                 u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_apply_f32")
+
+
+def affine2(a, b, k, out):
+    Cc, n = a.shape
+    check(L.load().sar_affine2_f32(ptr(a), ptr(b), ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(out), Cc, n, a.stride(0),
+                                   stream_ptr()), "sar_affine2_f32")
+
+
+def pool_fwd(y, B, TV, Mp, feat):
+    check(L.load().sar_pool_fwd_f32(ptr(y), y.stride(0), y.shape[0], B, TV, Mp, ptr(feat), stream_ptr()),
+          "sar_pool_fwd_f32")
+
+
+def fc_fwd(feat, W, bias, logits):
+    N, Cc = feat.shape
+    check(L.load().sar_fc_fwd_f32(ptr(feat), ptr(W), ptr(bias), N, Cc, logits.shape[1], ptr(logits), stream_ptr()),
+          "sar_fc_fwd_f32")
+
+
+def softmax_ce(logits, labels, inv_global_batch, loss_sum=None, dlogits=None, probs=None):
+    N, K = logits.shape
+    assert labels.dtype == torch.int64 and labels.is_cuda
+    check(L.load().sar_softmax_ce_f32(ptr(logits), ptr(labels), N, K, inv_global_batch, ptr(loss_sum), ptr(dlogits),
+                                      ptr(probs), stream_ptr()), "sar_softmax_ce_f32")
+
+
+def fc_bwd(feat, W, dlogits, dW, dbias, dfeat):
+    N, Cc = feat.shape
+    check(L.load().sar_fc_bwd_f32(ptr(feat), ptr(W), ptr(dlogits), N, Cc, dlogits.shape[1], ptr(dW), ptr(dbias),
+                                  ptr(dfeat), stream_ptr()), "sar_fc_bwd_f32")
+
+
+def pool_bwd(dfeat, B, TV, Mp, dy):
+    check(L.load().sar_pool_bwd_f32(ptr(dfeat), dy.stride(0), dy.shape[0], B, TV, Mp, ptr(dy), stream_ptr()),
+          "sar_pool_bwd_f32")
+
+
+def sgd_nesterov(w, v, g, lr_dev, momentum):
+    check(L.load().sar_sgd_nesterov_f32(ptr(w), ptr(v), ptr(g), w.numel(), ptr(lr_dev), momentum, stream_ptr()),
+          "sar_sgd_nesterov_f32")
+
+
+def transpose(inp, out, batch, R, Cc):
+    check(L.load().sar_transpose_f32(ptr(inp), ptr(out), batch, R, Cc, stream_ptr()), "sar_transpose_f32")

@@ -1,0 +1,364 @@
+"""ST-GCN training engine on the HIP kernels (one process = one MI355X).
+
+Mirrors the reference model (models/stgcn.py:101-160, blocks :11-64, GraphConvTD models/gcn.py:187-209)
+and its train step (main_gnn.py:219-239): forward, hand-scheduled backward, gradients into ONE flat
+fp32 buffer (so data parallelism is a single RCCL all-reduce, main_gnn.py:257 MirroredStrategy), fused
+Nesterov SGD (main_gnn.py:312-314).  Parameters keep the reference's Keras layouts and names.
+
+HBM layout: activations are [C][B*T*V] matrices (CN layout, include/sar_hip.h); per block the tensors
+that cross a BatchNorm barrier (g = graph conv out, u = temporal conv out, r = residual conv out,
+y = block out) are materialised once in forward and kept for backward; BN+ReLU is folded into the
+consumer's operand load, BN statistics into the producer's epilogue.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+BN_EPS = 1e-3        # Keras BatchNormalization defaults (models/stgcn.py:27,37,56,111)
+BN_MOMENTUM = 0.99
+KS, KT = 3, 9        # kernel_size=[3, 9], models/stgcn.py:14
+# (filters, stride, residual) -- models/stgcn.py:113-123
+BLOCKS = [(64, 1, False), (64, 1, True), (64, 1, True), (64, 1, True), (128, 2, True), (128, 1, True), (128, 1, True),
+          (256, 2, True), (256, 1, True), (256, 1, True)]
+
+
+def same_pad(T, k, s):
+    """TF 'SAME': (out, pad_begin, pad_end); the extra pad goes at the end."""
+    out = -(-T // s)
+    total = max((out - 1) * s + k - T, 0)
+    return out, total // 2, total - total // 2
+
+
+def ntu_adjacency():
+    """graph/ntu_rgb_d.py:6-40 + graph/tools.py:4-30 ('spatial' labelling) -> (3,25,25) float64."""
+    from graph.ntu_rgb_d import Graph  # the package's drop-in mirror of the reference module
+    return Graph().A
+
+
+class _BN:
+    """Per-BatchNorm device state: parameters are views of the flat buffer, statistics are buffers."""
+
+    def __init__(self, C, device):
+        z = lambda: torch.zeros(C, dtype=torch.float32, device=device)
+        self.moving_mean, self.moving_var = z(), torch.ones(C, dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.shift = z(), z(), z(), z()
+        self.k1, self.k2, self.k3 = z(), z(), z()
+
+
+class STGCN:
+    def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
+                 blocks=None):
+        L.load()  # fail loudly if the HIP library is missing
+        self.device = torch.device(device)
+        self.num_classes, self.C_in, self.V = num_classes, in_channels, num_node
+        self.blocks = list(blocks if blocks is not None else BLOCKS)
+        A = np.asarray(ntu_adjacency() if A is None else A, dtype=np.float64)
+        assert A.shape == (KS, num_node, num_node)
+        self.A_host = A.astype(np.float32)
+        self.A = torch.from_numpy(self.A_host).to(self.device)     # 'adjacency_matrix', non-trainable (stgcn.py:105-109)
+        self.tab_fwd = ops.GraphTables(self.A_host, self.device, transpose=False)
+        self.tab_bwd = ops.GraphTables(self.A_host, self.device, transpose=True)
+        self.bone_parent = None
+        if bone_pairs is not None:
+            bp = np.full(num_node, -1, dtype=np.int32)
+            for v1, v2 in bone_pairs:          # data_gen/gen_bone_data.py:36-41 (1-based pairs)
+                bp[v1 - 1] = v2 - 1
+            self.bone_parent = torch.from_numpy(bp).to(self.device)
+
+        # ---- parameter table (Keras layouts), flat storage
+        self.shapes = {}
+        nch = num_node * in_channels
+        self._add("data_bn.gamma", (nch,)), self._add("data_bn.beta", (nch,))
+        cin = in_channels
+        self.kinds = []
+        for i, (f, s, res) in enumerate(self.blocks):
+            pre = "l%d." % i
+            kind = "none" if not res else ("identity" if (cin == f and s == 1) else "conv")   # stgcn.py:41-56
+            self.kinds.append(kind)
+            self._add(pre + "gcn.kernel", (1, 1, cin, KS * f)), self._add(pre + "gcn.bias", (KS * f,))
+            self._add(pre + "bn1.gamma", (f,)), self._add(pre + "bn1.beta", (f,))
+            self._add(pre + "tcn.kernel", (KT, 1, f, f)), self._add(pre + "tcn.bias", (f,))
+            self._add(pre + "bn2.gamma", (f,)), self._add(pre + "bn2.beta", (f,))
+            if kind == "conv":
+                self._add(pre + "res.kernel", (1, 1, cin, f)), self._add(pre + "res.bias", (f,))
+                self._add(pre + "res_bn.gamma", (f,)), self._add(pre + "res_bn.beta", (f,))
+            cin = f
+        self.C_last = cin
+        self._add("logits.kernel", (1, 1, cin, num_classes)), self._add("logits.bias", (num_classes,))
+        total, self.offsets = 0, {}
+        for k, shp in self.shapes.items():
+            self.offsets[k] = total
+            total += int(np.prod(shp))
+        self.n_params = total
+        dev = self.device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.velocity = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.p = {k: self._view(self.flat, k) for k in self.shapes}
+        self.g = {k: self._view(self.grad, k) for k in self.shapes}
+        self.bn = {"data_bn": _BN(nch, dev)}
+        for i, (f, s, res) in enumerate(self.blocks):
+            self.bn["l%d.bn1" % i], self.bn["l%d.bn2" % i] = _BN(f, dev), _BN(f, dev)
+            if self.kinds[i] == "conv":
+                self.bn["l%d.res_bn" % i] = _BN(f, dev)
+        self._init_params(seed)
+        self._saved = None
+
+    # ------------------------------------------------------------------ parameters
+    def _add(self, name, shape):
+        self.shapes[name] = tuple(shape)
+
+    def _view(self, flat, name):
+        o = self.offsets[name]
+        return flat[o:o + int(np.prod(self.shapes[name]))].view(self.shapes[name])
+
+    def _init_params(self, seed):
+        """models/stgcn.py:7-8 VarianceScaling(2, fan_out, truncated_normal); biases 0; BN gamma 1, beta 0."""
+        gen = torch.Generator().manual_seed(seed)
+        for k, shp in self.shapes.items():
+            if k.endswith(".kernel"):
+                fan_out = shp[0] * shp[1] * shp[3]
+                std = math.sqrt(2.0 / fan_out) / .87962566103423978
+                w = torch.empty(shp, dtype=torch.float64)
+                torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std, generator=gen)
+                self.p[k].copy_(w.to(torch.float32))
+            elif k.endswith(".gamma"):
+                self.p[k].fill_(1.0)
+            else:
+                self.p[k].zero_()
+
+    def load_params(self, params):
+        """params: dict name -> tensor in the oracle / Keras layouts (incl. optional moving stats, 'A' ignored)."""
+        for k, v in params.items():
+            if k in self.p:
+                self.p[k].copy_(v.to(torch.float32).reshape(self.shapes[k]))
+            elif k.endswith(".moving_mean"):
+                self.bn[k[:-len(".moving_mean")]].moving_mean.copy_(v.to(torch.float32))
+            elif k.endswith(".moving_var"):
+                self.bn[k[:-len(".moving_var")]].moving_var.copy_(v.to(torch.float32))
+
+    def state_dict(self):
+        out = {k: v.detach().cpu().clone() for k, v in self.p.items()}
+        for k, b in self.bn.items():
+            out[k + ".moving_mean"] = b.moving_mean.cpu().clone()
+            out[k + ".moving_var"] = b.moving_var.cpu().clone()
+        out["A"] = self.A.cpu().clone()
+        return out
+
+    def grads(self):
+        return {k: v for k, v in self.g.items()}
+
+    # ------------------------------------------------------------------ forward
+    def _bn_forward_stats(self, name, partials, nparts, count, training, unbiased):
+        b = self.bn[name]
+        ops.bn_finalize(partials, nparts, b.mean.numel(), count, BN_EPS, BN_MOMENTUM, unbiased, self.p[name + ".gamma"],
+                        self.p[name + ".beta"], b.moving_mean if training else None, b.moving_var if training else None,
+                        b.mean, b.rstd, b.scale, b.shift)
+
+    def _bn_eval(self, name):
+        b = self.bn[name]
+        ops.bn_eval_affine(self.p[name + ".gamma"], self.p[name + ".beta"], b.moving_mean, b.moving_var, BN_EPS, b.scale,
+                           b.shift)
+
+    def forward(self, x, training=True, keep=None):
+        """x: (N, C, T, V, M) float32 cuda -> logits (N, classes).  keep: optional dict receiving
+        intermediate activations (tests)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
+        x = x.contiguous()
+        N, Cin, T, V, M = x.shape
+        assert Cin == self.C_in and V == self.V
+        dev, B = x.device, N * M
+        saved = {"x": x, "N": N, "M": M, "T": T, "blocks": [], "training": training}
+        # ---- data_bn (models/stgcn.py:142-147)
+        nch = V * Cin
+        if training:
+            part = torch.empty((nch, N, 2), dtype=torch.float32, device=dev)
+            ops.data_bn_stats(x, self.bone_parent, part)
+            self._bn_forward_stats("data_bn", part, N, N * M * T, True, False)
+        else:
+            self._bn_eval("data_bn")
+        dbn = self.bn["data_bn"]
+        h = torch.empty((Cin, B * T * V), dtype=torch.float32, device=dev)
+        ops.data_bn_apply(x, self.bone_parent, dbn.scale, dbn.shift, h)
+        if keep is not None:
+            keep["x0"] = h
+        Tc, cin = T, Cin
+        for i, (f, s, res) in enumerate(self.blocks):
+            h, Tc = self._block_forward(i, h, cin, f, s, B, Tc, training, saved, keep)
+            cin = f
+        # ---- head (models/stgcn.py:153-158)
+        feat = torch.empty((N, cin), dtype=torch.float32, device=dev)
+        ops.pool_fwd(h, B, Tc * V, M, feat)
+        logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=dev)
+        ops.fc_fwd(feat, self.p["logits.kernel"].view(cin, self.num_classes), self.p["logits.bias"], logits)
+        saved.update(feat=feat, T_last=Tc, y_last_shape=(cin, B * Tc * V))
+        self._saved = saved if training else None
+        if keep is not None:
+            keep["feat"] = feat
+        return logits
+
+    def _block_forward(self, i, X, cin, f, s, B, T, training, saved, keep):
+        V, dev = self.V, X.device
+        pre = "l%d." % i
+        kind = self.kinds[i]
+        To, pad, _ = same_pad(T, KT, s)
+        n_in, n_out = B * T * V, B * To * V
+        epi = L.SAR_EPI_STATS if training else L.SAR_EPI_NONE
+        # sgcn: GraphConvTD (models/gcn.py:199-209)
+        g = torch.empty((f, n_in), dtype=torch.float32, device=dev)
+        r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
+                           Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi)
+        if training:
+            self._bn_forward_stats(pre + "bn1", r1[0], r1[1], n_in, True, True)
+        else:
+            self._bn_eval(pre + "bn1")
+        bn1 = self.bn[pre + "bn1"]
+        # tgcn: BN -> ReLU folded into the operand load, Conv2D [9,1] stride s SAME (models/stgcn.py:26-36)
+        u = torch.empty((f, n_out), dtype=torch.float32, device=dev)
+        r2 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, g, u, self.p[pre + "tcn.kernel"], f * f, f, B=B, V=V, T_src=T, T_out=To,
+                           Kc=f, M=f, taps=KT, stride=s, pad=pad, bias=self.p[pre + "tcn.bias"],
+                           pro=(bn1.scale, bn1.shift), pro_relu=True, epi=epi)
+        if training:
+            self._bn_forward_stats(pre + "bn2", r2[0], r2[1], n_out, True, True)
+        else:
+            self._bn_eval(pre + "bn2")
+        bn2 = self.bn[pre + "bn2"]
+        r = None
+        rbn = None
+        if kind == "conv":  # models/stgcn.py:47-56
+            r = torch.empty((f, n_out), dtype=torch.float32, device=dev)
+            r3 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, X, r, self.p[pre + "res.kernel"], 0, f, B=B, V=V, T_src=T, T_out=To,
+                               Kc=cin, M=f, taps=1, stride=s, pad=0, bias=self.p[pre + "res.bias"], epi=epi)
+            if training:
+                self._bn_forward_stats(pre + "res_bn", r3[0], r3[1], n_out, True, True)
+            else:
+                self._bn_eval(pre + "res_bn")
+            rbn = self.bn[pre + "res_bn"]
+        y = torch.empty((f, n_out), dtype=torch.float32, device=dev)
+        res_kind = {"none": 0, "identity": 1, "conv": 2}[kind]
+        ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r,
+                            rbn.scale if rbn else None, rbn.shift if rbn else None, y)
+        if training:
+            saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind))
+        if keep is not None:
+            keep[pre + "g"], keep[pre + "u"], keep[pre + "y"] = g, u, y
+        return y, To
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits):
+        """dlogits (N, classes) -> fills self.grad (every trainable parameter).  main_gnn.py:233."""
+        sv = self._saved
+        assert sv is not None, "backward() needs a preceding forward(training=True)"
+        dev, V = dlogits.device, self.V
+        N, M = sv["N"], sv["M"]
+        B = N * M
+        c_last = self.C_last
+        feat = sv["feat"]
+        dfeat = torch.empty_like(feat)
+        ops.fc_bwd(feat, self.p["logits.kernel"].view(c_last, self.num_classes), dlogits.contiguous(),
+                   self.g["logits.kernel"].view(c_last, self.num_classes), self.g["logits.bias"], dfeat)
+        dY = torch.empty(sv["y_last_shape"], dtype=torch.float32, device=dev)
+        ops.pool_bwd(dfeat, B, sv["T_last"] * V, M, dY)
+        for i in reversed(range(len(self.blocks))):
+            dY = self._block_backward(i, sv["blocks"][i], dY, B)
+        # data_bn gamma/beta (the input needs no gradient)
+        x = sv["x"]
+        nch = V * self.C_in
+        part = torch.empty((nch, N, 2), dtype=torch.float32, device=dev)
+        ops.data_bn_bwd_reduce(x, self.bone_parent, dY, part)
+        dbn = self.bn["data_bn"]
+        ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, nch, N * M * sv["T"], self.p["data_bn.gamma"], dbn.mean, dbn.rstd,
+                            self.g["data_bn.gamma"], self.g["data_bn.beta"])
+        self._saved = None
+
+    def _block_backward(self, i, sb, dY, B):
+        V, dev = self.V, dY.device
+        pre = "l%d." % i
+        X, g, u, r, y = sb["X"], sb["g"], sb["u"], sb["r"], sb["y"]
+        T, To, pad, cin, f, s, kind = sb["T"], sb["To"], sb["pad"], sb["cin"], sb["f"], sb["s"], sb["kind"]
+        n_in, n_out = B * T * V, B * To * V
+        bn1, bn2 = self.bn[pre + "bn1"], self.bn[pre + "bn2"]
+        rbn = self.bn.get(pre + "res_bn")
+        # ---- tail: y = relu(bn2(u) + res)   (models/stgcn.py:37,62-63)
+        part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, u, r if kind == "conv" else None)
+        ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, self.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
+                            self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
+        rk = None
+        if kind == "conv":
+            ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 2, f, n_out, self.p[pre + "res_bn.gamma"], rbn.mean,
+                                rbn.rstd, self.g[pre + "res_bn.gamma"], self.g[pre + "res_bn.beta"], rbn.k1, rbn.k2,
+                                rbn.k3)
+            rk = (rbn.k1, rbn.k2, rbn.k3)
+        du = torch.empty_like(u)
+        dr = torch.empty_like(r) if kind == "conv" else None
+        dz = dY if kind == "identity" else None  # in place: dY becomes the pre-ReLU gradient for the skip path
+        ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz)
+        # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
+        wt = self.g[pre + "tcn.kernel"]
+        flat_w = self.grad[self.offsets[pre + "tcn.kernel"]:self.offsets[pre + "tcn.bias"] + f]
+        ops.conv_wgrad(L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s,
+                       pad=pad, pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
+                       wsize=wt.numel(), bsize=f)
+        wT = torch.empty((KT, f, f), dtype=torch.float32, device=dev)
+        ops.transpose(self.p[pre + "tcn.kernel"], wT, KT, f, f)          # [tap][c][f] -> [tap][f][c]
+        dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
+        pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, du, dz1, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=KT,
+                           stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g,
+                           aux_affine=(bn1.scale, bn1.shift))
+        ops.bn_bwd_finalize(pm[0], pm[1], pm[1] * 2, 2, 0, 1, f, n_in, self.p[pre + "bn1.gamma"], bn1.mean, bn1.rstd,
+                            self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
+        dg = dz1
+        ops.affine2(dz1, g, (bn1.k1, bn1.k2, bn1.k3), dg)                # BN1 backward apply (in place)
+        # ---- graph conv: weight / bias gradient
+        flat_w = self.grad[self.offsets[pre + "gcn.kernel"]:self.offsets[pre + "gcn.bias"] + KS * f]
+        ops.conv_wgrad(L.SAR_CONV_GRAPH, X, dg, flat_w, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS,
+                       tables=self.tab_fwd, w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f)
+        # ---- residual conv branch
+        dXres = None
+        if kind == "conv":
+            flat_w = self.grad[self.offsets[pre + "res.kernel"]:self.offsets[pre + "res.bias"] + f]
+            ops.conv_wgrad(L.SAR_CONV_TEMPORAL, X, dr, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s,
+                           pad=0, w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f)
+            rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
+            ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
+            dXres = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
+            ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
+                          stride=s, pad=0, transposed=True)
+        # ---- graph conv data gradient (+ skip-path gradient)
+        gT = torch.empty((KS * f, cin), dtype=torch.float32, device=dev)
+        ops.transpose(self.p[pre + "gcn.kernel"], gT, 1, cin, KS * f)    # [c][k*F+f] -> [k][f][c]
+        dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
+        aux = dY if kind == "identity" else dXres
+        ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
+                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux)
+        return dX
+
+    # ------------------------------------------------------------------ training step
+    def loss_and_grad(self, x, labels, global_batch_size=None):
+        """main_gnn.py:221-233: loss = sum CE / global_batch; gradients of every trainable variable."""
+        logits = self.forward(x, training=True)
+        N = x.shape[0]
+        gbs = global_batch_size or N
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dlogits = torch.empty_like(logits)
+        ops.softmax_ce(logits, labels, 1.0 / gbs, loss, dlogits)
+        self.backward(dlogits)
+        return logits, loss
+
+    def sgd_step(self, lr, momentum=0.9):
+        """tf.keras SGD(momentum, nesterov=True) over the flat buffers (main_gnn.py:312-314)."""
+        self.lr_dev.fill_(float(lr))
+        ops.sgd_nesterov(self.flat, self.velocity, self.grad, self.lr_dev, momentum)
+
+    def predict(self, x):
+        """main_gnn.py:205-208: softmax(model(features, training=False))."""
+        logits = self.forward(x, training=False)
+        probs = torch.empty_like(logits)
+        labels = torch.zeros(x.shape[0], dtype=torch.int64, device=x.device)
+        ops.softmax_ce(logits, labels, 1.0, None, None, probs)
+        return probs

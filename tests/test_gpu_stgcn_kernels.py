@@ -1,0 +1,347 @@
+"""GPU parity: every ST-GCN HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerance: north_star asks for fp32 logits/grads within 1e-4 relative of the reference's CPU
+forward/backward; single ops are held to 2e-5 (norm-wise: max|a-b| / max|b|) so the stack has room.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import stgcn as O
+from util import to_cn, from_cn, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from sar_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _tables(dev, transpose=False):
+    from sar_amd import ops
+    from oracle.graph import spatial_adjacency
+    return ops.GraphTables(spatial_adjacency().astype(np.float32), dev, transpose)
+
+
+def _A():
+    from oracle.graph import spatial_adjacency
+    return torch.tensor(spatial_adjacency().astype(np.float32))
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(3, 3, 64, 13), (2, 64, 64, 10), (2, 64, 128, 7), (1, 128, 256, 5), (4, 256, 256, 3)])
+def test_graph_conv_forward_and_stats(dev, B, cin, f, T):
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(B * 1000 + cin)
+    x = torch.randn(B, cin, T, 25, generator=g)
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    bias = torch.randn(3 * f, generator=g) * 0.1
+    ref = O.graph_conv_td(x.double(), kernel.double(), bias.double(), _A().double())
+    xc = to_cn(x).to(dev)
+    out = torch.empty((f, B * T * 25), device=dev)
+    r = ops.conv_gemm(L.SAR_CONV_GRAPH, xc, out, kernel.to(dev), f, 3 * f, B=B, V=25, T_src=T, T_out=T, Kc=cin, M=f, taps=3,
+                      bias=bias.to(dev), tables=_tables(dev), epi=L.SAR_EPI_STATS)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), B, T, 25), ref) < TOL
+    # BN statistics from the epilogue partials
+    mean = torch.empty(f, device=dev); rstd = torch.empty(f, device=dev)
+    scale = torch.empty(f, device=dev); shift = torch.empty(f, device=dev)
+    gamma = (1 + 0.1 * torch.randn(f, generator=g)).to(dev); beta = (0.1 * torch.randn(f, generator=g)).to(dev)
+    rm = torch.zeros(f, device=dev); rv = torch.ones(f, device=dev)
+    n = B * T * 25
+    ops.bn_finalize(r[0], r[1], f, n, 1e-3, 0.99, True, gamma, beta, rm, rv, mean, rstd, scale, shift)
+    torch.cuda.synchronize()
+    m_ref = ref.mean(dim=(0, 2, 3)); v_ref = ref.var(dim=(0, 2, 3), unbiased=False)
+    assert rel_err(mean.cpu(), m_ref) < TOL
+    assert rel_err(rstd.cpu(), torch.rsqrt(v_ref + 1e-3)) < TOL
+    assert rel_err(scale.cpu(), gamma.cpu().double() * torch.rsqrt(v_ref + 1e-3)) < TOL
+    assert rel_err(rm.cpu(), 0.01 * m_ref) < TOL
+    assert rel_err(rv.cpu(), 0.99 + 0.01 * v_ref * n / (n - 1)) < TOL
+
+
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (3, 64, 14, 2), (2, 128, 9, 2), (1, 256, 6, 1), (2, 128, 300, 2)])
+def test_temporal_conv_forward_fused_bn_relu(dev, B, f, T, s):
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(f + T + s)
+    x = torch.randn(B, f, T, 25, generator=g)
+    sc = 1 + 0.2 * torch.randn(f, generator=g); sh = 0.3 * torch.randn(f, generator=g)
+    kernel = torch.randn(9, 1, f, f, generator=g) * 0.05
+    bias = torch.randn(f, generator=g) * 0.1
+    h = torch.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    ref = O.temporal_conv(h, kernel.double(), bias.double(), s)
+    To, pad, _ = O.same_pad(T, 9, s)
+    out = torch.empty((f, B * To * 25), device=dev)
+    r = ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), out, kernel.to(dev), f * f, f, B=B, V=25, T_src=T, T_out=To,
+                      Kc=f, M=f, taps=9, stride=s, pad=pad, bias=bias.to(dev), pro=(sc.to(dev), sh.to(dev)),
+                      pro_relu=True, epi=L.SAR_EPI_STATS)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), B, To, 25), ref) < TOL
+    part = r[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], ref.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (ref * ref).sum(dim=(0, 2, 3))) < TOL
+
+
+@pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2), (1, 3, 64, 7, 1)])
+def test_residual_conv_forward(dev, B, cin, f, T, s):
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(cin + f)
+    x = torch.randn(B, cin, T, 25, generator=g)
+    kernel = torch.randn(1, 1, cin, f, generator=g) * 0.1
+    bias = torch.randn(f, generator=g) * 0.1
+    ref = F.conv2d(x.double(), O.hwio_to_oihw(kernel.double()), bias.double(), stride=(s, 1))
+    To = ref.shape[2]
+    out = torch.empty((f, B * To * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), out, kernel.to(dev), 0, f, B=B, V=25, T_src=T, T_out=To, Kc=cin, M=f,
+                  taps=1, stride=s, pad=0, bias=bias.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), B, To, 25), ref) < TOL
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9)])
+def test_graph_conv_gradients(dev, B, cin, f, T):
+    """data gradient (A^T gather lists + W^T) and weight/bias gradients of GraphConvTD."""
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(7 * cin + f)
+    x = torch.randn(B, cin, T, 25, generator=g).double().requires_grad_(True)
+    kernel = (torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1).double().requires_grad_(True)
+    bias = (torch.randn(3 * f, generator=g) * 0.1).double().requires_grad_(True)
+    dout = torch.randn(B, f, T, 25, generator=g)
+    y = O.graph_conv_td(x, kernel, bias, _A().double())
+    gx, gk, gb = torch.autograd.grad(y, (x, kernel, bias), dout.double())
+    n = B * T * 25
+    # data gradient
+    gT = torch.empty((3 * f, cin), device=dev)
+    ops.transpose(kernel.detach().float().to(dev).contiguous(), gT, 1, cin, 3 * f)
+    dx = torch.empty((cin, n), device=dev)
+    add = torch.randn(cin, n, generator=g)
+    ops.conv_gemm(L.SAR_CONV_GRAPH, to_cn(dout).to(dev), dx, gT, f * cin, cin, B=B, V=25, T_src=T, T_out=T, Kc=f, M=cin,
+                  taps=3, tables=_tables(dev, True), epi=L.SAR_EPI_ADD, aux=add.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(from_cn((dx.cpu() - add), B, T, 25), gx) < TOL
+    # weight + bias gradient
+    flat = torch.zeros(cin * 3 * f + 3 * f, device=dev)
+    ops.conv_wgrad(L.SAR_CONV_GRAPH, to_cn(x.detach().float()).to(dev), to_cn(dout).to(dev), flat, B=B, V=25, T_src=T, T_out=T,
+                   Kc=cin, M=f, taps=3, tables=_tables(dev), w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f,
+                   bsize=3 * f)
+    torch.cuda.synchronize()
+    assert rel_err(flat[:cin * 3 * f].cpu().view(1, 1, cin, 3 * f), gk) < TOL
+    assert rel_err(flat[cin * 3 * f:].cpu(), gb) < TOL
+
+
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2)])
+def test_temporal_conv_gradients(dev, B, f, T, s):
+    """weight/bias gradient (with the folded BN+ReLU operand) and the transposed-conv data gradient with the
+    fused ReLU mask + BN-backward reductions."""
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(11 * f + T + s)
+    gx = torch.randn(B, f, T, 25, generator=g).double()
+    sc = (1 + 0.2 * torch.randn(f, generator=g)).double(); sh = (0.3 * torch.randn(f, generator=g)).double()
+    kernel = (torch.randn(9, 1, f, f, generator=g) * 0.05).double().requires_grad_(True)
+    bias = (torch.randn(f, generator=g) * 0.1).double().requires_grad_(True)
+    pre = (gx * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    h = torch.relu(pre)
+    y = O.temporal_conv(h, kernel, bias, s)
+    To, pad, _ = O.same_pad(T, 9, s)
+    du = torch.randn(B, f, To, 25, generator=g)
+    g_pre, g_k, g_b = torch.autograd.grad(y, (pre, kernel, bias), du.double())   # g_pre = dh * relu mask
+    n_in = B * T * 25
+    scd, shd = sc.float().to(dev), sh.float().to(dev)
+    flat = torch.zeros(9 * f * f + f, device=dev)
+    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx.float()).to(dev), to_cn(du).to(dev), flat, B=B, V=25, T_src=T, T_out=To, Kc=f,
+                   M=f, taps=9, stride=s, pad=pad, pro=(scd, shd), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
+                   wsize=9 * f * f, bsize=f)
+    torch.cuda.synchronize()
+    assert rel_err(flat[:9 * f * f].cpu().view(9, 1, f, f), g_k) < TOL
+    assert rel_err(flat[9 * f * f:].cpu(), g_b) < TOL
+    wT = torch.empty((9, f, f), device=dev)
+    ops.transpose(kernel.detach().float().to(dev).contiguous(), wT, 9, f, f)
+    dz1 = torch.empty((f, n_in), device=dev)
+    gcn_d = to_cn(gx.float()).to(dev)
+    pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(du).to(dev), dz1, wT, f * f, f, B=B, V=25, T_src=To, T_out=T, Kc=f, M=f,
+                       taps=9, stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=gcn_d, aux_affine=(scd, shd))
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(dz1.cpu(), B, T, 25), g_pre) < TOL
+    part = pm[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], g_pre.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (g_pre * gx).sum(dim=(0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2)])
+def test_residual_conv_gradients(dev, B, cin, f, T, s):
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(cin * 3 + f)
+    x = torch.randn(B, cin, T, 25, generator=g).double().requires_grad_(True)
+    kernel = (torch.randn(1, 1, cin, f, generator=g) * 0.1).double().requires_grad_(True)
+    bias = (torch.randn(f, generator=g) * 0.1).double().requires_grad_(True)
+    y = F.conv2d(x, O.hwio_to_oihw(kernel), bias, stride=(s, 1))
+    To = y.shape[2]
+    dr = torch.randn(B, f, To, 25, generator=g)
+    gx, gk, gb = torch.autograd.grad(y, (x, kernel, bias), dr.double())
+    flat = torch.zeros(cin * f + f, device=dev)
+    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(x.detach().float()).to(dev), to_cn(dr).to(dev), flat, B=B, V=25, T_src=T,
+                   T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0, w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f)
+    rT = torch.empty((f, cin), device=dev)
+    ops.transpose(kernel.detach().float().to(dev).contiguous(), rT, 1, cin, f)
+    dx = torch.empty((cin, B * T * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(dr).to(dev), dx, rT, 0, cin, B=B, V=25, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
+                  stride=s, pad=0, transposed=True)
+    torch.cuda.synchronize()
+    assert rel_err(flat[:cin * f].cpu().view(1, 1, cin, f), gk) < TOL
+    assert rel_err(flat[cin * f:].cpu(), gb) < TOL
+    assert rel_err(from_cn(dx.cpu(), B, T, 25), gx) < TOL
+
+
+def test_block_tail_forward_backward(dev):
+    """y = relu(bn2(u) + bn_r(r)) and its backward (reductions, coefficients, apply)."""
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(5)
+    C, n = 64, 2 * 7 * 25
+    u = torch.randn(C, n, generator=g).double().requires_grad_(True)
+    r = torch.randn(C, n, generator=g).double().requires_grad_(True)
+    g2 = (1 + 0.2 * torch.randn(C, generator=g)).double().requires_grad_(True)
+    b2 = (0.2 * torch.randn(C, generator=g)).double().requires_grad_(True)
+    gr = (1 + 0.2 * torch.randn(C, generator=g)).double().requires_grad_(True)
+    br = (0.2 * torch.randn(C, generator=g)).double().requires_grad_(True)
+
+    def bn(x, ga, be):
+        m = x.mean(1, keepdim=True); v = x.var(1, unbiased=False, keepdim=True)
+        return (x - m) * torch.rsqrt(v + 1e-3) * ga.view(-1, 1) + be.view(-1, 1), m.squeeze(1), torch.rsqrt(v + 1e-3).squeeze(1)
+
+    zu, mu, ru = bn(u, g2, b2)
+    zr, mr, rr = bn(r, gr, br)
+    y = torch.relu(zu + zr)
+    dy = torch.randn(C, n, generator=g)
+    gu, grr, gg2, gb2, ggr, gbr = torch.autograd.grad(y, (u, r, g2, b2, gr, br), dy.double())
+    d = lambda t: t.detach().float().to(dev).contiguous()
+    sc2, sh2 = d(g2 * ru), d(b2 - mu * g2 * ru)
+    scr, shr = d(gr * rr), d(br - mr * gr * rr)
+    yd = torch.empty((C, n), device=dev)
+    ops.bn_add_relu_fwd(d(u), sc2, sh2, 2, d(r), scr, shr, yd)
+    torch.cuda.synchronize()
+    assert rel_err(yd.cpu(), y) < TOL
+    part, nparts = ops.bn_add_relu_bwd_reduce(d(dy), yd, d(u), d(r))
+    z = lambda: torch.empty(C, device=dev)
+    dg2, db2, k1, k2, k3 = z(), z(), z(), z(), z()
+    dgr, dbr, q1, q2, q3 = z(), z(), z(), z(), z()
+    ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, C, n, d(g2), d(mu), d(ru), dg2, db2, k1, k2, k3)
+    ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 2, C, n, d(gr), d(mr), d(rr), dgr, dbr, q1, q2, q3)
+    du, drr, dz = torch.empty((C, n), device=dev), torch.empty((C, n), device=dev), torch.empty((C, n), device=dev)
+    ops.bn_add_relu_bwd_apply(d(dy), yd, d(u), d(r), (k1, k2, k3), (q1, q2, q3), du, drr, dz)
+    torch.cuda.synchronize()
+    assert rel_err(du.cpu(), gu) < TOL and rel_err(drr.cpu(), grr) < TOL
+    assert rel_err(dg2.cpu(), gg2) < TOL and rel_err(db2.cpu(), gb2) < TOL
+    assert rel_err(dgr.cpu(), ggr) < TOL and rel_err(dbr.cpu(), gbr) < TOL
+    assert rel_err(dz.cpu(), dy.double() * (y > 0)) < 1e-7
+    # identity residual, odd row length (scalar path)
+    n2 = 3 * 25
+    u2, x2 = torch.randn(C, n2, generator=g), torch.randn(C, n2, generator=g)
+    y2 = torch.empty((C, n2), device=dev)
+    ops.bn_add_relu_fwd(u2.to(dev), sc2, sh2, 1, x2.to(dev), None, None, y2)
+    torch.cuda.synchronize()
+    ref2 = torch.relu(u2.double() * sc2.cpu().double().view(-1, 1) + sh2.cpu().double().view(-1, 1) + x2.double())
+    assert rel_err(y2.cpu(), ref2) < TOL
+
+
+def test_data_bn_forward_backward(dev):
+    from sar_amd import ops
+    p = O.randomize_affine(O.init_params(5, blocks=[(64, 1, False)]))
+    x, _ = O.synthetic_batch(3, seed=4, T=17, num_classes=5)
+    new = {}
+    xd = x.double().requires_grad_(False)
+    pd = {k: v.double() for k, v in p.items()}
+    gam = pd["data_bn.gamma"].clone().requires_grad_(True); bet = pd["data_bn.beta"].clone().requires_grad_(True)
+    pd["data_bn.gamma"], pd["data_bn.beta"] = gam, bet
+    ref = O.data_bn(xd, pd, True, new)                  # (N*M, C, T, V)
+    N, C, T, V, M = x.shape
+    part = torch.empty((V * C, N, 2), device=dev)
+    xg = x.to(dev)
+    ops.data_bn_stats(xg, None, part)
+    z = lambda: torch.empty(V * C, device=dev)
+    mean, rstd, scale, shift = z(), z(), z(), z()
+    rm, rv = p["data_bn.moving_mean"].to(dev), p["data_bn.moving_var"].to(dev)
+    ops.bn_finalize(part, N, V * C, N * M * T, 1e-3, 0.99, False, p["data_bn.gamma"].to(dev), p["data_bn.beta"].to(dev), rm, rv,
+                    mean, rstd, scale, shift)
+    out = torch.empty((C, N * M * T * V), device=dev)
+    ops.data_bn_apply(xg, None, scale, shift, out)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), N * M, T, V), ref) < TOL
+    assert rel_err(rm.cpu(), new["data_bn.moving_mean"]) < TOL and rel_err(rv.cpu(), new["data_bn.moving_var"]) < TOL
+    dy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    gg, gb = torch.autograd.grad(ref, (gam, bet), dy.double())
+    ops.data_bn_bwd_reduce(xg, None, to_cn(dy).to(dev), part)
+    dgam, dbet = z(), z()
+    ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, V * C, N * M * T, p["data_bn.gamma"].to(dev), mean, rstd, dgam, dbet)
+    torch.cuda.synchronize()
+    assert rel_err(dgam.cpu(), gg) < TOL and rel_err(dbet.cpu(), gb) < TOL
+
+
+def test_bone_transform_is_bit_exact(dev, golden_dir):
+    """data_gen/gen_bone_data.py:36-41 fused into the data_bn prologue: pure subtraction -> bit-exact."""
+    import os
+    from sar_amd import ops
+    from sar_amd.bone import NTU_BONE_PAIRS, bone_parent_array
+    x = torch.from_numpy(np.load(os.path.join(golden_dir, "ntu_clips_0_2.npy")))[:, :, :40].contiguous()
+    N, C, T, V, M = x.shape
+    bone = x.clone()
+    for v1, v2 in NTU_BONE_PAIRS:
+        bone[:, :, :, v1 - 1, :] = x[:, :, :, v1 - 1, :] - x[:, :, :, v2 - 1, :]
+    one = torch.ones(V * C, device=dev); zero = torch.zeros(V * C, device=dev)
+    out = torch.empty((C, N * M * T * V), device=dev)
+    ops.data_bn_apply(x.to(dev), torch.from_numpy(bone_parent_array(V)).to(dev), one, zero, out)
+    torch.cuda.synchronize()
+    got = out.cpu().view(C, N, M, T, V).permute(1, 0, 3, 4, 2)
+    assert torch.equal(got, bone)
+
+
+def test_head_loss_and_sgd(dev):
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, Mp, C, TV, K = 5, 2, 256, 3 * 25, 60
+    y = torch.randn(C, N * Mp * TV, generator=g).double().requires_grad_(True)
+    W = (torch.randn(C, K, generator=g) * 0.1).double().requires_grad_(True)
+    b = (torch.randn(K, generator=g) * 0.1).double().requires_grad_(True)
+    labels = torch.randint(0, K, (N,), generator=g)
+    pooled = y.view(C, N * Mp, TV).mean(2).t()
+    feat = pooled.reshape(N, Mp, C).mean(1)
+    logits = feat @ W + b
+    loss = O.loss_fn(logits, labels, 8)
+    gy, gW, gb = torch.autograd.grad(loss, (y, W, b))
+    d = lambda t: t.detach().float().to(dev).contiguous()
+    featd = torch.empty((N, C), device=dev); lg = torch.empty((N, K), device=dev)
+    ops.pool_fwd(d(y), N * Mp, TV, Mp, featd)
+    ops.fc_fwd(featd, d(W), d(b), lg)
+    lossd = torch.empty(1, device=dev); dl = torch.empty((N, K), device=dev); pr = torch.empty((N, K), device=dev)
+    ops.softmax_ce(lg, labels.to(dev), 1.0 / 8, lossd, dl, pr)
+    dW, db, dfeat = torch.empty((C, K), device=dev), torch.empty(K, device=dev), torch.empty((N, C), device=dev)
+    ops.fc_bwd(featd, d(W), dl, dW, db, dfeat)
+    dy = torch.empty((C, N * Mp * TV), device=dev)
+    ops.pool_bwd(dfeat, N * Mp, TV, Mp, dy)
+    torch.cuda.synchronize()
+    assert rel_err(lg.cpu(), logits) < TOL and rel_err(lossd.cpu(), loss.reshape(1)) < TOL
+    assert rel_err(pr.cpu(), torch.softmax(logits, 1)) < TOL
+    assert rel_err(dW.cpu(), gW) < TOL and rel_err(db.cpu(), gb) < TOL and rel_err(dy.cpu(), gy) < TOL
+    # Nesterov SGD, two steps
+    n = 1000
+    w0, g0, g1 = torch.randn(n, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p = {"w": w0.clone().double()}; vel = {}
+    wd, vd = w0.to(dev), torch.zeros(n, device=dev)
+    lr = torch.tensor([0.1], device=dev)
+    for gi in (g0, g1):
+        O.sgd_nesterov_step(p, {"w": gi.double()}, vel, 0.1)
+        ops.sgd_nesterov(wd, vd, gi.to(dev), lr, 0.9)
+    torch.cuda.synchronize()
+    assert rel_err(wd.cpu(), p["w"]) < 1e-6 and rel_err(vd.cpu(), vel["w"]) < 1e-6
+
+
+def test_argument_errors_are_reported(dev):
+    from sar_amd import ops, _lib as L
+    x = torch.zeros((4, 50), device=dev)
+    with pytest.raises(L.SarError):
+        ops.conv_gemm(L.SAR_CONV_TEMPORAL, x, x.clone(), x, 0, 4, B=1, V=25, T_src=2, T_out=2, Kc=4, M=4, taps=5)  # unbuilt taps
+    with pytest.raises(L.SarError):
+        ops.bn_add_relu_fwd(x, x[0], x[0], 2, None, None, None, x.clone())   # missing residual operand

@@ -1,0 +1,131 @@
+"""GPU parity: the whole ST-GCN train step (forward, loss, backward, SGD) on the HIP engine against
+the CPU oracle.  Tolerance 1e-4 norm-wise relative on logits and on every gradient tensor
+(north_star: "fp32 logits/grads within 1e-4 rel"), the fp64 oracle being the reference value."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stgcn as O
+from util import rel_err, from_cn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _compare(dev, blocks, N, T, classes, seed, tol=TOL, x=None, y=None):
+    from sar_amd.stgcn import STGCN
+    p = O.randomize_affine(O.init_params(classes, seed=seed, dtype=torch.float64, blocks=blocks), seed=seed + 1)
+    if x is None:
+        x, y = O.synthetic_batch(N, seed=seed, T=T, num_classes=classes)
+    logits_ref, loss_ref, grads_ref, new_stats, taps = O.loss_and_grads(p, x.double(), y, blocks=blocks)
+    eng = STGCN(num_classes=classes, device=dev, blocks=blocks)
+    eng.load_params(p)
+    keep = {}
+    xg, yg = x.to(dev), y.to(dev)
+    logits = eng.forward(xg, training=True, keep=keep)
+    torch.cuda.synchronize()
+    B = x.shape[0] * x.shape[4]
+    worst = {}
+    Tc = x.shape[2]
+    worst["x0"] = rel_err(from_cn(keep["x0"].cpu(), B, Tc, 25), taps["x0"])
+    for i, (f, s, _) in enumerate(blocks):
+        To = -(-Tc // s)
+        worst["l%d.g" % i] = rel_err(from_cn(keep["l%d.g" % i].cpu(), B, Tc, 25), taps["l%d.g" % i])
+        worst["l%d.u" % i] = rel_err(from_cn(keep["l%d.u" % i].cpu(), B, To, 25), taps["l%d.u" % i])
+        worst["l%d.y" % i] = rel_err(from_cn(keep["l%d.y" % i].cpu(), B, To, 25), taps["l%d.y" % i])
+        Tc = To
+    worst["logits"] = rel_err(logits.cpu(), logits_ref)
+    logits2, loss = eng.loss_and_grad(xg, yg)
+    torch.cuda.synchronize()
+    worst["loss"] = rel_err(loss.cpu(), loss_ref.reshape(1))
+    for k, gref in grads_ref.items():
+        scale = gref.abs().max().item()
+        if scale < 1e-9:      # conv biases in front of a BatchNorm: analytically zero gradient
+            wk = grads_ref[k.replace(".bias", ".kernel")].abs().max().item()
+            worst["grad " + k] = eng.g[k].abs().max().item() / max(wk, 1e-30)
+        else:
+            worst["grad " + k] = rel_err(eng.g[k].cpu(), gref)
+    for k, v in new_stats.items():
+        name = k.rsplit(".", 1)[0]
+        got = eng.bn[name].moving_mean if k.endswith("moving_mean") else eng.bn[name].moving_var
+        # two training forwards ran on the engine -> apply the momentum update twice for the reference
+        m = 0.99
+        batch = (v - m * p[k]) / (1 - m)
+        second = m * v + (1 - m) * batch
+        worst["stat " + k] = rel_err(got.cpu(), second)
+    bad = {k: v for k, v in worst.items() if not (v < tol)}
+    report = "\n".join("%-28s %.3e" % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:12])
+    print(report)
+    assert not bad, "parity failures (tol %g):\n%s\nworst:\n%s" % (tol, bad, report)
+    return worst, eng, p
+
+
+def test_two_blocks_small(dev):
+    _compare(dev, [(64, 1, False), (64, 1, True)], N=2, T=12, classes=10, seed=0)
+
+
+def test_stride2_conv_residual_blocks(dev):
+    _compare(dev, [(64, 1, False), (128, 2, True), (128, 1, True), (256, 2, True)], N=2, T=22, classes=12, seed=1)
+
+
+def test_odd_sizes_single_body(dev):
+    """T not a multiple of the frame tile, one body (M=1), odd batch."""
+    x, y = O.synthetic_batch(3, seed=7, T=17, M=1, num_classes=9)
+    _compare(dev, [(64, 1, False), (64, 1, True), (128, 2, True)], N=3, T=17, classes=9, seed=2, x=x, y=y)
+
+
+def test_full_model_ntu_shape(dev):
+    """All 10 blocks, T=300, V=25, M=2, 60 classes (config 1/2 shape at a batch the oracle handles)."""
+    _compare(dev, list(O.BLOCKS), N=2, T=300, classes=60, seed=3)
+
+
+def test_full_model_on_reference_clips(dev, golden_dir):
+    """The reference's bundled NTU clips (data/NTU_preprocessed_skeleton_examples.npy clips 0, 2):
+    real data with an all-zero second body and zero-padded tail frames."""
+    x = torch.from_numpy(np.load(os.path.join(golden_dir, "ntu_clips_0_2.npy")))
+    y = torch.tensor([3, 41])
+    _compare(dev, list(O.BLOCKS), N=2, T=300, classes=60, seed=4, x=x, y=y)
+
+
+def test_sgd_training_steps_track_the_oracle(dev):
+    """Three full train steps (loss -> grads -> Nesterov SGD with the reference LR schedule)."""
+    from sar_amd.stgcn import STGCN
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True)]
+    p = O.init_params(10, seed=5, dtype=torch.float64, blocks=blocks)
+    eng = STGCN(num_classes=10, device=dev, blocks=blocks)
+    eng.load_params(p)
+    vel = {}
+    for step in range(3):
+        x, y = O.synthetic_batch(4, seed=10 + step, T=20, num_classes=10)
+        _, loss_ref, grads, new, _ = O.loss_and_grads(p, x.double(), y, blocks=blocks)
+        lr = O.lr_schedule(step)
+        O.sgd_nesterov_step(p, grads, vel, lr)
+        p.update(new)
+        _, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+        eng.sgd_step(lr)
+        torch.cuda.synchronize()
+        assert rel_err(loss.cpu(), loss_ref.reshape(1)) < 1e-4
+    sd = eng.state_dict()
+    for k in O.trainable_names(p):
+        assert rel_err(sd[k], p[k]) < 2e-4, k
+
+
+def test_inference_mode_uses_moving_statistics(dev):
+    from sar_amd.stgcn import STGCN
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True)]
+    p = O.randomize_affine(O.init_params(10, seed=6, dtype=torch.float64, blocks=blocks))
+    x, _ = O.synthetic_batch(3, seed=3, T=16, num_classes=10)
+    ref = torch.softmax(O.forward(p, x.double(), False, blocks=blocks), 1)
+    eng = STGCN(num_classes=10, device=dev, blocks=blocks)
+    eng.load_params(p)
+    probs = eng.predict(x.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(probs.cpu(), ref) < 1e-4
