@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- ST-GCN training throughput on MI355X (BASELINE.json metric:
+"NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)").
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A step = one full train step of the hot path on one synthetic batch resident in HBM: forward (data_bn,
+10 ST-GCN blocks, head), softmax-CE, backward of everything, gradient all-reduce (N>1), Nesterov SGD.
+Workload = BASELINE.json configs[1]: fp32, synthetic NTU-xsub clips (3,300,25,2), 60 classes, bs=64/GPU.
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     -- the dominant kernel family (9x1 temporal-conv GEMMs), algorithmic FLOPs / HIP-event time
+  cpu_baseline -- the CPU oracle (torch CPU ops, "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "skeleton-action-recognition_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(sample_clips, budget_s=25.0):
+    """Times the CPU oracle (oracle/stgcn.py: torch CPU ops, fp32) -- fwd + bwd + Nesterov SGD -- on a bounded
+    sample of the same workload.  The oracle is used here ONLY as the reported CPU baseline."""
+    import torch
+    from oracle import stgcn as O
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    p = O.init_params(60, seed=0)
+    x, y = O.synthetic_batch(sample_clips, seed=0, T=300, num_classes=60)
+    vel = {}
+
+    def one():
+        _, _, grads, new, _ = O.loss_and_grads(p, x, y)
+        O.sgd_nesterov_step(p, grads, vel, 0.1)
+        p.update(new)
+
+    one()                                  # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 5:
+            break
+    dt = time.time() - t0
+    return {"value": round(sample_clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "%d timed steps of fwd+bwd+SGD on a %d-clip (3,300,25,2) fp32 batch, torch CPU ops, %d threads"
+                      % (n, sample_clips, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU (reference --batch-size)")
+    ap.add_argument("--classes", type=int, default=60)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="clips in the CPU-baseline sample batch")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sar_amd import profiler
+    from sar_amd.stgcn import STGCN
+    from sar_amd.train import Trainer, synthetic_clips
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+
+    eng = STGCN(num_classes=args.classes, device=dev, seed=0)  # identical init on every rank
+    trainer = Trainer(eng, batch_size=args.batch, world_size=world)
+    # a few distinct batches resident in HBM, cycled (per-rank seeds: each rank trains on its own shard)
+    nb = 4
+    batches = [synthetic_clips(args.batch, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(nb)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(*batches[i % nb])
+    timer = profiler.KernelTimer()
+    profiler.install(timer)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        _, loss = trainer.step(*batches[i % nb])
+    sync()
+    dt = time.perf_counter() - t0
+    profiler.install(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(loss.item())
+    assert loss_val == loss_val, "loss is NaN"
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / dt
+        summ = timer.summary()
+        fam = [k for k in summ if k.startswith("gemm_temporal9")]
+        ms = sum(summ[k]["ms"] for k in fam)
+        fl = sum(summ[k]["flops"] for k in fam)
+        calls = sum(summ[k]["calls"] for k in fam)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        kern_ms = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())}
+        kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
+        out = {
+            "metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ST-GCN fp32 training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
+                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (args.classes, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
+                         "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
+            "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from . import profiler
 from ._lib import ConvDesc, WgradDesc, check, ptr, stream_ptr
 
 
@@ -61,7 +62,12 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
             check(nparts or -1, "sar_conv_gemm_nparts")
         partials = torch.empty((M, nparts, 2), dtype=torch.float32, device=src.device)
         d.partials = ptr(partials)
-    check(lib.sar_conv_gemm_f32(C.byref(d), stream_ptr()), "sar_conv_gemm_f32")
+    # algorithmic work: the forward conv's MACs (a data gradient costs the same MACs as its forward conv)
+    n_conv = B * (T_src if transposed else T_out) * V
+    flops = 2.0 * M * Kc * taps * n_conv if mode == L.SAR_CONV_TEMPORAL else 2.0 * M * Kc * taps * n_conv
+    tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else "")))
+    with profiler.region(tag, flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+        check(lib.sar_conv_gemm_f32(C.byref(d), stream_ptr()), "sar_conv_gemm_f32")
     return (partials, nparts) if partials is not None else None
 
 
@@ -90,7 +96,9 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     d.w_stride_tap, d.w_stride_c, d.wsize, d.bsize = w_stride_tap, w_stride_c, wsize, bsize
     slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
     d.slab = ptr(slab)
-    check(lib.sar_conv_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv_wgrad_f32")
+    tag = "wgrad_graph" if mode == L.SAR_CONV_GRAPH else "wgrad_temporal%d" % taps
+    with profiler.region(tag, 2.0 * M * Kc * taps * B * T_out * V, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+        check(lib.sar_conv_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv_wgrad_f32")
     assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
     check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, wsize + bsize, wsize + bsize, ptr(dW_out), stream_ptr()),
           "sar_slab_reduce_f32")
