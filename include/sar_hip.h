@@ -33,6 +33,8 @@ extern "C" {
 typedef void* sar_stream_t;
 
 int sar_version(void);
+/* diagnostic: workgroups/CU the runtime predicts for the temporal GEMM at a dynamic-LDS size */
+int sar_debug_occupancy(int which, int lds_bytes);
 const char* sar_last_error_string(void);
 
 /* ------------------------------------------------------------------------------------------------

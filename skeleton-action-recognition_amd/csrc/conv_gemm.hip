@@ -26,24 +26,36 @@
 
 namespace {
 
-constexpr int KC = 8;  // src channels staged per main-loop iteration (4 MFMA k-steps)
+#ifndef SAR_KC
+#define SAR_KC 4
+#endif
+constexpr int KC = SAR_KC;  // src channels staged per main-loop iteration (KC/2 MFMA k-steps)
 
 struct ConvK {
   sar_conv_desc d;
   int FT, TPS, NF, RW, SROW, nparts;
-  float invRW;
+  int w_vec;   // weight rows may be read as aligned float4
 };
 
 template <int MODE, int TRANSPOSED, int TAPS, int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK k) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   constexpr int BM = 32 * MS * WM;
   constexpr int NZMAX = 4;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  // staging maps (no per-element division):
+  //  W tile: TAPS*KC rows of BM floats, one float4 per lane, 1024/BM rows per pass
+  //  S tile: KC rows, 256/KC consecutive lanes per row and pass, SJMAX passes cover RW columns
+  constexpr int WROWS = TAPS * KC;
+  constexpr int WRPP = 1024 / BM;                       // W rows per pass
+  constexpr int WIT = (WROWS + WRPP - 1) / WRPP;        // W passes
+  constexpr int SLPR = 256 / KC;                        // lanes per S row
+  constexpr int SJMAX = ((MODE == SAR_CONV_GRAPH) ? 32 * NS * WN : (NS * WN == 4 ? 448 : 704)) / SLPR;
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert((KC == 8 || KC == 4) && 256 % KC == 0, "S stager: 256/KC lanes per src channel row");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const sar_conv_desc& d = k.d;
-  float* S = smem;                       // [KC][SROW]
-  float* Wl = smem + KC * k.SROW;        // [TAPS][KC][BM]
+  float* Wl = smem;                      // [TAPS][KC][BM]   (16-byte aligned rows)
+  float* S = smem + WROWS * BM;          // [KC][SROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -118,33 +130,86 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK k) {
   const float* src_b = d.src + (int64_t)b * seq_len;
   const bool has_pro = d.pro_scale != nullptr;
 
-  for (int c0 = 0; c0 < d.Kc; c0 += KC) {
-    // ---- stage the src tile (with folded BN+ReLU; everything outside the sequence is exactly 0)
-    for (int idx = tid; idx < KC * k.RW; idx += 256) {
-      const int c = (int)(((float)idx + 0.5f) * k.invRW);
-      const int r = idx - c * k.RW;
-      const int rabs = t_lo * V + r;
-      const int cg = c0 + c;
-      float val = 0.f;
-      if (cg < d.Kc && (unsigned)rabs < (unsigned)seq_len) {
-        val = src_b[(int64_t)cg * d.ld_src + rabs];
-        if (has_pro) {
-          val = fmaf(val, d.pro_scale[cg], d.pro_shift[cg]);
+  // ---- staging state: the next stage's global loads are issued BEFORE the MFMA phase of the current
+  // stage and land in registers while the matrix pipe works; they are written to LDS after the barrier.
+  const int w_m4 = (tid % (BM / 4)) * 4;     // float4 column of this lane inside a W row
+  const int w_r0 = tid / (BM / 4);           // first W row of this lane
+  const bool w_vec = k.w_vec != 0;
+  const int s_row = tid / SLPR;              // S row (src channel inside the stage) of this lane
+  const int s_c0 = tid % SLPR;
+  float4 wreg[WIT];
+  float sreg[SJMAX];
+  float psc = 1.f, psh = 0.f;
+
+  // Loads are UNCONDITIONAL (out-of-range lanes read a clamped, valid address) and nothing consumes the
+  // loaded registers until store_lds(): a predicated load or an early select would make the compiler wait
+  // for the data at the issue point and serialise the whole stage on memory latency.
+  auto issue_loads = [&](int c0) {
+    if (w_vec) {
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) {
+        const int row = w_r0 + i * WRPP;
+        const int tp = row / KC, c = row % KC;
+        const int cg = c0 + c, mg = m0 + w_m4;
+        const bool ok = row < WROWS && cg < d.Kc && mg < d.M;
+        const float* wp = ok ? d.W + (int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg : d.W;
+        wreg[i] = *reinterpret_cast<const float4*>(wp);
+      }
+    }
+    const int cg = c0 + s_row;
+    const bool rowok = cg < d.Kc;
+    const float* sp = src_b + (int64_t)(rowok ? cg : 0) * d.ld_src;
+#pragma unroll
+    for (int j = 0; j < SJMAX; ++j) {
+      const int col = s_c0 + SLPR * j;
+      const int rabs = t_lo * V + col;
+      const bool ok = rowok && col < k.RW && (unsigned)rabs < (unsigned)seq_len;
+      sreg[j] = sp[ok ? rabs : 0];
+    }
+    if (has_pro) {
+      psc = d.pro_scale[rowok ? cg : 0];
+      psh = d.pro_shift[rowok ? cg : 0];
+    }
+  };
+
+  auto store_lds = [&](int c0) {
+    if (w_vec) {
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) {
+        const int row = w_r0 + i * WRPP;
+        const int c = row % KC;
+        const bool ok = (c0 + c) < d.Kc && (m0 + w_m4) < d.M;
+        if (row < WROWS) *reinterpret_cast<float4*>(Wl + row * BM + w_m4) = ok ? wreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {  // unaligned / M % 4 != 0 weights (3-channel layers only): plain strided copy
+      for (int idx = tid; idx < WROWS * BM; idx += 256) {
+        const int m = idx % BM, row = idx / BM;
+        const int tp = row / KC, cg = c0 + row % KC, mg = m0 + m;
+        Wl[idx] = (cg < d.Kc && mg < d.M) ? d.W[(int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg] : 0.f;
+      }
+    }
+    const bool rowok = (c0 + s_row) < d.Kc;
+#pragma unroll
+    for (int j = 0; j < SJMAX; ++j) {
+      const int col = s_c0 + SLPR * j;
+      const int rabs = t_lo * V + col;
+      if (col < k.RW) {
+        float val = sreg[j];
+        if (has_pro) {   // folded BN(+ReLU)
+          val = fmaf(val, psc, psh);
           if (d.pro_relu) val = fmaxf(val, 0.f);
         }
+        // everything outside the sequence (temporal zero padding) or beyond Kc is exactly 0
+        S[s_row * k.SROW + col] = (rowok && (unsigned)rabs < (unsigned)seq_len) ? val : 0.f;
       }
-      S[c * k.SROW + r] = val;
     }
-    // ---- stage the weight tile W[tap][c0..c0+KC][m0..m0+BM]
-    for (int idx = tid; idx < TAPS * KC * BM; idx += 256) {
-      const int m = idx % BM;
-      const int rest = idx / BM;
-      const int c = rest % KC;
-      const int tp = rest / KC;
-      const int cg = c0 + c, mg = m0 + m;
-      Wl[idx] = (cg < d.Kc && mg < d.M) ? d.W[(int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg] : 0.f;
-    }
+  };
+
+  issue_loads(0);
+  for (int c0 = 0; c0 < d.Kc; c0 += KC) {
+    store_lds(c0);
     __syncthreads();
+    if (c0 + KC < d.Kc) issue_loads(c0 + KC);
 
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) {
@@ -243,8 +308,10 @@ int tile_geometry(const sar_conv_desc& d, int NSv, ConvK& k) {
   else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
   k.RW = k.NF * d.V;
   k.SROW = k.RW;
-  k.invRW = 1.0f / (float)k.RW;
   k.nparts = d.B * k.TPS * WN;
+  k.w_vec = ((d.M & 3) == 0 && (d.w_stride_c & 3) == 0 && (d.w_stride_tap & 3) == 0 && ((uintptr_t)d.W & 15) == 0) ? 1 : 0;
+  const int rwmax = (d.mode == SAR_CONV_GRAPH) ? 32 * NSv * WN : (NSv * WN == 4 ? 448 : 704);
+  if (k.RW > rwmax) return -2;   // staged row does not fit the register prefetch (V too large)
   return 0;
 }
 
@@ -254,7 +321,7 @@ int launch_by_m(const sar_conv_desc& d, hipStream_t st, bool query_only, int* np
   k.d = d;
   if (d.M > 64) {
     constexpr int MS = 2, NS = 2, WM = 2, WN = 2;
-    if (tile_geometry<WN>(d, NS, k)) return SAR_E_ARG;
+    if (int g = tile_geometry<WN>(d, NS, k)) { sar_set_error("sar_conv_gemm: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride); return g == -2 ? SAR_E_UNSUP : SAR_E_ARG; }
     if (nparts_out) *nparts_out = k.nparts;
     if (query_only) return 0;
     const size_t lds = sizeof(float) * (KC * k.SROW + TAPS * KC * 32 * MS * WM);
@@ -263,7 +330,7 @@ int launch_by_m(const sar_conv_desc& d, hipStream_t st, bool query_only, int* np
                        st, k);
   } else if (d.M > 32) {
     constexpr int MS = 2, NS = 2, WM = 1, WN = 4;
-    if (tile_geometry<WN>(d, NS, k)) return SAR_E_ARG;
+    if (int g = tile_geometry<WN>(d, NS, k)) { sar_set_error("sar_conv_gemm: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride); return g == -2 ? SAR_E_UNSUP : SAR_E_ARG; }
     if (nparts_out) *nparts_out = k.nparts;
     if (query_only) return 0;
     const size_t lds = sizeof(float) * (KC * k.SROW + TAPS * KC * 32 * MS * WM);
@@ -272,7 +339,7 @@ int launch_by_m(const sar_conv_desc& d, hipStream_t st, bool query_only, int* np
                        st, k);
   } else {
     constexpr int MS = 1, NS = 2, WM = 1, WN = 4;
-    if (tile_geometry<WN>(d, NS, k)) return SAR_E_ARG;
+    if (int g = tile_geometry<WN>(d, NS, k)) { sar_set_error("sar_conv_gemm: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride); return g == -2 ? SAR_E_UNSUP : SAR_E_ARG; }
     if (nparts_out) *nparts_out = k.nparts;
     if (query_only) return 0;
     const size_t lds = sizeof(float) * (KC * k.SROW + TAPS * KC * 32 * MS * WM);
@@ -334,6 +401,25 @@ int dispatch(const sar_conv_desc& d, hipStream_t st, bool query_only, int* npart
 }
 
 }  // namespace
+
+// Diagnostic: resident workgroups per CU the runtime predicts for the 9-tap temporal forward kernel
+// (128x128 tile) at a given dynamic-LDS size.  which=1 selects the 64x256 tile.
+extern "C" int sar_debug_occupancy(int which, int lds_bytes) {
+  int n = -1;
+  hipError_t e;
+  if (which == 1)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_gemm_kernel<SAR_CONV_TEMPORAL, 0, 9, 2, 2, 1, 4, 1, 1, 1>, 256, lds_bytes);
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_gemm_kernel<SAR_CONV_TEMPORAL, 0, 9, 2, 2, 2, 2, 1, 1, 1>, 256, lds_bytes);
+  hipFuncAttributes at;
+  const void* fp = which == 1 ? (const void*)conv_gemm_kernel<SAR_CONV_TEMPORAL, 0, 9, 2, 2, 1, 4, 1, 1, 1>
+                              : (const void*)conv_gemm_kernel<SAR_CONV_TEMPORAL, 0, 9, 2, 2, 2, 2, 1, 1, 1>;
+  if (hipFuncGetAttributes(&at, fp) == hipSuccess)
+    fprintf(stderr, "[sar_debug] which=%d lds=%d: numRegs=%d sharedSizeBytes=%zu maxDynamicShared=%d localSizeBytes=%zu "
+            "constSizeBytes=%zu maxThreadsPerBlock=%d -> blocks/CU %d\n", which, lds_bytes, at.numRegs, at.sharedSizeBytes,
+            at.maxDynamicSharedSizeBytes, at.localSizeBytes, at.constSizeBytes, at.maxThreadsPerBlock, n);
+  return e == hipSuccess ? n : -(int)e;
+}
 
 extern "C" int sar_conv_gemm_nparts(const sar_conv_desc* d) {
   if (!d || d->V <= 0 || d->T_out <= 0 || d->B <= 0 || d->M <= 0) return SAR_E_ARG;

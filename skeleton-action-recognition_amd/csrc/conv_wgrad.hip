@@ -22,16 +22,19 @@ namespace {
 struct WgradK {
   sar_wgrad_desc d;
   int FT, TPS, NT, NF, RW, SP, NPOS, NP, DP;
-  float invRW, invNP;
 };
 
 template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   static_assert(WF * WC * WT == 4, "4 waves per workgroup");
   static_assert(WT * TPW >= TAPS, "taps must be covered");
   constexpr int BF = 32 * WF, CT = 32 * WC;
   constexpr int NZMAX = 4;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  // staging maps: a half-wave owns one row and reads 32 consecutive columns per pass (128-B segments)
+  constexpr int DI = BF / 8, DJ = 4;                           // dout tile: BF rows x <=128 positions
+  constexpr int SI = CT / 8;                                   // src tile: CT rows x RW columns
+  constexpr int SJMAX = (MODE == SAR_CONV_GRAPH) ? 4 : (TAPS == 1 ? 8 : 14);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const sar_wgrad_desc& d = k.d;
   const int V = d.V;
@@ -74,39 +77,91 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   const bool has_pro = d.pro_scale != nullptr;
   const bool do_bias = (wc == 0) && (MODE == SAR_CONV_GRAPH || wt == 0) && blockIdx.z == 0;
 
-  for (int tile = blockIdx.x; tile < k.NT; tile += gridDim.x) {
+  // ---- register prefetch of the next tile (unconditional loads from clamped addresses; predicates are
+  // applied when the registers are written to LDS, see conv_gemm.hip)
+  const int r8 = tid >> 5, c32 = tid & 31;
+  float dreg[DI][DJ];
+  float sreg[SI][SJMAX];
+  float psc[SI], psh[SI];
+#pragma unroll
+  for (int i = 0; i < SI; ++i) {
+    const int cg = c0 + r8 + 8 * i;
+    psc[i] = (has_pro && cg < d.Kc) ? d.pro_scale[cg] : 1.f;
+    psh[i] = (has_pro && cg < d.Kc) ? d.pro_shift[cg] : 0.f;
+  }
+
+  auto issue_loads = [&](int tile) {
     const int b = tile / k.TPS;
     const int t0 = (tile - b * k.TPS) * k.FT;
     const int t_lo = (MODE == SAR_CONV_GRAPH) ? t0 : t0 * d.stride - d.pad;
-    __syncthreads();  // previous tile's reads done (also orders the table writes before first use)
-    // ---- stage dout rows f0..f0+BF over the tile's positions (zero outside the sequence / tile)
     const float* dout_b = d.dout + (int64_t)b * seq_out;
-    for (int idx = tid; idx < BF * k.NP; idx += 256) {
-      const int f = (int)(((float)idx + 0.5f) * k.invNP);
-      const int p = idx - f * k.NP;
-      const int pabs = t0 * V + p;
-      float val = 0.f;
-      if (p < k.NPOS && pabs < seq_out && f0 + f < d.M) val = dout_b[(int64_t)(f0 + f) * d.ld_dout + pabs];
-      D[f * k.DP + p] = val;
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int f = f0 + r8 + 8 * i;
+      const float* rowp = dout_b + (int64_t)(f < d.M ? f : 0) * d.ld_dout;
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) {
+        const int p = c32 + 32 * j;
+        const int pabs = t0 * V + p;
+        const bool ok = f < d.M && p < k.NPOS && pabs < seq_out;
+        dreg[i][j] = rowp[ok ? pabs : 0];
+      }
     }
-    // ---- stage src rows c0..c0+CT (folded BN+ReLU, exact zero padding)
     const float* src_b = d.src + (int64_t)b * seq_src;
-    for (int idx = tid; idx < CT * k.RW; idx += 256) {
-      const int c = (int)(((float)idx + 0.5f) * k.invRW);
-      const int r = idx - c * k.RW;
-      const int rabs = t_lo * V + r;
-      const int cg = c0 + c;
-      float val = 0.f;
-      if (cg < d.Kc && (unsigned)rabs < (unsigned)seq_src) {
-        val = src_b[(int64_t)cg * d.ld_src + rabs];
-        if (has_pro) {
-          val = fmaf(val, d.pro_scale[cg], d.pro_shift[cg]);
-          if (d.pro_relu) val = fmaxf(val, 0.f);
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+      const int cg = c0 + r8 + 8 * i;
+      const float* rowp = src_b + (int64_t)(cg < d.Kc ? cg : 0) * d.ld_src;
+#pragma unroll
+      for (int j = 0; j < SJMAX; ++j) {
+        const int col = c32 + 32 * j;
+        const int rabs = t_lo * V + col;
+        const bool ok = cg < d.Kc && col < k.RW && (unsigned)rabs < (unsigned)seq_src;
+        sreg[i][j] = rowp[ok ? rabs : 0];
+      }
+    }
+  };
+
+  auto store_lds = [&](int tile) {
+    const int b = tile / k.TPS;
+    const int t0 = (tile - b * k.TPS) * k.FT;
+    const int t_lo = (MODE == SAR_CONV_GRAPH) ? t0 : t0 * d.stride - d.pad;
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int fr = r8 + 8 * i;
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) {
+        const int p = c32 + 32 * j;
+        const bool ok = (f0 + fr) < d.M && p < k.NPOS && (t0 * V + p) < seq_out;
+        if (p < k.NP) D[fr * k.DP + p] = ok ? dreg[i][j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+      const int cr = r8 + 8 * i;
+#pragma unroll
+      for (int j = 0; j < SJMAX; ++j) {
+        const int col = c32 + 32 * j;
+        const int rabs = t_lo * V + col;
+        if (col < k.RW) {
+          float val = sreg[i][j];
+          if (has_pro) {
+            val = fmaf(val, psc[i], psh[i]);
+            if (d.pro_relu) val = fmaxf(val, 0.f);
+          }
+          S[cr * k.SP + col] = ((c0 + cr) < d.Kc && (unsigned)rabs < (unsigned)seq_src) ? val : 0.f;
         }
       }
-      S[c * k.SP + r] = val;
     }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < k.NT) issue_loads(tile);
+  for (; tile < k.NT; tile += gridDim.x) {
+    __syncthreads();  // previous tile's LDS reads done (also orders the table writes before first use)
+    store_lds(tile);
     __syncthreads();
+    if (tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
 
     const float* Drow = D + (wf * 32 + l31) * k.DP;
     const float* Srow = S + (wc * 32 + l31) * k.SP;
@@ -175,20 +230,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-int geometry(const sar_wgrad_desc& d, WgradK& k) {
-  k.FT = 128 / d.V;
-  if (k.FT < 1) return -1;
-  if (k.FT > d.T_out) k.FT = d.T_out;
-  k.TPS = (d.T_out + k.FT - 1) / k.FT;
-  k.NT = d.B * k.TPS;
-  k.NPOS = k.FT * d.V;
-  k.NP = (k.NPOS + 1) & ~1;
-  k.DP = k.NP | 1;
-  k.NF = (d.mode == SAR_CONV_GRAPH) ? k.FT : (k.FT - 1) * d.stride + d.taps;
-  k.RW = k.NF * d.V;
-  k.SP = k.RW | 1;
-  k.invRW = 1.0f / (float)k.RW;
-  k.invNP = 1.0f / (float)k.NP;
+size_t lds_bytes(const sar_wgrad_desc& d, const WgradK& k, int BF, int CT) {
+  size_t lds = sizeof(float) * ((size_t)BF * k.DP + (size_t)CT * k.SP) + sizeof(int) * 2 * k.NP;
+  if (d.mode == SAR_CONV_GRAPH) lds += (sizeof(int) + sizeof(float)) * 3 * d.V * 4 + sizeof(float) * 3 * d.V;
+  return lds;
+}
+
+// Frame tile: as many whole frames as fit 128 positions, shrunk until two workgroups fit the CU's LDS.
+int geometry(const sar_wgrad_desc& d, WgradK& k, int BF, int CT) {
+  int ft = 128 / d.V;
+  if (ft < 1) return -1;
+  if (ft > d.T_out) ft = d.T_out;
+  for (;; --ft) {
+    k.FT = ft;
+    k.TPS = (d.T_out + k.FT - 1) / k.FT;
+    k.NT = d.B * k.TPS;
+    k.NPOS = k.FT * d.V;
+    k.NP = (k.NPOS + 1) & ~1;
+    k.DP = k.NP | 1;
+    k.NF = (d.mode == SAR_CONV_GRAPH) ? k.FT : (k.FT - 1) * d.stride + d.taps;
+    k.RW = k.NF * d.V;
+    k.SP = k.RW | 1;
+    if (lds_bytes(d, k, BF, CT) <= 78 * 1024 || ft == 1) break;
+  }
+  const int sjmax = (d.mode == SAR_CONV_GRAPH) ? 4 : (d.taps == 1 ? 8 : 14);
+  if (k.RW > 32 * sjmax || k.NP > 128) return -2;
   return 0;
 }
 
@@ -196,10 +262,12 @@ template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1,
 int launch(const sar_wgrad_desc& d, hipStream_t st) {
   WgradK k;
   k.d = d;
-  if (geometry(d, k)) return SAR_E_ARG;
   constexpr int BF = 32 * WF, CT = 32 * WC;
-  size_t lds = sizeof(float) * ((size_t)BF * k.DP + (size_t)CT * k.SP) + sizeof(int) * 2 * k.NP;
-  if (MODE == SAR_CONV_GRAPH) lds += (sizeof(int) + sizeof(float)) * 3 * d.V * 4 + sizeof(float) * 3 * d.V;
+  if (int g = geometry(d, k, BF, CT)) {
+    sar_set_error("sar_conv_wgrad: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
+  }
+  const size_t lds = lds_bytes(d, k, BF, CT);
   auto kern = conv_wgrad_kernel<MODE, TAPS, WF, WC, WT, TPW, NZ0, NZ1, NZ2>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -48,6 +48,7 @@ _i, _i64, _f, _d = C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     "sar_version": (_i, []),
     "sar_last_error_string": (C.c_char_p, []),
+    "sar_debug_occupancy": (_i, [_i, _i]),
     "sar_conv_gemm_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),

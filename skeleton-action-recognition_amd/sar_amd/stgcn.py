@@ -89,11 +89,17 @@ class STGCN:
             cin = f
         self.C_last = cin
         self._add("logits.kernel", (1, 1, cin, num_classes)), self._add("logits.bias", (num_classes,))
+        # flat storage: every offset is a multiple of 4 floats so that each weight view is 16-byte aligned
+        # (the GEMM kernels stage weight rows as float4); a bias stays glued to its kernel because the
+        # weight-gradient slabs are reduced as one contiguous [kernel | bias] range.
         total, self.offsets = 0, {}
         for k, shp in self.shapes.items():
+            n = int(np.prod(shp))
+            if k.endswith(".kernel"):
+                assert n % 4 == 0, k
             self.offsets[k] = total
-            total += int(np.prod(shp))
-        self.n_params = total
+            total += n if k.endswith(".kernel") else (n + 3) // 4 * 4
+        self.n_params = sum(int(np.prod(shp)) for shp in self.shapes.values())
         dev = self.device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)

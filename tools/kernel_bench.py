@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the conv-GEMM / wgrad kernels at the bench shapes (bs=64 => B=128 sequences).
+Usage: python tools/kernel_bench.py [--reps 5] [--only tconv_fwd,gcn_fwd,...] [--layers 2,6,9]
+Prints one line per (kernel, layer): ms, algorithmic TFLOP/s, fraction of the 157.3 TF fp32 MFMA peak."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "skeleton-action-recognition_amd")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+from sar_amd import _lib as L, ops  # noqa: E402
+from sar_amd.stgcn import BLOCKS, same_pad, ntu_adjacency  # noqa: E402
+
+PEAK = 157.3
+
+
+def timeit(fn, reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--layers", default="")
+    a = ap.parse_args()
+    only = set(a.only.split(",")) if a.only else None
+    layers = set(int(x) for x in a.layers.split(",")) if a.layers else None
+    dev = torch.device("cuda:0")
+    B, V = a.batch * 2, 25
+    A = ntu_adjacency().astype("float32")
+    tf_, tb_ = ops.GraphTables(A, dev), ops.GraphTables(A, dev, True)
+    T, cin = 300, 3
+    tot = {}
+    for i, (f, s, res) in enumerate(BLOCKS):
+        To, pad, _ = same_pad(T, 9, s)
+        n_in, n_out = B * T * V, B * To * V
+        if layers is None or i in layers:
+            g = torch.Generator(device=dev).manual_seed(i)
+            rn = lambda *sh: torch.randn(sh, device=dev, generator=g)
+            X, G, U = rn(cin, n_in), rn(f, n_in), rn(f, n_out)
+            Wg, bg = rn(cin, 3 * f) * 0.1, rn(3 * f) * 0.1
+            Wt, bt = rn(9, f, f) * 0.05, rn(f) * 0.1
+            sc, sh = 1 + 0.1 * rn(f), 0.1 * rn(f)
+            out_in, out_out = torch.empty((f, n_in), device=dev), torch.empty((f, n_out), device=dev)
+            dX = torch.empty((cin, n_in), device=dev)
+            gT = Wg.t().contiguous()
+            wT = Wt.transpose(1, 2).contiguous()
+            flat_g = torch.empty(cin * 3 * f + 3 * f, device=dev)
+            flat_t = torch.empty(9 * f * f + f, device=dev)
+            cases = {
+                "gcn_fwd": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_gemm(
+                    L.SAR_CONV_GRAPH, X, out_in, Wg, f, 3 * f, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, bias=bg,
+                    tables=tf_, epi=L.SAR_EPI_STATS)),
+                "tconv_fwd": (2.0 * f * f * 9 * n_out, lambda: ops.conv_gemm(
+                    L.SAR_CONV_TEMPORAL, G, out_out, Wt, f * f, f, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s,
+                    pad=pad, bias=bt, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS)),
+                "tconv_dgrad": (2.0 * f * f * 9 * n_out, lambda: ops.conv_gemm(
+                    L.SAR_CONV_TEMPORAL, U, out_in, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s,
+                    pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh))),
+                "gcn_dgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_gemm(
+                    L.SAR_CONV_GRAPH, G, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tb_,
+                    epi=L.SAR_EPI_ADD, aux=X)),
+                "tconv_wgrad": (2.0 * f * f * 9 * n_out, lambda: ops.conv_wgrad(
+                    L.SAR_CONV_TEMPORAL, G, U, flat_t, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad,
+                    pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f)),
+                "gcn_wgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_wgrad(
+                    L.SAR_CONV_GRAPH, X, G, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tf_,
+                    w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)),
+            }
+            for name, (flops, fn) in cases.items():
+                if only and name not in only:
+                    continue
+                ms = timeit(fn, a.reps)
+                tf = flops / (ms * 1e-3) / 1e12
+                tot.setdefault(name, [0.0, 0.0])
+                tot[name][0] += ms; tot[name][1] += flops
+                print("L%-2d %-12s cin=%3d f=%3d T=%3d->%3d s=%d  %8.3f ms  %7.2f TF  %5.1f%%" %
+                      (i + 1, name, cin, f, T, To, s, ms, tf, 100 * tf / PEAK), flush=True)
+        T, cin = To, f
+    for name, (ms, fl) in tot.items():
+        print("TOTAL %-12s %8.3f ms  %7.2f TF" % (name, ms, fl / (ms * 1e-3) / 1e12))
+
+
+if __name__ == "__main__":
+    main()
