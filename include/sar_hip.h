@@ -60,7 +60,7 @@ const char* sar_last_error_string(void);
  *   SAR_EPI_NONE   store
  *   SAR_EPI_STATS  store + per-row partial (sum, sum of squares) -> partials (train-mode BN statistics)
  *   SAR_EPI_MASK   val = (aux*aux_scale[m]+aux_shift[m] > 0) ? val : 0 ; store ;
- *                  partial (sum val, sum val*aux)   (ReLU+BN backward reductions)
+ *                  partial (sum val, sum val*(aux-aux_mean[m]))   (ReLU+BN backward reductions, centred)
  *   SAR_EPI_ADD    val += aux ; store               (residual gradient accumulation)
  * partials layout: [M][nparts][2] with nparts = sar_conv_gemm_nparts(desc).
  * ------------------------------------------------------------------------------------------------ */
@@ -88,6 +88,7 @@ typedef struct sar_conv_desc {
   const float* g_colsum;   /* GRAPH: [taps][V] column sums of A_k (bias term) */
   const float* aux; int64_t ld_aux;                  /* epilogue operand [M][ld_aux] */
   const float* aux_scale; const float* aux_shift;    /* [M] (SAR_EPI_MASK) */
+  const float* aux_mean;   /* [M] or NULL: centre of the second MASK reduction */
   float* partials;         /* [M][nparts][2] (SAR_EPI_STATS / SAR_EPI_MASK) */
 } sar_conv_desc;
 
@@ -142,7 +143,7 @@ int sar_bn_eval_affine_f32(const float* gamma, const float* beta, const float* r
  *   k1 = gamma*rstd, k2 = -gamma*rstd^2*b, k3 = gamma*rstd*(mean*rstd*b - a), a = S1/count, b = dgamma/count.
  * partial_stride: floats between consecutive channels; partial_step: floats between consecutive parts. */
 int sar_bn_bwd_finalize_f32(const float* partials, int nparts, int64_t chan_stride, int64_t part_stride,
-                            int off1, int off2, int C, double count,
+                            int off1, int off2, int centered, int C, double count,
                             const float* gamma, const float* mean, const float* rstd,
                             float* dgamma, float* dbeta, float* k1, float* k2, float* k3, sar_stream_t s);
 
@@ -153,9 +154,9 @@ int sar_data_bn_stats_f32(const float* x, int N, int C, int T, int V, int M, con
                           float* partials /* [V*C][N][2] */, sar_stream_t s);
 int sar_data_bn_apply_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
                           const float* scale, const float* shift, float* out, int64_t ld_out, sar_stream_t s);
-/* backward: partials [V*C][N][2] = (sum dy, sum dy*x_raw) from dy in CN layout. */
+/* backward: partials [V*C][N][2] = (sum dy, sum dy*(x_raw - mean[ch])) from dy in CN layout (mean may be NULL). */
 int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
-                               const float* dy, int64_t ld_dy, float* partials, sar_stream_t s);
+                               const float* dy, int64_t ld_dy, const float* mean, float* partials, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Block tail, models/stgcn.py:37,62-63:  y = relu(u*sc[c]+sh[c] + res)
@@ -163,9 +164,10 @@ int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M
  * ------------------------------------------------------------------------------------------------ */
 int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
                             const float* rsc, const float* rsh, float* y, int C, int64_t n, int64_t ld, sar_stream_t s);
-/* backward pass 1: dz = (y>0)?dy:0 ; partials[C][nparts][4] = (sum dz, sum dz*u, sum dz*r, 0) */
+/* backward pass 1: dz = (y>0)?dy:0 ; partials[C][nparts][4] = (sum dz, sum dz*(u-mu[c]), sum dz*(r-mr[c]), 0);
+ * mu / mr (the batch means) may be NULL = 0 */
 int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
-                                   float* partials, int nparts, int C, int64_t n, int64_t ld, sar_stream_t s);
+                                   const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n, int64_t ld, sar_stream_t s);
 /* backward pass 2: du = k1*dz+k2*u+k3 ; dr = rk1*dz+rk2*r+rk3 (if dr != NULL) ; dz_out = dz (if != NULL) */
 int sar_bn_add_relu_bwd_apply_f32(const float* dy, const float* y, const float* u, const float* r,
                                   const float* k1, const float* k2, const float* k3,

@@ -252,10 +252,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
       const int row = m0 + (wm * MS + ms) * 32 + mfma_row(r, hi);
       const bool rowok = row < d.M;  // uniform over the 32 lanes of a half-wave
       float s1 = 0.f, s2 = 0.f;
-      float asc = 0.f, ash = 0.f;
+      float asc = 0.f, ash = 0.f, amu = 0.f;
       if (d.epi == SAR_EPI_MASK && rowok) {
         asc = d.aux_scale[row];
         ash = d.aux_shift[row];
+        if (d.aux_mean) amu = d.aux_mean[row];
       }
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
             const float ax = d.aux[(int64_t)row * d.ld_aux + coln[ns]];
             val = (fmaf(ax, asc, ash) > 0.f) ? val : 0.f;
             s1 += val;
-            s2 = fmaf(val, ax, s2);
+            s2 = fmaf(val, ax - amu, s2);
           } else if (d.epi == SAR_EPI_ADD) {
             val += d.aux[(int64_t)row * d.ld_aux + coln[ns]];
           }

@@ -7,11 +7,13 @@
 //
 // Design (MI355X): the MFMA reduction axis is the position axis.  A workgroup owns a (32*WF) x
 // (32*WC) x taps block of the weight tensor and walks its share of the sequence-aligned position
-// tiles (FT whole frames, same tiling as conv_gemm): per tile it stages the dout rows and the src
-// rows (+ temporal halo, BN+ReLU folded, zero padding materialised) in LDS with ODD row strides so
-// that the per-lane-row operand reads are bank-conflict free, then issues one
-// v_mfma_f32_32x32x2_f32 per tap per two positions.  The graph operand (x.A_k) is gathered on the
-// fly from the staged x rows through a <=4-entry list per adjacency slice.  Partial results go to
+// tiles (an EVEN number FT of whole frames): per tile it stages the dout rows and the src rows
+// (+ temporal halo, BN+ReLU folded, zero padding materialised) in LDS with ODD row strides so that
+// the per-lane-row operand reads are bank-conflict free.  Each v_mfma_f32_32x32x2_f32 reduces over
+// the SAME joint v of two consecutive frames (k = 0 on lanes 0-31, k = 1 on lanes 32-63), so every
+// LDS address is "per-lane constant + wave-uniform scalar": no position tables, no dependent reads,
+// and the graph gather lists (<=4 entries per joint and adjacency slice) are wave-uniform and come
+// through scalar loads.  One MFMA per tap per joint per frame pair.  Partial results go to
 // per-split slabs (plain coalesced stores; summed in split order by sar_slab_reduce_f32), so the
 // result is deterministic -- no float atomics.  MFMA orientation: A = src operand (rows c),
 // B = dout (cols m), so the accumulator columns are m and slab stores are 128-B contiguous.
@@ -21,8 +23,101 @@ namespace {
 
 struct WgradK {
   sar_wgrad_desc d;
-  int FT, TPS, NT, NF, RW, SP, NPOS, NP, DP;
+  int FT, FP, TPS, NT, NF, RW, SP, NPOS, NP, DP;
 };
+
+// One tile of the temporal reduction for a wave that owns NT consecutive taps starting at Sbase's tap.
+// No per-MFMA conditions: NT is a compile-time count, every address is lane-constant + uniform, and the
+// operands of joint v+1 are read from LDS while the MFMAs of joint v issue (register double buffer).
+template <int NT, int TPW>
+__device__ __forceinline__ void temporal_tile(f32x16 (&acc)[TPW], float& bsum, const float* Dbase, const float* Sbase,
+                                              int FP, int V, int sfs) {
+  for (int fp = 0; fp < FP; ++fp) {
+    const float* Dq = Dbase + fp * 2 * V;
+    const float* Sq = Sbase + fp * 2 * sfs;
+    float dn = Dq[0], sn[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) sn[i] = Sq[i * V];
+    for (int v = 0; v < V; ++v) {
+      const float dc = dn;
+      float sc[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) sc[i] = sn[i];
+      const int vn = (v + 1 < V) ? v + 1 : v;
+      dn = Dq[vn];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) sn[i] = Sq[i * V + vn];
+      bsum += dc;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[i], dc, acc[i], 0, 0, 0);
+    }
+  }
+}
+
+// Graph reduction: per joint v one packed LDS table row {gather joints[E], weights[E], colsum[3]} read with a
+// wave-uniform address.  Three-stage register pipeline: table row of joint v+2, gathered x values of joint
+// v+1 and the MFMAs of joint v are in flight together.
+template <int NZ0, int NZ1, int NZ2>
+struct GraphTab {
+  static constexpr int E = NZ0 + NZ1 + NZ2;
+  static constexpr int ROW = (2 * E + 3 + 3) / 4 * 4;
+};
+
+template <int NZ0, int NZ1, int NZ2>
+__device__ __forceinline__ void graph_tile(f32x16 (&acc)[3], float (&bsum)[3], const float* Dbase, const float* Sbase,
+                                           const float* T, int FP, int V) {
+  using GT = GraphTab<NZ0, NZ1, NZ2>;
+  constexpr int E = GT::E, ROW = GT::ROW, Q = ROW / 4;
+  constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  auto load_row = [&](float4 (&r)[Q], int v) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) r[q] = reinterpret_cast<const float4*>(T + v * ROW)[q];
+  };
+  auto elem = [&](const float4 (&r)[Q], int i) -> float {
+    const float4 x = r[i >> 2];
+    return (i & 3) == 0 ? x.x : (i & 3) == 1 ? x.y : (i & 3) == 2 ? x.z : x.w;
+  };
+  for (int fp = 0; fp < FP; ++fp) {
+    const float* Dq = Dbase + fp * 2 * V;
+    const float* Sq = Sbase + fp * 2 * V;
+    float4 tc[Q], tn[Q];          // table rows of joint v and v+1
+    float xn[E], dn;              // gathered x values / dout value of joint v (loaded one iteration early)
+    load_row(tc, 0);
+    load_row(tn, V > 1 ? 1 : 0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) xn[e] = Sq[__float_as_int(elem(tc, e))];
+    dn = Dq[0];
+    for (int v = 0; v < V; ++v) {
+      float xc[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) xc[e] = xn[e];
+      const float dc = dn;
+      float4 tcur[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) tcur[q] = tc[q];
+      // stage joint v+1 (its table row is already in tn) and fetch the row of joint v+2
+      const int v1 = (v + 1 < V) ? v + 1 : v;
+      const int v2 = (v + 2 < V) ? v + 2 : V - 1;
+#pragma unroll
+      for (int e = 0; e < E; ++e) xn[e] = Sq[__float_as_int(elem(tn, e))];
+      dn = Dq[v1];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) tc[q] = tn[q];
+      load_row(tn, v2);
+      int e0 = 0;
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) {
+        float sval = elem(tcur, E + e0) * xc[e0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+          if (j < NZ[tp]) sval = fmaf(elem(tcur, E + e0 + j), xc[e0 + j], sval);
+        bsum[tp] = fmaf(dc, elem(tcur, 2 * E + tp), bsum[tp]);
+        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(sval, dc, acc[tp], 0, 0, 0);
+        e0 += NZ[tp];
+      }
+    }
+  }
+}
 
 template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
@@ -34,36 +129,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   // staging maps: a half-wave owns one row and reads 32 consecutive columns per pass (128-B segments)
   constexpr int DI = BF / 8, DJ = 4;                           // dout tile: BF rows x <=128 positions
   constexpr int SI = CT / 8;                                   // src tile: CT rows x RW columns
-  constexpr int SJMAX = (MODE == SAR_CONV_GRAPH) ? 4 : (TAPS == 1 ? 8 : 14);
+  constexpr int SJMAX = (MODE == SAR_CONV_GRAPH) ? 4 : (TAPS == 1 ? 6 : 12);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const sar_wgrad_desc& d = k.d;
   const int V = d.V;
   float* D = smem;                          // [BF][DP]
   float* S = D + BF * k.DP;                 // [CT][SP]
-  int* PT = (int*)(S + CT * k.SP);          // [NP][2] : (src column offset of position p, joint v)
-  int* GI = PT + 2 * k.NP;                  // GRAPH [3][V][4] gather joint
-  float* GW = (float*)(GI + 3 * V * NZMAX); // GRAPH [3][V][4] gather weight
-  float* GC = GW + 3 * V * NZMAX;           // GRAPH [3][V] colsum
+  float* T = S + CT * k.SP + ((4 - ((BF * k.DP + CT * k.SP) & 3)) & 3);   // GRAPH: [V][ROW] packed gather rows (16-B aligned)
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction
   const int l31 = lane & 31, hi = lane >> 5;
   const int wf = wave % WF, wc = (wave / WF) % WC, wt = wave / (WF * WC);
   const int f0 = blockIdx.y * BF, c0 = blockIdx.z * CT;
 
-  // ---- tile-independent tables
-  for (int p = tid; p < k.NP; p += 256) {
-    int fo = p / V, v = p - (p / V) * V;
-    if (p >= k.NPOS) { fo = 0; v = 0; }
-    PT[2 * p] = (MODE == SAR_CONV_GRAPH) ? fo * V : fo * d.stride * V + v;
-    PT[2 * p + 1] = v;
-  }
-  if (MODE == SAR_CONV_GRAPH) {
-    for (int i = tid; i < 3 * V * NZMAX; i += 256) {
-      GI[i] = d.g_idx[i];
-      GW[i] = d.g_wt[i];
+  if (MODE == SAR_CONV_GRAPH) {   // pack {joints[E], weights[E], colsum[3]} per joint
+    using GT = GraphTab<NZ0, NZ1, NZ2>;
+    constexpr int NZc[3] = {NZ0, NZ1, NZ2};
+    for (int v = tid; v < V; v += 256) {
+      int e = 0;
+      for (int tp = 0; tp < 3; ++tp) {
+        for (int j = 0; j < NZc[tp]; ++j, ++e) {
+          T[v * GT::ROW + e] = __int_as_float(d.g_idx[(tp * V + v) * NZMAX + j]);
+          T[v * GT::ROW + GT::E + e] = d.g_wt[(tp * V + v) * NZMAX + j];
+        }
+        T[v * GT::ROW + 2 * GT::E + tp] = d.g_colsum ? d.g_colsum[tp * V + v] : 0.f;
+      }
     }
-    for (int i = tid; i < 3 * V; i += 256) GC[i] = d.g_colsum ? d.g_colsum[i] : 0.f;
   }
 
   f32x16 acc[TPW];
@@ -155,45 +247,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
     }
   };
 
+  // per-lane operand bases: lanes 0-31 reduce over the even frame of a pair, lanes 32-63 over the odd one
+  const int sfs = (MODE == SAR_CONV_GRAPH) ? V : d.stride * V;      // src columns per output frame
+  const float* Dbase = D + (wf * 32 + l31) * k.DP + hi * V;
+  const float* Sbase = S + (wc * 32 + l31) * k.SP + hi * sfs;
+
   int tile = blockIdx.x;
   if (tile < k.NT) issue_loads(tile);
   for (; tile < k.NT; tile += gridDim.x) {
-    __syncthreads();  // previous tile's LDS reads done (also orders the table writes before first use)
+    __syncthreads();  // previous tile's LDS reads done
     store_lds(tile);
     __syncthreads();
     if (tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
 
-    const float* Drow = D + (wf * 32 + l31) * k.DP;
-    const float* Srow = S + (wc * 32 + l31) * k.SP;
-    for (int step = 0; step < k.NP / 2; ++step) {
-      const int p = 2 * step + hi;
-      const int poff = PT[2 * p];
-      const int v = PT[2 * p + 1];
-      const float dval = Drow[p];
-      if (MODE == SAR_CONV_TEMPORAL) {
-        bsum[0] += dval;
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-          const int tp = wt * TPW + i;
-          if (tp < TAPS) {
-            const float sval = Srow[poff + tp * V];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sval, dval, acc[i], 0, 0, 0);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-          const int tp = i;  // WT == 1 in graph mode
-          const int* gi = GI + (tp * V + v) * NZMAX;
-          const float* gwp = GW + (tp * V + v) * NZMAX;
-          float sval = gwp[0] * Srow[poff + gi[0]];
-#pragma unroll
-          for (int j = 1; j < NZMAX; ++j)
-            if (j < NZ[tp]) sval = fmaf(gwp[j], Srow[poff + gi[j]], sval);
-          bsum[i] = fmaf(dval, GC[tp * V + v], bsum[i]);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sval, dval, acc[i], 0, 0, 0);
-        }
-      }
+    if constexpr (MODE == SAR_CONV_TEMPORAL) {
+      // every wave runs TPW taps: taps beyond TAPS (last wave class when WT*TPW > TAPS) read the padded
+      // tail of the S rows and land in accumulators that are never stored -- those SIMDs would otherwise
+      // idle at the tile barrier, and one code path keeps the accumulators in AGPRs.
+      temporal_tile<TPW, TPW>(acc, bsum[0], Dbase, Sbase + wt * TPW * V, k.FP, V, sfs);
+    } else {
+      graph_tile<NZ0, NZ1, NZ2>(acc, bsum, Dbase, Sbase, T, k.FP, V);
     }
   }
 
@@ -231,29 +304,32 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 size_t lds_bytes(const sar_wgrad_desc& d, const WgradK& k, int BF, int CT) {
-  size_t lds = sizeof(float) * ((size_t)BF * k.DP + (size_t)CT * k.SP) + sizeof(int) * 2 * k.NP;
-  if (d.mode == SAR_CONV_GRAPH) lds += (sizeof(int) + sizeof(float)) * 3 * d.V * 4 + sizeof(float) * 3 * d.V;
+  size_t lds = sizeof(float) * ((size_t)BF * k.DP + (size_t)CT * k.SP);
+  if (d.mode == SAR_CONV_GRAPH) lds += sizeof(float) * (4 + (size_t)d.V * 28);   // packed gather rows (ROW <= 28)
   return lds;
 }
 
-// Frame tile: as many whole frames as fit 128 positions, shrunk until two workgroups fit the CU's LDS.
-int geometry(const sar_wgrad_desc& d, WgradK& k, int BF, int CT) {
-  int ft = 128 / d.V;
-  if (ft < 1) return -1;
-  if (ft > d.T_out) ft = d.T_out;
-  for (;; --ft) {
+// Frame tile: an even number of whole frames (frame PAIRS feed the two MFMA k-lanes) with at most 128
+// positions, shrunk until two workgroups fit the CU's LDS.
+int geometry(const sar_wgrad_desc& d, WgradK& k, int BF, int CT, int extra_taps) {
+  int ft = (128 / d.V) & ~1;
+  if (ft < 2) return -1;
+  const int t_even = (d.T_out + 1) & ~1;
+  if (ft > t_even) ft = t_even;
+  for (;; ft -= 2) {
     k.FT = ft;
+    k.FP = ft / 2;
     k.TPS = (d.T_out + k.FT - 1) / k.FT;
     k.NT = d.B * k.TPS;
     k.NPOS = k.FT * d.V;
-    k.NP = (k.NPOS + 1) & ~1;
+    k.NP = k.NPOS;
     k.DP = k.NP | 1;
     k.NF = (d.mode == SAR_CONV_GRAPH) ? k.FT : (k.FT - 1) * d.stride + d.taps;
     k.RW = k.NF * d.V;
-    k.SP = k.RW | 1;
-    if (lds_bytes(d, k, BF, CT) <= 78 * 1024 || ft == 1) break;
+    k.SP = (k.RW + extra_taps * d.V) | 1;   // room for the phantom taps of the last wave class
+    if (lds_bytes(d, k, BF, CT) <= 78 * 1024 || ft == 2) break;
   }
-  const int sjmax = (d.mode == SAR_CONV_GRAPH) ? 4 : (d.taps == 1 ? 8 : 14);
+  const int sjmax = (d.mode == SAR_CONV_GRAPH) ? 4 : (d.taps == 1 ? 6 : 12);
   if (k.RW > 32 * sjmax || k.NP > 128) return -2;
   return 0;
 }
@@ -263,7 +339,7 @@ int launch(const sar_wgrad_desc& d, hipStream_t st) {
   WgradK k;
   k.d = d;
   constexpr int BF = 32 * WF, CT = 32 * WC;
-  if (int g = geometry(d, k, BF, CT)) {
+  if (int g = geometry(d, k, BF, CT, WT * TPW - TAPS)) {
     sar_set_error("sar_conv_wgrad: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride);
     return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
   }

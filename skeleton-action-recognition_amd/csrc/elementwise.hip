@@ -90,7 +90,7 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 
 __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts,
                                                               int64_t chan_stride, int64_t part_stride, int off1, int off2,
-                                                              double count, const float* __restrict__ gamma,
+                                                              int centered, double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               float* dgamma, float* dbeta, float* k1, float* k2, float* k3) {
   const int c = blockIdx.x;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* __res
     s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double m = mean[c], rs = rstd[c], g = gamma ? (double)gamma[c] : 1.0;
-    const double dg = rs * (s2 - m * s1);  // sum dz * xhat
+    const double dg = centered ? rs * s2 : rs * (s2 - m * s1);  // sum dz * xhat
     if (dgamma) dgamma[c] = (float)dg;
     if (dbeta) dbeta[c] = (float)s1;
     const double a = s1 / count, b = dg / count;
@@ -139,6 +139,7 @@ template <bool BWD>
 __global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __restrict__ x, int N, int C, int T, int V, int M,
                                                              const int* __restrict__ bone_parent,
                                                              const float* __restrict__ dy, int64_t ld_dy,
+                                                             const float* __restrict__ mean,
                                                              float* __restrict__ partials) {
   const int n = blockIdx.x / C, c = blockIdx.x - n * C;
   const float* slab = x + (int64_t)blockIdx.x * T * V * M;
@@ -147,9 +148,10 @@ __global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __rest
   const int col = threadIdx.x % VM, rg = threadIdx.x / VM;
   const int v = col / M, m = col - v * M;
   float s1 = 0.f, s2 = 0.f;
+  const float mu = (BWD && mean && rg < groups) ? mean[v * C + c] : 0.f;
   if (rg < groups) {
     for (int t = rg; t < T; t += groups) {
-      const float val = load_joint(slab, t, v, m, V, M, bone_parent);
+      const float val = load_joint(slab, t, v, m, V, M, bone_parent) - mu;
       if (BWD) {
         const float g = dy[(int64_t)c * ld_dy + ((int64_t)(n * M + m) * T + t) * V + v];
         s1 += g;
@@ -233,8 +235,10 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
 template <int VEC>
 __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                      const float* __restrict__ u, const float* __restrict__ r,
+                                                                     const float* __restrict__ mu_p, const float* __restrict__ mr_p,
                                                                      float* __restrict__ partials, int64_t n, int64_t ldm) {
   const int c = blockIdx.y;
+  const float mu = mu_p ? mu_p[c] : 0.f, mr = (r && mr_p) ? mr_p[c] : 0.f;
   const int64_t base = (int64_t)c * ldm;
   float acc[3] = {0.f, 0.f, 0.f};
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
@@ -247,8 +251,8 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_kernel(const float
     for (int j = 0; j < VEC; ++j) {
       const float dz = yv[j] > 0.f ? g[j] : 0.f;
       acc[0] += dz;
-      acc[1] = fmaf(dz, uv[j], acc[1]);
-      if (r) acc[2] = fmaf(dz, rv[j], acc[2]);
+      acc[1] = fmaf(dz, uv[j] - mu, acc[1]);
+      if (r) acc[2] = fmaf(dz, rv[j] - mr, acc[2]);
     }
   }
   __shared__ float red[4 * 3];
@@ -459,13 +463,13 @@ extern "C" int sar_bn_eval_affine_f32(const float* gamma, const float* beta, con
 }
 
 extern "C" int sar_bn_bwd_finalize_f32(const float* partials, int nparts, int64_t chan_stride, int64_t part_stride,
-                                       int off1, int off2, int C, double count, const float* gamma, const float* mean,
+                                       int off1, int off2, int centered, int C, double count, const float* gamma, const float* mean,
                                        const float* rstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
                                        sar_stream_t s) {
   SAR_REQUIRE(partials && nparts > 0 && C > 0 && count > 0 && mean && rstd, "sar_bn_bwd_finalize: bad arguments");
   SAR_REQUIRE((k1 == nullptr) == (k2 == nullptr) && (k1 == nullptr) == (k3 == nullptr), "sar_bn_bwd_finalize: k1/k2/k3");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(TPB), 0, as_stream(s), partials, nparts, chan_stride,
-                     part_stride, off1, off2, count, gamma, mean, rstd, dgamma, dbeta, k1, k2, k3);
+                     part_stride, off1, off2, centered, count, gamma, mean, rstd, dgamma, dbeta, k1, k2, k3);
   SAR_LAUNCH_CHECK("sar_bn_bwd_finalize_f32");
   return 0;
 }
@@ -482,7 +486,7 @@ extern "C" int sar_data_bn_stats_f32(const float* x, int N, int C, int T, int V,
   if (rc) return rc;
   SAR_REQUIRE(partials, "sar_data_bn_stats: null partials");
   hipLaunchKernelGGL(data_bn_reduce_kernel<false>, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M,
-                     bone_parent, (const float*)nullptr, (int64_t)0, partials);
+                     bone_parent, (const float*)nullptr, (int64_t)0, (const float*)nullptr, partials);
   SAR_LAUNCH_CHECK("sar_data_bn_stats_f32");
   return 0;
 }
@@ -499,12 +503,12 @@ extern "C" int sar_data_bn_apply_f32(const float* x, int N, int C, int T, int V,
 }
 
 extern "C" int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
-                                          const float* dy, int64_t ld_dy, float* partials, sar_stream_t s) {
+                                          const float* dy, int64_t ld_dy, const float* mean, float* partials, sar_stream_t s) {
   int rc = data_bn_check(x, N, C, T, V, M);
   if (rc) return rc;
   SAR_REQUIRE(dy && partials && ld_dy >= (int64_t)N * M * T * V, "sar_data_bn_bwd_reduce: bad arguments");
   hipLaunchKernelGGL(data_bn_reduce_kernel<true>, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent,
-                     dy, ld_dy, partials);
+                     dy, ld_dy, mean, partials);
   SAR_LAUNCH_CHECK("sar_data_bn_bwd_reduce_f32");
   return 0;
 }
@@ -527,15 +531,15 @@ extern "C" int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const fl
 }
 
 extern "C" int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
-                                              float* partials, int nparts, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+                                              const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n, int64_t ldm, sar_stream_t s) {
   SAR_REQUIRE(dy && y && u && partials && nparts > 0 && nparts <= 65535 && C > 0 && n > 0 && ldm >= n,
               "sar_bn_add_relu_bwd_reduce: bad arguments");
   if (vec4_ok(n, ldm, {dy, y, u, r})) {
     hipLaunchKernelGGL(bn_add_relu_bwd_reduce_kernel<4>, dim3(nparts, C), dim3(TPB), 0, as_stream(s), dy, y, u, r,
-                       partials, n, ldm);
+                       mu, mr, partials, n, ldm);
   } else {
     hipLaunchKernelGGL(bn_add_relu_bwd_reduce_kernel<1>, dim3(nparts, C), dim3(TPB), 0, as_stream(s), dy, y, u, r,
-                       partials, n, ldm);
+                       mu, mr, partials, n, ldm);
   }
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_f32");
   return 0;

@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ("W", _fp), ("w_stride_tap", C.c_int64), ("w_stride_c", C.c_int64), ("bias", _fp),
         ("pro_scale", _fp), ("pro_shift", _fp),
         ("g_idx", _fp), ("g_wt", _fp), ("g_colsum", _fp),
-        ("aux", _fp), ("ld_aux", C.c_int64), ("aux_scale", _fp), ("aux_shift", _fp),
+        ("aux", _fp), ("ld_aux", C.c_int64), ("aux_scale", _fp), ("aux_shift", _fp), ("aux_mean", _fp),
         ("partials", _fp),
     ]
 
@@ -55,12 +55,12 @@ SIGNATURES = {
     "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),
     "sar_bn_finalize_f32": (_i, [_fp, _i, _i, _d, _f, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_bn_eval_affine_f32": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _fp]),
-    "sar_bn_bwd_finalize_f32": (_i, [_fp, _i, _i64, _i64, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "sar_bn_bwd_finalize_f32": (_i, [_fp, _i, _i64, _i64, _i, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_data_bn_stats_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp]),
     "sar_data_bn_apply_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i64, _fp]),
-    "sar_data_bn_bwd_reduce_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i64, _fp, _fp]),
+    "sar_data_bn_bwd_reduce_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i64, _fp, _fp, _fp]),
     "sar_bn_add_relu_fwd_f32": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
-    "sar_bn_add_relu_bwd_reduce_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_reduce_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_apply_f32": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),
     "sar_affine2_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_pool_fwd_f32": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),

@@ -32,7 +32,7 @@ class GraphTables:
 
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
-              aux_affine=None, want_partials=False):
+              aux_affine=None, aux_mean=None):
     """Launch sar_conv_gemm_f32.  Returns (partials, nparts) when the epilogue reduces, else None."""
     lib = L.load()
     d = ConvDesc()
@@ -54,6 +54,7 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
         d.aux, d.ld_aux = ptr(_f32(aux)), aux.stride(0)
     if aux_affine is not None:
         d.aux_scale, d.aux_shift = ptr(_f32(aux_affine[0])), ptr(_f32(aux_affine[1]))
+    d.aux_mean = ptr(_f32(aux_mean))
     partials = None
     nparts = 0
     if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
@@ -64,7 +65,7 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
         d.partials = ptr(partials)
     # algorithmic work: the forward conv's MACs (a data gradient costs the same MACs as its forward conv)
     n_conv = B * (T_src if transposed else T_out) * V
-    flops = 2.0 * M * Kc * taps * n_conv if mode == L.SAR_CONV_TEMPORAL else 2.0 * M * Kc * taps * n_conv
+    flops = 2.0 * M * Kc * taps * n_conv
     tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else "")))
     with profiler.region(tag, flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
         check(lib.sar_conv_gemm_f32(C.byref(d), stream_ptr()), "sar_conv_gemm_f32")
@@ -80,7 +81,7 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
     ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
     if nsplit is None:
-        ft = max(1, min(128 // V, T_out))
+        ft = max(2, min((128 // V) & ~1, (T_out + 1) & ~1))
         ntiles = B * ((T_out + ft - 1) // ft)
         wgs = ((M + 63) // 64) * ((Kc + ct - 1) // ct)
         nsplit = max(1, min(ntiles, (1024 + wgs - 1) // wgs))
@@ -118,8 +119,9 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
 
 
 def bn_bwd_finalize(partials, nparts, chan_stride, part_stride, off1, off2, C_, count, gamma, mean, rstd, dgamma, dbeta,
-                    k1=None, k2=None, k3=None):
-    check(L.load().sar_bn_bwd_finalize_f32(ptr(partials), nparts, chan_stride, part_stride, off1, off2, C_, float(count),
+                    k1=None, k2=None, k3=None, centered=True):
+    check(L.load().sar_bn_bwd_finalize_f32(ptr(partials), nparts, chan_stride, part_stride, off1, off2, int(centered), C_,
+                                           float(count),
                                            ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(k1), ptr(k2),
                                            ptr(k3), stream_ptr()), "sar_bn_bwd_finalize_f32")
 
@@ -136,9 +138,9 @@ def data_bn_apply(x, bone_parent, scale, shift, out):
                                          out.stride(0), stream_ptr()), "sar_data_bn_apply_f32")
 
 
-def data_bn_bwd_reduce(x, bone_parent, dy, partials):
+def data_bn_bwd_reduce(x, bone_parent, dy, mean, partials):
     N, C_, T, V, M = x.shape
-    check(L.load().sar_data_bn_bwd_reduce_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(dy), dy.stride(0),
+    check(L.load().sar_data_bn_bwd_reduce_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(dy), dy.stride(0), ptr(mean),
                                               ptr(partials), stream_ptr()), "sar_data_bn_bwd_reduce_f32")
 
 
@@ -147,11 +149,11 @@ def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y):
                                            u.shape[0], u.shape[1], u.stride(0), stream_ptr()), "sar_bn_add_relu_fwd_f32")
 
 
-def bn_add_relu_bwd_reduce(dy, y, u, r):
+def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None):
     Cc, n = u.shape
     nparts = max(1, min(256, (n + 8191) // 8192))
     partials = torch.empty((Cc, nparts, 4), dtype=torch.float32, device=u.device)
-    check(L.load().sar_bn_add_relu_bwd_reduce_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(partials), nparts, Cc, n,
+    check(L.load().sar_bn_add_relu_bwd_reduce_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(mu), ptr(mr), ptr(partials), nparts, Cc, n,
                                                   u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_reduce_f32")
     return partials, nparts
 

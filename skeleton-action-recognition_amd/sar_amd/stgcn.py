@@ -276,8 +276,8 @@ class STGCN:
         x = sv["x"]
         nch = V * self.C_in
         part = torch.empty((nch, N, 2), dtype=torch.float32, device=dev)
-        ops.data_bn_bwd_reduce(x, self.bone_parent, dY, part)
         dbn = self.bn["data_bn"]
+        ops.data_bn_bwd_reduce(x, self.bone_parent, dY, dbn.mean, part)
         ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, nch, N * M * sv["T"], self.p["data_bn.gamma"], dbn.mean, dbn.rstd,
                             self.g["data_bn.gamma"], self.g["data_bn.beta"])
         self._saved = None
@@ -291,7 +291,8 @@ class STGCN:
         bn1, bn2 = self.bn[pre + "bn1"], self.bn[pre + "bn2"]
         rbn = self.bn.get(pre + "res_bn")
         # ---- tail: y = relu(bn2(u) + res)   (models/stgcn.py:37,62-63)
-        part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, u, r if kind == "conv" else None)
+        part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, u, r if kind == "conv" else None, bn2.mean,
+                                                  rbn.mean if kind == "conv" else None)
         ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, self.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
                             self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
         rk = None
@@ -315,7 +316,7 @@ class STGCN:
         dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
         pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, du, dz1, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=KT,
                            stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g,
-                           aux_affine=(bn1.scale, bn1.shift))
+                           aux_affine=(bn1.scale, bn1.shift), aux_mean=bn1.mean)
         ops.bn_bwd_finalize(pm[0], pm[1], pm[1] * 2, 2, 0, 1, f, n_in, self.p[pre + "bn1.gamma"], bn1.mean, bn1.rstd,
                             self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
         dg = dz1

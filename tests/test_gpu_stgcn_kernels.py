@@ -102,7 +102,7 @@ def test_residual_conv_forward(dev, B, cin, f, T, s):
     assert rel_err(from_cn(out.cpu(), B, To, 25), ref) < TOL
 
 
-@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9)])
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9), (4, 256, 256, 75)])
 def test_graph_conv_gradients(dev, B, cin, f, T):
     """data gradient (A^T gather lists + W^T) and weight/bias gradients of GraphConvTD."""
     from sar_amd import ops, _lib as L
@@ -133,7 +133,7 @@ def test_graph_conv_gradients(dev, B, cin, f, T):
     assert rel_err(flat[cin * 3 * f:].cpu(), gb) < TOL
 
 
-@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2)])
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2), (4, 256, 75, 1), (3, 128, 150, 2)])
 def test_temporal_conv_gradients(dev, B, f, T, s):
     """weight/bias gradient (with the folded BN+ReLU operand) and the transposed-conv data gradient with the
     fused ReLU mask + BN-backward reductions."""
@@ -168,7 +168,7 @@ def test_temporal_conv_gradients(dev, B, f, T, s):
     assert rel_err(from_cn(dz1.cpu(), B, T, 25), g_pre) < TOL
     part = pm[0].cpu().double().sum(dim=1)
     assert rel_err(part[:, 0], g_pre.sum(dim=(0, 2, 3))) < 1e-4
-    assert rel_err(part[:, 1], (g_pre * gx).sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (g_pre * gx).sum(dim=(0, 2, 3))) < 1e-4   # aux_mean=None -> raw second moment
 
 
 @pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2)])
@@ -224,7 +224,7 @@ def test_block_tail_forward_backward(dev):
     ops.bn_add_relu_fwd(d(u), sc2, sh2, 2, d(r), scr, shr, yd)
     torch.cuda.synchronize()
     assert rel_err(yd.cpu(), y) < TOL
-    part, nparts = ops.bn_add_relu_bwd_reduce(d(dy), yd, d(u), d(r))
+    part, nparts = ops.bn_add_relu_bwd_reduce(d(dy), yd, d(u), d(r), d(mu), d(mr))
     z = lambda: torch.empty(C, device=dev)
     dg2, db2, k1, k2, k3 = z(), z(), z(), z(), z()
     dgr, dbr, q1, q2, q3 = z(), z(), z(), z(), z()
@@ -273,7 +273,7 @@ def test_data_bn_forward_backward(dev):
     assert rel_err(rm.cpu(), new["data_bn.moving_mean"]) < TOL and rel_err(rv.cpu(), new["data_bn.moving_var"]) < TOL
     dy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
     gg, gb = torch.autograd.grad(ref, (gam, bet), dy.double())
-    ops.data_bn_bwd_reduce(xg, None, to_cn(dy).to(dev), part)
+    ops.data_bn_bwd_reduce(xg, None, to_cn(dy).to(dev), mean, part)
     dgam, dbet = z(), z()
     ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, V * C, N * M * T, p["data_bn.gamma"].to(dev), mean, rstd, dgam, dbet)
     torch.cuda.synchronize()
