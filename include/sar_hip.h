@@ -92,6 +92,8 @@ typedef struct sar_conv_desc {
   float* partials;         /* [M][nparts][2] (SAR_EPI_STATS / SAR_EPI_MASK) */
 } sar_conv_desc;
 
+/* sizeof(sar_conv_desc) (which=0) / sizeof(sar_wgrad_desc) (which=1) as compiled: lets a binding verify its mirror */
+int sar_struct_size(int which);
 int sar_conv_gemm_nparts(const sar_conv_desc* d);                 /* host query, no GPU work */
 int sar_conv_gemm_f32(const sar_conv_desc* d, sar_stream_t s);
 

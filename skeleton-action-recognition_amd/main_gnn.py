@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's main_gnn.py on the MI355X-native path: same command-line flags
+(main_gnn.py:25-77), same train step (main_gnn.py:219-239: softmax-CE summed / global batch, every trainable
+variable except `adjacency_matrix`, SGD momentum 0.9 Nesterov, PiecewiseConstantDecay main_gnn.py:303-308),
+same synchronous data parallelism (MirroredStrategy, main_gnn.py:257-258 -> one process per GPU + one RCCL
+all-reduce of the flat gradient buffer), per-iteration loss / top-1 / top-5, per-epoch test accuracy and a
+checkpoint every --save-freq epochs (main_gnn.py:359-428).
+
+Launch:  python main_gnn.py --model stgcn ...                      (1 GPU)
+         python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main_gnn.py --model stgcn ...
+Data: --train-data-path / --test-data-path point at `<prefix>` for which `<prefix>.npy` and the sibling
+`*_label.pkl` exist (output of the reference's data_gen/gen_joint_data.py), or pass --synthetic.
+TensorBoard is not available in this image: scalars go to <log-dir>/scalars.jsonl with the reference's tags.
+"""
+import argparse
+import inspect
+import json
+import os
+import shutil
+import time
+
+import torch
+import torch.distributed as dist
+
+from utils import import_class, save_arg
+
+
+def get_parser():
+    # flags and defaults of the reference, main_gnn.py:31-75
+    parser = argparse.ArgumentParser(
+        description='Graph Convolutional Neural Network for Skeleton-Based Action Recognition')
+    parser.add_argument('--model', required=True, help='model used to train')
+    parser.add_argument('--base-lr', type=float, default=1e-1, help='initial learning rate')
+    parser.add_argument('--num-classes', type=int, default=60, help='number of classes in dataset')
+    parser.add_argument('--batch-size', type=int, default=64, help='training batch size')
+    parser.add_argument('--num-epochs', type=int, default=80, help='total epochs to train')
+    parser.add_argument('--save-freq', type=int, default=10, help='periodicity of saving model weights')
+    parser.add_argument('--freeze-graph-until', type=int, default=80,
+                        help='adjacency matrices will be trained only after this epoch')
+    parser.add_argument('--log-dir', default="logs/",
+                        help='folder to store model-definition/training-logs/hyperparameters')
+    parser.add_argument('--train-data-path', default="data/ntu/xview/train_data_joint",
+                        help='path prefix of the training data (<prefix>.npy + label pkl)')
+    parser.add_argument('--test-data-path', default="data/ntu/xview/val_data_joint",
+                        help='path prefix of the testing data')
+    parser.add_argument('--notes', default="", help='run details')
+    parser.add_argument('--steps', type=int, default=[10, 50], nargs='+',
+                        help='the epoch where optimizer reduce the learning rate, eg: 10 50')
+    # additions of this implementation
+    parser.add_argument('--synthetic', action='store_true', help='train on synthetic NTU-like clips')
+    parser.add_argument('--synthetic-size', type=int, default=40000)
+    parser.add_argument('--max-iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
+    return parser
+
+
+def _label_path(prefix):
+    d, base = os.path.split(prefix)
+    return os.path.join(d, base.replace("_data_joint", "").replace("_data_bone", "") + "_label.pkl")
+
+
+def topk_correct(logits, labels, k):
+    return (logits.topk(k, dim=1).indices == labels[:, None]).any(dim=1).sum()
+
+
+def main():
+    arg = get_parser().parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)        # RCCL over xGMI
+    arg.gpus = world
+    global_batch_size = arg.batch_size * world                # main_gnn.py:258
+
+    run_params = {k: v for k, v in vars(arg).items()
+                  if k not in ("train_data_path", "test_data_path", "log_dir", "save_freq", "freeze_graph_until", "gpus")}
+    run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
+    if arg.notes:
+        run_name += "-" + arg.notes
+    arg.log_dir = os.path.join(arg.log_dir, run_name)
+    ckpt_dir = os.path.join(arg.log_dir, "checkpoints")
+    model_mod = import_class('models.' + arg.model)
+    if rank == 0:
+        save_arg(arg)
+        shutil.copy2(inspect.getfile(model_mod), arg.log_dir)   # main_gnn.py:284
+        os.makedirs(ckpt_dir, exist_ok=True)
+
+    from sar_amd.data import NpySkeletonData, SyntheticSkeletonData
+    from sar_amd.train import Trainer, allreduce_sum_
+    if arg.synthetic:
+        train_data = SyntheticSkeletonData(arg.synthetic_size, arg.num_classes)
+        test_data = SyntheticSkeletonData(max(arg.batch_size * 4, 256), arg.num_classes)
+    else:
+        train_data = NpySkeletonData(arg.train_data_path + ".npy", _label_path(arg.train_data_path))
+        test_data = NpySkeletonData(arg.test_data_path + ".npy", _label_path(arg.test_data_path))
+
+    model = model_mod.Model(num_classes=arg.num_classes, device=dev)
+    eng = model.engine
+    trainer = Trainer(eng, batch_size=arg.batch_size, base_lr=arg.base_lr, steps=arg.steps, world_size=world)
+    log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None
+
+    def scalar(tag, value, step):
+        if log:
+            log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+    train_iter = test_iter = 0
+    for epoch in range(arg.num_epochs):
+        if rank == 0:
+            print("Epoch: {}".format(epoch + 1), flush=True)
+        t0 = time.time()
+        # `train_adj` (epoch > freeze_graph_until, main_gnn.py:228-232,364) has no effect for models.stgcn: its
+        # adjacency is a non-trainable variable (models/stgcn.py:105-109).
+        for it, (x, y) in enumerate(train_data.batches(arg.batch_size, rank, world, dev, shuffle=True, epoch=epoch)):
+            logits, loss = trainer.step(x, y)
+            stats = torch.stack([loss.reshape(()) * 1.0, topk_correct(logits, y, 1).float(),
+                                 topk_correct(logits, y, 5).float()])
+            stats[1:] /= global_batch_size
+            allreduce_sum_(stats)                              # loss is already divided by the global batch
+            scalar("cross_entropy_loss", stats[0], train_iter)
+            scalar("train_acc", stats[1], train_iter)
+            scalar("train_acc_top_5", stats[2], train_iter)
+            train_iter += 1
+            if arg.max_iters and it + 1 >= arg.max_iters:
+                break
+        if rank == 0:
+            torch.cuda.synchronize()
+            print("  train: %d iters, %.1f clips/s" % (it + 1, (it + 1) * global_batch_size / (time.time() - t0)),
+                  flush=True)
+        # ---- test (main_gnn.py:381-408), un-distributed like the reference: rank 0 evaluates
+        if rank == 0:
+            c1 = c5 = n = 0
+            for it, (x, y) in enumerate(test_data.batches(arg.batch_size, 0, 1, dev, shuffle=False,
+                                                          drop_remainder=False)):
+                probs = eng.predict(x)
+                b1, b5 = topk_correct(probs, y, 1).item(), topk_correct(probs, y, 5).item()
+                scalar("test_acc", b1 / len(y), test_iter)
+                scalar("test_acc_top_5", b5 / len(y), test_iter)
+                test_iter += 1
+                c1, c5, n = c1 + b1, c5 + b5, n + len(y)
+                if arg.max_iters and it + 1 >= arg.max_iters:
+                    break
+            scalar("epoch_test_acc", c1 / n, epoch)
+            scalar("epoch_test_acc_top_5", c5 / n, epoch)
+            print("  test: top1 %.4f top5 %.4f" % (c1 / n, c5 / n), flush=True)
+            if (epoch + 1) % arg.save_freq == 0 or epoch + 1 == arg.num_epochs:
+                path = os.path.join(ckpt_dir, "ckpt-%d.pt" % (epoch + 1))
+                torch.save({"model": eng.state_dict(), "velocity": eng.velocity.cpu(), "iteration": trainer.iteration,
+                            "epoch": epoch + 1}, path)
+                print('Saving checkpoint for epoch {} at {}'.format(epoch + 1, path), flush=True)
+            log.flush()
+        if world > 1:
+            dist.barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sar_version": (_i, []),
     "sar_last_error_string": (C.c_char_p, []),
     "sar_debug_occupancy": (_i, [_i, _i]),
+    "sar_struct_size": (_i, [_i]),
     "sar_conv_gemm_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
@@ -95,6 +96,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.sar_struct_size(0) != C.sizeof(ConvDesc) or lib.sar_struct_size(1) != C.sizeof(WgradDesc):
+        raise SarError("descriptor layout mismatch between include/sar_hip.h and sar_amd/_lib.py")
     _lib = lib
     return lib
 
