@@ -5,8 +5,8 @@
 //   stride -> conflict-free per-frame reads); each lane then walks the E edges x M bodies of its
 //   frame entirely in registers: range, aspect angles, ellipsoid RCS, phase, complex sum.  The dozens
 //   of full-tensor temporaries the reference materialises (each a HBM round trip) never exist.
-//   Numerics: built with -ffp-contract=off; range and phase follow the oracle's operation order
-//   bit for bit (psi ~ 1e5 rad at lambda = 5e-4, so one ulp of range is 0.02 rad of phase); sin/cos
+//   Numerics: built with -ffp-contract=off, IEEE-correct sqrtf and '/' (NOT __fsqrt_rn, which lowers to the
+//   1-ulp v_sqrt_f32); range and phase follow the oracle's operation order bit for bit (psi ~ 1e5 rad at lambda = 5e-4, so one ulp of range is 0.02 rad of phase); sin/cos
 //   are the accurate ocml routines (Payne-Hanek reduction), never the fast-math approximations.
 // Kernel 2 (sar_stft_logmag_f32, :124-133 + nnAudio 0.1.1 STFT): one workgroup per (clip, output
 //   frame): reflect-padded, Hann-windowed complex frame and the n_fft-entry twiddle table live in
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_kernel(const float* __restri
     for (int e = 0; e < E; ++e) {
       const int js = es[e] * M + m, jd = ed[e] * M + m;
       const float dx = X0[js] - X0[jd], dy = X1[js] - X1[jd], dz = X2[js] - X2[jd];
-      acc = acc + __fsqrt_rn((dx * dx + dy * dy) + dz * dz);
+      acc = acc + sqrtf((dx * dx + dy * dy) + dz * dz);
     }
-    const float c = __fdiv_rn(acc, (float)E);
+    const float c = acc / (float)E;
     cm[m] = c * c;
   }
   for (int e = 0; e < E; ++e) {
@@ -74,19 +74,19 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_kernel(const float* __restri
       const float dx = X0[jd], dy = X1[jd], dz = X2[jd];
       const float rx = fabsf(sx - lx), ry = fabsf(sy - ly), rz = fabsf(sz - lz);
       const float rxy2 = rx * rx + ry * ry;
-      const float dist = __fsqrt_rn(rxy2 + rz * rz);
-      const float ax = lx - __fdiv_rn(sx + dx, 2.f), ay = ly - __fdiv_rn(sy + dy, 2.f), az = lz - __fdiv_rn(sz + dz, 2.f);
+      const float dist = sqrtf(rxy2 + rz * rz);
+      const float ax = lx - ((sx + dx) / (2.f)), ay = ly - ((sy + dy) / (2.f)), az = lz - ((sz + dz) / (2.f));
       const float bx = dx - sx, by = dy - sy, bz = dz - sz;
       const float dot = (ax * bx + ay * by) + az * bz;
-      const float nA = __fsqrt_rn((ax * ax + ay * ay) + az * az);
-      const float nB = __fsqrt_rn((bx * bx + by * by) + bz * bz);
-      const float theta = acosf(__fdiv_rn(dot, nA * nB + 1e-6f));
-      const float phi = asinf(__fdiv_rn(ly - sy, __fsqrt_rn(rxy2) + 1e-6f));
+      const float nA = sqrtf((ax * ax + ay * ay) + az * az);
+      const float nB = sqrtf((bx * bx + by * by) + bz * bz);
+      const float theta = acosf(((dot) / (nA * nB + 1e-6f)));
+      const float phi = asinf((ly - sy) / (sqrtf(rxy2) + 1e-6f));
       const float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
       const float c = cm[m];
       const float den = ((st * st) * (cp * cp) + (st * st) * (sp * sp)) + c * (ct * ct);
-      const float amp = __fsqrt_rn(__fdiv_rn(PI_F * c, den * den));
-      const float psi = __fdiv_rn(FOURPI_F * dist, lam);
+      const float amp = sqrtf(((PI_F * c) / (den * den)));
+      const float psi = ((FOURPI_F * dist) / (lam));
       zr = zr + amp * cosf(psi);
       zi = zi + amp * sinf(psi);
     }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
   const int b = blockIdx.y, j = blockIdx.x;
   int f = j;
   if (select) {   // F.interpolate nearest: src = min(floor(j * fl32(F/ncols)), F-1)
-    const float scale = __fdiv_rn((float)F, (float)ncols);
+    const float scale = (float)F / (float)ncols;
     f = min((int)floorf((float)j * scale), F - 1);
   }
   const int half = n_fft / 2;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
     const float w = window[n];
     wz[n] = make_float2(w * z_re[(int64_t)b * T + i], w * z_im[(int64_t)b * T + i]);
     float s, c;
-    sincospif(__fdiv_rn((float)(2 * n), (float)n_fft), &s, &c);
+    sincospif((float)(2 * n) / (float)n_fft, &s, &c);
     tw[n] = make_float2(c, s);
   }
   __syncthreads();
@@ -131,9 +131,10 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
       idx += k;
       if (idx >= n_fft) idx -= n_fft;
     }
-    const float mag = __fsqrt_rn(re * re + im * im);
+    const float mag = sqrtf(re * re + im * im);
     const int row = (k + half) % n_fft;
-    out[((int64_t)b * n_fft + row) * ncols + j] = logf(mag + 1e-6f);
+    // log in double, rounded once: silent frames give exactly float32(log(1e-6)) like the reference's CPU logf
+    out[((int64_t)b * n_fft + row) * ncols + j] = (float)log((double)(mag + 1e-6f));
   }
 }
 
