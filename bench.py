@@ -26,6 +26,18 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel family from the committed PMC profile of this same workload
+    (profiles/rNN_kernel_summary.json, written by tools/summarize_profiles.py from separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("dominant_family_hbm_bytes_per_launch"), os.path.basename(files[-1])
+
+
 def physical_cores():
     try:
         import psutil
@@ -133,6 +145,7 @@ def main():
         fl = sum(summ[k]["flops"] for k in fam)
         calls = sum(summ[k]["calls"] for k in fam)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic()
         kern_ms = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())}
         kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
         out = {
@@ -145,7 +158,9 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
+                         "algorithmic_bytes_per_launch": int(sum(summ[k]["bytes"] for k in fam) / max(calls, 1)),
                          "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
                          "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
             "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),

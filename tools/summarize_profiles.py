@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/prof) into the tracked evidence under
+profiles/: the kernel-stats CSV as collected, and a per-kernel table of launches, average duration and HBM
+traffic per launch.  HBM bytes follow MI355X_MICROARCH.md section HBM: WRITE_SIZE is exact, FETCH_SIZE reports
+exactly half of a coalesced streaming read on gfx950 (re-verified here on kernels with a known byte count:
+sgd_nesterov, bn_add_relu_fwd, affine2), both counters are in KiB:   bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+P = os.path.join(ROOT, "gpurun_out", "prof")
+OUT = os.path.join(ROOT, "profiles")
+os.makedirs(OUT, exist_ok=True)
+
+
+def short(n):
+    return n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+
+
+def pmc(sub, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(P, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                a = agg[short(r["Kernel_Name"])]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    return agg
+
+
+stats = glob.glob(os.path.join(P, "trace", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(OUT, "%s_bench_kernel_stats.csv" % tag))
+dur = {}
+for r in csv.DictReader(open(stats)):
+    dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]), float(r["Percentage"]))
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+rows = []
+for k, (calls, avg_ns, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
+    f = fetch[k][1] / fetch[k][0] if fetch[k][0] else None
+    w = write[k][1] / write[k][0] if write[k][0] else None
+    hbm = (2 * f + w) * 1024 if f is not None and w is not None else None
+    rows.append({"kernel": k, "calls": calls, "avg_us": round(avg_ns / 1e3, 2), "pct_time": pct,
+                 "fetch_kib_raw": None if f is None else round(f, 1), "write_kib": None if w is None else round(w, 1),
+                 "hbm_bytes_per_launch": None if hbm is None else int(hbm),
+                 "hbm_gbps": None if hbm is None else round(hbm / avg_ns, 1)})
+fam = [r for r in rows if r["kernel"].startswith("conv_gemm_kernel<1, 0, 9") or r["kernel"].startswith("conv_gemm_kernel<1, 1, 9")]
+calls = sum(r["calls"] for r in fam)
+summary = {
+    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ; "
+               "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "hbm_rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a coalesced stream; calibrated on "
+                "sgd_nesterov / bn_add_relu_fwd / affine2 whose byte counts are known)",
+    "dominant_family": "conv_gemm_kernel<TEMPORAL, 9 taps> (forward + data-gradient instantiations)",
+    "dominant_family_launches": calls,
+    "dominant_family_avg_us": round(sum(r["avg_us"] * r["calls"] for r in fam) / calls, 2),
+    "dominant_family_hbm_bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["calls"] for r in fam) / calls),
+    "kernels": rows,
+}
+json.dump(summary, open(os.path.join(OUT, "%s_kernel_summary.json" % tag), "w"), indent=1)
+for name in ("bench_plain.log", "bench_under_trace.log"):
+    src = os.path.join(P, name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(OUT, "%s_%s" % (tag, name)))
+print("dominant family: %d launches, avg %.1f us, %.1f MB HBM per launch" %
+      (calls, summary["dominant_family_avg_us"], summary["dominant_family_hbm_bytes_per_launch"] / 1e6))
+for r in rows[:12]:
+    print("%-62s %4d x %9.1f us  %5.1f%%  %s" % (r["kernel"][:62], r["calls"], r["avg_us"], r["pct_time"],
+          "-" if r["hbm_bytes_per_launch"] is None else "%.0f MB/launch %.0f GB/s" % (r["hbm_bytes_per_launch"] / 1e6, r["hbm_gbps"])))
