@@ -92,7 +92,7 @@ typedef struct sar_conv_desc {
   float* partials;         /* [M][nparts][2] (SAR_EPI_STATS / SAR_EPI_MASK) */
 } sar_conv_desc;
 
-/* sizeof(sar_conv_desc) (which=0) / sizeof(sar_wgrad_desc) (which=1) as compiled: lets a binding verify its mirror */
+/* sizeof(sar_conv_desc) (which=0) / sizeof(sar_wgrad_desc) (1) / sizeof(sar_conv2d_desc) (2) as compiled: lets a binding verify its mirror */
 int sar_struct_size(int which);
 int sar_conv_gemm_nparts(const sar_conv_desc* d);                 /* host query, no GPU work */
 int sar_conv_gemm_f32(const sar_conv_desc* d, sar_stream_t s);
@@ -219,6 +219,55 @@ int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, const int32_t*
                       const float* loc, const float* wavelength, float* z_re, float* z_im, sar_stream_t s);
 int sar_stft_logmag_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
                         const float* window /* [n_fft] */, int out_cols, float* out, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * ResNet-18 of the spectrogram path, models/resnet18.py:131-254 (torch Conv2d bias=False / BatchNorm2d /
+ * MaxPool2d / Linear) on the CN layout: an image batch (B,C,H,W) is the matrix [C][B*H*W].
+ *
+ * sar_conv2d_gemm_f32: out[m,(b,ho,wo)] = sum_{kh,kw,c} W[tap][c][m] * pro(src)[c,(b, ho*s+kh-pad, wo*s+kw-pad)]
+ *   (nn.Conv2d, models/resnet18.py:5-23,159-164); transposed=1 is its data gradient (out at the conv's INPUT
+ *   resolution, src = gradient at its output resolution).  Supported: 3x3 and 1x1, stride 1|2; the 7x7/2 stem
+ *   (1 input channel, models/resnet18.py:159-164) forward.  W is the repacked weight: element (tap=kh*KW+kw, c, m)
+ *   at tap*w_stride_tap + c*w_stride_c + m.  pro / epi / aux / partials as in sar_conv_gemm_f32.
+ * sar_conv2d_wgrad_f32: dW[tap][c][m] = sum_n dout[m,n] * OP_tap(pro(src))[c,n] as per-split slabs laid out
+ *   (tap, c, m) with m contiguous: slab[split][taps*Kc*M]; reduce with sar_slab_reduce_f32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct sar_conv2d_desc {
+  int32_t transposed;
+  int32_t B, Kc, M;
+  int32_t H_src, W_src, H_out, W_out;
+  int32_t KH, KW, stride, pad;
+  int32_t pro_relu, epi;
+  int32_t nsplit;          /* wgrad only */
+  int32_t reserved;
+  const float* src; int64_t ld_src;
+  float* out; int64_t ld_out;                        /* gemm: output activations; wgrad: unused */
+  const float* dout; int64_t ld_dout;                /* wgrad only */
+  const float* W; int64_t w_stride_tap, w_stride_c;  /* gemm only */
+  const float* pro_scale; const float* pro_shift;
+  const float* aux; int64_t ld_aux; const float* aux_scale; const float* aux_shift; const float* aux_mean;
+  float* partials;         /* gemm: [M][nparts][2] */
+  float* slab;             /* wgrad: [nsplit][KH*KW*Kc*M] */
+} sar_conv2d_desc;
+
+int sar_conv2d_nparts(const sar_conv2d_desc* d);
+int sar_conv2d_gemm_f32(const sar_conv2d_desc* d, sar_stream_t s);
+int sar_conv2d_wgrad_f32(const sar_conv2d_desc* d, sar_stream_t s);
+
+/* out[i][j][k] (contiguous [d0][d1][d2]) = in[i*s0 + j*s1 + k*s2]: weight repacking OIHW <-> (tap, c, m). */
+int sar_permute3_f32(const float* in, float* out, int d0, int d1, int d2, int64_t s0, int64_t s1, int64_t s2,
+                     sar_stream_t s);
+/* stem tail, models/resnet18.py:236-239: y = MaxPool2d(3,2,1)(relu(x*scale[c]+shift[c])); x [C][B*H*W] -> y [C][B*Ho*Wo]. */
+int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, const float* shift, float* y, int C, int B, int H,
+                                int W, int64_t ld_x, int64_t ld_y, sar_stream_t s);
+/* its backward: dz[c,n] = gradient w.r.t. the BatchNorm output (ReLU mask applied, max routed to the first
+ * maximal element of each window like torch); partials[C][nparts][2] = (sum dz, sum dz*(x-mean[c])). */
+int sar_bn_relu_maxpool_bwd_f32(const float* x, const float* scale, const float* shift, const float* mean,
+                                const float* dy, float* dz, float* partials, int nparts, int C, int B, int H, int W,
+                                int64_t ld_x, int64_t ld_y, sar_stream_t s);
+/* torch.optim.Adam (main_spectrogram.py:106) over flat buffers; step_dev[0] = t (>= 1), lr_dev[0] = lr. */
+int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_t n, const float* lr_dev, const float* step_dev,
+                 float beta1, float beta2, float eps, sar_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -54,12 +54,21 @@ def _bn(x, p, name, training, new_stats):
     return (x - mean.view(sh)) * (torch.rsqrt(var + BN_EPS) * w).view(sh) + b.view(sh)
 
 
-def forward(p, x, training=True, new_stats=None, taps=None, num_filters=None):
+def _relu(z, masks, site):
+    """ReLU, or -- when `masks` is given -- multiplication by a prescribed activation pattern (bool tensor).  Used by
+    the GPU parity tests: two float32 implementations may put a pre-activation that is zero to within rounding on
+    different sides; conditioning the oracle on the product's pattern removes that (measure-zero) ambiguity."""
+    if masks is None:
+        return torch.relu(z)
+    return z * masks[site].to(z.dtype)
+
+
+def forward(p, x, training=True, new_stats=None, taps=None, num_filters=None, masks=None):
     """models/resnet18.py:235-251.  x (B,1,H,W) -> logits."""
     h = F.conv2d(x, p["conv1.weight"], None, stride=2, padding=3)
     if taps is not None:
         taps["conv1"] = h
-    h = torch.relu(_bn(h, p, "bn1", training, new_stats))
+    h = _relu(_bn(h, p, "bn1", training, new_stats), masks, "bn1")
     h = F.max_pool2d(h, 3, 2, 1)
     if taps is not None:
         taps["pool"] = h
@@ -69,13 +78,13 @@ def forward(p, x, training=True, new_stats=None, taps=None, num_filters=None):
             stride = 2 if (li > 0 and bi == 0) else 1
             identity = h
             o = F.conv2d(h, p[pre + "conv1.weight"], None, stride=stride, padding=1)
-            o = torch.relu(_bn(o, p, pre + "bn1", training, new_stats))
+            o = _relu(_bn(o, p, pre + "bn1", training, new_stats), masks, pre + "bn1")
             o = F.conv2d(o, p[pre + "conv2.weight"], None, stride=1, padding=1)
             o = _bn(o, p, pre + "bn2", training, new_stats)
             if (pre + "downsample.0.weight") in p:
                 identity = F.conv2d(h, p[pre + "downsample.0.weight"], None, stride=stride)
                 identity = _bn(identity, p, pre + "downsample.1", training, new_stats)
-            h = torch.relu(o + identity)
+            h = _relu(o + identity, masks, pre + "out")
             if taps is not None:
                 taps[pre + "out"] = h
     h = h.mean(dim=(2, 3))
@@ -86,14 +95,14 @@ def trainable(p):
     return [k for k in p if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
 
 
-def loss_and_grads(p, x, labels):
+def loss_and_grads(p, x, labels, masks=None):
     """main_spectrogram.py:152-157: CrossEntropyLoss() (mean over the batch) + backward."""
     names = trainable(p)
     leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
     q = dict(p)
     q.update(leaves)
     new_stats, taps = {}, {}
-    logits = forward(q, x, True, new_stats, taps)
+    logits = forward(q, x, True, new_stats, taps, masks=masks)
     loss = F.cross_entropy(logits, labels)
     grads = torch.autograd.grad(loss, [leaves[k] for k in names])
     return logits.detach(), loss.detach(), dict(zip(names, grads)), new_stats, {k: v.detach() for k, v in taps.items()}

@@ -184,7 +184,14 @@ def data_bn(x, p, training, new_stats=None):
     return h
 
 
-def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None):
+def _relu(z, masks, site):
+    """ReLU, or multiplication by a prescribed activation pattern (see oracle/resnet.py:_relu)."""
+    if masks is None:
+        return torch.relu(z)
+    return z * masks[site].to(z.dtype)
+
+
+def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None, masks=None):
     """models/stgcn.py:58-64 for block i.  x (B,Cin,T,V)."""
     f, s, res = (blocks or BLOCKS)[i]
     pre = "l%d." % i
@@ -200,13 +207,13 @@ def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None):
     g = graph_conv_td(x, p[pre + "gcn.kernel"], p[pre + "gcn.bias"], A)
     h = batch_norm(g, p[pre + "bn1.gamma"], p[pre + "bn1.beta"], p[pre + "bn1.moving_mean"],
                    p[pre + "bn1.moving_var"], training, (0, 2, 3), True, new_stats, pre + "bn1")
-    h = torch.relu(h)
+    h = _relu(h, masks, pre + "h")
     u = temporal_conv(h, p[pre + "tcn.kernel"], p[pre + "tcn.bias"], s)
     z = batch_norm(u, p[pre + "bn2.gamma"], p[pre + "bn2.beta"], p[pre + "bn2.moving_mean"],
                    p[pre + "bn2.moving_var"], training, (0, 2, 3), True, new_stats, pre + "bn2")
     if r is not None:
         z = z + r
-    y = torch.relu(z)
+    y = _relu(z, masks, pre + "y")
     if taps is not None:
         taps[pre + "g"] = g
         taps[pre + "u"] = u
@@ -214,7 +221,7 @@ def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None):
     return y
 
 
-def forward(p, x, training, new_stats=None, taps=None, blocks=None):
+def forward(p, x, training, new_stats=None, taps=None, blocks=None, masks=None):
     """models/stgcn.py:135-160.  x (N,C,T,V,M) -> logits (N, classes)."""
     N, C, T, V, M = x.shape
     h = data_bn(x, p, training, new_stats)
@@ -222,7 +229,7 @@ def forward(p, x, training, new_stats=None, taps=None, blocks=None):
         taps["x0"] = h
     A = p["A"]
     for i in range(len(blocks or BLOCKS)):
-        h = st_block(h, p, i, A, training, new_stats, taps, blocks)
+        h = st_block(h, p, i, A, training, new_stats, taps, blocks, masks)
     pooled = h.mean(dim=(2, 3))                    # GlobalAveragePooling2D, stgcn.py:154
     feat = pooled.reshape(N, M, -1).mean(dim=1)    # stgcn.py:155-156
     if taps is not None:
@@ -237,14 +244,14 @@ def loss_fn(logits, labels, global_batch_size):
     return ce * (1.0 / global_batch_size)
 
 
-def loss_and_grads(p, x, labels, global_batch_size=None, blocks=None):
+def loss_and_grads(p, x, labels, global_batch_size=None, blocks=None, masks=None):
     """One train_step's differentiable part (main_gnn.py:221-233)."""
     names = trainable_names(p)
     leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
     q = dict(p)
     q.update(leaves)
     new_stats, taps = {}, {}
-    logits = forward(q, x, True, new_stats, taps, blocks)
+    logits = forward(q, x, True, new_stats, taps, blocks, masks)
     gbs = global_batch_size or x.shape[0]
     loss = loss_fn(logits, labels, gbs)
     used = names

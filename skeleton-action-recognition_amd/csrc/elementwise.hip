@@ -17,7 +17,7 @@ void sar_set_error(const char* fmt, ...) {
 }
 extern "C" const char* sar_last_error_string(void) { return g_err; }
 extern "C" int sar_version(void) { return 100; }
-extern "C" int sar_struct_size(int which) { return which == 0 ? (int)sizeof(sar_conv_desc) : which == 1 ? (int)sizeof(sar_wgrad_desc) : -1; }
+extern "C" int sar_struct_size(int which) { return which == 0 ? (int)sizeof(sar_conv_desc) : which == 1 ? (int)sizeof(sar_wgrad_desc) : which == 2 ? (int)sizeof(sar_conv2d_desc) : -1; }
 
 namespace {
 

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's main_spectrogram.py on the MI355X-native path: same flags (main_spectrogram.py:13-62),
+same loop (main_spectrogram.py:124-189): CrossEntropyLoss, Adam(lr=base_lr), CyclicLR(1e-4 -> base_lr,
+step_size_up=lr_cycle, cycle_momentum=False) stepped once per epoch, train / val phases with loss and accuracy.
+The reference wraps the model in nn.DataParallel (main_spectrogram.py:118-119); here it is one process per GPU with
+one RCCL all-reduce of the flat gradient buffer (launch with torch.distributed.run).
+Data: `--data-path data/ntu/xview/{}_data_joint.npy --label-path data/ntu/xview/{}_label.pkl` as in the reference, or
+--synthetic.  The reference's CPU-side 250x frame upsampling (utils.py:105,134-140) is a SURVEY 8(f) next item:
+clips are fed at their native T."""
+import argparse
+import inspect
+import json
+import os
+import shutil
+
+import torch
+import torch.distributed as dist
+
+from utils import import_class, save_arg
+
+
+def get_parser():
+    parser = argparse.ArgumentParser(description='Skeleton-Based Action Recognition')
+    parser.add_argument('--base-lr', type=float, default=1e-1, help='initial learning rate')
+    parser.add_argument('--num-classes', type=int, default=60, help='number of classes in dataset')
+    parser.add_argument('--batch-size', type=int, default=64, help='training batch size')
+    parser.add_argument('--num-epochs', type=int, default=80, help='total epochs to train')
+    parser.add_argument('--num-filters', type=int, default=64, help='number of base filters in model')
+    parser.add_argument('--log-dir', default="logs/", help='folder to store model-definition/training-logs/hyperparameters')
+    parser.add_argument('--data-path', default="data/ntu/xview/{}_data_joint.npy", help='path to data files')
+    parser.add_argument('--label-path', default="data/ntu/xview/{}_label.pkl", help='path to label files')
+    parser.add_argument('--notes', default="", help='run details')
+    parser.add_argument('--model-type', default="resnet", help='model to train')
+    parser.add_argument('--lr_cycle', type=int, default=10, help='number of epochs for the cyclic LR cycle')
+    parser.add_argument('--lambda-train-epoch', type=int, default=1000, help='epoch to training the radar_lambda')
+    parser.add_argument('--loc-train-epoch', type=int, default=1000, help='epoch to training the radar_loc')
+    parser.add_argument('--synthetic', action='store_true')
+    parser.add_argument('--synthetic-size', type=int, default=2048)
+    parser.add_argument('--max-iters', type=int, default=0)
+    return parser
+
+
+def cyclic_lr(epoch, base_lr, max_lr, step_size_up):
+    """torch CyclicLR 'triangular', stepped per epoch (main_spectrogram.py:107-111,189)."""
+    total = 2 * step_size_up
+    cycle = 1 + epoch // total
+    xx = 1 + epoch / total - cycle
+    scale = xx / 0.5 if xx <= 0.5 else (xx - 1) / (0.5 - 1)
+    return base_lr + (max_lr - base_lr) * scale
+
+
+def main():
+    arg = get_parser().parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if arg.loc_train_epoch <= arg.num_epochs or arg.lambda_train_epoch <= arg.num_epochs:
+        raise NotImplementedError("training the radar parameters needs the VirtualRadar backward kernels (not built yet)")
+    arg.model_type = 'models.' + arg.model_type.strip() + '.Model'
+    run_params = {k: v for k, v in vars(arg).items() if k not in ("data_path", "label_path", "log_dir")}
+    run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
+    if arg.notes:
+        run_name += "-" + arg.notes
+    arg.log_dir = os.path.join(arg.log_dir, run_name)
+    Model = import_class(arg.model_type)
+    if rank == 0:
+        save_arg(arg)
+        shutil.copy2(inspect.getfile(Model), arg.log_dir)
+        shutil.copy2(os.path.abspath(__file__), arg.log_dir)
+
+    from sar_amd.data import NpySkeletonData, SyntheticSkeletonData
+    from sar_amd.train import allreduce_sum_
+    if arg.synthetic:
+        data = {"train": SyntheticSkeletonData(arg.synthetic_size, arg.num_classes),
+                "val": SyntheticSkeletonData(max(arg.batch_size * 2, 64), arg.num_classes)}
+    else:
+        data = {x: NpySkeletonData(arg.data_path.format(x), arg.label_path.format(x)) for x in ['train', 'val']}
+    model = Model(num_classes=arg.num_classes, num_filters=arg.num_filters, device=dev)
+    eng = model.base_model.engine
+    log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None
+
+    def scalar(tag, value, step):
+        if log:
+            log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+    for epoch in range(arg.num_epochs):
+        if rank == 0:
+            print('Epoch {}/{}'.format(epoch + 1, arg.num_epochs), flush=True)
+        lr = cyclic_lr(epoch, 1e-4, arg.base_lr, arg.lr_cycle)
+        for phase in ['train', 'val']:
+            run_loss = run_ok = n_seen = n_it = 0
+            for it, (x, y) in enumerate(data[phase].batches(arg.batch_size, rank if phase == 'train' else 0,
+                                                            world if phase == 'train' else 1, dev, shuffle=True, epoch=epoch,
+                                                            drop_remainder=phase == 'train')):
+                img = model.spectrogram(x)
+                if phase == 'train':
+                    logits, loss = eng.loss_and_grad(img, y)
+                    if world > 1:
+                        allreduce_sum_(eng.grad)
+                        eng.grad.div_(world)                     # mean over the global batch, as DataParallel's gather+mean
+                    eng.adam_step(lr)
+                else:
+                    logits = eng.forward(img, training=False)
+                    loss = torch.nn.functional.cross_entropy(logits, y).reshape(1)
+                ok = (logits.argmax(1) == y).sum()
+                scalar('{}_cross_entropy_loss'.format(phase), loss.item(), epoch * 100000 + it)
+                scalar('{}_acc'.format(phase), ok.item() / len(y), epoch * 100000 + it)
+                run_loss, run_ok, n_seen, n_it = run_loss + loss.item(), run_ok + ok.item(), n_seen + len(y), n_it + 1
+                if arg.max_iters and it + 1 >= arg.max_iters:
+                    break
+            if rank == 0:
+                scalar('{}_epoch_cross_entropy_loss'.format(phase), run_loss / max(n_it, 1), epoch)
+                scalar('{}_epoch_acc'.format(phase), run_ok / max(n_seen, 1), epoch)
+                print('{} Loss: {:.4f} Acc: {:.4f}'.format(phase, run_loss / max(n_it, 1), run_ok / max(n_seen, 1)), flush=True)
+        if log:
+            log.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

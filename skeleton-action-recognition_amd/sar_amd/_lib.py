@@ -43,6 +43,21 @@ class WgradDesc(C.Structure):
     ]
 
 
+class Conv2dDesc(C.Structure):
+    _fields_ = [
+        ("transposed", C.c_int32), ("B", C.c_int32), ("Kc", C.c_int32), ("M", C.c_int32),
+        ("H_src", C.c_int32), ("W_src", C.c_int32), ("H_out", C.c_int32), ("W_out", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("pro_relu", C.c_int32), ("epi", C.c_int32), ("nsplit", C.c_int32), ("reserved", C.c_int32),
+        ("src", _fp), ("ld_src", C.c_int64), ("out", _fp), ("ld_out", C.c_int64),
+        ("dout", _fp), ("ld_dout", C.c_int64),
+        ("W", _fp), ("w_stride_tap", C.c_int64), ("w_stride_c", C.c_int64),
+        ("pro_scale", _fp), ("pro_shift", _fp),
+        ("aux", _fp), ("ld_aux", C.c_int64), ("aux_scale", _fp), ("aux_shift", _fp), ("aux_mean", _fp),
+        ("partials", _fp), ("slab", _fp),
+    ]
+
+
 # name -> (restype, argtypes); every name must also be declared in include/sar_hip.h
 _i, _i64, _f, _d = C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
@@ -71,6 +86,13 @@ SIGNATURES = {
     "sar_pool_bwd_f32": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
     "sar_sgd_nesterov_f32": (_i, [_fp, _fp, _fp, _i64, _fp, _f, _fp]),
     "sar_transpose_f32": (_i, [_fp, _fp, _i, _i, _i, _fp]),
+    "sar_conv2d_nparts": (_i, [C.POINTER(Conv2dDesc)]),
+    "sar_conv2d_gemm_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
+    "sar_conv2d_wgrad_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
+    "sar_permute3_f32": (_i, [_fp, _fp, _i, _i, _i, _i64, _i64, _i64, _fp]),
+    "sar_bn_relu_maxpool_fwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_relu_maxpool_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i64, _i64, _fp]),
+    "sar_adam_f32": (_i, [_fp, _fp, _fp, _fp, _i64, _fp, _fp, _f, _f, _f, _fp]),
     "sar_vr_signal_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_stft_logmag_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _fp]),
 }
@@ -96,7 +118,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.sar_struct_size(0) != C.sizeof(ConvDesc) or lib.sar_struct_size(1) != C.sizeof(WgradDesc):
+    if (lib.sar_struct_size(0) != C.sizeof(ConvDesc) or lib.sar_struct_size(1) != C.sizeof(WgradDesc)
+            or lib.sar_struct_size(2) != C.sizeof(Conv2dDesc)):
         raise SarError("descriptor layout mismatch between include/sar_hip.h and sar_amd/_lib.py")
     _lib = lib
     return lib

@@ -208,3 +208,85 @@ def sgd_nesterov(w, v, g, lr_dev, momentum):
 
 def transpose(inp, out, batch, R, Cc):
     check(L.load().sar_transpose_f32(ptr(inp), ptr(out), batch, R, Cc, stream_ptr()), "sar_transpose_f32")
+
+
+# ------------------------------------------------------------------------------------------------ ResNet-18 ops
+def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, pad, transposed=False, pro=None,
+                 pro_relu=False):
+    d = L.Conv2dDesc()
+    d.transposed, d.B, d.Kc, d.M = int(transposed), B, Kc, M
+    d.H_src, d.W_src, d.H_out, d.W_out = H_src, W_src, H_out, W_out
+    d.KH, d.KW, d.stride, d.pad, d.pro_relu = KH, KW, stride, pad, int(pro_relu)
+    d.src, d.ld_src = ptr(_f32(src)), src.stride(0)
+    if pro is not None:
+        d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
+    return d
+
+
+def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, aux=None, aux_affine=None, aux_mean=None,
+                **geo):
+    """sar_conv2d_gemm_f32.  Returns (partials, nparts) when the epilogue reduces."""
+    lib = L.load()
+    d = _conv2d_desc(src, **geo)
+    d.out, d.ld_out = ptr(_f32(out)), out.stride(0)
+    d.W, d.w_stride_tap, d.w_stride_c, d.epi = ptr(_f32(W)), w_stride_tap, w_stride_c, epi
+    if aux is not None:
+        d.aux, d.ld_aux = ptr(_f32(aux)), aux.stride(0)
+    if aux_affine is not None:
+        d.aux_scale, d.aux_shift = ptr(_f32(aux_affine[0])), ptr(_f32(aux_affine[1]))
+    d.aux_mean = ptr(_f32(aux_mean))
+    partials = None
+    nparts = 0
+    if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
+        nparts = lib.sar_conv2d_nparts(C.byref(d))
+        if nparts <= 0:
+            check(nparts or -1, "sar_conv2d_nparts")
+        partials = torch.empty((geo["M"], nparts, 2), dtype=torch.float32, device=src.device)
+        d.partials = ptr(partials)
+    n_conv = geo["B"] * (geo["H_src"] * geo["W_src"] if geo.get("transposed") else geo["H_out"] * geo["W_out"])
+    flops = 2.0 * geo["M"] * geo["Kc"] * geo["KH"] * geo["KW"] * n_conv
+    with profiler.region("conv2d_%dx%d%s" % (geo["KH"], geo["KW"], "_dgrad" if geo.get("transposed") else ""), flops):
+        check(lib.sar_conv2d_gemm_f32(C.byref(d), stream_ptr()), "sar_conv2d_gemm_f32")
+    return (partials, nparts) if partials is not None else None
+
+
+def conv2d_wgrad(src, dout, dW_tcm, **geo):
+    """dW in (tap, c, m) layout -> dW_tcm (flat, taps*Kc*M floats)."""
+    lib = L.load()
+    d = _conv2d_desc(src, **geo)
+    d.dout, d.ld_dout = ptr(_f32(dout)), dout.stride(0)
+    taps = geo["KH"] * geo["KW"]
+    n = taps * geo["Kc"] * geo["M"]
+    wgs = ((geo["M"] + 63) // 64) * max(1, (geo["Kc"] + 31) // 32)
+    nsplit = max(1, min(geo["B"] * max(1, geo["H_out"] // 2), (768 + wgs - 1) // wgs))
+    d.nsplit = nsplit
+    slab = torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
+    d.slab = ptr(slab)
+    flops = 2.0 * geo["M"] * geo["Kc"] * taps * geo["B"] * geo["H_out"] * geo["W_out"]
+    with profiler.region("conv2d_wgrad_%dx%d" % (geo["KH"], geo["KW"]), flops):
+        check(lib.sar_conv2d_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv2d_wgrad_f32")
+    check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")
+
+
+def permute3(inp, out, d0, d1, d2, s0, s1, s2):
+    check(L.load().sar_permute3_f32(ptr(inp), ptr(out), d0, d1, d2, s0, s1, s2, stream_ptr()), "sar_permute3_f32")
+
+
+def bn_relu_maxpool_fwd(x, scale, shift, y, B, H, W):
+    check(L.load().sar_bn_relu_maxpool_fwd_f32(ptr(x), ptr(scale), ptr(shift), ptr(y), x.shape[0], B, H, W, x.stride(0),
+                                               y.stride(0), stream_ptr()), "sar_bn_relu_maxpool_fwd_f32")
+
+
+def bn_relu_maxpool_bwd(x, scale, shift, mean, dy, dz, B, H, W):
+    Cc = x.shape[0]
+    nparts = max(1, min(256, (B * H * W + 8191) // 8192))
+    partials = torch.empty((Cc, nparts, 2), dtype=torch.float32, device=x.device)
+    check(L.load().sar_bn_relu_maxpool_bwd_f32(ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(dy), ptr(dz), ptr(partials),
+                                               nparts, Cc, B, H, W, x.stride(0), dy.stride(0), stream_ptr()),
+          "sar_bn_relu_maxpool_bwd_f32")
+    return partials, nparts
+
+
+def adam(w, m, v, g, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(L.load().sar_adam_f32(ptr(w), ptr(m), ptr(v), ptr(g), w.numel(), ptr(lr_dev), ptr(step_dev), beta1, beta2, eps,
+                                stream_ptr()), "sar_adam_f32")

@@ -1,0 +1,289 @@
+"""ResNet-18 (1 input channel, configurable width) training engine on the HIP kernels -- the spectrogram path's
+classifier (reference models/resnet18.py:131-254: stem Conv7x7/2 + BN + ReLU + MaxPool3x3/2, four stages of two
+BasicBlocks :26-72, AdaptiveAvgPool, Linear) and its train step (main_spectrogram.py:105-111,152-158: mean
+CrossEntropyLoss, Adam).
+
+Parameters keep the reference's state_dict names and torch layouts (conv OIHW, fc (classes, 512)) as views of one
+flat fp32 buffer; per step the conv weights are re-packed once into the (tap, c, m) / (tap, m, c) layouts the GEMM
+kernels read.  Activations are CN matrices [C][B*H*W]; per BasicBlock the tensors crossing a BatchNorm barrier
+(c1, c2, downsample out, block out) are materialised once; BN+ReLU is folded into the consumer conv's operand load,
+BN statistics into the producer's epilogue, the block tail reuses the ST-GCN BN+add+ReLU kernels.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .stgcn import _BN
+
+BN_EPS = 1e-5            # torch BatchNorm2d defaults (models/resnet18.py norm_layer = nn.BatchNorm2d)
+BN_KEEP = 0.9            # running = 0.9*running + 0.1*batch  (torch momentum 0.1)
+LAYERS = [2, 2, 2, 2]    # models/resnet18.py:274
+
+
+class _Conv:
+    def __init__(self, name, cin, cout, k, stride, pad):
+        self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        self.taps = k * k
+
+
+class ResNet18:
+    def __init__(self, num_classes=60, num_filters=64, device="cuda", seed=0):
+        L.load()
+        self.device = torch.device(device)
+        self.num_classes, self.nf = num_classes, num_filters
+        self.shapes, self.convs, self.bn_names, self.blocks = {}, {}, [], []
+
+        def conv(name, cin, cout, k, stride):
+            self.shapes[name + ".weight"] = (cout, cin, k, k)
+            self.convs[name] = _Conv(name, cin, cout, k, stride, k // 2)
+
+        def bn(name, c):
+            self.shapes[name + ".weight"] = (c,)
+            self.shapes[name + ".bias"] = (c,)
+            self.bn_names.append((name, c))
+
+        conv("conv1", 1, num_filters, 7, 2)
+        bn("bn1", num_filters)
+        inpl = num_filters
+        for li, nb in enumerate(LAYERS):
+            planes = num_filters * 2 ** li
+            for bi in range(nb):
+                pre = "layer%d.%d." % (li + 1, bi)
+                stride = 2 if (li > 0 and bi == 0) else 1
+                conv(pre + "conv1", inpl, planes, 3, stride)
+                bn(pre + "bn1", planes)
+                conv(pre + "conv2", planes, planes, 3, 1)
+                bn(pre + "bn2", planes)
+                ds = stride != 1 or inpl != planes
+                if ds:
+                    conv(pre + "downsample.0", inpl, planes, 1, stride)
+                    bn(pre + "downsample.1", planes)
+                self.blocks.append((pre, inpl, planes, stride, ds))
+                inpl = planes
+        self.c_last = inpl
+        self.shapes["fc.weight"] = (num_classes, inpl)
+        self.shapes["fc.bias"] = (num_classes,)
+        total, self.offsets = 0, {}
+        for k, shp in self.shapes.items():
+            self.offsets[k] = total
+            total += (int(np.prod(shp)) + 3) // 4 * 4
+        self.n_params = sum(int(np.prod(s)) for s in self.shapes.values())
+        dev = self.device
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat, self.grad, self.adam_m, self.adam_v = z(total), z(total), z(total), z(total)
+        self.lr_dev, self.step_dev = z(1), z(1)
+        self.p = {k: self._view(self.flat, k) for k in self.shapes}
+        self.g = {k: self._view(self.grad, k) for k in self.shapes}
+        self.bn = {name: _BN(c, dev) for name, c in self.bn_names}
+        self._init_params(seed)
+        self._packed = {}
+        self._saved = None
+
+    def _view(self, flat, name):
+        o = self.offsets[name]
+        return flat[o:o + int(np.prod(self.shapes[name]))].view(self.shapes[name])
+
+    def _init_params(self, seed):
+        """models/resnet18.py:187-194: kaiming_normal_(fan_out, relu) for convs, BN weight 1 / bias 0;
+        nn.Linear default init for fc."""
+        gen = torch.Generator().manual_seed(seed)
+        for k, shp in self.shapes.items():
+            if len(shp) == 4:
+                fan_out = shp[0] * shp[2] * shp[3]
+                self.p[k].copy_(torch.randn(shp, generator=gen) * math.sqrt(2.0 / fan_out))
+            elif k == "fc.weight":
+                bound = 1.0 / math.sqrt(shp[1])
+                self.p[k].copy_((torch.rand(shp, generator=gen) * 2 - 1) * bound)
+            elif k == "fc.bias":
+                bound = 1.0 / math.sqrt(self.shapes["fc.weight"][1])
+                self.p[k].copy_((torch.rand(shp, generator=gen) * 2 - 1) * bound)
+            elif k.endswith(".weight"):
+                self.p[k].fill_(1.0)
+            else:
+                self.p[k].zero_()
+
+    def load_params(self, params):
+        for k, v in params.items():
+            if k in self.p:
+                self.p[k].copy_(v.to(torch.float32).reshape(self.shapes[k]))
+            elif k.endswith(".running_mean"):
+                self.bn[k[:-13]].moving_mean.copy_(v.to(torch.float32))
+            elif k.endswith(".running_var"):
+                self.bn[k[:-12]].moving_var.copy_(v.to(torch.float32))
+
+    def state_dict(self):
+        out = {k: v.detach().cpu().clone() for k, v in self.p.items()}
+        for k, b in self.bn.items():
+            out[k + ".running_mean"] = b.moving_mean.cpu().clone()
+            out[k + ".running_var"] = b.moving_var.cpu().clone()
+        return out
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, need_bwd):
+        """(tap, c, m) forward and (tap, m, c) data-gradient layouts of every conv weight (once per step)."""
+        dev = self.device
+        for name, cv in self.convs.items():
+            w = self.p[name + ".weight"]
+            f = torch.empty(cv.taps * cv.cin * cv.cout, dtype=torch.float32, device=dev)
+            ops.permute3(w, f, cv.taps, cv.cin, cv.cout, 1, cv.taps, cv.cin * cv.taps)
+            bk = None
+            if need_bwd and name != "conv1":
+                bk = torch.empty_like(f)
+                ops.permute3(w, bk, cv.taps, cv.cout, cv.cin, 1, cv.cin * cv.taps, cv.taps)
+            self._packed[name] = (f, bk)
+
+    def _conv_fwd(self, name, X, B, H, W, training, pro=None):
+        cv = self.convs[name]
+        Ho, Wo = (H + 2 * cv.pad - cv.k) // cv.stride + 1, (W + 2 * cv.pad - cv.k) // cv.stride + 1
+        out = torch.empty((cv.cout, B * Ho * Wo), dtype=torch.float32, device=X.device)
+        r = ops.conv2d_gemm(X, out, self._packed[name][0], cv.cin * cv.cout, cv.cout,
+                            epi=L.SAR_EPI_STATS if training else L.SAR_EPI_NONE, B=B, Kc=cv.cin, M=cv.cout, H_src=H,
+                            W_src=W, H_out=Ho, W_out=Wo, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro,
+                            pro_relu=pro is not None)
+        return out, r, Ho, Wo
+
+    def _bn_stats(self, name, r, count, training):
+        b = self.bn[name]
+        if training:
+            ops.bn_finalize(r[0], r[1], b.mean.numel(), count, BN_EPS, BN_KEEP, True, self.p[name + ".weight"],
+                            self.p[name + ".bias"], b.moving_mean, b.moving_var, b.mean, b.rstd, b.scale, b.shift)
+        else:
+            ops.bn_eval_affine(self.p[name + ".weight"], self.p[name + ".bias"], b.moving_mean, b.moving_var, BN_EPS,
+                               b.scale, b.shift)
+        return b
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training=True, keep=None):
+        """x: (B, 1, H, W) float32 cuda -> logits (B, classes).  models/resnet18.py:235-251."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        dev = x.device
+        self._pack(training)
+        X0 = x.view(1, B * H * W)
+        c0, r, H1, W1 = self._conv_fwd("conv1", X0, B, H, W, training)
+        bn0 = self._bn_stats("bn1", r, B * H1 * W1, training)
+        H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        h = torch.empty((self.nf, B * H2 * W2), dtype=torch.float32, device=dev)
+        ops.bn_relu_maxpool_fwd(c0, bn0.scale, bn0.shift, h, B, H1, W1)
+        if keep is not None:
+            keep["conv1"], keep["pool"] = c0, h
+        saved = dict(x0=X0, c0=c0, B=B, H=H, W=W, H1=H1, W1=W1, H2=H2, W2=W2, blocks=[])
+        Hc, Wc = H2, W2
+        for pre, inpl, planes, stride, ds in self.blocks:
+            c1, r1, Ho, Wo = self._conv_fwd(pre + "conv1", h, B, Hc, Wc, training)
+            b1 = self._bn_stats(pre + "bn1", r1, B * Ho * Wo, training)
+            c2, r2, _, _ = self._conv_fwd(pre + "conv2", c1, B, Ho, Wo, training, pro=(b1.scale, b1.shift))
+            b2 = self._bn_stats(pre + "bn2", r2, B * Ho * Wo, training)
+            dsc = bd = None
+            if ds:
+                dsc, rd, _, _ = self._conv_fwd(pre + "downsample.0", h, B, Hc, Wc, training)
+                bd = self._bn_stats(pre + "downsample.1", rd, B * Ho * Wo, training)
+            y = torch.empty_like(c2)
+            ops.bn_add_relu_fwd(c2, b2.scale, b2.shift, 2 if ds else 1, dsc if ds else h, bd.scale if ds else None,
+                                bd.shift if ds else None, y)
+            if training:
+                saved["blocks"].append(dict(X=h, c1=c1, c2=c2, dsc=dsc, y=y, H=Hc, W=Wc, Ho=Ho, Wo=Wo))
+            if keep is not None:
+                keep[pre + "out"], keep[pre + "c1"] = y, c1
+            h, Hc, Wc = y, Ho, Wo
+        feat = torch.empty((B, self.c_last), dtype=torch.float32, device=dev)
+        ops.pool_fwd(h, B, Hc * Wc, 1, feat)
+        wt = torch.empty((self.c_last, self.num_classes), dtype=torch.float32, device=dev)
+        ops.transpose(self.p["fc.weight"], wt, 1, self.num_classes, self.c_last)
+        logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=dev)
+        ops.fc_fwd(feat, wt, self.p["fc.bias"], logits)
+        saved.update(feat=feat, wt=wt, Hl=Hc, Wl=Wc)
+        self._saved = saved if training else None
+        return logits
+
+    # ------------------------------------------------------------------ backward
+    def _conv_wgrad(self, name, X, dout, B, H, W, Ho, Wo, pro=None):
+        cv = self.convs[name]
+        tmp = torch.empty(cv.taps * cv.cin * cv.cout, dtype=torch.float32, device=X.device)
+        ops.conv2d_wgrad(X, dout, tmp, B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k, KW=cv.k,
+                         stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None)
+        # (tap, c, m) -> OIHW gradient view
+        ops.permute3(tmp, self.g[name + ".weight"], cv.cout, cv.cin, cv.taps, 1, cv.cout, cv.cin * cv.cout)
+
+    def _conv_dgrad(self, name, dout, B, H, W, Ho, Wo, **epi):
+        """gradient w.r.t. the conv's input (H, W) from dout at (Ho, Wo)."""
+        cv = self.convs[name]
+        dx = torch.empty((cv.cin, B * H * W), dtype=torch.float32, device=dout.device)
+        r = ops.conv2d_gemm(dout, dx, self._packed[name][1], cv.cout * cv.cin, cv.cin, B=B, Kc=cv.cout, M=cv.cin, H_src=Ho,
+                            W_src=Wo, H_out=H, W_out=W, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, transposed=True,
+                            **epi)
+        return dx, r
+
+    def _bn_bwd(self, name, part, nparts, chan_stride, part_stride, off2, count):
+        b = self.bn[name]
+        ops.bn_bwd_finalize(part, nparts, chan_stride, part_stride, 0, off2, b.mean.numel(), count,
+                            self.p[name + ".weight"], b.mean, b.rstd, self.g[name + ".weight"], self.g[name + ".bias"],
+                            b.k1, b.k2, b.k3)
+        return b
+
+    def backward(self, dlogits):
+        sv = self._saved
+        assert sv is not None
+        dev, B = dlogits.device, sv["B"]
+        dwt = torch.empty_like(sv["wt"])
+        dfeat = torch.empty_like(sv["feat"])
+        ops.fc_bwd(sv["feat"], sv["wt"], dlogits.contiguous(), dwt, self.g["fc.bias"], dfeat)
+        ops.transpose(dwt, self.g["fc.weight"], 1, self.c_last, self.num_classes)
+        dY = torch.empty((self.c_last, B * sv["Hl"] * sv["Wl"]), dtype=torch.float32, device=dev)
+        ops.pool_bwd(dfeat, B, sv["Hl"] * sv["Wl"], 1, dY)
+        for (pre, inpl, planes, stride, ds), sb in zip(reversed(self.blocks), reversed(sv["blocks"])):
+            X, c1, c2, dsc, y = sb["X"], sb["c1"], sb["c2"], sb["dsc"], sb["y"]
+            H, W, Ho, Wo = sb["H"], sb["W"], sb["Ho"], sb["Wo"]
+            n_out = B * Ho * Wo
+            b1, b2 = self.bn[pre + "bn1"], self.bn[pre + "bn2"]
+            bd = self.bn.get(pre + "downsample.1")
+            part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None)
+            self._bn_bwd(pre + "bn2", part, nparts, nparts * 4, 4, 1, n_out)
+            rk = None
+            if ds:
+                self._bn_bwd(pre + "downsample.1", part, nparts, nparts * 4, 4, 2, n_out)
+                rk = (bd.k1, bd.k2, bd.k3)
+            dc2 = torch.empty_like(c2)
+            ddsc = torch.empty_like(dsc) if ds else None
+            ops.bn_add_relu_bwd_apply(dY, y, c2, dsc, (b2.k1, b2.k2, b2.k3), rk, dc2, ddsc, None if ds else dY)
+            # conv2 (input = relu(bn1(c1)), folded)
+            self._conv_wgrad(pre + "conv2", c1, dc2, B, Ho, Wo, Ho, Wo, pro=(b1.scale, b1.shift))
+            dz1, pm = self._conv_dgrad(pre + "conv2", dc2, B, Ho, Wo, Ho, Wo, epi=L.SAR_EPI_MASK, aux=c1,
+                                       aux_affine=(b1.scale, b1.shift), aux_mean=b1.mean)
+            self._bn_bwd(pre + "bn1", pm[0], pm[1], pm[1] * 2, 2, 1, n_out)
+            ops.affine2(dz1, c1, (b1.k1, b1.k2, b1.k3), dz1)            # dc1 in place
+            self._conv_wgrad(pre + "conv1", X, dz1, B, H, W, Ho, Wo)
+            aux = dY
+            if ds:
+                self._conv_wgrad(pre + "downsample.0", X, ddsc, B, H, W, Ho, Wo)
+                aux, _ = self._conv_dgrad(pre + "downsample.0", ddsc, B, H, W, Ho, Wo)
+            dY, _ = self._conv_dgrad(pre + "conv1", dz1, B, H, W, Ho, Wo, epi=L.SAR_EPI_ADD, aux=aux)
+        # stem: maxpool + relu + bn backward, then the 7x7 weight gradient (the image needs no gradient)
+        bn0 = self.bn["bn1"]
+        c0 = sv["c0"]
+        dz0 = torch.empty_like(c0)
+        part, nparts = ops.bn_relu_maxpool_bwd(c0, bn0.scale, bn0.shift, bn0.mean, dY, dz0, B, sv["H1"], sv["W1"])
+        self._bn_bwd("bn1", part, nparts, nparts * 2, 2, 1, B * sv["H1"] * sv["W1"])
+        ops.affine2(dz0, c0, (bn0.k1, bn0.k2, bn0.k3), dz0)
+        self._conv_wgrad("conv1", sv["x0"], dz0, B, sv["H"], sv["W"], sv["H1"], sv["W1"])
+        self._saved = None
+
+    # ------------------------------------------------------------------ training step
+    def loss_and_grad(self, x, labels):
+        """main_spectrogram.py:152-157: CrossEntropyLoss() (mean) and backward."""
+        logits = self.forward(x, training=True)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dlogits = torch.empty_like(logits)
+        ops.softmax_ce(logits, labels, 1.0 / x.shape[0], loss, dlogits)
+        self.backward(dlogits)
+        return logits, loss
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        """torch.optim.Adam(lr) (main_spectrogram.py:106) over the flat buffers."""
+        self.step_dev += 1.0
+        self.lr_dev.fill_(float(lr))
+        ops.adam(self.flat, self.adam_m, self.adam_v, self.grad, self.lr_dev, self.step_dev, betas[0], betas[1], eps)

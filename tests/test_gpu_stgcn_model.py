@@ -4,15 +4,13 @@ the CPU oracle.
 Tolerance (norm-wise relative, max|a-b|/max|b|, reference value = the float64 oracle):
   * activations, logits, loss, BN moving statistics: 1e-4 (north_star: "fp32 logits/grads within 1e-4 rel");
   * gradients of stacks up to 4 blocks: 1e-4 on every tensor;
-  * gradients of the full 10-block stack: measured against the float32 CPU oracle's OWN error band.  There the
-    float32 CPU restatement (the precision class of the reference's CPU forward/backward) is itself up to
-    ~3e-3 away from the float64 truth (activations agree to 3e-6): BatchNorm-backward sums cancel heavily, and a
-    single ReLU whose pre-activation is within rounding of 0 flips its mask, which moves that channel's
-    sum(dz) -- hence that block's bn1.beta and gcn.kernel gradients -- by ~1/sqrt(positions) ~ 6e-3.  Which
-    elements flip differs between ANY two float32 implementations, so the deep-stack criterion is statistical:
-      - every gradient tensor <= 1e-2,
-      - >= 90 % of the tensors <= max(1e-4, 3 x that tensor's float32-oracle error, worst float32-oracle error),
-      - median over tensors <= 3 x max(median float32-oracle error, 1e-4)."""
+  * gradients of the full 10-block stack: 1e-4 on every tensor against the float64 oracle CONDITIONED ON THE
+    ENGINE'S ACTIVATION PATTERN (every ReLU replaced by multiplication with the mask the HIP path used).  Why: a
+    pre-activation that is zero to within rounding lands on either side in any two float32 implementations; one
+    such flip moves that channel's heavily-cancelled sum(dz) -- hence that block's bn1.beta / gcn.kernel
+    gradients -- by ~1/sqrt(positions) ~ 6e-3 (the float32 CPU oracle itself is up to 3e-3 from the float64
+    truth on this stack for the same reason).  With the pattern fixed the comparison is exact again; the number
+    of flipped elements is printed (a handful out of ~1e8)."""
 import os
 
 import numpy as np
@@ -58,6 +56,22 @@ def _compare(dev, blocks, N, T, classes, seed, tol=TOL, x=None, y=None):
         worst["l%d.y" % i] = rel_err(from_cn(keep["l%d.y" % i].cpu(), B, To, 25), taps["l%d.y" % i])
         Tc = To
     worst["logits"] = rel_err(logits.cpu(), logits_ref)
+    if len(blocks) > 4:
+        # activation pattern of the HIP path: block outputs y > 0; the ReLU folded into the temporal conv's operand
+        # load is re-evaluated with the engine's own arithmetic relu(fma(g, scale, shift))
+        from sar_amd import ops
+        masks, flips, Tm = {}, 0, x.shape[2]
+        for i, (f, s, _) in enumerate(blocks):
+            To = -(-Tm // s)
+            bn1 = eng.bn["l%d.bn1" % i]
+            hbuf = torch.empty_like(keep["l%d.g" % i])
+            ops.bn_add_relu_fwd(keep["l%d.g" % i], bn1.scale, bn1.shift, 0, None, None, None, hbuf)
+            masks["l%d.h" % i] = from_cn((hbuf > 0).cpu(), B, Tm, 25)
+            masks["l%d.y" % i] = from_cn((keep["l%d.y" % i] > 0).cpu(), B, To, 25)
+            flips += int((masks["l%d.y" % i] != (taps["l%d.y" % i] > 0)).sum())
+            Tm = To
+        print("ReLU-tie flips vs the unconditioned oracle (block outputs): %d" % flips)
+        _, _, grads_ref, _, _ = O.loss_and_grads(p, x.double(), y, blocks=blocks, masks=masks)
     logits2, loss = eng.loss_and_grad(xg, yg)
     torch.cuda.synchronize()
     worst["loss"] = rel_err(loss.cpu(), loss_ref.reshape(1))
@@ -76,33 +90,8 @@ def _compare(dev, blocks, N, T, classes, seed, tol=TOL, x=None, y=None):
         batch = (v - m * p[k]) / (1 - m)
         second = m * v + (1 - m) * batch
         worst["stat " + k] = rel_err(got.cpu(), second)
-    deep = len(blocks) > 4
-    def limit(k):
-        if deep and k.startswith("grad ") and k[5:] in band:
-            return max(tol, 3 * band[k[5:]], band_max)
-        return tol
-    bad = {k: (v, limit(k)) for k, v in worst.items() if not (v < limit(k))}
-    if deep:   # statistical criterion for ReLU-tie-limited deep-stack gradients (see module docstring)
-        import statistics
-        gk = [k for k in worst if k.startswith("grad ") and k[5:] in band]
-        outliers = {k: v for k, v in bad.items() if k in gk}
-        hard = {k: v for k, v in bad.items() if k not in gk}
-        med_hip = statistics.median(worst[k] for k in gk)
-        med_ref = statistics.median(band[k[5:]] for k in gk)
-        print("deep-stack gradients: %d/%d tensors outside their band, median %.2e (float32 oracle %.2e)" %
-              (len(outliers), len(gk), med_hip, med_ref))
-        assert all(worst[k] < 1e-2 for k in gk), {k: worst[k] for k in gk if worst[k] >= 1e-2}
-        assert len(outliers) <= 0.1 * len(gk), outliers
-        assert med_hip <= 3 * max(med_ref, tol), (med_hip, med_ref)
-        bad = hard
-    print("float32-oracle gradient error band: max %.3e" % band_max)
-    try:   # full per-tensor report for offline inspection (gpurun_out/ is merged back by gpurun)
-        import json
-        os.makedirs("gpurun_out", exist_ok=True)
-        with open("gpurun_out/parity_%dblocks_T%d_seed%d.json" % (len(blocks), x.shape[2], seed), "w") as fh:
-            json.dump({"hip_vs_fp64": worst, "fp32oracle_vs_fp64": band}, fh, indent=0)
-    except OSError:
-        pass
+    bad = {k: (v, tol) for k, v in worst.items() if not (v < tol)}
+    print("float32-oracle gradient error band (unconditioned): max %.3e" % band_max)
     report = "\n".join("%-28s %.3e" % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:12])
     print(report)
     assert not bad, "parity failures (tol %g):\n%s\nworst:\n%s" % (tol, bad, report)
