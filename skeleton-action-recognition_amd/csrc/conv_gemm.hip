@@ -23,42 +23,56 @@
 //  * fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD: 2 LDS dwords per MFMA per lane at most,
 //    so the kernel is matrix-pipe bound, not LDS bound; occupancy (2-3 workgroups/CU) hides staging.
 #include "sar_common.h"
+#include <type_traits>
 
 namespace {
 
-#ifndef SAR_KC
-#define SAR_KC 4
-#endif
-constexpr int KC = SAR_KC;  // src channels staged per main-loop iteration (KC/2 MFMA k-steps)
+constexpr int KC = 4;  // src channels staged per main-loop iteration (2 MFMA k-steps); one S row per wave
 
 struct ConvK {
   sar_conv_desc d;
-  int FT, TPS, NF, RW, SROW, nparts;
+  int FT, TPS, NF, RW, nparts;
   int w_vec;   // weight rows may be read as aligned float4
 };
 
-template <int MODE, int TRANSPOSED, int TAPS, int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
+// compile-time tile description shared by the kernel and the host launcher
+template <int MODE, int TAPS, int MS, int NS, int WM, int WN>
+struct TileCfg {
+  static constexpr int BM = 32 * MS * WM;
+  static constexpr int TN = 32 * NS * WN;
+  static constexpr int WROWS = TAPS * KC;
+  static constexpr int WRPP = 1024 / BM;                        // W rows staged per pass (one float4 per lane)
+  static constexpr int WIT = (WROWS + WRPP - 1) / WRPP;         // W passes
+  static constexpr int WSTR = BM;                               // W row stride
+  static constexpr int RWMAX = (MODE == SAR_CONV_GRAPH) ? TN : (TN == 128 ? 448 : 704);
+  static constexpr int SJ = RWMAX / 64;                         // S columns per lane
+  static constexpr int SSTR = RWMAX + 32;                       // S row stride (== 32 mod 64: the two k rows of a read
+                                                                // fall into different bank halves)
+  static constexpr int BUF = WIT * WRPP * WSTR + KC * SSTR;     // floats per LDS buffer
+};
+
+// TR selects the temporal variant: 0 forward; 1 data gradient at stride 1 (every tap valid); 2 data gradient,
+// generic stride (per-lane tap validity mask); 3 data gradient at stride 2 with the PARITY-SPLIT column map: the
+// first half of the tile's columns holds the even frames and the second half the odd ones, so a wave's columns
+// share the frame parity and only the <= 5 taps that reach a real source frame are issued at all (the masked
+// variant spends half of its MFMAs on zeros).
+template <int MODE, int TR, int TAPS, int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
-  constexpr int BM = 32 * MS * WM;
+  using TC = TileCfg<MODE, TAPS, MS, NS, WM, WN>;
+  constexpr int TRANSPOSED = TR != 0;
+  constexpr int PAR = (TR == 3);
+  constexpr int JT = PAR ? (TAPS + 1) / 2 : TAPS;   // tap slots a wave iterates
+  constexpr int BM = TC::BM;
   constexpr int NZMAX = 4;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
-  // staging maps (no per-element division):
-  //  W tile: TAPS*KC rows of BM floats, one float4 per lane, 1024/BM rows per pass
-  //  S tile: KC rows, 256/KC consecutive lanes per row and pass, SJMAX passes cover RW columns
-  constexpr int WROWS = TAPS * KC;
-  constexpr int WRPP = 1024 / BM;                       // W rows per pass
-  constexpr int WIT = (WROWS + WRPP - 1) / WRPP;        // W passes
-  constexpr int SLPR = 256 / KC;                        // lanes per S row
-  constexpr int SJMAX = ((MODE == SAR_CONV_GRAPH) ? 32 * NS * WN : (NS * WN == 4 ? 448 : 704)) / SLPR;
+  constexpr int WROWS = TC::WROWS, WRPP = TC::WRPP, WIT = TC::WIT, WSTR = TC::WSTR, SJ = TC::SJ, SSTR = TC::SSTR;
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert((KC == 8 || KC == 4) && 256 % KC == 0, "S stager: 256/KC lanes per src channel row");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // two LDS buffers: the stage being multiplied and the stage being written (one barrier per stage)
+  __shared__ __attribute__((aligned(16))) float smem[2 * TC::BUF];
   const sar_conv_desc& d = k.d;
-  float* Wl = smem;                      // [TAPS][KC][BM]   (16-byte aligned rows)
-  float* S = smem + WROWS * BM;          // [KC][SROW]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int V = d.V;
@@ -70,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   // ---- per-lane column geometry (fixed for the whole kernel)
   bool colok[NS];
   int64_t coln[NS];  // output column index n
-  int off[TAPS][NS];           // TEMPORAL: LDS column offset per tap
-  unsigned vmask[NS];          // TEMPORAL transposed: tap validity bits
+  int off[JT][NS];             // TEMPORAL: LDS column offset per tap slot
+  unsigned vmask[NS];          // TEMPORAL TR==2: tap validity bits
   int goff[3][NS][NZMAX];      // GRAPH: LDS column offset of each gather entry
   float gw[3][NS][NZMAX];      // GRAPH: weight of each gather entry
   float gcs[3][NS];            // GRAPH: colsum(A_k)[v] for the bias term
@@ -81,20 +95,37 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   else if (!TRANSPOSED) t_lo = t0 * d.stride - d.pad;
   else t_lo = floordiv(t0 + d.pad - (TAPS - 1), d.stride);
 
+  // parity split (TR==3): t0 is even (FT even), so the frame parity of a column is that of its half-tile
+  constexpr int HALFC = 16 * NS * WN;
+  const int par = PAR ? (wn * NS * 32 >= HALFC ? 1 : 0) : 0;
+  const int tp0 = PAR ? ((par + d.pad) & 1) : 0;          // first valid tap of this wave; then every other one
+  const int ntap_w = PAR ? (TAPS - tp0 + 1) / 2 : TAPS;   // wave-uniform
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const int p = (wn * NS + ns) * 32 + l31;
-    int fo = p / V;
-    const int v = p - fo * V;
-    colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
-    if (!colok[ns]) fo = 0;
+    int fo, v;
+    if (PAR) {
+      const int pp = p - par * HALFC;
+      const int fh = pp / V;
+      v = pp - fh * V;
+      fo = 2 * fh + par;
+      colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
+    } else {
+      fo = p / V;
+      v = p - fo * V;
+      colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
+    }
+    if (!colok[ns]) fo = par;
     coln[ns] = ((int64_t)b * d.T_out + (t0 + fo)) * V + v;
     vmask[ns] = 0;
     if (MODE == SAR_CONV_TEMPORAL) {
 #pragma unroll
-      for (int tp = 0; tp < TAPS; ++tp) {
+      for (int tp = 0; tp < JT; ++tp) {
         if (!TRANSPOSED) {
           off[tp][ns] = (fo * d.stride + tp) * V + v;
+        } else if (PAR) {
+          const int to = (t0 + fo + d.pad - (tp0 + 2 * tp)) >> 1;   // exact: the numerator is even
+          off[tp][ns] = (to - t_lo) * V + v;
         } else {
           const int q = t0 + fo + d.pad - tp;
           const int to = floordiv(q, d.stride);
@@ -128,119 +159,214 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
 
   const int seq_len = d.T_src * V;
   const float* src_b = d.src + (int64_t)b * seq_len;
-  const bool has_pro = d.pro_scale != nullptr;
 
-  // ---- staging state: the next stage's global loads are issued BEFORE the MFMA phase of the current
-  // stage and land in registers while the matrix pipe works; they are written to LDS after the barrier.
+  // ---- staging.  Everything that does not change from stage to stage is computed here once: per-lane byte
+  // offsets, validity masks, LDS addresses.  The loads are buffer loads (wave-uniform base in SGPRs, advanced by
+  // scalar arithmetic), so that a stage costs the vector ALU -- which the fp32 MFMA shares -- 3 instructions
+  // per staged src element (BN scale/shift, ReLU, zero-pad select) and none per weight.
+  //   S: wave w stages src channel c0 + w; lane -> columns lane + 64 j
+  //   W: one float4 per lane and pass, WRPP rows per pass
+  int svo[SJ];
+  bool sok[SJ];
+#pragma unroll
+  for (int j = 0; j < SJ; ++j) {
+    const int col = lane + 64 * j;
+    const int rabs = t_lo * V + col;
+    sok[j] = col < k.RW && (unsigned)rabs < (unsigned)seq_len;   // else: temporal zero padding / lane padding
+    svo[j] = sok[j] ? rabs * 4 : 0;
+  }
+  const bool w_vec = k.w_vec != 0;
+  const bool ktail = (d.Kc % KC) != 0;
   const int w_m4 = (tid % (BM / 4)) * 4;     // float4 column of this lane inside a W row
   const int w_r0 = tid / (BM / 4);           // first W row of this lane
-  const bool w_vec = k.w_vec != 0;
-  const int s_row = tid / SLPR;              // S row (src channel inside the stage) of this lane
-  const int s_c0 = tid % SLPR;
+  int wvo[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int row = w_r0 + i * WRPP;
+    const int tp = row / KC, c = row % KC;
+    const bool ok = row < WROWS && (m0 + w_m4) < d.M;   // rows >= M only feed output rows that are never stored
+    wvo[i] = ok ? (int)(((int64_t)tp * d.w_stride_tap + (int64_t)c * d.w_stride_c + m0 + w_m4) * 4) : 0;
+  }
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
   float4 wreg[WIT];
-  float sreg[SJMAX];
+  float sreg[SJ];
   float psc = 1.f, psh = 0.f;
 
-  // Loads are UNCONDITIONAL (out-of-range lanes read a clamped, valid address) and nothing consumes the
-  // loaded registers until store_lds(): a predicated load or an early select would make the compiler wait
-  // for the data at the issue point and serialise the whole stage on memory latency.
+  // nothing consumes the loaded registers until store_lds(): the loads of stage i+1 are in flight during
+  // the MFMA phase of stage i
   auto issue_loads = [&](int c0) {
     if (w_vec) {
+      const __amdgpu_buffer_rsrc_t rw =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(d.W + (int64_t)c0 * d.w_stride_c), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
       for (int i = 0; i < WIT; ++i) {
-        const int row = w_r0 + i * WRPP;
-        const int tp = row / KC, c = row % KC;
-        const int cg = c0 + c, mg = m0 + w_m4;
-        const bool ok = row < WROWS && cg < d.Kc && mg < d.M;
-        const float* wp = ok ? d.W + (int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg : d.W;
-        wreg[i] = *reinterpret_cast<const float4*>(wp);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], 0, 0);
+        wreg[i] = *reinterpret_cast<const float4*>(&v);
       }
     }
-    const int cg = c0 + s_row;
-    const bool rowok = cg < d.Kc;
-    const float* sp = src_b + (int64_t)(rowok ? cg : 0) * d.ld_src;
+    const int cg = (c0 + wave < d.Kc) ? c0 + wave : 0;   // wave-uniform
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq_len * 4, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < SJMAX; ++j) {
-      const int col = s_c0 + SLPR * j;
-      const int rabs = t_lo * V + col;
-      const bool ok = rowok && col < k.RW && (unsigned)rabs < (unsigned)seq_len;
-      sreg[j] = sp[ok ? rabs : 0];
-    }
-    if (has_pro) {
-      psc = d.pro_scale[rowok ? cg : 0];
-      psh = d.pro_shift[rowok ? cg : 0];
+    for (int j = 0; j < SJ; ++j) sreg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo[j], 0, 0));
+    if (d.pro_scale) {
+      psc = d.pro_scale[cg];
+      psh = d.pro_shift[cg];
     }
   };
 
-  auto store_lds = [&](int c0) {
+  auto store_lds = [&](int c0, float* buf) {
+    float* Wl = buf;
+    float* S = buf + WIT * WRPP * WSTR;
     if (w_vec) {
 #pragma unroll
       for (int i = 0; i < WIT; ++i) {
-        const int row = w_r0 + i * WRPP;
-        const int c = row % KC;
-        const bool ok = (c0 + c) < d.Kc && (m0 + w_m4) < d.M;
-        if (row < WROWS) *reinterpret_cast<float4*>(Wl + row * BM + w_m4) = ok ? wreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int row = w_r0 + i * WRPP;   // rows >= WROWS land in the padding rows of the tile
+        float4 v = wreg[i];
+        if (ktail && c0 + row % KC >= d.Kc) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Wl + row * WSTR + w_m4) = v;
       }
     } else {  // unaligned / M % 4 != 0 weights (3-channel layers only): plain strided copy
       for (int idx = tid; idx < WROWS * BM; idx += 256) {
         const int m = idx % BM, row = idx / BM;
         const int tp = row / KC, cg = c0 + row % KC, mg = m0 + m;
-        Wl[idx] = (cg < d.Kc && mg < d.M) ? d.W[(int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg] : 0.f;
+        Wl[row * WSTR + m] = (cg < d.Kc && mg < d.M) ? d.W[(int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg] : 0.f;
       }
     }
-    const bool rowok = (c0 + s_row) < d.Kc;
+    const bool rowok = (c0 + wave) < d.Kc;   // wave-uniform
 #pragma unroll
-    for (int j = 0; j < SJMAX; ++j) {
-      const int col = s_c0 + SLPR * j;
-      const int rabs = t_lo * V + col;
-      if (col < k.RW) {
-        float val = sreg[j];
-        if (has_pro) {   // folded BN(+ReLU)
-          val = fmaf(val, psc, psh);
-          if (d.pro_relu) val = fmaxf(val, 0.f);
-        }
-        // everything outside the sequence (temporal zero padding) or beyond Kc is exactly 0
-        S[s_row * k.SROW + col] = (rowok && (unsigned)rabs < (unsigned)seq_len) ? val : 0.f;
-      }
+    for (int j = 0; j < SJ; ++j) {
+      // folded BN(+ReLU); everything outside the sequence (temporal zero padding) or beyond Kc is exactly 0
+      const float val = fmaxf(fmaf(sreg[j], psc, psh), relu_lo);
+      S[wave * SSTR + lane + 64 * j] = (sok[j] && rowok) ? val : 0.f;
     }
   };
 
+#ifndef SAR_ABLATE
+#define SAR_ABLATE 0   // diagnostic builds only (tools/ablate.sh): 1 no epilogue, 2 stage once, 4 no barriers (bit mask)
+#endif
   issue_loads(0);
-  for (int c0 = 0; c0 < d.Kc; c0 += KC) {
-    store_lds(c0);
-    __syncthreads();
-    if (c0 + KC < d.Kc) issue_loads(c0 + KC);
+  store_lds(0, smem);
+  __syncthreads();
+  // one main-loop stage on LDS buffer IT (compile-time, so every LDS address is register + immediate)
+  auto stage = [&](int c0, auto IT) {
+    constexpr int it = decltype(IT)::value;
+    const bool more = c0 + KC < d.Kc && !(SAR_ABLATE & 2);
+    if (more) issue_loads(c0 + KC);
+    const float* Wl = smem + it * TC::BUF;
+    const float* S = Wl + WIT * WRPP * WSTR;
 
+    // ---- MFMA phase.  The fp32 MFMA runs on the vector ALU of the SIMD (no co-issue with VALU work; measured:
+    // tools/mfma_fill.hip), so the loop carries LDS reads and MFMAs only, and the operands of step s+1 are read
+    // while the MFMAs of step s issue (register double buffer) so that no MFMA waits on LDS latency.
+    constexpr int HS = KC / 2;                       // k-steps per tap
+    constexpr int RZ = (MODE == SAR_CONV_GRAPH) ? NZMAX : 1;
+    const float* Sh = S + hi * SSTR;
+    const float* Wa = Wl + (tp0 * KC + hi) * WSTR + wm * MS * 32 + l31;
+    auto fetch = [&](int st, float (&a)[MS], float (&r)[NS][RZ]) {
+      const int j = st / HS, cc = (st % HS) * 2;
+      const int tpw = PAR ? 2 * j : j;
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
+      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[(tpw * KC + cc) * WSTR + ms * 32];
+      const float* Srow = Sh + cc * SSTR;
 #pragma unroll
-      for (int cc = 0; cc < KC; cc += 2) {
-        float a[MS], bv[NS];
+      for (int ns = 0; ns < NS; ++ns) {
+        if (MODE == SAR_CONV_TEMPORAL) {
+          r[ns][0] = Srow[off[j][ns]];
+        } else {
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) a[ms] = Wl[(tp * KC + cc + hi) * BM + (wm * MS + ms) * 32 + l31];
-        const float* Srow = S + (cc + hi) * k.SROW;
+          for (int q = 0; q < NZMAX; ++q)
+            if (q < NZ[j]) r[ns][q] = Srow[goff[j][ns][q]];
+        }
+      }
+    };
+    auto mma = [&](int st, const float (&a)[MS], const float (&r)[NS][RZ]) {
+      const int j = st / HS;
+      float bv[NS];
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) {
-          if (MODE == SAR_CONV_TEMPORAL) {
-            float x = Srow[off[tp][ns]];
-            if (TRANSPOSED) x = ((vmask[ns] >> tp) & 1u) ? x : 0.f;
-            bv[ns] = x;
-          } else {
-            float x = gw[tp][ns][0] * Srow[goff[tp][ns][0]];
+      for (int ns = 0; ns < NS; ++ns) {
+        if (MODE == SAR_CONV_TEMPORAL) {
+          bv[ns] = (TR == 2) ? (((vmask[ns] >> j) & 1u) ? r[ns][0] : 0.f) : r[ns][0];
+        } else {
+          float x = gw[j][ns][0] * r[ns][0];
 #pragma unroll
-            for (int j = 1; j < NZMAX; ++j)
-              if (j < NZ[tp]) x = fmaf(gw[tp][ns][j], Srow[goff[tp][ns][j]], x);
-            bv[ns] = x;
+          for (int q = 1; q < NZMAX; ++q)
+            if (q < NZ[j]) x = fmaf(gw[j][ns][q], r[ns][q], x);
+          bv[ns] = x;
+        }
+      }
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
+    };
+    constexpr int NSTEP_ALL = JT * HS;
+    constexpr int NSTEP_SURE = PAR ? (JT - 1) * HS : NSTEP_ALL;   // the last parity slot exists for tp0 == 0 only
+    // issue order inside one step: the MFMAs of step st alternate with the LDS reads of step st+1 (the
+    // compiler's own schedule sinks every read to just before its use and waits for it there)
+    auto order = [&](int st_next, bool have_next) {
+      constexpr int NM = MS * NS;
+      const int jn = st_next / HS;
+      const int rd = have_next ? MS + NS * (MODE == SAR_CONV_GRAPH ? NZ[jn < 3 ? jn : 0] : 1) : 0;
+      int done = 0;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        const int n = (rd - done + (NM - i) - 1) / (NM - i);
+        if (n == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (n == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (n == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        else if (n >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        done += n;
+      }
+    };
+    {
+      float a0[MS], r0[NS][RZ], a1[MS], r1[NS][RZ];
+      fetch(0, a0, r0);
+#pragma unroll
+      for (int st = 0; st < NSTEP_SURE; st += 2) {
+        if (st + 1 < NSTEP_SURE) fetch(st + 1, a1, r1);
+        mma(st, a0, r0);
+        order(st + 1, st + 1 < NSTEP_SURE);
+        if (st + 1 < NSTEP_SURE) {
+          if (st + 2 < NSTEP_SURE) fetch(st + 2, a0, r0);
+          mma(st + 1, a1, r1);
+          order(st + 2, st + 2 < NSTEP_SURE);
+        }
+      }
+      if (PAR && ntap_w == JT) {   // wave-uniform
+        fetch(NSTEP_SURE, a0, r0);
+#pragma unroll
+        for (int st = NSTEP_SURE; st < NSTEP_ALL; st += 2) {
+          if (st + 1 < NSTEP_ALL) fetch(st + 1, a1, r1);
+          mma(st, a0, r0);
+          order(st + 1, st + 1 < NSTEP_ALL);
+          if (st + 1 < NSTEP_ALL) {
+            if (st + 2 < NSTEP_ALL) fetch(st + 2, a0, r0);
+            mma(st + 1, a1, r1);
+            order(st + 2, st + 2 < NSTEP_ALL);
           }
         }
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns)
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if (more) store_lds(c0 + KC, smem + (it ^ 1) * TC::BUF);
+    if (!(SAR_ABLATE & 4)) __syncthreads();
+  };
+  for (int c0 = 0; c0 < d.Kc; c0 += 2 * KC) {
+    stage(c0, std::integral_constant<int, 0>());
+    if (c0 + KC < d.Kc) stage(c0 + KC, std::integral_constant<int, 1>());
+  }
+  if (SAR_ABLATE & 1) {
+    float t = 0.f;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[ms][ns][r];
+    if (t == 123.456f) d.out[tid] = t;
+    return;
   }
 
   // ---- epilogue: bias, mask / add, store, BN partial reductions
@@ -298,17 +424,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
 }
 
 template <int WN>
-int tile_geometry(const sar_conv_desc& d, int NSv, ConvK& k) {
+int tile_geometry(const sar_conv_desc& d, int NSv, bool parity, ConvK& k) {
   const int tile_n = 32 * NSv * WN;
-  k.FT = tile_n / d.V;
+  if (parity) {   // frames per parity half, FT even so that every tile starts on an even frame
+    k.FT = 2 * ((tile_n / 2) / d.V);
+    const int t_even = d.T_out + (d.T_out & 1);
+    if (k.FT > t_even) k.FT = t_even;
+  } else {
+    k.FT = tile_n / d.V;
+    if (k.FT > d.T_out) k.FT = d.T_out;
+  }
   if (k.FT < 1) return -1;
-  if (k.FT > d.T_out) k.FT = d.T_out;
   k.TPS = (d.T_out + k.FT - 1) / k.FT;
   if (d.mode == SAR_CONV_GRAPH) k.NF = k.FT;
   else if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
   else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
   k.RW = k.NF * d.V;
-  k.SROW = k.RW;
   k.nparts = d.B * k.TPS * WN;
   k.w_vec = ((d.M & 3) == 0 && (d.w_stride_c & 3) == 0 && (d.w_stride_tap & 3) == 0 && ((uintptr_t)d.W & 15) == 0) ? 1 : 0;
   const int rwmax = (d.mode == SAR_CONV_GRAPH) ? 32 * NSv * WN : (NSv * WN == 4 ? 448 : 704);
@@ -316,39 +447,30 @@ int tile_geometry(const sar_conv_desc& d, int NSv, ConvK& k) {
   return 0;
 }
 
-template <int MODE, int TRANSPOSED, int TAPS, int NZ0, int NZ1, int NZ2>
-int launch_by_m(const sar_conv_desc& d, hipStream_t st, bool query_only, int* nparts_out) {
+template <int MODE, int TR, int TAPS, int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
+int launch_cfg(const sar_conv_desc& d, hipStream_t st, bool query_only, int* nparts_out) {
   ConvK k;
   k.d = d;
-  if (d.M > 64) {
-    constexpr int MS = 2, NS = 2, WM = 2, WN = 2;
-    if (int g = tile_geometry<WN>(d, NS, k)) { sar_set_error("sar_conv_gemm: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride); return g == -2 ? SAR_E_UNSUP : SAR_E_ARG; }
-    if (nparts_out) *nparts_out = k.nparts;
-    if (query_only) return 0;
-    const size_t lds = sizeof(float) * (KC * k.SROW + TAPS * KC * 32 * MS * WM);
-    dim3 grid(d.B * k.TPS, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, TRANSPOSED, TAPS, MS, NS, WM, WN, NZ0, NZ1, NZ2>), grid, dim3(256), lds,
-                       st, k);
-  } else if (d.M > 32) {
-    constexpr int MS = 2, NS = 2, WM = 1, WN = 4;
-    if (int g = tile_geometry<WN>(d, NS, k)) { sar_set_error("sar_conv_gemm: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride); return g == -2 ? SAR_E_UNSUP : SAR_E_ARG; }
-    if (nparts_out) *nparts_out = k.nparts;
-    if (query_only) return 0;
-    const size_t lds = sizeof(float) * (KC * k.SROW + TAPS * KC * 32 * MS * WM);
-    dim3 grid(d.B * k.TPS, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, TRANSPOSED, TAPS, MS, NS, WM, WN, NZ0, NZ1, NZ2>), grid, dim3(256), lds,
-                       st, k);
-  } else {
-    constexpr int MS = 1, NS = 2, WM = 1, WN = 4;
-    if (int g = tile_geometry<WN>(d, NS, k)) { sar_set_error("sar_conv_gemm: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride); return g == -2 ? SAR_E_UNSUP : SAR_E_ARG; }
-    if (nparts_out) *nparts_out = k.nparts;
-    if (query_only) return 0;
-    const size_t lds = sizeof(float) * (KC * k.SROW + TAPS * KC * 32 * MS * WM);
-    dim3 grid(d.B * k.TPS, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, TRANSPOSED, TAPS, MS, NS, WM, WN, NZ0, NZ1, NZ2>), grid, dim3(256), lds,
-                       st, k);
+  if (int g = tile_geometry<WN>(d, NS, TR == 3, k)) {
+    sar_set_error("sar_conv_gemm: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
   }
+  if (nparts_out) *nparts_out = k.nparts;
+  if (query_only) return 0;
+  constexpr int BM = 32 * MS * WM;
+  dim3 grid(d.B * k.TPS, (d.M + BM - 1) / BM);
+  hipLaunchKernelGGL((conv_gemm_kernel<MODE, TR, TAPS, MS, NS, WM, WN, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
   return 0;
+}
+
+// tile by output rows: M > 64 -> 128 x 128 (2x2 waves of 64x64); 32 < M <= 64 -> 64 x 256; M <= 32 -> 32 x 256.
+// The parity-split variant needs the 4-waves-along-N layouts (a wave's 64 columns lie in one parity half).
+template <int MODE, int TR, int TAPS, int NZ0, int NZ1, int NZ2>
+int launch_by_m(const sar_conv_desc& d, hipStream_t st, bool query_only, int* nparts_out) {
+  if constexpr (TR != 3)
+    if (d.M > 64) return launch_cfg<MODE, TR, TAPS, 2, 2, 2, 2, NZ0, NZ1, NZ2>(d, st, query_only, nparts_out);
+  if (d.M > 32) return launch_cfg<MODE, TR, TAPS, 2, 2, 1, 4, NZ0, NZ1, NZ2>(d, st, query_only, nparts_out);
+  return launch_cfg<MODE, TR, TAPS, 1, 2, 1, 4, NZ0, NZ1, NZ2>(d, st, query_only, nparts_out);
 }
 
 int validate(const sar_conv_desc* d) {
@@ -362,6 +484,10 @@ int validate(const sar_conv_desc* d) {
   SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_out >= (int64_t)d->B * d->T_out * d->V,
               "sar_conv_gemm: leading dimension smaller than B*T*V");
   SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_gemm: pro_scale/pro_shift mismatch");
+  // the stagers address one sequence row / the weight tensor with 32-bit byte offsets
+  SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 28), "sar_conv_gemm: sequence row too long");
+  SAR_REQUIRE(((int64_t)(d->taps - 1) * d->w_stride_tap + (int64_t)4 * d->w_stride_c + d->M) < (1 << 28),
+              "sar_conv_gemm: weight tensor too large for 32-bit offsets");
   SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm: bad epilogue %d", d->epi);
   if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm: partials required");
   if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
@@ -397,8 +523,15 @@ int dispatch(const sar_conv_desc& d, hipStream_t st, bool query_only, int* npart
     if (d.taps == 9) return launch_by_m<SAR_CONV_TEMPORAL, 0, 9, 1, 1, 1>(d, st, query_only, nparts_out);
     return launch_by_m<SAR_CONV_TEMPORAL, 0, 1, 1, 1, 1>(d, st, query_only, nparts_out);
   }
-  if (d.taps == 9) return launch_by_m<SAR_CONV_TEMPORAL, 1, 9, 1, 1, 1>(d, st, query_only, nparts_out);
-  return launch_by_m<SAR_CONV_TEMPORAL, 1, 1, 1, 1, 1>(d, st, query_only, nparts_out);
+  if (d.stride == 1) {   // every tap of every column reaches a real source frame: no validity mask
+    if (d.taps == 9) return launch_by_m<SAR_CONV_TEMPORAL, 1, 9, 1, 1, 1>(d, st, query_only, nparts_out);
+    return launch_by_m<SAR_CONV_TEMPORAL, 1, 1, 1, 1, 1>(d, st, query_only, nparts_out);
+  }
+  if (d.taps == 9) {
+    if (d.stride == 2) return launch_by_m<SAR_CONV_TEMPORAL, 3, 9, 1, 1, 1>(d, st, query_only, nparts_out);
+    return launch_by_m<SAR_CONV_TEMPORAL, 2, 9, 1, 1, 1>(d, st, query_only, nparts_out);
+  }
+  return launch_by_m<SAR_CONV_TEMPORAL, 2, 1, 1, 1, 1>(d, st, query_only, nparts_out);
 }
 
 }  // namespace

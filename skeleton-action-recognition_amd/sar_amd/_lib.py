@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsar_hip.so")
+LIB_PATH = os.environ.get("SAR_HIP_LIB") or os.path.join(_HERE, "libsar_hip.so")   # env override: diagnostic builds
 
 SAR_CONV_GRAPH, SAR_CONV_TEMPORAL = 0, 1
 SAR_EPI_NONE, SAR_EPI_STATS, SAR_EPI_MASK, SAR_EPI_ADD = 0, 1, 2, 3
