@@ -66,9 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   constexpr int NZMAX = 4;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
   constexpr int WROWS = TC::WROWS, WRPP = TC::WRPP, WIT = TC::WIT, WSTR = TC::WSTR, SJ = TC::SJ, SSTR = TC::SSTR;
+  constexpr int ZCOL = TC::RWMAX;   // first padding column of an S row: written once with 0, never staged
   static_assert(WM * WN == 4, "4 waves per workgroup");
   // two LDS buffers: the stage being multiplied and the stage being written (one barrier per stage)
   __shared__ __attribute__((aligned(16))) float smem[2 * TC::BUF];
+  __shared__ float4 rowp[BM];   // per-output-row parameters: bias (prologue), then the aux affine (epilogue)
   const sar_conv_desc& d = k.d;
 
   const int tid = threadIdx.x;
@@ -115,6 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
       v = p - fo * V;
       colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
     }
+    // a column outside the tile reads the always-zero LDS column ZCOL in every tap: its accumulators stay
+    // exactly 0, so the epilogue needs no column predicate for the BatchNorm sums
     if (!colok[ns]) fo = par;
     coln[ns] = ((int64_t)b * d.T_out + (t0 + fo)) * V + v;
     vmask[ns] = 0;
@@ -133,15 +137,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
           vmask[ns] |= (ok ? 1u : 0u) << tp;
           off[tp][ns] = (to - t_lo) * V + v;
         }
+        if (!colok[ns]) off[tp][ns] = ZCOL;
       }
     } else {
 #pragma unroll
       for (int tp = 0; tp < 3; ++tp) {
-        gcs[tp][ns] = d.g_colsum ? d.g_colsum[tp * V + v] : 0.f;
+        gcs[tp][ns] = (d.g_colsum && colok[ns]) ? d.g_colsum[tp * V + v] : 0.f;
 #pragma unroll
         for (int j = 0; j < NZMAX; ++j) {
           if (j < NZ[tp]) {
-            goff[tp][ns][j] = fo * V + d.g_idx[(tp * V + v) * NZMAX + j];
+            goff[tp][ns][j] = colok[ns] ? fo * V + d.g_idx[(tp * V + v) * NZMAX + j] : ZCOL;
             gw[tp][ns][j] = d.g_wt[(tp * V + v) * NZMAX + j];
           }
         }
@@ -149,13 +154,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
     }
   }
 
+  // per-row bias -> LDS (read back after the first barrier as the initial accumulator value); zero columns
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) {
+      bp.x = d.bias[row];
+      if (MODE == SAR_CONV_GRAPH) {
+        bp.y = d.bias[d.M + row];
+        bp.z = d.bias[2 * d.M + row];
+      }
+    }
+    rowp[tid] = bp;
+  }
+  if (tid < 2 * KC) smem[(tid / KC) * TC::BUF + WIT * WRPP * WSTR + (tid % KC) * SSTR + ZCOL] = 0.f;
   f32x16 acc[MS][NS];
-#pragma unroll
-  for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-    for (int ns = 0; ns < NS; ++ns)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
   const int seq_len = d.T_src * V;
   const float* src_b = d.src + (int64_t)b * seq_len;
@@ -248,6 +261,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   issue_loads(0);
   store_lds(0, smem);
   __syncthreads();
+  // accumulators start at the bias term: b[m] (temporal) or sum_k b_k[m] colsum(A_k)[v] (graph), 0 off-tile
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        if (MODE == SAR_CONV_TEMPORAL) acc[ms][ns][r] = colok[ns] ? bp.x : 0.f;
+        else acc[ms][ns][r] = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
+      }
+    }
   // one main-loop stage on LDS buffer IT (compile-time, so every LDS address is register + immediate)
   auto stage = [&](int c0, auto IT) {
     constexpr int it = decltype(IT)::value;
@@ -369,8 +394,113 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
     return;
   }
 
-  // ---- epilogue: bias, mask / add, store, BN partial reductions
+  // ---- epilogue: mask / add, store, BatchNorm partial sums.
+  // (the bias is already in the accumulators; off-tile columns hold exact zeros)
   const int part = tile * WN + wn;
+  const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK;
+  auto fast_epilogue = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
+    // Fast path.  A lane's 16 accumulator rows of one 32-row block are rows (r&3) + 8 (r>>2) + 4 hi: with
+    // M % 8 == 0 validity is uniform per group of 4 registers (scalar branch), the row part of every address is
+    // a scalar offset and the column part one per-lane byte offset: buffer loads / stores, no address VALU.
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
+    if (EPI == SAR_EPI_MASK) {   // per-row affine of the mask -> LDS (all waves are past the main loop)
+      if (tid < BM) {
+        const int row = m0 + tid;
+        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < d.M) {
+          ap.x = d.aux_scale[row];
+          ap.y = d.aux_shift[row];
+          if (d.aux_mean) ap.z = d.aux_mean[row];
+        }
+        rowp[tid] = ap;
+      }
+      __syncthreads();
+    }
+    const int rows_w = m0 + wm * MS * 32;   // first row of this wave
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, 0x80000000u, 0x00020000);
+    unsigned vo_out[NS], vo_aux[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {   // off-tile columns: an offset the range check rejects
+      vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
+      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+    }
+    const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);   // bytes per row
+    float* P = smem + wave * (16 * 65);   // wave-private transpose area for the sums (16 sums x 64 lanes, stride 65)
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      float ax[NS][16];
+      if (has_aux) {   // every aux load of this row block is issued before the first use
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {   // 8 registers = 16 sums per transpose round
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = rb * 8 + r8;
+          const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;   // wave-uniform
+          float s1 = 0.f, s2 = 0.f;
+          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            float val = acc[ms][ns][r];
+            if (EPI == SAR_EPI_STATS) {
+              s1 += val;
+              s2 = fmaf(val, val, s2);
+            } else if (EPI == SAR_EPI_MASK) {
+              val = (fmaf(ax[ns][r], ap.x, ap.y) > 0.f) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ax[ns][r] - ap.z, s2);
+            } else if (EPI == SAR_EPI_ADD) {
+              val += ax[ns][r];
+            }
+            if (grp_ok)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
+                                                    (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_out, 0);
+          }
+          if (stats) {
+            P[(2 * r8) * 65 + lane] = s1;
+            P[(2 * r8 + 1) * 65 + lane] = s2;
+          }
+        }
+        if (stats) {
+          // sum q of half-wave h = sum over 32 lanes; lane L adds 16 of them: q = L & 15, lanes 16 (L>>4 & 1) ..,
+          // half h = L >> 5; bank = (q + 16 (L>>4&1) + i) % 32 is distinct over each group of 32 lanes
+          __builtin_amdgcn_wave_barrier();
+          const int q = lane & 15, sub = (lane >> 4) & 1;
+          const float* pr = P + q * 65 + hi * 32 + sub * 16;
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t += pr[i];
+          t += __shfl_xor(t, 16);
+          __builtin_amdgcn_wave_barrier();
+          const int r = rb * 8 + (q >> 1);
+          const int row = rows_w + ms * 32 + mfma_row(r, hi);
+          if (sub == 0 && row < d.M) d.partials[((int64_t)row * k.nparts + part) * 2 + (q & 1)] = t;
+        }
+      }
+    }
+  };
+  if ((d.M & 7) == 0) {
+    switch (d.epi) {
+      case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
+      case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
+      case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
+      default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
+    }
+    return;
+  }
+  // Generic path (M % 8 != 0: the 3-channel input layer's data gradient)
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
@@ -388,14 +518,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
       for (int ns = 0; ns < NS; ++ns) {
         float val = acc[ms][ns][r];
         if (rowok && colok[ns]) {
-          if (d.bias) {
-            if (MODE == SAR_CONV_TEMPORAL) {
-              val += d.bias[row];
-            } else {
-#pragma unroll
-              for (int tp = 0; tp < 3; ++tp) val = fmaf(d.bias[tp * d.M + row], gcs[tp][ns], val);
-            }
-          }
           if (d.epi == SAR_EPI_STATS) {
             s1 += val;
             s2 = fmaf(val, val, s2);
@@ -410,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
           d.out[(int64_t)row * d.ld_out + coln[ns]] = val;
         }
       }
-      if (d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK) {
+      if (stats) {
         s1 = half_wave_sum(s1);
         s2 = half_wave_sum(s2);
         if (l31 == 0 && rowok) {
@@ -486,6 +608,7 @@ int validate(const sar_conv_desc* d) {
   SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_gemm: pro_scale/pro_shift mismatch");
   // the stagers address one sequence row / the weight tensor with 32-bit byte offsets
   SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 28), "sar_conv_gemm: sequence row too long");
+  SAR_REQUIRE(d->ld_out < (1 << 22) && d->ld_aux < (1 << 22), "sar_conv_gemm: leading dimension too large (2^22 columns)");
   SAR_REQUIRE(((int64_t)(d->taps - 1) * d->w_stride_tap + (int64_t)4 * d->w_stride_c + d->M) < (1 << 28),
               "sar_conv_gemm: weight tensor too large for 32-bit offsets");
   SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm: bad epilogue %d", d->epi);
