@@ -54,6 +54,48 @@ __device__ __forceinline__ void temporal_tile(f32x16 (&acc)[TPW], float& bsum, c
   }
 }
 
+// The same reduction with the geometry known at compile time (VC joints, FPC frame pairs per tile, conv stride
+// STRIDE): fully unrolled, every LDS address is "per-lane base register + immediate", the loop carries no vector
+// ALU work besides the optional bias sum (the fp32 MFMA shares the vector ALU with everything else: tools/mfma_fill.hip),
+// and the operands of step s+1 are read while the MFMAs of step s issue.
+template <int TPW, int VC, int STRIDE, int FPC, bool BIAS>
+__device__ __forceinline__ void temporal_tile_fixed(f32x16 (&acc)[TPW], float& bsum, const float* Dbase, const float* Sbase) {
+  constexpr int NSTEP = FPC * VC;
+  auto fetch = [&](int st, float& dv, float (&sv)[TPW]) {
+    const int fp = st / VC, v = st % VC;
+    dv = Dbase[fp * 2 * VC + v];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) sv[i] = Sbase[fp * 2 * STRIDE * VC + i * VC + v];
+  };
+  auto mma = [&](float dv, const float (&sv)[TPW], bool have_next) {
+    if (BIAS) bsum += dv;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i], dv, acc[i], 0, 0, 0);
+    // issue order: MFMA, then the next step's reads spread behind the MFMAs
+    int done = 0;
+    const int rd = have_next ? TPW + 1 : 0;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      const int n = (rd - done + (TPW - i) - 1) / (TPW - i);
+      if (n == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      else if (n == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      done += n;
+    }
+  };
+  float d0, s0[TPW], d1, s1[TPW];
+  fetch(0, d0, s0);
+#pragma unroll
+  for (int st = 0; st < NSTEP; st += 2) {
+    if (st + 1 < NSTEP) fetch(st + 1, d1, s1);
+    mma(d0, s0, st + 1 < NSTEP);
+    if (st + 1 < NSTEP) {
+      if (st + 2 < NSTEP) fetch(st + 2, d0, s0);
+      mma(d1, s1, st + 2 < NSTEP);
+    }
+  }
+}
+
 // Graph reduction: per joint v one packed LDS table row {gather joints[E], weights[E], colsum[3]} read with a
 // wave-uniform address.  Three-stage register pipeline: table row of joint v+2, gathered x values of joint
 // v+1 and the MFMAs of joint v are in flight together.
@@ -119,7 +161,8 @@ __device__ __forceinline__ void graph_tile(f32x16 (&acc)[3], float (&bsum)[3], c
   }
 }
 
-template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2>
+// VC / STRIDEC != 0: V, the conv stride and FP == 2 frame pairs per tile are compile-time (NTU: V = 25)
+template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2, int VC, int STRIDEC>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   static_assert(WF * WC * WT == 4, "4 waves per workgroup");
   static_assert(WT * TPW >= TAPS, "taps must be covered");
@@ -182,11 +225,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
     psh[i] = (has_pro && cg < d.Kc) ? d.pro_shift[cg] : 0.f;
   }
 
+  // Tile classes (uniform over the workgroup).  An INTERIOR tile lies inside its sequence with every row valid:
+  // its loads are buffer loads whose row / column-pass parts are a scalar offset and an immediate (one per-lane
+  // offset register per tensor, no address or predicate VALU -- the fp32 MFMA shares the vector ALU), and its
+  // LDS stores need the folded BN+ReLU only.  EDGE tiles (temporal zero padding, ragged last tile, M / Kc
+  // tails) take the clamped-address + predicate path.
+  const bool rows_full = (f0 + BF <= d.M) && (c0 + CT <= d.Kc);
+  const unsigned dvo = (unsigned)(((int64_t)hi * d.ld_dout + c32) * 4);   // hi = second row of the wave's row pair
+  const unsigned svo = (unsigned)(((int64_t)hi * d.ld_src + c32) * 4);
+  bool dlane[DJ], slane[SJMAX];   // tile-invariant lane masks of the column passes (stay inside the LDS row)
+#pragma unroll
+  for (int j = 0; j < DJ; ++j) dlane[j] = c32 + 32 * j < k.NP;
+#pragma unroll
+  for (int j = 0; j < SJMAX; ++j) slane[j] = c32 + 32 * j < k.SP;
+  auto bytes_to_end = [](int64_t elems) { return (unsigned)(elems * 4 > 0xFFFFFFFFll ? 0xFFFFFFFFll : elems * 4); };
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  auto is_edge = [&](int t0, int t_lo) {
+    return !rows_full || t0 * V + k.NPOS > seq_out || t_lo < 0 || t_lo * V + k.RW > seq_src;
+  };
+
   auto issue_loads = [&](int tile) {
     const int b = tile / k.TPS;
     const int t0 = (tile - b * k.TPS) * k.FT;
     const int t_lo = (MODE == SAR_CONV_GRAPH) ? t0 : t0 * d.stride - d.pad;
     const float* dout_b = d.dout + (int64_t)b * seq_out;
+    const float* src_b = d.src + (int64_t)b * seq_src;
+    if (!is_edge(t0, t_lo)) {
+      // num_records = bytes up to the end of the tensor: the lane-padding columns of the last rows read 0, not
+      // memory past the allocation (the range check sees voffset + soffset + imm; tools/buffer_range.hip)
+      const int64_t do_ = (int64_t)b * seq_out + t0 * V, so_ = (int64_t)b * seq_src + t_lo * V;
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(d.dout + (int64_t)(f0 + 2 * wave) * d.ld_dout + do_), 0,
+          bytes_to_end((int64_t)(d.M - f0 - 2 * wave) * d.ld_dout - do_), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(d.src + (int64_t)(c0 + 2 * wave) * d.ld_src + so_), 0,
+          bytes_to_end((int64_t)(d.Kc - c0 - 2 * wave) * d.ld_src - so_), 0x00020000);
+      const int drow = (int)(d.ld_dout * 32), srow = (int)(d.ld_src * 32);   // 8 rows, bytes
+#pragma unroll
+      for (int i = 0; i < DI; ++i)
+#pragma unroll
+        for (int j = 0; j < DJ; ++j)
+          dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
+#pragma unroll
+      for (int i = 0; i < SI; ++i)
+#pragma unroll
+        for (int j = 0; j < SJMAX; ++j)
+          sreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo + 128 * j, i * srow, 0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
       const int f = f0 + r8 + 8 * i;
@@ -199,7 +285,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
         dreg[i][j] = rowp[ok ? pabs : 0];
       }
     }
-    const float* src_b = d.src + (int64_t)b * seq_src;
 #pragma unroll
     for (int i = 0; i < SI; ++i) {
       const int cg = c0 + r8 + 8 * i;
@@ -218,6 +303,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
     const int b = tile / k.TPS;
     const int t0 = (tile - b * k.TPS) * k.FT;
     const int t_lo = (MODE == SAR_CONV_GRAPH) ? t0 : t0 * d.stride - d.pad;
+    if (!is_edge(t0, t_lo)) {
+      float* Dw = D + r8 * k.DP + c32;
+      float* Sw = S + r8 * k.SP + c32;
+#pragma unroll
+      for (int i = 0; i < DI; ++i)
+#pragma unroll
+        for (int j = 0; j < DJ; ++j)
+          if (dlane[j]) Dw[i * 8 * k.DP + 32 * j] = dreg[i][j];
+#pragma unroll
+      for (int i = 0; i < SI; ++i)
+#pragma unroll
+        for (int j = 0; j < SJMAX; ++j)   // columns in [RW, SP) only feed the phantom taps
+          if (slane[j]) Sw[i * 8 * k.SP + 32 * j] = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
       const int fr = r8 + 8 * i;
@@ -236,11 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
         const int col = c32 + 32 * j;
         const int rabs = t_lo * V + col;
         if (col < k.RW) {
-          float val = sreg[i][j];
-          if (has_pro) {
-            val = fmaf(val, psc[i], psh[i]);
-            if (d.pro_relu) val = fmaxf(val, 0.f);
-          }
+          const float val = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
           S[cr * k.SP + col] = ((c0 + cr) < d.Kc && (unsigned)rabs < (unsigned)seq_src) ? val : 0.f;
         }
       }
@@ -252,19 +348,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   const float* Dbase = D + (wf * 32 + l31) * k.DP + hi * V;
   const float* Sbase = S + (wc * 32 + l31) * k.SP + hi * sfs;
 
+#ifndef SAR_ABLATE
+#define SAR_ABLATE 0   // diagnostic builds only (tools/ablate.sh): 2 = stage the first tile only
+#endif
   int tile = blockIdx.x;
   if (tile < k.NT) issue_loads(tile);
   for (; tile < k.NT; tile += gridDim.x) {
     __syncthreads();  // previous tile's LDS reads done
-    store_lds(tile);
+    if (!(SAR_ABLATE & 2) || tile == (int)blockIdx.x) store_lds(tile);
     __syncthreads();
-    if (tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
+    if (!(SAR_ABLATE & 2) && tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
 
     if constexpr (MODE == SAR_CONV_TEMPORAL) {
       // every wave runs TPW taps: taps beyond TAPS (last wave class when WT*TPW > TAPS) read the padded
       // tail of the S rows and land in accumulators that are never stored -- those SIMDs would otherwise
       // idle at the tile barrier, and one code path keeps the accumulators in AGPRs.
-      temporal_tile<TPW, TPW>(acc, bsum[0], Dbase, Sbase + wt * TPW * V, k.FP, V, sfs);
+      if constexpr (VC != 0) {
+        // (one code path for every wave: a do_bias / no-bias pair of unrolled loops makes the register allocator
+        // keep two copies of the accumulators)
+        temporal_tile_fixed<TPW, VC, STRIDEC, 2, true>(acc, bsum[0], Dbase, Sbase + wt * TPW * VC);
+      } else {
+        temporal_tile<TPW, TPW>(acc, bsum[0], Dbase, Sbase + wt * TPW * V, k.FP, V, sfs);
+      }
     } else {
       graph_tile<NZ0, NZ1, NZ2>(acc, bsum, Dbase, Sbase, T, k.FP, V);
     }
@@ -294,13 +399,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   }
 }
 
+// out[i] = sum over the nsplit slabs, in a fixed order (deterministic): wave g of a workgroup adds the slabs
+// g, g+4, g+8, ... for 64 consecutive outputs (4 loads in flight per lane), then the four partial sums are
+// combined in wave order through LDS.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit,
                                                           int64_t slab_stride, int64_t n, float* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * slab_stride + i];
-    out[i] = s;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    const float* p = slab + i;
+    int k = g;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += p[(int64_t)k * slab_stride];
+      s1 += p[(int64_t)(k + 4) * slab_stride];
+      s2 += p[(int64_t)(k + 8) * slab_stride];
+      s3 += p[(int64_t)(k + 12) * slab_stride];
+    }
+    for (; k < nsplit; k += 4) s0 += p[(int64_t)k * slab_stride];
   }
+  part[g][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && i < n) out[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 size_t lds_bytes(const sar_wgrad_desc& d, const WgradK& k, int BF, int CT) {
@@ -334,7 +455,7 @@ int geometry(const sar_wgrad_desc& d, WgradK& k, int BF, int CT, int extra_taps)
   return 0;
 }
 
-template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2>
+template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2, int VC = 0, int STRIDEC = 0>
 int launch(const sar_wgrad_desc& d, hipStream_t st) {
   WgradK k;
   k.d = d;
@@ -343,8 +464,11 @@ int launch(const sar_wgrad_desc& d, hipStream_t st) {
     sar_set_error("sar_conv_wgrad: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride);
     return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
   }
+  if constexpr (VC != 0) {   // the fixed-geometry loop needs exactly two frame pairs per tile
+    if (k.FP != 2) return launch<MODE, TAPS, WF, WC, WT, TPW, NZ0, NZ1, NZ2, 0, 0>(d, st);
+  }
   const size_t lds = lds_bytes(d, k, BF, CT);
-  auto kern = conv_wgrad_kernel<MODE, TAPS, WF, WC, WT, TPW, NZ0, NZ1, NZ2>;
+  auto kern = conv_wgrad_kernel<MODE, TAPS, WF, WC, WT, TPW, NZ0, NZ1, NZ2, VC, STRIDEC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -387,8 +511,16 @@ extern "C" int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s) {
   } else {
     SAR_REQUIRE(d->stride >= 1 && d->pad >= 0, "sar_conv_wgrad: bad stride/pad");
     SAR_REQUIRE(d->bsize == 0 || d->bsize == d->M, "sar_conv_wgrad: temporal bias slab is [M]");
-    if (d->taps == 9) rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1>(*d, st);
-    else if (d->taps == 1) rc = launch<SAR_CONV_TEMPORAL, 1, 2, 2, 1, 1, 1, 1, 1>(*d, st);
+    const bool ntu = d->V == 25;
+    if (d->taps == 9) {
+      if (ntu && d->stride == 1) rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1, 25, 1>(*d, st);
+      else if (ntu && d->stride == 2) rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1, 25, 2>(*d, st);
+      else rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1>(*d, st);
+    } else if (d->taps == 1) {
+      if (ntu && d->stride == 1) rc = launch<SAR_CONV_TEMPORAL, 1, 2, 2, 1, 1, 1, 1, 1, 25, 1>(*d, st);
+      else if (ntu && d->stride == 2) rc = launch<SAR_CONV_TEMPORAL, 1, 2, 2, 1, 1, 1, 1, 1, 25, 2>(*d, st);
+      else rc = launch<SAR_CONV_TEMPORAL, 1, 2, 2, 1, 1, 1, 1, 1>(*d, st);
+    }
     else {
       sar_set_error("sar_conv_wgrad: temporal kernel size %d not built (1 and 9 are)", d->taps);
       return SAR_E_UNSUP;
@@ -402,9 +534,9 @@ extern "C" int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s) {
 extern "C" int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out,
                                    sar_stream_t s) {
   SAR_REQUIRE(slab && out && nsplit >= 1 && n > 0 && slab_stride >= n, "sar_slab_reduce: bad arguments");
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), slab, nsplit, slab_stride, n, out);
+  const int64_t blocks = (n + 63) / 64;
+  SAR_REQUIRE(blocks < (1ll << 31), "sar_slab_reduce: n too large");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), slab, nsplit, slab_stride, n, out);
   SAR_LAUNCH_CHECK("sar_slab_reduce_f32");
   return 0;
 }

@@ -3,8 +3,7 @@ the CPU oracle.
 
 Tolerance (norm-wise relative, max|a-b|/max|b|, reference value = the float64 oracle):
   * activations, logits, loss, BN moving statistics: 1e-4 (north_star: "fp32 logits/grads within 1e-4 rel");
-  * gradients of stacks up to 4 blocks: 1e-4 on every tensor;
-  * gradients of the full 10-block stack: 1e-4 on every tensor against the float64 oracle CONDITIONED ON THE
+  * gradients: 1e-4 on every tensor against the float64 oracle CONDITIONED ON THE
     ENGINE'S ACTIVATION PATTERN (every ReLU replaced by multiplication with the mask the HIP path used).  Why: a
     pre-activation that is zero to within rounding lands on either side in any two float32 implementations; one
     such flip moves that channel's heavily-cancelled sum(dz) -- hence that block's bn1.beta / gcn.kernel
@@ -28,6 +27,22 @@ TOL = 1e-4
 def dev():
     assert torch.cuda.is_available()
     return torch.device("cuda:0")
+
+
+def _engine_masks(eng, keep, blocks, B, T):
+    """Activation pattern of the HIP path: block outputs y > 0; the ReLU folded into the temporal conv's operand
+    load is re-evaluated with the engine's own arithmetic relu(fma(g, scale, shift))."""
+    from sar_amd import ops
+    masks = {}
+    for i, (f, s, _) in enumerate(blocks):
+        To = -(-T // s)
+        bn1 = eng.bn["l%d.bn1" % i]
+        hbuf = torch.empty_like(keep["l%d.g" % i])
+        ops.bn_add_relu_fwd(keep["l%d.g" % i], bn1.scale, bn1.shift, 0, None, None, None, hbuf)
+        masks["l%d.h" % i] = from_cn((hbuf > 0).cpu(), B, T, 25)
+        masks["l%d.y" % i] = from_cn((keep["l%d.y" % i] > 0).cpu(), B, To, 25)
+        T = To
+    return masks
 
 
 def _compare(dev, blocks, N, T, classes, seed, tol=TOL, x=None, y=None):
@@ -56,22 +71,10 @@ def _compare(dev, blocks, N, T, classes, seed, tol=TOL, x=None, y=None):
         worst["l%d.y" % i] = rel_err(from_cn(keep["l%d.y" % i].cpu(), B, To, 25), taps["l%d.y" % i])
         Tc = To
     worst["logits"] = rel_err(logits.cpu(), logits_ref)
-    if len(blocks) > 4:
-        # activation pattern of the HIP path: block outputs y > 0; the ReLU folded into the temporal conv's operand
-        # load is re-evaluated with the engine's own arithmetic relu(fma(g, scale, shift))
-        from sar_amd import ops
-        masks, flips, Tm = {}, 0, x.shape[2]
-        for i, (f, s, _) in enumerate(blocks):
-            To = -(-Tm // s)
-            bn1 = eng.bn["l%d.bn1" % i]
-            hbuf = torch.empty_like(keep["l%d.g" % i])
-            ops.bn_add_relu_fwd(keep["l%d.g" % i], bn1.scale, bn1.shift, 0, None, None, None, hbuf)
-            masks["l%d.h" % i] = from_cn((hbuf > 0).cpu(), B, Tm, 25)
-            masks["l%d.y" % i] = from_cn((keep["l%d.y" % i] > 0).cpu(), B, To, 25)
-            flips += int((masks["l%d.y" % i] != (taps["l%d.y" % i] > 0)).sum())
-            Tm = To
-        print("ReLU-tie flips vs the unconditioned oracle (block outputs): %d" % flips)
-        _, _, grads_ref, _, _ = O.loss_and_grads(p, x.double(), y, blocks=blocks, masks=masks)
+    masks = _engine_masks(eng, keep, blocks, B, x.shape[2])
+    flips = sum(int((masks["l%d.y" % i] != (taps["l%d.y" % i] > 0)).sum()) for i in range(len(blocks)))
+    print("ReLU-tie flips vs the unconditioned oracle (block outputs): %d" % flips)
+    _, _, grads_ref, _, _ = O.loss_and_grads(p, x.double(), y, blocks=blocks, masks=masks)
     logits2, loss = eng.loss_and_grad(xg, yg)
     torch.cuda.synchronize()
     worst["loss"] = rel_err(loss.cpu(), loss_ref.reshape(1))
@@ -135,7 +138,16 @@ def test_sgd_training_steps_track_the_oracle(dev):
     vel = {}
     for step in range(3):
         x, y = O.synthetic_batch(4, seed=10 + step, T=20, num_classes=10)
-        _, loss_ref, grads, new, _ = O.loss_and_grads(p, x.double(), y, blocks=blocks)
+        # the oracle's gradients are conditioned on the engine's activation pattern (module docstring); the extra
+        # forward that reads the pattern must not advance the moving statistics
+        stats = {n: (bn.moving_mean.clone(), bn.moving_var.clone()) for n, bn in eng.bn.items()}
+        keep = {}
+        eng.forward(x.to(dev), training=True, keep=keep)
+        masks = _engine_masks(eng, keep, blocks, x.shape[0] * x.shape[4], x.shape[2])
+        for n, (mm, mv) in stats.items():
+            eng.bn[n].moving_mean.copy_(mm)
+            eng.bn[n].moving_var.copy_(mv)
+        _, loss_ref, grads, new, _ = O.loss_and_grads(p, x.double(), y, blocks=blocks, masks=masks)
         lr = O.lr_schedule(step)
         O.sgd_nesterov_step(p, grads, vel, lr)
         p.update(new)

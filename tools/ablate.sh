@@ -7,14 +7,15 @@ cd "$(dirname "$0")/.."
 C=skeleton-action-recognition_amd/csrc
 if [ "$1" = build ]; then
   mkdir -p tools/bin
-  for m in 1 2 3 6 7; do
+  for m in ${MODES:-1 2 3}; do
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSAR_ABLATE=$m -c $C/conv_gemm.hip -o tools/bin/conv_gemm_a$m.o
-    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libsar_a$m.so tools/bin/conv_gemm_a$m.o $C/conv_wgrad.o $C/conv2d.o $C/elementwise.o $C/radar.o
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSAR_ABLATE=$m -c $C/conv_wgrad.hip -o tools/bin/conv_wgrad_a$m.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libsar_a$m.so tools/bin/conv_gemm_a$m.o tools/bin/conv_wgrad_a$m.o $C/conv2d.o $C/elementwise.o $C/radar.o
   done
 else
   K=${KERNELS:-tconv_fwd,tconv_dgrad,gcn_fwd}
   echo "== full"; python tools/kernel_bench.py --only $K --layers 2,6,9 | grep -v TOTAL
-  for m in 1 2 3 6 7; do
+  for m in ${MODES:-1 2 3}; do
     echo "== SAR_ABLATE=$m"; SAR_HIP_LIB=$PWD/tools/bin/libsar_a$m.so python tools/kernel_bench.py --only $K --layers 2,6,9 | grep -v TOTAL
   done
 fi
