@@ -399,6 +399,282 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Graph weight gradient, fixed geometry (V = 25 joints, tiles of 2 frames = one frame pair).
+//
+// The gather  z_k[c, (t,v)] = sum_j w_kj(v) x[c, (t, idx_kj(v))]  is applied ONCE per tile while the tile is
+// staged (LDS -> LDS, by the half-wave that stored the row: no extra barrier), not per MFMA operand by every
+// wave: the MFMA loop then reads plain operands with immediate offsets (3 z + MB dout reads per 3 MB MFMAs, no
+// vector-ALU work -- the fp32 MFMA shares the vector ALU).  Workgroup = (64 MB) m x 64 c x 3 slices, waves =
+// 2 (m) x 2 (c), a wave owns MB x 3 accumulator tiles.  LDS: D (64 MB) x 51, Z 3 x 64 x 51 (Z[0] holds the raw
+// x rows until the transform overwrites them in place).
+#ifdef SAR_ABLATE
+#define SAR_ABLATE_G SAR_ABLATE
+#else
+#define SAR_ABLATE_G 0   // diagnostic builds only (tools/ablate.sh): 2 = stage the first tile only, 8 = no gather transform
+#endif
+template <int NZ0, int NZ1, int NZ2, int MB>
+__global__ __launch_bounds__(256, 2) void graph_wgrad_fixed_kernel(const WgradK k) {
+  constexpr int VC = 25, NPOS = 50, BF = 64 * MB, CT = 64, DP = 51, ZP = 51, ZS = CT * ZP;
+  constexpr int NZMAX = 4, E = NZ0 + NZ1 + NZ2;
+  constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  constexpr int DI = BF / 8, XI = CT / 8;   // rows per half-wave; two column passes (32 + 18 lanes)
+  __shared__ float D[BF * DP];
+  __shared__ float Z[3 * ZS];
+  __shared__ float CS[3 * VC];   // colsum(A_k)[v] for the bias sums
+  const sar_wgrad_desc& d = k.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wf = wave & 1, wc = wave >> 1;
+  const int r8 = tid >> 5, c32 = tid & 31;
+  const int f0 = blockIdx.y * BF, c0 = blockIdx.z * CT;
+  // the bias sums (sum_n dout * colsum(A_k)) are needed once per m: the c-block 0 waves of the z == 0 slice carry them
+  const bool do_bias = d.bsize > 0 && blockIdx.z == 0 && wc == 0;
+  const int seq = d.T_src * VC;   // T_src == T_out
+
+  if (tid < 3 * VC) CS[tid] = d.g_colsum ? d.g_colsum[tid] : 0.f;   // visible after the first tile barrier
+  // gather lists of joint v = c32 (transform lanes): source pointers into this half-wave's first row, weights
+  const int vq = c32 < VC ? c32 : 0;
+  unsigned gp[E];   // LDS byte addresses (the low 32 bits of a shared-memory pointer are its LDS offset)
+  float gwt[E];
+  {
+    int e = 0;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+      for (int j = 0; j < NZMAX; ++j)
+        if (j < NZ[tp]) {
+          gp[e] = (unsigned)(uintptr_t)(Z + r8 * ZP + d.g_idx[(tp * VC + vq) * NZMAX + j]);
+          gwt[e] = d.g_wt[(tp * VC + vq) * NZMAX + j];
+          ++e;
+        }
+  }
+
+  f32x16 acc[MB][3];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+  float bsum[MB][3];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) bsum[mb][0] = bsum[mb][1] = bsum[mb][2] = 0.f;
+
+  const bool rows_full = (f0 + BF <= d.M) && (c0 + CT <= d.Kc);
+  const unsigned dvo = (unsigned)(((int64_t)hi * d.ld_dout + c32) * 4);
+  const unsigned svo = (unsigned)(((int64_t)hi * d.ld_src + c32) * 4);
+  const bool lane1 = c32 + 32 < NPOS;   // the second column pass is partial (18 lanes)
+  auto bytes_to_end = [](int64_t elems) { return (unsigned)(elems * 4 > 0xFFFFFFFFll ? 0xFFFFFFFFll : elems * 4); };
+  float dreg[DI][2], xreg[XI][2];
+
+  auto issue_loads = [&](int tile) {
+    const int b = tile / k.TPS;
+    const int t0 = (tile - b * k.TPS) * 2;
+    const int64_t o = (int64_t)b * seq + t0 * VC;
+    if (rows_full && t0 * VC + NPOS <= seq) {   // interior tile: buffer loads, scalar row offsets
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(d.dout + (int64_t)(f0 + 2 * wave) * d.ld_dout + o), 0,
+          bytes_to_end((int64_t)(d.M - f0 - 2 * wave) * d.ld_dout - o), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(d.src + (int64_t)(c0 + 2 * wave) * d.ld_src + o), 0,
+          bytes_to_end((int64_t)(d.Kc - c0 - 2 * wave) * d.ld_src - o), 0x00020000);
+      const int drow = (int)(d.ld_dout * 32), srow = (int)(d.ld_src * 32);   // 8 rows, bytes
+#pragma unroll
+      for (int i = 0; i < DI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
+#pragma unroll
+      for (int i = 0; i < XI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          xreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo + 128 * j, i * srow, 0));
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int f = f0 + r8 + 8 * i;
+      const float* rowp = d.dout + (int64_t)(f < d.M ? f : 0) * d.ld_dout + (int64_t)b * seq;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pabs = t0 * VC + c32 + 32 * j;
+        dreg[i][j] = rowp[(f < d.M && c32 + 32 * j < NPOS && pabs < seq) ? pabs : 0];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int cg = c0 + r8 + 8 * i;
+      const float* rowp = d.src + (int64_t)(cg < d.Kc ? cg : 0) * d.ld_src + (int64_t)b * seq;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pabs = t0 * VC + c32 + 32 * j;
+        xreg[i][j] = rowp[(cg < d.Kc && c32 + 32 * j < NPOS && pabs < seq) ? pabs : 0];
+      }
+    }
+  };
+
+  auto store_lds = [&](int tile) {
+    const int b = tile / k.TPS;
+    const int t0 = (tile - b * k.TPS) * 2;
+    float* Dw = D + r8 * DP + c32;
+    float* Xw = Z + r8 * ZP + c32;
+    if (!(rows_full && t0 * VC + NPOS <= seq)) {   // edge tile: rows >= M / Kc and positions past the sequence are 0
+#pragma unroll
+      for (int i = 0; i < DI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          dreg[i][j] = ((f0 + r8 + 8 * i) < d.M && t0 * VC + c32 + 32 * j < seq) ? dreg[i][j] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      Dw[i * 8 * DP] = dreg[i][0];
+      if (lane1) Dw[i * 8 * DP + 32] = dreg[i][1];
+    }
+    if (!(rows_full && t0 * VC + NPOS <= seq)) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          xreg[i][j] = ((c0 + r8 + 8 * i) < d.Kc && t0 * VC + c32 + 32 * j < seq) ? xreg[i][j] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      Xw[i * 8 * ZP] = xreg[i][0];
+      if (lane1) Xw[i * 8 * ZP + 32] = xreg[i][1];
+    }
+    // in-place gather transform of the rows this half-wave just stored (lane = joint v).  Software-pipelined
+    // over the rows: the gathered values of row i+1 are read before the results of row i are written
+    // (different rows never overlap, so the in-place update is safe).
+    __builtin_amdgcn_wave_barrier();
+    if (c32 < VC && !(SAR_ABLATE_G & 8)) {
+      const unsigned Zw = (unsigned)(uintptr_t)(Z + r8 * ZP + c32);
+      float xs[2][2][E];
+      // ds_read_b32 with a 16-bit immediate: written as asm because the compiler pairs the gathers into
+      // ds_read2_b32 (8-bit offsets) and then spends one v_add per pair on new base addresses -- vector-ALU
+      // work the MFMAs of the co-resident workgroup pay for.  The waits are explicit (counted lgkmcnt).
+      auto gather = [&](int i, float (&x)[2][E]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x[t][e]) : "v"(gp[e]), "n"((i * 8 * ZP + t * VC) * 4));
+      };
+      auto scatter = [&](int i, float (&x)[2][E], bool more_in_flight) {
+        // wait for this row's 2 E gathers; the 2 E reads of the next row may stay in flight
+        if (more_in_flight) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * E) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float zk[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          int e0 = 0;
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp) {
+            float zz = gwt[e0] * x[t][e0];
+#pragma unroll
+            for (int j = 1; j < NZMAX; ++j)
+              if (j < NZ[tp]) zz = fmaf(gwt[e0 + j], x[t][e0 + j], zz);
+            zk[t][tp] = zz;
+            e0 += NZ[tp];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp)
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(Zw), "v"(zk[t][tp]), "n"((tp * ZS + i * 8 * ZP + t * VC) * 4) : "memory");
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this half-wave's x rows are in LDS
+      gather(0, xs[0]);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        if (i + 1 < XI) gather(i + 1, xs[(i + 1) & 1]);
+        scatter(i, xs[i & 1], i + 1 < XI);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+
+  const float* Dq = D + (wf * 32 * MB + l31) * DP + hi * VC;
+  const float* Zq = Z + (wc * 32 + l31) * ZP + hi * VC;
+  auto fetch = [&](int v, float (&dv)[MB], float (&zv)[3]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) dv[mb] = Dq[mb * 32 * DP + v];
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) zv[tp] = Zq[tp * ZS + v];
+  };
+  auto mma = [&](int v, const float (&dv)[MB], const float (&zv)[3], bool have_next) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+        acc[mb][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(zv[tp], dv[mb], acc[mb][tp], 0, 0, 0);
+    // issue order: the next step's 3 + MB reads spread behind this step's MFMAs
+    constexpr int NM = 3 * MB, RD = 3 + MB;
+    int done = 0;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      const int n = have_next ? (RD - done + (NM - i) - 1) / (NM - i) : 0;
+      if (n == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      else if (n == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      done += n;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < k.NT) issue_loads(tile);
+  for (; tile < k.NT; tile += gridDim.x) {
+    __syncthreads();   // previous tile's operand reads done
+    if (!(SAR_ABLATE_G & 2) || tile == (int)blockIdx.x) store_lds(tile);
+    __syncthreads();
+    if (!(SAR_ABLATE_G & 2) && tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
+    float d0[MB], z0[3], d1[MB], z1[3];
+    fetch(0, d0, z0);
+#pragma unroll
+    for (int v = 0; v < VC; v += 2) {
+      if (v + 1 < VC) fetch(v + 1, d1, z1);
+      mma(v, d0, z0, v + 1 < VC);
+      if (v + 1 < VC) {
+        if (v + 2 < VC) fetch(v + 2, d0, z0);
+        mma(v + 1, d1, z1, v + 2 < VC);
+      }
+    }
+    if (do_bias) {   // wave-uniform; kept out of the MFMA loop so that its issue order and registers stay untouched
+#pragma unroll
+      for (int v = 0; v < VC; ++v)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float dv = Dq[mb * 32 * DP + v];
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp) bsum[mb][tp] = fmaf(dv, CS[tp * VC + v], bsum[mb][tp]);
+        }
+    }
+  }
+
+  // ---- write this split's slab
+  float* slab = d.slab + (int64_t)blockIdx.x * (d.wsize + d.bsize);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int f = f0 + (wf * MB + mb) * 32 + l31;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wc * 32 + mfma_row(r, hi);
+        if (c < d.Kc && f < d.M) slab[(int64_t)tp * d.w_stride_tap + (int64_t)c * d.w_stride_c + f] = acc[mb][tp][r];
+      }
+    if (do_bias) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) {
+        const float t = bsum[mb][tp] + __shfl_xor(bsum[mb][tp], 32);
+        if (hi == 0 && f < d.M) slab[d.wsize + (int64_t)tp * d.M + f] = t;
+      }
+    }
+  }
+}
+
 // out[i] = sum over the nsplit slabs, in a fixed order (deterministic): wave g of a workgroup adds the slabs
 // g, g+4, g+8, ... for 64 consecutive outputs (4 loads in flight per lane), then the four partial sums are
 // combined in wave order through LDS.
@@ -481,6 +757,34 @@ int launch(const sar_wgrad_desc& d, hipStream_t st) {
   return 0;
 }
 
+bool graph_fixed_supported(const sar_wgrad_desc& d) {
+  return (d.nz[0] == 1 && d.nz[1] == 1 && d.nz[2] == 4) || (d.nz[0] == 1 && d.nz[2] == 1 && d.nz[1] == 4);
+}
+
+template <int NZ0, int NZ1, int NZ2, int MB>
+int launch_graph_fixed_mb(const sar_wgrad_desc& d, hipStream_t st) {
+  WgradK k;
+  k.d = d;
+  k.FT = 2;
+  k.FP = 1;
+  k.TPS = (d.T_out + 1) / 2;
+  k.NT = d.B * k.TPS;
+  const int gy = (d.M + 64 * MB - 1) / (64 * MB), gz = (d.Kc + 63) / 64;
+  hipLaunchKernelGGL((graph_wgrad_fixed_kernel<NZ0, NZ1, NZ2, MB>), dim3(d.nsplit, gy, gz), dim3(256), 0, st, k);
+  return 0;
+}
+
+template <int NZ0, int NZ1, int NZ2>
+int launch_graph_fixed_nz(const sar_wgrad_desc& d, hipStream_t st) {
+  if (d.M > 64) return launch_graph_fixed_mb<NZ0, NZ1, NZ2, 2>(d, st);
+  return launch_graph_fixed_mb<NZ0, NZ1, NZ2, 1>(d, st);
+}
+
+int launch_graph_fixed(const sar_wgrad_desc& d, hipStream_t st) {
+  if (d.nz[0] == 1 && d.nz[1] == 1) return launch_graph_fixed_nz<1, 1, 4>(d, st);
+  return launch_graph_fixed_nz<1, 4, 1>(d, st);
+}
+
 }  // namespace
 
 extern "C" int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s) {
@@ -505,7 +809,8 @@ extern "C" int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s) {
         sar_set_error("sar_conv_wgrad: adjacency slice %d needs %d gather entries per column (max 4)", i, d->nz[i]);
         return SAR_E_UNSUP;
       }
-    if (d->nz[0] == 1 && d->nz[1] == 1) rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 1, 1, 4>(*d, st);
+    if (d->V == 25 && d->Kc >= 32 && !d->pro_scale && graph_fixed_supported(*d)) rc = launch_graph_fixed(*d, st);
+    else if (d->nz[0] == 1 && d->nz[1] == 1) rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 1, 1, 4>(*d, st);
     else if (d->nz[0] == 1 && d->nz[2] == 1) rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 1, 4, 1>(*d, st);
     else rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 4, 4, 4>(*d, st);
   } else {

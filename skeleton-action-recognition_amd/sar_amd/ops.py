@@ -82,8 +82,11 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
     if nsplit is None:
         ft = max(2, min((128 // V) & ~1, (T_out + 1) & ~1))
+        bf = 64
+        if mode == L.SAR_CONV_GRAPH and V == 25 and Kc >= 32 and pro is None:      # fixed-geometry kernel: 2-frame tiles, 128 x 64 blocks when M > 64
+            ft, bf = 2, (128 if M > 64 else 64)
         ntiles = B * ((T_out + ft - 1) // ft)
-        wgs = ((M + 63) // 64) * ((Kc + ct - 1) // ct)
+        wgs = ((M + bf - 1) // bf) * ((Kc + ct - 1) // ct)
         nsplit = max(1, min(ntiles, (1024 + wgs - 1) // wgs))
     d.nsplit = nsplit
     _f32(src), _f32(dout)
