@@ -189,7 +189,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
     svo[j] = sok[j] ? rabs * 4 : 0;
   }
   const bool w_vec = k.w_vec != 0;
-  const bool ktail = (d.Kc % KC) != 0;
   const int w_m4 = (tid % (BM / 4)) * 4;     // float4 column of this lane inside a W row
   const int w_r0 = tid / (BM / 4);           // first W row of this lane
   int wvo[WIT];
@@ -235,9 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
 #pragma unroll
       for (int i = 0; i < WIT; ++i) {
         const int row = w_r0 + i * WRPP;   // rows >= WROWS land in the padding rows of the tile
-        float4 v = wreg[i];
-        if (ktail && c0 + row % KC >= d.Kc) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(Wl + row * WSTR + w_m4) = v;
+        *reinterpret_cast<float4*>(Wl + row * WSTR + w_m4) = wreg[i];
       }
     } else {  // unaligned / M % 4 != 0 weights (3-channel layers only): plain strided copy
       for (int idx = tid; idx < WROWS * BM; idx += 256) {
@@ -256,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   };
 
 #ifndef SAR_ABLATE
-#define SAR_ABLATE 0   // diagnostic builds only (tools/ablate.sh): 1 no epilogue, 2 stage once, 4 no barriers (bit mask)
+#define SAR_ABLATE 0   // diagnostic builds only (tools/ablate.sh): 1 no epilogue, 2 stage once, 4 no barriers, 16 / 32 see below
 #endif
   issue_loads(0);
   store_lds(0, smem);
@@ -277,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   auto stage = [&](int c0, auto IT) {
     constexpr int it = decltype(IT)::value;
     const bool more = c0 + KC < d.Kc && !(SAR_ABLATE & 2);
-    if (more) issue_loads(c0 + KC);
+    if (more && !(SAR_ABLATE & 16)) issue_loads(c0 + KC);   // 16: LDS stores of stale registers only
     const float* Wl = smem + it * TC::BUF;
     const float* S = Wl + WIT * WRPP * WSTR;
 
@@ -287,12 +284,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
     constexpr int HS = KC / 2;                       // k-steps per tap
     constexpr int RZ = (MODE == SAR_CONV_GRAPH) ? NZMAX : 1;
     const float* Sh = S + hi * SSTR;
-    const float* Wa = Wl + (tp0 * KC + hi) * WSTR + wm * MS * 32 + l31;
+    // one base register per 32-row block, made opaque to the optimiser: left alone it fuses the MS reads of a
+    // step into ds_read2_b32, whose 8-bit offsets then need one v_add per step for a new base -- vector-ALU
+    // work that the MFMA pipe pays for; a plain ds_read_b32 carries the whole offset as a 16-bit immediate.
+    typedef const float __attribute__((address_space(3))) * lds_cptr;
+    lds_cptr Wa[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      unsigned a = (unsigned)(uintptr_t)(Wl + (tp0 * KC + hi) * WSTR + (wm * MS + ms) * 32 + l31);   // LDS byte address
+      asm volatile("" : "+v"(a));
+      Wa[ms] = (lds_cptr)(uintptr_t)a;
+    }
     auto fetch = [&](int st, float (&a)[MS], float (&r)[NS][RZ]) {
       const int j = st / HS, cc = (st % HS) * 2;
       const int tpw = PAR ? 2 * j : j;
 #pragma unroll
-      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[(tpw * KC + cc) * WSTR + ms * 32];
+      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[ms][(tpw * KC + cc) * WSTR];
       const float* Srow = Sh + cc * SSTR;
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
@@ -375,7 +382,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
         }
       }
     }
-    if (more) store_lds(c0 + KC, smem + (it ^ 1) * TC::BUF);
+    if (more && !(SAR_ABLATE & 32)) store_lds(c0 + KC, smem + (it ^ 1) * TC::BUF);
+    if (more && (SAR_ABLATE & 32)) {   // 32: global loads only (wait for them, keep them alive, no LDS store)
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) asm volatile("" ::"v"(sreg[j]));
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) asm volatile("" ::"v"(wreg[i].x), "v"(wreg[i].w));
+    }
     if (!(SAR_ABLATE & 4)) __syncthreads();
   };
   for (int c0 = 0; c0 < d.Kc; c0 += 2 * KC) {
@@ -563,7 +576,8 @@ int tile_geometry(const sar_conv_desc& d, int NSv, bool parity, ConvK& k) {
   else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
   k.RW = k.NF * d.V;
   k.nparts = d.B * k.TPS * WN;
-  k.w_vec = ((d.M & 3) == 0 && (d.w_stride_c & 3) == 0 && (d.w_stride_tap & 3) == 0 && ((uintptr_t)d.W & 15) == 0) ? 1 : 0;
+  // (the vector path stages whole KC-channel slabs: a Kc tail takes the scalar path, which zero-fills it)
+  k.w_vec = ((d.Kc % KC) == 0 && (d.M & 3) == 0 && (d.w_stride_c & 3) == 0 && (d.w_stride_tap & 3) == 0 && ((uintptr_t)d.W & 15) == 0) ? 1 : 0;
   const int rwmax = (d.mode == SAR_CONV_GRAPH) ? 32 * NSv * WN : (NSv * WN == 4 ? 448 : 704);
   if (k.RW > rwmax) return -2;   // staged row does not fit the register prefetch (V too large)
   return 0;

@@ -177,8 +177,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   const sar_wgrad_desc& d = k.d;
   const int V = d.V;
   float* D = smem;                          // [BF][DP]
-  float* S = D + BF * k.DP;                 // [CT][SP]
-  float* T = S + CT * k.SP + ((4 - ((BF * k.DP + CT * k.SP) & 3)) & 3);   // GRAPH: [V][ROW] packed gather rows (16-B aligned)
+  // LDS row strides: compile-time in the fixed-geometry variants (every LDS address is then register + immediate;
+  // the S rows are as wide as the column passes of the stager, so its stores need no lane mask)
+  const int DP = (VC != 0) ? (4 * VC) | 1 : k.DP;
+  const int SP = (VC != 0) ? 32 * SJMAX + 1 : k.SP;
+  float* S = D + BF * DP;                   // [CT][SP]
+  float* T = S + CT * SP + ((4 - ((BF * DP + CT * SP) & 3)) & 3);   // GRAPH: [V][ROW] packed gather rows (16-B aligned)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction
@@ -235,66 +239,57 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   const unsigned svo = (unsigned)(((int64_t)hi * d.ld_src + c32) * 4);
   bool dlane[DJ], slane[SJMAX];   // tile-invariant lane masks of the column passes (stay inside the LDS row)
 #pragma unroll
-  for (int j = 0; j < DJ; ++j) dlane[j] = c32 + 32 * j < k.NP;
+  for (int j = 0; j < DJ; ++j) dlane[j] = (VC != 0 && j < 3) || c32 + 32 * j < k.NP;
 #pragma unroll
-  for (int j = 0; j < SJMAX; ++j) slane[j] = c32 + 32 * j < k.SP;
-  auto bytes_to_end = [](int64_t elems) { return (unsigned)(elems * 4 > 0xFFFFFFFFll ? 0xFFFFFFFFll : elems * 4); };
+  for (int j = 0; j < SJMAX; ++j) slane[j] = (VC != 0) || c32 + 32 * j < SP;
+  auto bytes_to_end = [](int64_t elems) { return (unsigned)(elems <= 0 ? 0 : elems * 4 > 0xFFFFFFFFll ? 0xFFFFFFFFll : elems * 4); };
   const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
   auto is_edge = [&](int t0, int t_lo) {
     return !rows_full || t0 * V + k.NPOS > seq_out || t_lo < 0 || t_lo * V + k.RW > seq_src;
   };
 
+  // Loads are the same for every tile: buffer loads from the start of the sequence row; the tile offset is added
+  // to the per-lane offset (one v_add per tensor and tile).  What a tile must not see reads as 0 or is masked at
+  // store time: a negative offset (temporal padding before the sequence) and anything past the end of the
+  // tensor fail the range check (which sees voffset + soffset + imm: tools/buffer_range.hip) and return 0;
+  // positions past the end of the sequence and rows past M / Kc are zeroed by the edge-tile store path.
   auto issue_loads = [&](int tile) {
     const int b = tile / k.TPS;
     const int t0 = (tile - b * k.TPS) * k.FT;
     const int t_lo = (MODE == SAR_CONV_GRAPH) ? t0 : t0 * d.stride - d.pad;
-    const float* dout_b = d.dout + (int64_t)b * seq_out;
-    const float* src_b = d.src + (int64_t)b * seq_src;
-    if (!is_edge(t0, t_lo)) {
-      // num_records = bytes up to the end of the tensor: the lane-padding columns of the last rows read 0, not
-      // memory past the allocation (the range check sees voffset + soffset + imm; tools/buffer_range.hip)
-      const int64_t do_ = (int64_t)b * seq_out + t0 * V, so_ = (int64_t)b * seq_src + t_lo * V;
-      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(d.dout + (int64_t)(f0 + 2 * wave) * d.ld_dout + do_), 0,
-          bytes_to_end((int64_t)(d.M - f0 - 2 * wave) * d.ld_dout - do_), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(d.src + (int64_t)(c0 + 2 * wave) * d.ld_src + so_), 0,
-          bytes_to_end((int64_t)(d.Kc - c0 - 2 * wave) * d.ld_src - so_), 0x00020000);
-      const int drow = (int)(d.ld_dout * 32), srow = (int)(d.ld_src * 32);   // 8 rows, bytes
+    // the tile offset goes into the (scalar) base address; a tile that starts in the temporal padding before
+    // the sequence (t_lo < 0, first tile only) keeps the base at the sequence start and shifts the per-lane
+    // offsets instead: a negative offset must reach the range check as ONE out-of-range value (the hardware
+    // does not wrap voffset + imm), so it is resolved in the vector ALU there
+    const int t_base = t_lo > 0 ? t_lo : 0;
+    const int64_t do_ = (int64_t)b * seq_out + t0 * V, so_ = (int64_t)b * seq_src + t_base * V;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(d.dout + (int64_t)(f0 + 2 * wave) * d.ld_dout + do_), 0,
+        bytes_to_end((int64_t)(d.M - f0 - 2 * wave) * d.ld_dout - do_), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(d.src + (int64_t)(c0 + 2 * wave) * d.ld_src + so_), 0,
+        bytes_to_end((int64_t)(d.Kc - c0 - 2 * wave) * d.ld_src - so_), 0x00020000);
+    const int drow = (int)(d.ld_dout * 32), srow = (int)(d.ld_src * 32);   // 8 rows, bytes
 #pragma unroll
-      for (int i = 0; i < DI; ++i)
+    for (int i = 0; i < DI; ++i)
 #pragma unroll
-        for (int j = 0; j < DJ; ++j)
-          dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
+      for (int j = 0; j < DJ; ++j)
+        dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
+    if (t_lo >= 0) {
 #pragma unroll
       for (int i = 0; i < SI; ++i)
 #pragma unroll
         for (int j = 0; j < SJMAX; ++j)
           sreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo + 128 * j, i * srow, 0));
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < DI; ++i) {
-      const int f = f0 + r8 + 8 * i;
-      const float* rowp = dout_b + (int64_t)(f < d.M ? f : 0) * d.ld_dout;
-#pragma unroll
-      for (int j = 0; j < DJ; ++j) {
-        const int p = c32 + 32 * j;
-        const int pabs = t0 * V + p;
-        const bool ok = f < d.M && p < k.NPOS && pabs < seq_out;
-        dreg[i][j] = rowp[ok ? pabs : 0];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < SI; ++i) {
-      const int cg = c0 + r8 + 8 * i;
-      const float* rowp = src_b + (int64_t)(cg < d.Kc ? cg : 0) * d.ld_src;
+    } else {
+      const int shift = t_lo * V * 4;
 #pragma unroll
       for (int j = 0; j < SJMAX; ++j) {
-        const int col = c32 + 32 * j;
-        const int rabs = t_lo * V + col;
-        const bool ok = cg < d.Kc && col < k.RW && (unsigned)rabs < (unsigned)seq_src;
-        sreg[i][j] = rowp[ok ? rabs : 0];
+        const int o = (int)(c32 * 4) + 128 * j + shift;                    // offset inside the row
+        const unsigned vo = o < 0 ? 0x80000000u : svo + (unsigned)(128 * j + shift);
+#pragma unroll
+        for (int i = 0; i < SI; ++i)
+          sreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * srow, 0));
       }
     }
   };
@@ -304,18 +299,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
     const int t0 = (tile - b * k.TPS) * k.FT;
     const int t_lo = (MODE == SAR_CONV_GRAPH) ? t0 : t0 * d.stride - d.pad;
     if (!is_edge(t0, t_lo)) {
-      float* Dw = D + r8 * k.DP + c32;
-      float* Sw = S + r8 * k.SP + c32;
+      float* Dw = D + r8 * DP + c32;
+      float* Sw = S + r8 * SP + c32;
 #pragma unroll
       for (int i = 0; i < DI; ++i)
 #pragma unroll
         for (int j = 0; j < DJ; ++j)
-          if (dlane[j]) Dw[i * 8 * k.DP + 32 * j] = dreg[i][j];
+          if (dlane[j]) Dw[i * 8 * DP + 32 * j] = dreg[i][j];
 #pragma unroll
       for (int i = 0; i < SI; ++i)
 #pragma unroll
         for (int j = 0; j < SJMAX; ++j)   // columns in [RW, SP) only feed the phantom taps
-          if (slane[j]) Sw[i * 8 * k.SP + 32 * j] = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
+          if (slane[j]) Sw[i * 8 * SP + 32 * j] = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
       return;
     }
 #pragma unroll
@@ -325,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
       for (int j = 0; j < DJ; ++j) {
         const int p = c32 + 32 * j;
         const bool ok = (f0 + fr) < d.M && p < k.NPOS && (t0 * V + p) < seq_out;
-        if (p < k.NP) D[fr * k.DP + p] = ok ? dreg[i][j] : 0.f;
+        if (p < k.NP) D[fr * DP + p] = ok ? dreg[i][j] : 0.f;
       }
     }
 #pragma unroll
@@ -337,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
         const int rabs = t_lo * V + col;
         if (col < k.RW) {
           const float val = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
-          S[cr * k.SP + col] = ((c0 + cr) < d.Kc && (unsigned)rabs < (unsigned)seq_src) ? val : 0.f;
+          S[cr * SP + col] = ((c0 + cr) < d.Kc && (unsigned)rabs < (unsigned)seq_src) ? val : 0.f;
         }
       }
     }
@@ -345,8 +340,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
 
   // per-lane operand bases: lanes 0-31 reduce over the even frame of a pair, lanes 32-63 over the odd one
   const int sfs = (MODE == SAR_CONV_GRAPH) ? V : d.stride * V;      // src columns per output frame
-  const float* Dbase = D + (wf * 32 + l31) * k.DP + hi * V;
-  const float* Sbase = S + (wc * 32 + l31) * k.SP + hi * sfs;
+  const float* Dbase = D + (wf * 32 + l31) * DP + hi * V;
+  const float* Sbase = S + (wc * 32 + l31) * SP + hi * sfs;
 
 #ifndef SAR_ABLATE
 #define SAR_ABLATE 0   // diagnostic builds only (tools/ablate.sh): 2 = stage the first tile only
@@ -466,53 +461,32 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_fixed_kernel(const WgradK 
   const unsigned dvo = (unsigned)(((int64_t)hi * d.ld_dout + c32) * 4);
   const unsigned svo = (unsigned)(((int64_t)hi * d.ld_src + c32) * 4);
   const bool lane1 = c32 + 32 < NPOS;   // the second column pass is partial (18 lanes)
-  auto bytes_to_end = [](int64_t elems) { return (unsigned)(elems * 4 > 0xFFFFFFFFll ? 0xFFFFFFFFll : elems * 4); };
+  auto bytes_to_end = [](int64_t elems) { return (unsigned)(elems <= 0 ? 0 : elems * 4 > 0xFFFFFFFFll ? 0xFFFFFFFFll : elems * 4); };
   float dreg[DI][2], xreg[XI][2];
 
+  // same loads for every tile (see conv_wgrad_kernel): what lies past the end of the tensor reads as 0, positions
+  // past the end of the sequence and rows past M / Kc are zeroed by the edge-tile store path
   auto issue_loads = [&](int tile) {
     const int b = tile / k.TPS;
     const int t0 = (tile - b * k.TPS) * 2;
     const int64_t o = (int64_t)b * seq + t0 * VC;
-    if (rows_full && t0 * VC + NPOS <= seq) {   // interior tile: buffer loads, scalar row offsets
-      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(d.dout + (int64_t)(f0 + 2 * wave) * d.ld_dout + o), 0,
-          bytes_to_end((int64_t)(d.M - f0 - 2 * wave) * d.ld_dout - o), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(d.src + (int64_t)(c0 + 2 * wave) * d.ld_src + o), 0,
-          bytes_to_end((int64_t)(d.Kc - c0 - 2 * wave) * d.ld_src - o), 0x00020000);
-      const int drow = (int)(d.ld_dout * 32), srow = (int)(d.ld_src * 32);   // 8 rows, bytes
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(d.dout + (int64_t)(f0 + 2 * wave) * d.ld_dout + o), 0,
+        bytes_to_end((int64_t)(d.M - f0 - 2 * wave) * d.ld_dout - o), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(d.src + (int64_t)(c0 + 2 * wave) * d.ld_src + o), 0,
+        bytes_to_end((int64_t)(d.Kc - c0 - 2 * wave) * d.ld_src - o), 0x00020000);
+    const int drow = (int)(d.ld_dout * 32), srow = (int)(d.ld_src * 32);   // 8 rows, bytes
 #pragma unroll
-      for (int i = 0; i < DI; ++i)
+    for (int i = 0; i < DI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
+      for (int j = 0; j < 2; ++j)
+        dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
 #pragma unroll
-      for (int i = 0; i < XI; ++i)
+    for (int i = 0; i < XI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          xreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo + 128 * j, i * srow, 0));
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < DI; ++i) {
-      const int f = f0 + r8 + 8 * i;
-      const float* rowp = d.dout + (int64_t)(f < d.M ? f : 0) * d.ld_dout + (int64_t)b * seq;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int pabs = t0 * VC + c32 + 32 * j;
-        dreg[i][j] = rowp[(f < d.M && c32 + 32 * j < NPOS && pabs < seq) ? pabs : 0];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int cg = c0 + r8 + 8 * i;
-      const float* rowp = d.src + (int64_t)(cg < d.Kc ? cg : 0) * d.ld_src + (int64_t)b * seq;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int pabs = t0 * VC + c32 + 32 * j;
-        xreg[i][j] = rowp[(cg < d.Kc && c32 + 32 * j < NPOS && pabs < seq) ? pabs : 0];
-      }
-    }
+      for (int j = 0; j < 2; ++j)
+        xreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo + 128 * j, i * srow, 0));
   };
 
   auto store_lds = [&](int tile) {
@@ -550,47 +524,55 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_fixed_kernel(const WgradK 
     __builtin_amdgcn_wave_barrier();
     if (c32 < VC && !(SAR_ABLATE_G & 8)) {
       const unsigned Zw = (unsigned)(uintptr_t)(Z + r8 * ZP + c32);
-      float xs[2][2][E];
+      float xs[2][E];
       // ds_read_b32 with a 16-bit immediate: written as asm because the compiler pairs the gathers into
       // ds_read2_b32 (8-bit offsets) and then spends one v_add per pair on new base addresses -- vector-ALU
       // work the MFMAs of the co-resident workgroup pay for.  The waits are explicit (counted lgkmcnt).
-      auto gather = [&](int i, float (&x)[2][E]) {
+      // Order per row: wait for the row's gathers, compute its 6 results, issue the next row's gathers into
+      // the same registers, then write the results (the writes queue behind the gathers in the LDS pipe).
+      auto gather = [&](int i) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int e = 0; e < E; ++e)
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x[t][e]) : "v"(gp[e]), "n"((i * 8 * ZP + t * VC) * 4));
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xs[t][e]) : "v"(gp[e]), "n"((i * 8 * ZP + t * VC) * 4));
       };
-      auto scatter = [&](int i, float (&x)[2][E], bool more_in_flight) {
-        // wait for this row's 2 E gathers; the 2 E reads of the next row may stay in flight
-        if (more_in_flight) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * E) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this half-wave's x rows are in LDS
+      gather(0);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        // the wait carries the gathered registers as in/out operands: their uses cannot be scheduled above it
+        static_assert(E == 6, "wait operand list below");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[0][2]), "+v"(xs[0][3]), "+v"(xs[0][4]), "+v"(xs[0][5]),
+                       "+v"(xs[1][0]), "+v"(xs[1][1]), "+v"(xs[1][2]), "+v"(xs[1][3]), "+v"(xs[1][4]), "+v"(xs[1][5])
+                     :
+                     : "memory");
         float zk[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           int e0 = 0;
 #pragma unroll
           for (int tp = 0; tp < 3; ++tp) {
-            float zz = gwt[e0] * x[t][e0];
+            float zz = gwt[e0] * xs[t][e0];
 #pragma unroll
             for (int j = 1; j < NZMAX; ++j)
-              if (j < NZ[tp]) zz = fmaf(gwt[e0 + j], x[t][e0 + j], zz);
+              if (j < NZ[tp]) zz = fmaf(gwt[e0 + j], xs[t][e0 + j], zz);
             zk[t][tp] = zz;
             e0 += NZ[tp];
           }
         }
+        // the results are pinned before the gathers may overwrite their inputs
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp) asm volatile("" : "+v"(zk[t][tp]));
+        if (i + 1 < XI) gather(i + 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int tp = 0; tp < 3; ++tp)
             asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(Zw), "v"(zk[t][tp]), "n"((tp * ZS + i * 8 * ZP + t * VC) * 4) : "memory");
-      };
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this half-wave's x rows are in LDS
-      gather(0, xs[0]);
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        if (i + 1 < XI) gather(i + 1, xs[(i + 1) & 1]);
-        scatter(i, xs[i & 1], i + 1 < XI);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -742,8 +724,10 @@ int launch(const sar_wgrad_desc& d, hipStream_t st) {
   }
   if constexpr (VC != 0) {   // the fixed-geometry loop needs exactly two frame pairs per tile
     if (k.FP != 2) return launch<MODE, TAPS, WF, WC, WT, TPW, NZ0, NZ1, NZ2, 0, 0>(d, st);
+    k.DP = (4 * VC) | 1;
+    k.SP = 32 * ((MODE == SAR_CONV_GRAPH) ? 4 : (TAPS == 1 ? 6 : 12)) + 1;   // = 32 SJMAX + 1 in the kernel
   }
-  const size_t lds = lds_bytes(d, k, BF, CT);
+  const size_t lds = lds_bytes(d, k, BF, CT) + 256;   // the phantom taps of the last row may read a few floats on
   auto kern = conv_wgrad_kernel<MODE, TAPS, WF, WC, WT, TPW, NZ0, NZ1, NZ2, VC, STRIDEC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
