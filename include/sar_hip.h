@@ -219,6 +219,23 @@ int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, const int32_t*
                       const float* loc, const float* wavelength, float* z_re, float* z_im, sar_stream_t s);
 int sar_stft_logmag_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
                         const float* window /* [n_fft] */, int out_cols, float* out, sar_stream_t s);
+/* Backward of the two stages, for training radar_location / wavelength (layers/virtual_radar.py:46-52 with
+ * train_* = True; main_spectrogram.py:133-136 unfreezes `radar_loc*` after --loc-train-epoch): torch autograd
+ * of :93-133 in the reference.
+ * sar_stft_logmag_bwd_f32: dout [B][n_fft][F or out_cols] (gradient of sar_stft_logmag_f32's output) ->
+ *   dz_re, dz_im [B][T] (cotangent of the complex signal).  Recomputes the spectrum from z; workspace of
+ *   sar_stft_logmag_bwd_workspace_floats(...) floats; fixed summation order (no atomics).
+ * sar_vr_signal_bwd_f32: partials[nparts][4] with sum over parts = d loss / d (loc_x, loc_y, loc_z, wavelength)
+ *   = sum_{b,t} Re(conj(dz) * dz/dp); nparts = sar_vr_signal_bwd_nparts(B, T).  Forward-mode tangents of the
+ *   geometry / RCS / phase, contracted with dz per (clip, frame). */
+int64_t sar_stft_logmag_bwd_workspace_floats(int B, int T, int n_fft, int hop);
+int sar_stft_logmag_bwd_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
+                            const float* window, int out_cols, const float* dout, float* workspace,
+                            float* dz_re, float* dz_im, sar_stream_t s);
+int sar_vr_signal_bwd_nparts(int B, int T);
+int sar_vr_signal_bwd_f32(const float* x, int B, int T, int V, int M, const int32_t* e_src, const int32_t* e_dst,
+                          int E, const float* loc, const float* wavelength, const float* dz_re, const float* dz_im,
+                          float* partials, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * ResNet-18 of the spectrogram path, models/resnet18.py:131-254 (torch Conv2d bias=False / BatchNorm2d /
@@ -253,6 +270,12 @@ typedef struct sar_conv2d_desc {
 int sar_conv2d_nparts(const sar_conv2d_desc* d);
 int sar_conv2d_gemm_f32(const sar_conv2d_desc* d, sar_stream_t s);
 int sar_conv2d_wgrad_f32(const sar_conv2d_desc* d, sar_stream_t s);
+/* Data gradient of a ONE-input-channel conv (the 7x7/2 stem, models/resnet18.py:159): dx[b][h][w] = sum_{kh,kw,m}
+ * dout[m][(b, (h+pad-kh)/s, (w+pad-kw)/s)] * w_packed[kh*KW+kw][m] over the taps that divide evenly.  Needed only
+ * when the image itself depends on trainable parameters (VirtualRadar location / wavelength). */
+int sar_conv2d_stem_dgrad_f32(const float* dout, int64_t ld_dout, const float* w_packed, int B, int H, int W,
+                              int H_out, int W_out, int M, int KH, int KW, int stride, int pad, float* dx,
+                              sar_stream_t s);
 
 /* out[i][j][k] (contiguous [d0][d1][d2]) = in[i*s0 + j*s1 + k*s2]: weight repacking OIHW <-> (tap, c, m). */
 int sar_permute3_f32(const float* in, float* out, int d0, int d1, int d2, int64_t s0, int64_t s1, int64_t s2,

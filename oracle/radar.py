@@ -136,3 +136,59 @@ def nearest_columns(F_, out_cols):
     scale = f32(F_) / f32(out_cols)
     j = np.arange(out_cols, dtype=f32)
     return np.minimum(np.floor(j * scale).astype(np.int64), F_ - 1)
+
+
+def spectrogram_torch(x, loc, lam, edges=EDGES, n_fft=256, hop=16, out_cols=0, dtype=None):
+    """Differentiable restatement of the whole layer (layers/virtual_radar.py:93-133) in torch, for the gradients of
+    radar_location / wavelength (autograd of the reference when train_* are set, main_spectrogram.py:133-136).
+    x (B,3,T,V,M) tensor; loc (3,) and lam () tensors (requires_grad as wanted); float64 unless dtype is given.
+    out_cols > 0 applies the nearest column select of models/resnet.py:26."""
+    import torch
+    dtype = dtype or torch.float64
+    x = torch.as_tensor(x).to(dtype)
+    src, dst = map(list, zip(*edges))
+    S, D = x[:, :, :, src], x[:, :, :, dst]                         # (B,3,T,E,M)
+    L = loc.to(dtype)[:, None, None, None]
+    rev = (S - L).abs()
+    rx, ry, rz = rev[:, 0], rev[:, 1], rev[:, 2]
+    dist = torch.sqrt(rx * rx + ry * ry + rz * rz)
+    Av = L - (S + D) / 2
+    Bv = D - S
+    dot = (Av * Bv).sum(1)
+    nA, nB = torch.sqrt((Av * Av).sum(1)), torch.sqrt((Bv * Bv).sum(1))
+    theta = torch.acos(dot / (nA * nB + 1e-6))
+    phi = torch.asin((loc.to(dtype)[1] - S[:, 1]) / (torch.sqrt(rx * rx + ry * ry) + 1e-6))
+    c = torch.sqrt(((S - D) ** 2).sum(1)).mean(dim=2, keepdim=True) ** 2
+    st, ct, sp, cp = torch.sin(theta), torch.cos(theta), torch.sin(phi), torch.cos(phi)
+    den = st * st * cp * cp + st * st * sp * sp + c * ct * ct
+    amp = torch.sqrt(np.pi * c / (den * den))
+    psi = 4 * np.pi * dist / lam.to(dtype)
+    zr, zi = (amp * torch.cos(psi)).sum(dim=[2, 3]), (amp * torch.sin(psi)).sum(dim=[2, 3])       # (B,T)
+    pad = n_fft // 2
+    w = torch.from_numpy(hann_periodic(n_fft)).to(dtype)
+    n = torch.arange(n_fft, dtype=dtype)
+    ang = 2 * np.pi * n[:, None] * n[None, :] / n_fft                                          # [k, n]
+    wcos, wsin = w * torch.cos(ang), w * torch.sin(ang)
+
+    def frames(u):
+        up = torch.nn.functional.pad(u[:, None, :], (pad, pad), mode="reflect")[:, 0]
+        return up.unfold(1, n_fft, hop)                                                         # (B,F,n_fft)
+    fr, fi = frames(zr), frames(zi)
+    # Z[k,f] = sum_n (zr + j zi)[n] w[n] e^{-j 2 pi k n / N}
+    Z_re = torch.einsum("bfn,kn->bkf", fr, wcos) + torch.einsum("bfn,kn->bkf", fi, wsin)
+    Z_im = torch.einsum("bfn,kn->bkf", fi, wcos) - torch.einsum("bfn,kn->bkf", fr, wsin)
+    out = torch.log(torch.sqrt(Z_re * Z_re + Z_im * Z_im) + 1e-6)
+    out = torch.roll(out, n_fft // 2, dims=1)
+    if out_cols > 0:
+        out = out[:, :, torch.from_numpy(nearest_columns(out.shape[2], out_cols).astype(np.int64))]
+    return out
+
+
+def radar_param_grads(x, weights, loc, lam, **kw):
+    """d/d(loc, lam) of sum(spectrogram * weights) in float64 -> (dloc (3,), dlam ()) numpy."""
+    import torch
+    loc_t = torch.tensor(np.asarray(loc, dtype=np.float64), requires_grad=True)
+    lam_t = torch.tensor(float(lam), dtype=torch.float64, requires_grad=True)
+    out = spectrogram_torch(x, loc_t, lam_t, **kw)
+    (out * torch.as_tensor(weights).to(out.dtype)).sum().backward()
+    return loc_t.grad.numpy(), lam_t.grad.numpy()

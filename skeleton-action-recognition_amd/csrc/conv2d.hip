@@ -761,6 +761,41 @@ int launch_wgrad(const sar_conv2d_desc& d, hipStream_t st) {
   return 0;
 }
 
+// Data gradient of the one-input-channel stem conv (needed only when something upstream of the image trains:
+// the radar location / wavelength, main_spectrogram.py:133-136).  Cin = 1, so this is 51 MMAC per image of plain
+// FMA work: one thread per image pixel walks the <= ceil(KH/s) x ceil(KW/s) taps that reach it and the M filters;
+// the packed weights [tap][m] sit in LDS.
+__global__ __launch_bounds__(256) void conv2d_stem_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ Wt,
+                                                                int B, int H, int W, int Ho, int Wo, int M, int KH, int KW,
+                                                                int stride, int pad, int64_t ld_dout,
+                                                                float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [KH*KW][M]
+  for (int i = threadIdx.x; i < KH * KW * M; i += blockDim.x) wl[i] = Wt[i];
+  __syncthreads();
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * H * W) return;
+  const int w = (int)(gid % W);
+  const int h = (int)((gid / W) % H);
+  const int b = (int)(gid / ((int64_t)W * H));
+  float acc = 0.f;
+  for (int kh = 0; kh < KH; ++kh) {
+    const int hh = h + pad - kh;
+    if (hh < 0 || hh % stride != 0) continue;
+    const int ho = hh / stride;
+    if (ho >= Ho) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      const int ww = w + pad - kw;
+      if (ww < 0 || ww % stride != 0) continue;
+      const int wo = ww / stride;
+      if (wo >= Wo) continue;
+      const float* dp = dout + ((int64_t)b * Ho + ho) * Wo + wo;
+      const float* wp = wl + (kh * KW + kw) * M;
+      for (int m = 0; m < M; ++m) acc = fmaf(dp[(int64_t)m * ld_dout], wp[m], acc);
+    }
+  }
+  dx[gid] = acc;
+}
+
 }  // namespace
 
 extern "C" int sar_conv2d_nparts(const sar_conv2d_desc* d) {
@@ -853,5 +888,21 @@ extern "C" int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, m, v, g, n, lr_dev, step_dev, beta1, beta2, eps);
   SAR_LAUNCH_CHECK("sar_adam_f32");
+  return 0;
+}
+
+extern "C" int sar_conv2d_stem_dgrad_f32(const float* dout, int64_t ld_dout, const float* w_packed, int B, int H, int W,
+                                         int H_out, int W_out, int M, int KH, int KW, int stride, int pad, float* dx,
+                                         sar_stream_t s) {
+  SAR_REQUIRE(dout && w_packed && dx, "sar_conv2d_stem_dgrad: null pointer");
+  SAR_REQUIRE(B > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0 && M > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+              "sar_conv2d_stem_dgrad: bad sizes");
+  SAR_REQUIRE(ld_dout >= (int64_t)B * H_out * W_out, "sar_conv2d_stem_dgrad: leading dimension smaller than B*Ho*Wo");
+  const size_t lds = sizeof(float) * KH * KW * M;
+  SAR_REQUIRE(lds <= 64 * 1024, "sar_conv2d_stem_dgrad: weight tile too large");
+  const int64_t n = (int64_t)B * H * W;
+  hipLaunchKernelGGL(conv2d_stem_dgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, as_stream(s), dout,
+                     w_packed, B, H, W, H_out, W_out, M, KH, KW, stride, pad, ld_dout, dx);
+  SAR_LAUNCH_CHECK("sar_conv2d_stem_dgrad_f32");
   return 0;
 }

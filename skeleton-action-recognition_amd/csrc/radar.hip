@@ -138,6 +138,250 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward (training radar_location / wavelength, main_spectrogram.py:133-136 + torch autograd of
+// layers/virtual_radar.py:93-133).  Only 4 scalars are trainable, so the signal stage is differentiated in
+// FORWARD mode: each (clip, frame) thread re-evaluates the geometry with the tangents w.r.t. (loc_x, loc_y,
+// loc_z, lambda) and contracts d z / d p with the upstream cotangent of z; the STFT stage is the adjoint of the
+// forward kernel (recomputes Z, no saved spectrum).  All reductions have a fixed order (no atomics).
+
+// Stage 1, one workgroup per (clip, STFT frame f): dS = sum of dout over the output columns that consumed f,
+// dZ = dS * Z / (|Z| (|Z| + 1e-6)), adjoint DFT, times the window -> G[b][f][n] (gradient of the reflect-padded
+// sample f*hop + n - n_fft/2).
+__global__ __launch_bounds__(256) void stft_logmag_bwd_frames_kernel(const float* __restrict__ z_re,
+                                                                     const float* __restrict__ z_im, int T, int n_fft,
+                                                                     int hop, const float* __restrict__ window, int F,
+                                                                     int ncols, int select,
+                                                                     const float* __restrict__ dout,
+                                                                     float2* __restrict__ G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* wz = (float2*)smem;            // [n_fft] windowed complex frame
+  float2* tw = wz + n_fft;               // [n_fft] (cos, sin)(2 pi m / n_fft)
+  float2* dZ = tw + n_fft;               // [n_fft]
+  const int b = blockIdx.y, f = blockIdx.x;
+  // output columns that read frame f: j with min(floor(j * fl32(F/ncols)), F-1) == f (select) or j == f
+  int j0 = f, j1 = f + 1;
+  if (select) {
+    const float scale = (float)F / (float)ncols;
+    j0 = ncols;
+    j1 = 0;
+    for (int j = 0; j < ncols; ++j) {   // uniform scalar loop; ncols is small
+      const int src = min((int)floorf((float)j * scale), F - 1);
+      if (src == f) {
+        j0 = min(j0, j);
+        j1 = max(j1, j + 1);
+      }
+    }
+  }
+  float2* Gf = G + ((int64_t)b * F + f) * n_fft;
+  if (j0 >= j1) {   // frame not consumed
+    for (int n = threadIdx.x; n < n_fft; n += blockDim.x) Gf[n] = make_float2(0.f, 0.f);
+    return;
+  }
+  const int half = n_fft / 2;
+  for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+    int i = f * hop + n - half;
+    if (i < 0) i = -i;
+    if (i >= T) i = 2 * (T - 1) - i;
+    const float w = window[n];
+    wz[n] = make_float2(w * z_re[(int64_t)b * T + i], w * z_im[(int64_t)b * T + i]);
+    float s, c;
+    sincospif((float)(2 * n) / (float)n_fft, &s, &c);
+    tw[n] = make_float2(c, s);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_fft; k += blockDim.x) {
+    float re = 0.f, im = 0.f;
+    int idx = 0;
+    for (int n = 0; n < n_fft; ++n) {
+      const float2 v = wz[n];
+      const float2 t = tw[idx];
+      re = fmaf(v.x, t.x, fmaf(v.y, t.y, re));
+      im = fmaf(v.y, t.x, fmaf(-v.x, t.y, im));
+      idx += k;
+      if (idx >= n_fft) idx -= n_fft;
+    }
+    const float mag = sqrtf(re * re + im * im);
+    const int row = (k + half) % n_fft;
+    float ds = 0.f;
+    for (int j = j0; j < j1; ++j) ds += dout[((int64_t)b * n_fft + row) * ncols + j];
+    // d log(|Z| + eps) / d(re, im) = (re, im) / (|Z| (|Z| + eps)); |Z| = 0 takes the zero subgradient
+    const float g = mag > 0.f ? ds / (mag * (mag + 1e-6f)) : 0.f;
+    dZ[k] = make_float2(g * re, g * im);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+    // re_k = sum_n vx cos + vy sin ; im_k = sum_n vy cos - vx sin  (theta = 2 pi k n / n_fft)
+    float gx = 0.f, gy = 0.f;
+    int idx = 0;
+    for (int k = 0; k < n_fft; ++k) {
+      const float2 dz = dZ[k];
+      const float2 t = tw[idx];
+      gx = fmaf(dz.x, t.x, fmaf(-dz.y, t.y, gx));
+      gy = fmaf(dz.x, t.y, fmaf(dz.y, t.x, gy));
+      idx += n;
+      if (idx >= n_fft) idx -= n_fft;
+    }
+    const float w = window[n];
+    Gf[n] = make_float2(w * gx, w * gy);
+  }
+}
+
+// Stage 2, one thread per (clip, sample t): gather the frame gradients that touch sample t -- directly or through
+// the reflect padding at either end -- in a fixed order.
+__global__ __launch_bounds__(256) void stft_logmag_bwd_gather_kernel(const float2* __restrict__ G, int B, int T,
+                                                                     int n_fft, int hop, int F,
+                                                                     float* __restrict__ dz_re,
+                                                                     float* __restrict__ dz_im) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * T) return;
+  const int b = (int)(gid / T), t = (int)(gid - (int64_t)b * T);
+  const int half = n_fft / 2;
+  float sx = 0.f, sy = 0.f;
+  // a padded index i maps to sample t if i == t, or i == -t (i < 0), or i == 2(T-1) - t (i >= T)
+  const int cand[3] = {t, -t, 2 * (T - 1) - t};
+  for (int c = 0; c < 3; ++c) {
+    const int i = cand[c];
+    if (c == 1 && !(i < 0)) continue;
+    if (c == 2 && !(i >= T)) continue;
+    // frames with 0 <= i + half - f*hop < n_fft
+    int f_lo = (i + half - n_fft + hop) / hop;   // ceil((i + half - n_fft + 1) / hop) for the non-negative case
+    if (i + half - n_fft + 1 <= 0) f_lo = 0;
+    int f_hi = (i + half >= 0) ? (i + half) / hop : -1;
+    if (f_hi > F - 1) f_hi = F - 1;
+    for (int f = f_lo; f <= f_hi; ++f) {
+      const int n = i + half - f * hop;
+      if (n < 0 || n >= n_fft) continue;
+      const float2 g = G[((int64_t)b * F + f) * n_fft + n];
+      sx += g.x;
+      sy += g.y;
+    }
+  }
+  dz_re[gid] = sx;
+  dz_im[gid] = sy;
+}
+
+// Signal stage: partials[block][4] = sum over the block's frames of Re(conj(dz) . d z / d p), p = (loc_x, loc_y,
+// loc_z, lambda).  Same slab staging as the forward kernel.
+__global__ __launch_bounds__(FRAMES) void vr_signal_bwd_kernel(const float* __restrict__ x, int T, int V, int M,
+                                                               const int* __restrict__ e_src,
+                                                               const int* __restrict__ e_dst, int E,
+                                                               const float* __restrict__ loc_p,
+                                                               const float* __restrict__ lam_p,
+                                                               const float* __restrict__ dz_re,
+                                                               const float* __restrict__ dz_im,
+                                                               float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int VM = V * M;
+  const int RS = VM | 1;
+  float* xs = smem;
+  int* es = (int*)(xs + 3 * FRAMES * RS);
+  int* ed = es + E;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * FRAMES;
+  const int nt = min(FRAMES, T - t0);
+  for (int c = 0; c < 3; ++c) {
+    const float* g = x + (((int64_t)b * 3 + c) * T + t0) * VM;
+    for (int i = threadIdx.x; i < nt * VM; i += FRAMES) {
+      const int tt = i / VM;
+      xs[(c * FRAMES + tt) * RS + (i - tt * VM)] = g[i];
+    }
+  }
+  for (int i = threadIdx.x; i < E; i += FRAMES) {
+    es[i] = e_src[i];
+    ed[i] = e_dst[i];
+  }
+  __syncthreads();
+  const int tt = threadIdx.x;
+  float gp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tt < nt) {
+    const float lx = loc_p[0], ly = loc_p[1], lz = loc_p[2];
+    const float lam = lam_p[0];
+    const float* X0 = xs + (0 * FRAMES + tt) * RS;
+    const float* X1 = xs + (1 * FRAMES + tt) * RS;
+    const float* X2 = xs + (2 * FRAMES + tt) * RS;
+    const float PI_F = 3.14159274101257324f;
+    const float FOURPI_F = 12.5663706143591725f;
+    const float ur = dz_re[(int64_t)b * T + t0 + tt], ui = dz_im[(int64_t)b * T + t0 + tt];
+    float cm[4];
+    for (int m = 0; m < M; ++m) {
+      float acc = 0.f;
+      for (int e = 0; e < E; ++e) {
+        const int js = es[e] * M + m, jd = ed[e] * M + m;
+        const float dx = X0[js] - X0[jd], dy = X1[js] - X1[jd], dz = X2[js] - X2[jd];
+        acc = acc + sqrtf((dx * dx + dy * dy) + dz * dz);
+      }
+      const float c = acc / (float)E;
+      cm[m] = c * c;
+    }
+    for (int e = 0; e < E; ++e) {
+      for (int m = 0; m < M; ++m) {
+        const int js = es[e] * M + m, jd = ed[e] * M + m;
+        const float sx = X0[js], sy = X1[js], sz = X2[js];
+        const float dx = X0[jd], dy = X1[jd], dz = X2[jd];
+        // value path: same expressions as the forward kernel
+        const float ex = sx - lx, ey = sy - ly, ez = sz - lz;
+        const float rx = fabsf(ex), ry = fabsf(ey), rz = fabsf(ez);
+        const float rxy2 = rx * rx + ry * ry;
+        const float rxy = sqrtf(rxy2);
+        const float dist = sqrtf(rxy2 + rz * rz);
+        const float ax = lx - ((sx + dx) / 2.f), ay = ly - ((sy + dy) / 2.f), az = lz - ((sz + dz) / 2.f);
+        const float bx = dx - sx, by = dy - sy, bz = dz - sz;
+        const float dot = (ax * bx + ay * by) + az * bz;
+        const float nA = sqrtf((ax * ax + ay * ay) + az * az);
+        const float nB = sqrtf((bx * bx + by * by) + bz * bz);
+        const float den_u = nA * nB + 1e-6f;
+        const float u = dot / den_u;
+        const float theta = acosf(u);
+        const float den_q = rxy + 1e-6f;
+        const float q = (ly - sy) / den_q;
+        const float phi = asinf(q);
+        const float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
+        const float c = cm[m];
+        const float den = ((st * st) * (cp * cp) + (st * st) * (sp * sp)) + c * (ct * ct);
+        const float amp = sqrtf((PI_F * c) / (den * den));
+        const float psi = (FOURPI_F * dist) / lam;
+        const float cps = cosf(psi), sps = sinf(psi);
+        // tangents w.r.t. loc (3 components); d|e|/dl = -e/|e| component-wise (e = s - l)
+        // Degenerate points (a joint at the radar position, an absent all-zero body, |u| or |q| = 1) take the zero
+        // subgradient.  The reference's autograd returns NaN there (0/0 in the norm backward, sqrt'(0) * 0 for an
+        // absent body's zero RCS), i.e. NaN radar_location gradients on every NTU clip with a missing second body.
+        const float idist = dist > 0.f ? 1.f / dist : 0.f, irxy = rxy > 0.f ? 1.f / rxy : 0.f, inA = nA > 0.f ? 1.f / nA : 0.f;
+        const float ddist[3] = {-ex * idist, -ey * idist, -ez * idist};
+        const float drxy[3] = {-ex * irxy, -ey * irxy, 0.f};
+        const float ddot[3] = {bx, by, bz};
+        const float dnA[3] = {ax * inA, ay * inA, az * inA};
+        const float su2 = 1.f - u * u, sq2 = 1.f - q * q;
+        const float inv_su = su2 > 0.f ? -1.f / sqrtf(su2) : 0.f;       // d acos
+        const float inv_sq = sq2 > 0.f ? 1.f / sqrtf(sq2) : 0.f;        // d asin
+        for (int p = 0; p < 3; ++p) {
+          const float du = (ddot[p] * den_u - dot * nB * dnA[p]) / (den_u * den_u);
+          const float dth = inv_su * du;
+          const float dq = ((p == 1 ? 1.f : 0.f) * den_q - (ly - sy) * drxy[p]) / (den_q * den_q);
+          const float dph = inv_sq * dq;
+          const float dden = 2.f * st * ct * dth * (cp * cp + sp * sp) + (st * st) * (2.f * sp * cp - 2.f * cp * sp) * dph -
+                             2.f * c * ct * st * dth;
+          const float damp = -amp * dden / den;
+          const float dpsi = FOURPI_F * ddist[p] / lam;
+          const float dzr = damp * cps - amp * sps * dpsi;
+          const float dzi = damp * sps + amp * cps * dpsi;
+          gp[p] += ur * dzr + ui * dzi;
+        }
+        {   // wavelength: only the phase depends on it
+          const float dpsi = -psi / lam;
+          gp[3] += ur * (-amp * sps * dpsi) + ui * (amp * cps * dpsi);
+        }
+      }
+    }
+  }
+  // block reduction (one wave), fixed order
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float t = wave_sum(gp[p]);
+    if (threadIdx.x == 0) partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + p] = t;
+  }
+}
+
 }  // namespace
 
 extern "C" int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, const int32_t* e_src, const int32_t* e_dst,
@@ -165,5 +409,47 @@ extern "C" int sar_stft_logmag_f32(const float* z_re, const float* z_im, int B, 
   hipLaunchKernelGGL(stft_logmag_kernel, grid, dim3(256), sizeof(float2) * 2 * n_fft, as_stream(s), z_re, z_im, T, n_fft,
                      hop, window, F, ncols, out_cols > 0 ? 1 : 0, out);
   SAR_LAUNCH_CHECK("sar_stft_logmag_f32");
+  return 0;
+}
+
+extern "C" int64_t sar_stft_logmag_bwd_workspace_floats(int B, int T, int n_fft, int hop) {
+  if (B <= 0 || T <= 0 || n_fft <= 0 || hop <= 0) return -1;
+  return (int64_t)B * (T / hop + 1) * n_fft * 2;
+}
+
+extern "C" int sar_stft_logmag_bwd_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
+                                       const float* window, int out_cols, const float* dout, float* workspace,
+                                       float* dz_re, float* dz_im, sar_stream_t s) {
+  SAR_REQUIRE(z_re && z_im && window && dout && workspace && dz_re && dz_im, "sar_stft_logmag_bwd: null pointer");
+  SAR_REQUIRE(B > 0 && n_fft >= 2 && n_fft <= 2048 && (n_fft % 2) == 0 && hop > 0, "sar_stft_logmag_bwd: bad sizes");
+  SAR_REQUIRE(T > n_fft / 2, "sar_stft_logmag_bwd: reflect padding needs T > n_fft/2 (T=%d, n_fft=%d)", T, n_fft);
+  const int F = T / hop + 1;
+  const int ncols = out_cols > 0 ? out_cols : F;
+  hipLaunchKernelGGL(stft_logmag_bwd_frames_kernel, dim3(F, B), dim3(256), sizeof(float2) * 3 * n_fft, as_stream(s),
+                     z_re, z_im, T, n_fft, hop, window, F, ncols, out_cols > 0 ? 1 : 0, dout, (float2*)workspace);
+  SAR_LAUNCH_CHECK("sar_stft_logmag_bwd_f32 (frames)");
+  const int64_t n = (int64_t)B * T;
+  hipLaunchKernelGGL(stft_logmag_bwd_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s),
+                     (const float2*)workspace, B, T, n_fft, hop, F, dz_re, dz_im);
+  SAR_LAUNCH_CHECK("sar_stft_logmag_bwd_f32 (gather)");
+  return 0;
+}
+
+extern "C" int sar_vr_signal_bwd_nparts(int B, int T) {
+  if (B <= 0 || T <= 0) return SAR_E_ARG;
+  return B * ((T + FRAMES - 1) / FRAMES);
+}
+
+extern "C" int sar_vr_signal_bwd_f32(const float* x, int B, int T, int V, int M, const int32_t* e_src,
+                                     const int32_t* e_dst, int E, const float* loc, const float* wavelength,
+                                     const float* dz_re, const float* dz_im, float* partials, sar_stream_t s) {
+  SAR_REQUIRE(x && e_src && e_dst && loc && wavelength && dz_re && dz_im && partials, "sar_vr_signal_bwd: null pointer");
+  SAR_REQUIRE(B > 0 && T > 0 && V > 0 && M > 0 && M <= 4 && E > 0, "sar_vr_signal_bwd: bad sizes (M <= 4)");
+  const size_t lds = sizeof(float) * 3 * FRAMES * ((V * M) | 1) + sizeof(int) * 2 * E;
+  SAR_REQUIRE(lds <= 64 * 1024, "sar_vr_signal_bwd: V*M = %d too large for the LDS slab", V * M);
+  dim3 grid((T + FRAMES - 1) / FRAMES, B);
+  hipLaunchKernelGGL(vr_signal_bwd_kernel, grid, dim3(FRAMES), lds, as_stream(s), x, T, V, M, e_src, e_dst, E, loc,
+                     wavelength, dz_re, dz_im, partials);
+  SAR_LAUNCH_CHECK("sar_vr_signal_bwd_f32");
   return 0;
 }

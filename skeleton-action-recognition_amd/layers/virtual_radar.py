@@ -7,9 +7,12 @@ phase, sum over edges and bodies) and sar_stft_logmag_f32 (reflect pad, periodic
 magnitude, roll).  The window is the one nnAudio 0.1.1's STFT builds
 (scipy.signal.get_window('hann', n_fft, fftbins=True)); no nnAudio dependency.
 
-`wavelength` and `radar_location` are torch Parameters with the reference's names; training them
-(train_wavelength / train_radar_location / train_stft_kernel) needs the backward kernels, which are not
-built yet: requesting them raises NotImplementedError instead of silently freezing.
+`wavelength` and `radar_location` are torch Parameters with the reference's names.  When either requires a gradient
+(train_wavelength / train_radar_location, or `requires_grad = True` set later as main_spectrogram.py:133-136 does)
+the forward records an autograd node whose backward runs sar_stft_logmag_bwd_f32 (adjoint of the STFT / log-magnitude
+stage) and sar_vr_signal_bwd_f32 (forward-mode tangents of the geometry w.r.t. the 4 scalars, contracted with the
+signal cotangent).  The skeleton input gets no gradient (it is data).  train_stft_kernel (trainable DFT kernels of
+nnAudio) is not built: requesting it raises NotImplementedError instead of silently freezing.
 """
 import numpy as np
 import torch
@@ -24,16 +27,50 @@ _CHAINS = [(0, 1, 20, 2, 3), (20, 4, 5, 6, 7, 21), (7, 22), (20, 8, 9, 10, 11, 2
 edges = [(c[i], c[i + 1]) for c in _CHAINS for i in range(len(c) - 1)]
 
 
+class _RadarFunction(torch.autograd.Function):
+    """log|STFT(z(x; loc, lambda))| with gradients for radar_location and wavelength."""
+
+    @staticmethod
+    def forward(ctx, loc, wavelength, mod, x, out_cols):
+        zr, zi = mod.signal(x)
+        ctx.mod, ctx.out_cols = mod, out_cols
+        ctx.save_for_backward(x, zr, zi)
+        return mod._stft(zr, zi, out_cols)
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        x, zr, zi = ctx.saved_tensors
+        lib = L.load()
+        B, T = zr.shape
+        _, _, _, V, M = x.shape
+        dout = dout.contiguous().float()
+        ws = torch.empty(lib.sar_stft_logmag_bwd_workspace_floats(B, T, mod.n_fft, mod.hop_length), dtype=torch.float32,
+                         device=x.device)
+        dzr, dzi = torch.empty_like(zr), torch.empty_like(zi)
+        check(lib.sar_stft_logmag_bwd_f32(ptr(zr), ptr(zi), B, T, mod.n_fft, mod.hop_length, ptr(mod.window), ctx.out_cols,
+                                          ptr(dout), ptr(ws), ptr(dzr), ptr(dzi), stream_ptr()), "sar_stft_logmag_bwd_f32")
+        nparts = lib.sar_vr_signal_bwd_nparts(B, T)
+        part = torch.empty((nparts, 4), dtype=torch.float32, device=x.device)
+        check(lib.sar_vr_signal_bwd_f32(ptr(x), B, T, V, M, ptr(mod._src), ptr(mod._dst), len(mod.src),
+                                        ptr(mod.radar_location.data), ptr(mod.wavelength.data.reshape(1)), ptr(dzr), ptr(dzi),
+                                        ptr(part), stream_ptr()), "sar_vr_signal_bwd_f32")
+        g = part.double().sum(0).float()          # fixed-order reduction of the per-block partial sums
+        return g[:3].clone(), g[3].reshape(mod.wavelength.shape), None, None, None
+
+
 class VirtualRadar(torch.nn.Module):
     def __init__(self, edges=edges, wavelength=1e-3, radar_location=[0., 0., 0.], train_wavelength=False,
                  train_radar_location=False, train_stft_kernel=False, n_fft=256, hop_length=16, device='cuda:0'):
         super().__init__()
-        if train_wavelength or train_radar_location or train_stft_kernel:
-            raise NotImplementedError("trainable radar parameters need the VirtualRadar backward kernels (not built yet)")
+        if train_stft_kernel:
+            raise NotImplementedError("trainable STFT kernels (nnAudio trainable=True) are not built")
         L.load()
-        self.wavelength = torch.nn.Parameter(torch.as_tensor(wavelength, dtype=torch.float32), requires_grad=False)
+        # layers/virtual_radar.py:46-52
+        self.wavelength = torch.nn.Parameter(torch.as_tensor(wavelength, dtype=torch.float32),
+                                             requires_grad=bool(train_wavelength))
         self.radar_location = torch.nn.Parameter(torch.as_tensor(radar_location, dtype=torch.float32),
-                                                 requires_grad=False)
+                                                 requires_grad=bool(train_radar_location))
         self.src, self.dst = map(list, zip(*edges))
         self.n_fft, self.hop_length = n_fft, hop_length
         n = np.arange(n_fft, dtype=np.float64)
@@ -58,10 +95,15 @@ class VirtualRadar(torch.nn.Module):
     def forward(self, x, out_cols=0):
         """out_cols > 0 produces only the frames a nearest-neighbour F.interpolate(..., out_cols) would read
         (models/resnet.py:26 fused as a column select) -> (B, n_fft, out_cols)."""
+        if torch.is_grad_enabled() and (self.radar_location.requires_grad or self.wavelength.requires_grad):
+            return _RadarFunction.apply(self.radar_location, self.wavelength, self, x.contiguous(), out_cols)
         zr, zi = self.signal(x)
+        return self._stft(zr, zi, out_cols)
+
+    def _stft(self, zr, zi, out_cols=0):
         B, T = zr.shape
         F_ = T // self.hop_length + 1
-        out = torch.empty((B, self.n_fft, out_cols if out_cols > 0 else F_), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, self.n_fft, out_cols if out_cols > 0 else F_), dtype=torch.float32, device=zr.device)
         check(L.load().sar_stft_logmag_f32(ptr(zr), ptr(zi), B, T, self.n_fft, self.hop_length, ptr(self.window), out_cols,
                                            ptr(out), stream_ptr()), "sar_stft_logmag_f32")
         return out

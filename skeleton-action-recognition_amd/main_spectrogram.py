@@ -59,8 +59,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    if arg.loc_train_epoch <= arg.num_epochs or arg.lambda_train_epoch <= arg.num_epochs:
-        raise NotImplementedError("training the radar parameters needs the VirtualRadar backward kernels (not built yet)")
     arg.model_type = 'models.' + arg.model_type.strip() + '.Model'
     run_params = {k: v for k, v in vars(arg).items() if k not in ("data_path", "label_path", "log_dir")}
     run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
@@ -82,6 +80,8 @@ def main():
         data = {x: NpySkeletonData(arg.data_path.format(x), arg.label_path.format(x)) for x in ['train', 'val']}
     model = Model(num_classes=arg.num_classes, num_filters=arg.num_filters, device=dev)
     eng = model.base_model.engine
+    radar_params = list(model.virtual_radar.parameters())
+    radar_opt = torch.optim.Adam(radar_params, lr=arg.base_lr)   # same Adam hyper-parameters as main_spectrogram.py:106
     log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None
 
     def scalar(tag, value, step):
@@ -92,19 +92,46 @@ def main():
         if rank == 0:
             print('Epoch {}/{}'.format(epoch + 1, arg.num_epochs), flush=True)
         lr = cyclic_lr(epoch, 1e-4, arg.base_lr, arg.lr_cycle)
+        # main_spectrogram.py:127-136: parameters are un-frozen by NAME at the given epochs ('radar_lambda' matches no
+        # parameter of the reference model either -- the wavelength is called `wavelength`)
+        if epoch == arg.lambda_train_epoch:
+            for name, param in model.named_parameters():
+                if 'radar_lambda' in name:
+                    param.requires_grad = True
+        if epoch == arg.loc_train_epoch:
+            for name, param in model.named_parameters():
+                if 'radar_loc' in name:
+                    param.requires_grad = True
+        train_radar = any(p.requires_grad for p in radar_params)
+        for g in radar_opt.param_groups:
+            g['lr'] = lr
         for phase in ['train', 'val']:
             run_loss = run_ok = n_seen = n_it = 0
             for it, (x, y) in enumerate(data[phase].batches(arg.batch_size, rank if phase == 'train' else 0,
                                                             world if phase == 'train' else 1, dev, shuffle=True, epoch=epoch,
                                                             drop_remainder=phase == 'train')):
-                img = model.spectrogram(x)
                 if phase == 'train':
-                    logits, loss = eng.loss_and_grad(img, y)
+                    with torch.set_grad_enabled(train_radar):
+                        img = model.spectrogram(x)
+                    if train_radar:                                  # the image depends on trainable radar parameters
+                        logits, loss, dimg = eng.loss_and_grad(img.detach(), y, need_dx=True)
+                        radar_opt.zero_grad(set_to_none=False)
+                        img.backward(dimg)
+                    else:
+                        logits, loss = eng.loss_and_grad(img, y)
                     if world > 1:
                         allreduce_sum_(eng.grad)
                         eng.grad.div_(world)                     # mean over the global batch, as DataParallel's gather+mean
+                        for p_ in radar_params:
+                            if p_.requires_grad and p_.grad is not None:
+                                allreduce_sum_(p_.grad)
+                                p_.grad.div_(world)
                     eng.adam_step(lr)
+                    if train_radar:
+                        radar_opt.step()
                 else:
+                    with torch.no_grad():
+                        img = model.spectrogram(x)
                     logits = eng.forward(img, training=False)
                     loss = torch.nn.functional.cross_entropy(logits, y).reshape(1)
                 ok = (logits.argmax(1) == y).sum()
@@ -117,6 +144,9 @@ def main():
                 scalar('{}_epoch_cross_entropy_loss'.format(phase), run_loss / max(n_it, 1), epoch)
                 scalar('{}_epoch_acc'.format(phase), run_ok / max(n_seen, 1), epoch)
                 print('{} Loss: {:.4f} Acc: {:.4f}'.format(phase, run_loss / max(n_it, 1), run_ok / max(n_seen, 1)), flush=True)
+        if rank == 0 and train_radar:
+            print('radar_location {} wavelength {:.6g}'.format([round(v, 6) for v in model.virtual_radar.radar_location.tolist()],
+                                                               model.virtual_radar.wavelength.item()), flush=True)
         if log:
             log.flush()
     if world > 1:

@@ -17,8 +17,8 @@ class _ResNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.engine
-        eng.backward(dlogits.contiguous())
-        return (None, None) + tuple(eng.g[k].clone() for k in eng.shapes)
+        dx = eng.backward(dlogits.contiguous(), need_dx=ctx.needs_input_grad[0])
+        return (dx, None) + tuple(eng.g[k].clone() for k in eng.shapes)
 
 
 class ResNet(torch.nn.Module):

@@ -95,6 +95,11 @@ SIGNATURES = {
     "sar_adam_f32": (_i, [_fp, _fp, _fp, _fp, _i64, _fp, _fp, _f, _f, _f, _fp]),
     "sar_vr_signal_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_stft_logmag_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _fp]),
+    "sar_stft_logmag_bwd_workspace_floats": (_i64, [_i, _i, _i, _i]),
+    "sar_stft_logmag_bwd_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
+    "sar_vr_signal_bwd_nparts": (_i, [_i, _i]),
+    "sar_vr_signal_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "sar_conv2d_stem_dgrad_f32": (_i, [_fp, _i64, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
 }
 
 _lib = None

@@ -293,3 +293,9 @@ def bn_relu_maxpool_bwd(x, scale, shift, mean, dy, dz, B, H, W):
 def adam(w, m, v, g, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8):
     check(L.load().sar_adam_f32(ptr(w), ptr(m), ptr(v), ptr(g), w.numel(), ptr(lr_dev), ptr(step_dev), beta1, beta2, eps,
                                 stream_ptr()), "sar_adam_f32")
+
+
+def conv2d_stem_dgrad(dout, w_packed, dx, *, B, H, W, H_out, W_out, M, KH, KW, stride, pad):
+    """Image gradient of the one-input-channel stem conv (dout CN [M][B*Ho*Wo], w_packed [KH*KW][1][M])."""
+    check(L.load().sar_conv2d_stem_dgrad_f32(ptr(_f32(dout)), dout.stride(0), ptr(_f32(w_packed)), B, H, W, H_out, W_out, M,
+                                             KH, KW, stride, pad, ptr(dx), stream_ptr()), "sar_conv2d_stem_dgrad_f32")

@@ -225,7 +225,9 @@ class ResNet18:
                             b.k1, b.k2, b.k3)
         return b
 
-    def backward(self, dlogits):
+    def backward(self, dlogits, need_dx=False):
+        """Gradients of every parameter into self.g; need_dx additionally returns d loss / d image (B,1,H,W) -- only
+        wanted when the image depends on trainable VirtualRadar parameters."""
         sv = self._saved
         assert sv is not None
         dev, B = dlogits.device, sv["B"]
@@ -270,17 +272,25 @@ class ResNet18:
         self._bn_bwd("bn1", part, nparts, nparts * 2, 2, 1, B * sv["H1"] * sv["W1"])
         ops.affine2(dz0, c0, (bn0.k1, bn0.k2, bn0.k3), dz0)
         self._conv_wgrad("conv1", sv["x0"], dz0, B, sv["H"], sv["W"], sv["H1"], sv["W1"])
+        dx = None
+        if need_dx:
+            cv = self.convs["conv1"]
+            dx = torch.empty((B, 1, sv["H"], sv["W"]), dtype=torch.float32, device=dev)
+            ops.conv2d_stem_dgrad(dz0, self._packed["conv1"][0], dx, B=B, H=sv["H"], W=sv["W"], H_out=sv["H1"], W_out=sv["W1"],
+                                  M=cv.cout, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad)
         self._saved = None
+        return dx
 
     # ------------------------------------------------------------------ training step
-    def loss_and_grad(self, x, labels):
-        """main_spectrogram.py:152-157: CrossEntropyLoss() (mean) and backward."""
+    def loss_and_grad(self, x, labels, need_dx=False):
+        """main_spectrogram.py:152-157: CrossEntropyLoss() (mean) and backward.  With need_dx also returns
+        d loss / d image as a third value."""
         logits = self.forward(x, training=True)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlogits = torch.empty_like(logits)
         ops.softmax_ce(logits, labels, 1.0 / x.shape[0], loss, dlogits)
-        self.backward(dlogits)
-        return logits, loss
+        dx = self.backward(dlogits, need_dx)
+        return (logits, loss, dx) if need_dx else (logits, loss)
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         """torch.optim.Adam(lr) (main_spectrogram.py:106) over the flat buffers."""

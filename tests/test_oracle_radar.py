@@ -83,3 +83,19 @@ def test_zero_body_and_degenerate_geometry_are_finite(clips):
     x[:, :, :, :, 1] = 0                                          # empty second body
     zr, zi = R.radar_signal(x, wavelength=5e-4)
     assert np.isfinite(zr).all() and np.isfinite(zi).all()
+
+
+@pytest.mark.parametrize("lam,loc", [(1e-1, [0.5, -1.0, 2.0]), (1e-2, [0.3, 0.2, -1.5]), (5e-4, [0., 0., 0.])])
+def test_parameter_gradients_match_the_reference_autograd(golden_dir, lam, loc):
+    """d sum(out*w) / d(radar_location, wavelength): the float64 torch restatement against autograd through the
+    reference's own layers/virtual_radar.py run in float64 (tests/golden/make_golden_radar_grad.py)."""
+    g = np.load(os.path.join(golden_dir, "radar_reference_grads.npz"))
+    x = g["x"]
+    w = np.random.default_rng(7).standard_normal((2, 256, 19)).astype(np.float32)
+    # the reference's parameters are float32 tensors (converted to double for the float64 run)
+    dloc, dlam = R.radar_param_grads(x, w, np.asarray(loc, dtype=np.float32).astype(np.float64), float(np.float32(lam)))
+    key = "lam%g" % lam
+    # 2e-5: the reference's double run keeps its float32-rounded DFT kernels and constants (measured 3e-7 .. 6e-6)
+    assert np.abs(dloc - g[key + "_dloc_f64"]).max() <= 2e-5 * np.abs(g[key + "_dloc_f64"]).max()
+    assert abs(dlam - g[key + "_dlam_f64"]) <= 2e-5 * abs(g[key + "_dlam_f64"])
+    assert g["ntu_dloc_is_nan"].all()     # the reference's own gradient is NaN on clips with an absent body / zero padding
