@@ -79,6 +79,129 @@ def cpu_baseline(sample_clips, budget_s=25.0):
                       % (n, sample_clips, cores)}
 
 
+def cpu_baseline_spectrogram(sample_clips, budget_s=25.0):
+    """The CPU oracle of Path B (oracle/radar.py numpy + oracle/resnet.py torch CPU ops): spectrogram, resnet18
+    fwd + bwd, Adam -- as the reported CPU baseline only."""
+    import numpy as np
+    import torch
+    from oracle import radar as RO
+    from oracle import resnet as RN
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    p = RN.init_params(60, num_filters=64, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = (0.12 * torch.randn((sample_clips, 3, 300, 25, 2), generator=g)).clamp_(-1.1, 0.75)
+    y = torch.randint(0, 60, (sample_clips,), generator=g)
+    cols = RO.nearest_columns(300 // 16 + 1, 256)
+    state = {}
+
+    def one():
+        spec = RO.virtual_radar(x.numpy(), wavelength=5e-4)
+        img = torch.from_numpy(np.ascontiguousarray(spec[:, :, cols]))[:, None]
+        _, _, grads, new, _ = RN.loss_and_grads(p, img, y)
+        RN.adam_step(p, grads, state, 1e-3)
+        p.update(new)
+
+    one()
+    t0 = time.time()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 5:
+            break
+    dt = time.time() - t0
+    return {"value": round(sample_clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "%d timed steps of VirtualRadar + resnet18 fwd+bwd+Adam on %d (3,300,25,2) clips, numpy / torch CPU ops, "
+                      "%d threads" % (n, sample_clips, cores)}
+
+
+def main_spectrogram(args):
+    """Path B: VirtualRadar (signal + STFT/log-magnitude/column select) -> resnet18 fwd+bwd -> Adam; bs = --batch per GPU
+    (configs[3] uses 32).  Not the headline metric: selected with --workload spectrogram."""
+    import torch
+    import torch.distributed as dist
+    from sar_amd import profiler
+    from sar_amd.train import allreduce_sum_, synthetic_clips
+    from models.resnet import Model
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    bs = 32 if args.batch == 64 else args.batch
+    model = Model(num_classes=args.classes, num_filters=64, device=dev)
+    eng = model.base_model.engine
+    batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
+
+    def step(i):
+        x, y = batches[i % 4]
+        with torch.no_grad():
+            img = model.spectrogram(x)
+        _, loss = eng.loss_and_grad(img, y)
+        if world > 1:
+            allreduce_sum_(eng.grad)
+            eng.grad.div_(world)
+        eng.adam_step(1e-3)
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timer = profiler.KernelTimer()
+    profiler.install(timer)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    profiler.install(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        summ = timer.summary()
+        fam = [k for k in summ if k.startswith("conv2d_3x3")]
+        ms = sum(summ[k]["ms"] for k in fam)
+        fl = sum(summ[k]["flops"] for k in fam)
+        calls = sum(summ[k]["calls"] for k in fam)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        value = bs * world * args.steps / dt
+        out = {
+            "metric": "spectrogram clips/sec training (VirtualRadar + resnet18, bs=%d/GPU)" % bs,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VirtualRadar -> (B,1,256,256) log-spectrogram -> resnet18 fp32 training step (fwd+bwd+Adam), "
+                                   "synthetic NTU clips (3,300,25,2), %d classes, bs=%d/GPU" % (args.classes, bs),
+                       "global_batch": bs * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches": calls,
+                         "avg_launch_ms": round(ms / max(calls, 1), 4)},
+            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())},
+            "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
+            "final_loss": round(float(loss.item()), 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_spectrogram(4)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +209,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU (reference --batch-size)")
     ap.add_argument("--classes", type=int, default=60)
+    ap.add_argument("--workload", default="stgcn", choices=["stgcn", "spectrogram"],
+                    help="stgcn = BASELINE.json's headline (configs[1]); spectrogram = Path B (configs[3] shape per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="clips in the CPU-baseline sample batch")
     args = ap.parse_args()
@@ -96,6 +221,8 @@ def main():
     from sar_amd.stgcn import STGCN
     from sar_amd.train import Trainer, synthetic_clips
 
+    if args.workload == "spectrogram":
+        return main_spectrogram(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -38,6 +38,41 @@ def param_names(num_filters=64):
     return names
 
 
+def init_params(num_classes=60, num_filters=64, seed=0, dtype=torch.float32):
+    """models/resnet18.py:181-186: kaiming_normal_(fan_out, relu) conv weights, BN weight 1 / bias 0, running stats 0 / 1;
+    nn.Linear default init for fc.  (Seeded with a torch CPU generator -- not bit-identical to any reference run.)"""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+
+    def conv(name, cout, cin, k):
+        p[name] = (torch.randn((cout, cin, k, k), generator=g, dtype=torch.float64) * (2.0 / (cout * k * k)) ** 0.5).to(dtype)
+
+    def bn(name, c):
+        p[name + ".weight"], p[name + ".bias"] = torch.ones(c, dtype=dtype), torch.zeros(c, dtype=dtype)
+        p[name + ".running_mean"], p[name + ".running_var"] = torch.zeros(c, dtype=dtype), torch.ones(c, dtype=dtype)
+
+    conv("conv1.weight", num_filters, 1, 7)
+    bn("bn1", num_filters)
+    inpl = num_filters
+    for li, nblocks in enumerate(LAYERS):
+        planes = num_filters * (2 ** li)
+        for bi in range(nblocks):
+            pre = "layer%d.%d." % (li + 1, bi)
+            stride = 2 if (li > 0 and bi == 0) else 1
+            conv(pre + "conv1.weight", planes, inpl, 3)
+            bn(pre + "bn1", planes)
+            conv(pre + "conv2.weight", planes, planes, 3)
+            bn(pre + "bn2", planes)
+            if stride != 1 or inpl != planes:
+                conv(pre + "downsample.0.weight", planes, inpl, 1)
+                bn(pre + "downsample.1", planes)
+            inpl = planes
+    bound = 1.0 / inpl ** 0.5
+    p["fc.weight"] = ((torch.rand((num_classes, inpl), generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+    p["fc.bias"] = ((torch.rand((num_classes,), generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+    return p
+
+
 def _bn(x, p, name, training, new_stats):
     w, b = p[name + ".weight"], p[name + ".bias"]
     rm, rv = p[name + ".running_mean"], p[name + ".running_var"]

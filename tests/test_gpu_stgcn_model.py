@@ -175,3 +175,31 @@ def test_inference_mode_uses_moving_statistics(dev):
     probs = eng.predict(x.to(dev))
     torch.cuda.synchronize()
     assert rel_err(probs.cpu(), ref) < 1e-4
+
+
+def test_bone_stream_120_classes(dev):
+    """Config 5: the bone stream (data_gen/gen_bone_data.py:36-41 fused into the data_bn prologue) with the NTU-120
+    head: a full train step of the engine fed JOINTS with bone_pairs must equal the oracle fed the BONE tensor the
+    reference's offline pass would have written."""
+    from sar_amd.stgcn import STGCN
+    from sar_amd.bone import NTU_BONE_PAIRS
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True), (256, 2, True)]
+    p = O.randomize_affine(O.init_params(120, seed=9, dtype=torch.float64, blocks=blocks), seed=10)
+    x, y = O.synthetic_batch(3, seed=9, T=20, num_classes=120)
+    bone = x.clone()
+    for v1, v2 in NTU_BONE_PAIRS:
+        bone[:, :, :, v1 - 1, :] = x[:, :, :, v1 - 1, :] - x[:, :, :, v2 - 1, :]
+    eng = STGCN(num_classes=120, device=dev, blocks=blocks, bone_pairs=NTU_BONE_PAIRS)
+    eng.load_params(p)
+    keep = {}
+    logits = eng.forward(x.to(dev), training=True, keep=keep)
+    masks = _engine_masks(eng, keep, blocks, x.shape[0] * x.shape[4], x.shape[2])
+    logits_ref, loss_ref, grads_ref, _, _ = O.loss_and_grads(p, bone.double(), y, blocks=blocks, masks=masks)
+    eng.load_params(p)
+    logits, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+    torch.cuda.synchronize()
+    assert logits.shape == (3, 120)
+    assert rel_err(logits.cpu(), logits_ref) < TOL and rel_err(loss.cpu(), loss_ref.reshape(1)) < TOL
+    for k, g in grads_ref.items():
+        if g.abs().max().item() >= 1e-9:
+            assert rel_err(eng.g[k].cpu(), g) < TOL, k
