@@ -12,6 +12,8 @@ consumer's operand load, BN statistics into the producer's epilogue.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -62,6 +64,8 @@ class STGCN:
         self.A = torch.from_numpy(self.A_host).to(self.device)     # 'adjacency_matrix', non-trainable (stgcn.py:105-109)
         self.tab_fwd = ops.GraphTables(self.A_host, self.device, transpose=False)
         self.tab_bwd = ops.GraphTables(self.A_host, self.device, transpose=True)
+        self._side = (torch.cuda.Stream(device=self.device)
+                      if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "0") == "1" else None)
         self.bone_parent = None
         if bone_pairs is not None:
             bp = np.full(num_node, -1, dtype=np.int32)
@@ -256,6 +260,24 @@ class STGCN:
         return y, To
 
     # ------------------------------------------------------------------ backward
+    def _off_critical_path(self, fn, *tensors):
+        """Weight-gradient kernels feed nothing but the optimizer: they run on a second stream, ordered after
+        everything issued so far, so that the MFMA-bound reductions overlap the HBM-bound BatchNorm / ReLU passes of
+        the main chain.  `tensors` are the inputs whose memory the caching allocator must not hand out again before
+        the side stream is done with them.  Opt-in (SAR_WGRAD_STREAM=1): measured +2 % clips/s at bs = 64 -- the MFMA
+        kernels fill the register file, so little of the element-wise work can co-reside -- at the price of per-kernel
+        timings that overlap (bench.py's roofline object is measured on one stream)."""
+        if self._side is None:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self._side)
+
     def backward(self, dlogits):
         """dlogits (N, classes) -> fills self.grad (every trainable parameter).  main_gnn.py:233."""
         sv = self._saved
@@ -280,6 +302,8 @@ class STGCN:
         ops.data_bn_bwd_reduce(x, self.bone_parent, dY, dbn.mean, part)
         ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, nch, N * M * sv["T"], self.p["data_bn.gamma"], dbn.mean, dbn.rstd,
                             self.g["data_bn.gamma"], self.g["data_bn.beta"])
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)      # every weight gradient is in self.grad
         self._saved = None
 
     def _block_backward(self, i, sb, dY, B):
@@ -308,9 +332,9 @@ class STGCN:
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
         wt = self.g[pre + "tcn.kernel"]
         flat_w = self.grad[self.offsets[pre + "tcn.kernel"]:self.offsets[pre + "tcn.bias"] + f]
-        ops.conv_wgrad(L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s,
-                       pad=pad, pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
-                       wsize=wt.numel(), bsize=f)
+        self._off_critical_path(lambda: ops.conv_wgrad(
+            L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
+            pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f), g, du)
         wT = torch.empty((KT, f, f), dtype=torch.float32, device=dev)
         ops.transpose(self.p[pre + "tcn.kernel"], wT, KT, f, f)          # [tap][c][f] -> [tap][f][c]
         dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
@@ -322,15 +346,17 @@ class STGCN:
         dg = dz1
         ops.affine2(dz1, g, (bn1.k1, bn1.k2, bn1.k3), dg)                # BN1 backward apply (in place)
         # ---- graph conv: weight / bias gradient
-        flat_w = self.grad[self.offsets[pre + "gcn.kernel"]:self.offsets[pre + "gcn.bias"] + KS * f]
-        ops.conv_wgrad(L.SAR_CONV_GRAPH, X, dg, flat_w, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS,
-                       tables=self.tab_fwd, w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f)
+        flat_g = self.grad[self.offsets[pre + "gcn.kernel"]:self.offsets[pre + "gcn.bias"] + KS * f]
+        self._off_critical_path(lambda: ops.conv_wgrad(
+            L.SAR_CONV_GRAPH, X, dg, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS, tables=self.tab_fwd,
+            w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f), X, dg)
         # ---- residual conv branch
         dXres = None
         if kind == "conv":
-            flat_w = self.grad[self.offsets[pre + "res.kernel"]:self.offsets[pre + "res.bias"] + f]
-            ops.conv_wgrad(L.SAR_CONV_TEMPORAL, X, dr, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s,
-                           pad=0, w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f)
+            flat_r = self.grad[self.offsets[pre + "res.kernel"]:self.offsets[pre + "res.bias"] + f]
+            self._off_critical_path(lambda: ops.conv_wgrad(
+                L.SAR_CONV_TEMPORAL, X, dr, flat_r, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
+                w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f), X, dr)
             rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
             ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
             dXres = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
