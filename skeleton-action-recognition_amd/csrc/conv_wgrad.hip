@@ -163,15 +163,17 @@ __device__ __forceinline__ void graph_tile(f32x16 (&acc)[3], float (&bsum)[3], c
 
 // VC / STRIDEC != 0: V, the conv stride and FP == 2 frame pairs per tile are compile-time (NTU: V = 25)
 template <int MODE, int TAPS, int WF, int WC, int WT, int TPW, int NZ0, int NZ1, int NZ2, int VC, int STRIDEC>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
-  static_assert(WF * WC * WT == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) void conv_wgrad_kernel(const WgradK k) {
+  // NW waves per workgroup: 4, or 6 for the 9-tap kernel (2 m-blocks x 3 tap groups of 3: no phantom tap slot)
+  constexpr int NW = WF * WC * WT, NHW = 2 * NW, NTH = 64 * NW;
+  static_assert(NW == 4 || NW == 6, "4 or 6 waves per workgroup");
   static_assert(WT * TPW >= TAPS, "taps must be covered");
   constexpr int BF = 32 * WF, CT = 32 * WC;
   constexpr int NZMAX = 4;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
   // staging maps: a half-wave owns one row and reads 32 consecutive columns per pass (128-B segments)
-  constexpr int DI = BF / 8, DJ = 4;                           // dout tile: BF rows x <=128 positions
-  constexpr int SI = CT / 8;                                   // src tile: CT rows x RW columns
+  constexpr int DI = (BF + NHW - 1) / NHW, DJ = 4;             // dout tile: BF rows x <=128 positions
+  constexpr int SI = (CT + NHW - 1) / NHW;                     // src tile: CT rows x RW columns
   constexpr int SJMAX = (MODE == SAR_CONV_GRAPH) ? 4 : (TAPS == 1 ? 6 : 12);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const sar_wgrad_desc& d = k.d;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   if (MODE == SAR_CONV_GRAPH) {   // pack {joints[E], weights[E], colsum[3]} per joint
     using GT = GraphTab<NZ0, NZ1, NZ2>;
     constexpr int NZc[3] = {NZ0, NZ1, NZ2};
-    for (int v = tid; v < V; v += 256) {
+    for (int v = tid; v < V; v += NTH) {
       int e = 0;
       for (int tp = 0; tp < 3; ++tp) {
         for (int j = 0; j < NZc[tp]; ++j, ++e) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
   float psc[SI], psh[SI];
 #pragma unroll
   for (int i = 0; i < SI; ++i) {
-    const int cg = c0 + r8 + 8 * i;
+    const int cg = c0 + r8 + NHW * i;
     psc[i] = (has_pro && cg < d.Kc) ? d.pro_scale[cg] : 1.f;
     psh[i] = (has_pro && cg < d.Kc) ? d.pro_shift[cg] : 0.f;
   }
@@ -269,18 +271,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(d.src + (int64_t)(c0 + 2 * wave) * d.ld_src + so_), 0,
         bytes_to_end((int64_t)(d.Kc - c0 - 2 * wave) * d.ld_src - so_), 0x00020000);
-    const int drow = (int)(d.ld_dout * 32), srow = (int)(d.ld_src * 32);   // 8 rows, bytes
+    const int drow = (int)(d.ld_dout * 4 * NHW), srow = (int)(d.ld_src * 4 * NHW);   // NHW rows, bytes
+    // (rows past the tile in the last row pass -- BF or CT not a multiple of NHW -- are skipped: wave-uniform)
 #pragma unroll
     for (int i = 0; i < DI; ++i)
+      if (BF % NHW == 0 || 2 * wave + NHW * i < BF) {
 #pragma unroll
-      for (int j = 0; j < DJ; ++j)
-        dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
+        for (int j = 0; j < DJ; ++j)
+          dreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo + 128 * j, i * drow, 0));
+      }
     if (t_lo >= 0) {
 #pragma unroll
       for (int i = 0; i < SI; ++i)
+        if (CT % NHW == 0 || 2 * wave + NHW * i < CT) {
 #pragma unroll
-        for (int j = 0; j < SJMAX; ++j)
-          sreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo + 128 * j, i * srow, 0));
+          for (int j = 0; j < SJMAX; ++j)
+            sreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo + 128 * j, i * srow, 0));
+        }
     } else {
       const int shift = t_lo * V * 4;
 #pragma unroll
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
         const unsigned vo = o < 0 ? 0x80000000u : svo + (unsigned)(128 * j + shift);
 #pragma unroll
         for (int i = 0; i < SI; ++i)
-          sreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * srow, 0));
+          if (CT % NHW == 0 || 2 * wave + NHW * i < CT) sreg[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * srow, 0));
       }
     }
   };
@@ -303,34 +310,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradK k) {
       float* Sw = S + r8 * SP + c32;
 #pragma unroll
       for (int i = 0; i < DI; ++i)
+        if (BF % NHW == 0 || 2 * wave + NHW * i < BF) {
 #pragma unroll
-        for (int j = 0; j < DJ; ++j)
-          if (dlane[j]) Dw[i * 8 * DP + 32 * j] = dreg[i][j];
+          for (int j = 0; j < DJ; ++j)
+            if (dlane[j]) Dw[i * NHW * DP + 32 * j] = dreg[i][j];
+        }
 #pragma unroll
       for (int i = 0; i < SI; ++i)
+        if (CT % NHW == 0 || 2 * wave + NHW * i < CT) {
 #pragma unroll
-        for (int j = 0; j < SJMAX; ++j)   // columns in [RW, SP) only feed the phantom taps
-          if (slane[j]) Sw[i * 8 * SP + 32 * j] = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
+          for (int j = 0; j < SJMAX; ++j)   // columns in [RW, SP) only feed the phantom taps
+            if (slane[j]) Sw[i * NHW * SP + 32 * j] = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
+        }
       return;
     }
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
-      const int fr = r8 + 8 * i;
+      const int fr = r8 + NHW * i;
 #pragma unroll
       for (int j = 0; j < DJ; ++j) {
         const int p = c32 + 32 * j;
         const bool ok = (f0 + fr) < d.M && p < k.NPOS && (t0 * V + p) < seq_out;
-        if (p < k.NP) D[fr * DP + p] = ok ? dreg[i][j] : 0.f;
+        if (p < k.NP && (BF % NHW == 0 || fr < BF)) D[fr * DP + p] = ok ? dreg[i][j] : 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < SI; ++i) {
-      const int cr = r8 + 8 * i;
+      const int cr = r8 + NHW * i;
 #pragma unroll
       for (int j = 0; j < SJMAX; ++j) {
         const int col = c32 + 32 * j;
         const int rabs = t_lo * V + col;
-        if (col < k.RW) {
+        if (col < k.RW && (CT % NHW == 0 || cr < CT)) {
           const float val = fmaxf(fmaf(sreg[i][j], psc[i], psh[i]), relu_lo);
           S[cr * SP + col] = ((c0 + cr) < d.Kc && (unsigned)rabs < (unsigned)seq_src) ? val : 0.f;
         }
@@ -737,7 +748,7 @@ int launch(const sar_wgrad_desc& d, hipStream_t st) {
     }
   }
   dim3 grid(d.nsplit, (d.M + BF - 1) / BF, (d.Kc + CT - 1) / CT);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WF * WC * WT), lds, st, k);
   return 0;
 }
 
@@ -802,6 +813,9 @@ extern "C" int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s) {
     SAR_REQUIRE(d->bsize == 0 || d->bsize == d->M, "sar_conv_wgrad: temporal bias slab is [M]");
     const bool ntu = d->V == 25;
     if (d->taps == 9) {
+      // 4 waves = 2 m-blocks x 2 groups of 5 tap slots (one phantom).  The 6-wave split <9,2,1,3,3> (3 groups of 3
+      // taps, no phantom slot) is supported by the kernel but measured slower: 82 TF at 202 VGPR (one workgroup per
+      // CU) and 75 TF squeezed to 168 VGPR (spills) against 105 TF here.
       if (ntu && d->stride == 1) rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1, 25, 1>(*d, st);
       else if (ntu && d->stride == 2) rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1, 25, 2>(*d, st);
       else rc = launch<SAR_CONV_TEMPORAL, 9, 2, 1, 2, 5, 1, 1, 1>(*d, st);
