@@ -46,9 +46,10 @@ struct TileCfg {
   static constexpr int WSTR = BM;                               // W row stride
   static constexpr int RWMAX = (MODE == SAR_CONV_GRAPH) ? TN : (TN == 128 ? 448 : 704);
   static constexpr int SJ = RWMAX / 64;                         // S columns per lane
-  static constexpr int SSTR = RWMAX + 32;                       // S row stride (== 32 mod 64: the two k rows of a read
+  static constexpr int SSTR = RWMAX + 8;                        // S row stride (room for the zero column; RWMAX + 32 would put the two k rows of a read
                                                                 // fall into different bank halves)
-  static constexpr int BUF = WIT * WRPP * WSTR + KC * SSTR;     // floats per LDS buffer
+  static constexpr int WPAD = ((WROWS + 3) / 4) * 4;            // W rows kept in LDS (the last stager pass is masked)
+  static constexpr int BUF = WPAD * WSTR + KC * SSTR;           // floats per LDS buffer (3 workgroups per CU fit 160 KB)
 };
 
 // TR selects the temporal variant: 0 forward; 1 data gradient at stride 1 (every tap valid); 2 data gradient,
@@ -56,8 +57,11 @@ struct TileCfg {
 // first half of the tile's columns holds the even frames and the second half the odd ones, so a wave's columns
 // share the frame parity and only the <= 5 taps that reach a real source frame are issued at all (the masked
 // variant spends half of its MFMAs on zeros).
+#ifndef SAR_OCC3
+#define SAR_OCC3 1   // 3 workgroups per CU (LDS <= 53 KB and <= 168 VGPR per workgroup)
+#endif
 template <int MODE, int TR, int TAPS, int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
+__global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_kernel(const ConvK k) {
   using TC = TileCfg<MODE, TAPS, MS, NS, WM, WN>;
   constexpr int TRANSPOSED = TR != 0;
   constexpr int PAR = (TR == 3);
@@ -69,8 +73,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
   constexpr int ZCOL = TC::RWMAX;   // first padding column of an S row: written once with 0, never staged
   static_assert(WM * WN == 4, "4 waves per workgroup");
   // two LDS buffers: the stage being multiplied and the stage being written (one barrier per stage)
-  __shared__ __attribute__((aligned(16))) float smem[2 * TC::BUF];
-  __shared__ float4 rowp[BM];   // per-output-row parameters: bias (prologue), then the aux affine (epilogue)
+  // per-output-row parameters (bias in the prologue, the aux affine in the epilogue) live behind buffer 0 -- in
+  // buffer 1, which is not written before the end of stage 0 and not read after the last stage -- and behind the
+  // epilogue's transpose area (4 waves x 16 x 65 floats at the start of smem)
+  constexpr int PAREA = 4 * 16 * 65;
+  static_assert(TC::BUF < PAREA || 4 * BM <= TC::WPAD * WSTR, "rowp must fit the W region of buffer 1");
+  constexpr int ROWP_OFF = TC::BUF >= PAREA ? TC::BUF : (2 * TC::BUF > PAREA ? 2 * TC::BUF : PAREA);   // small tiles: own space
+  constexpr int LDS_FLOATS = 2 * TC::BUF > ROWP_OFF + 4 * BM ? 2 * TC::BUF : ROWP_OFF + 4 * BM;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  float4* rowp = reinterpret_cast<float4*>(smem + ROWP_OFF);
   const sar_conv_desc& d = k.d;
 
   const int tid = threadIdx.x;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
     }
     rowp[tid] = bp;
   }
-  if (tid < 2 * KC) smem[(tid / KC) * TC::BUF + WIT * WRPP * WSTR + (tid % KC) * SSTR + ZCOL] = 0.f;
+  if (tid < 2 * KC) smem[(tid / KC) * TC::BUF + TC::WPAD * WSTR + (tid % KC) * SSTR + ZCOL] = 0.f;
   f32x16 acc[MS][NS];
 
   const int seq_len = d.T_src * V;
@@ -229,12 +240,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
 
   auto store_lds = [&](int c0, float* buf) {
     float* Wl = buf;
-    float* S = buf + WIT * WRPP * WSTR;
+    float* S = buf + TC::WPAD * WSTR;
     if (w_vec) {
 #pragma unroll
       for (int i = 0; i < WIT; ++i) {
-        const int row = w_r0 + i * WRPP;   // rows >= WROWS land in the padding rows of the tile
-        *reinterpret_cast<float4*>(Wl + row * WSTR + w_m4) = wreg[i];
+        const int row = w_r0 + i * WRPP;
+        if ((i + 1) * WRPP <= TC::WPAD || row < TC::WPAD) *reinterpret_cast<float4*>(Wl + row * WSTR + w_m4) = wreg[i];
       }
     } else {  // unaligned / M % 4 != 0 weights (3-channel layers only): plain strided copy
       for (int idx = tid; idx < WROWS * BM; idx += 256) {
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
     const bool more = c0 + KC < d.Kc && !(SAR_ABLATE & 2);
     if (more && !(SAR_ABLATE & 16)) issue_loads(c0 + KC);   // 16: LDS stores of stale registers only
     const float* Wl = smem + it * TC::BUF;
-    const float* S = Wl + WIT * WRPP * WSTR;
+    const float* S = Wl + TC::WPAD * WSTR;
 
     // ---- MFMA phase.  The fp32 MFMA runs on the vector ALU of the SIMD (no co-issue with VALU work; measured:
     // tools/mfma_fill.hip), so the loop carries LDS reads and MFMAs only, and the operands of step s+1 are read
@@ -446,17 +457,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK k) {
     float* P = smem + wave * (16 * 65);   // wave-private transpose area for the sums (16 sums x 64 lanes, stride 65)
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
-      float ax[NS][16];
-      if (has_aux) {   // every aux load of this row block is issued before the first use
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns)
-            ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
-      }
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {   // 8 registers = 16 sums per transpose round
+        float ax[NS][16];
+        if (has_aux) {   // the aux loads of this half row block are issued before the first use
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const int r = rb * 8 + r8;
+              ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+            }
+        }
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) {
           const int r = rb * 8 + r8;
