@@ -49,7 +49,7 @@ for k, (calls, avg_ns, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
                  "fetch_kib_raw": None if f is None else round(f, 1), "write_kib": None if w is None else round(w, 1),
                  "hbm_bytes_per_launch": None if hbm is None else int(hbm),
                  "hbm_gbps": None if hbm is None else round(hbm / avg_ns, 1)})
-fam = [r for r in rows if r["kernel"].startswith("conv_gemm_kernel<1, 0, 9") or r["kernel"].startswith("conv_gemm_kernel<1, 1, 9")]
+fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_kernel<1, %d, 9" % tr) for tr in (0, 1, 2, 3))]
 calls = sum(r["calls"] for r in fam)
 summary = {
     "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ; "
