@@ -12,6 +12,7 @@
 //                           output rows (frame-pair trick of conv_wgrad.hip); the stem variant puts the 49 taps
 //                           on the lane (row) axis of the A operand.
 #include "sar_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -24,20 +25,38 @@ struct C2K {
 };
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
-template <int TRANSPOSED, int KH, int KW, int MS, int NS, int WM, int WN>
+// Same machinery as conv_gemm.hip (read its header): buffer-load stagers with per-lane offsets / masks computed
+// once, two LDS buffers and one barrier per stage, software-pipelined operand reads with immediate offsets, bias-
+// free epilogue with buffer stores and the wave-private LDS transpose for the BatchNorm sums, 3 workgroups per CU
+// where LDS allows.  TR: 0 forward, 1 data gradient at stride 1 (no tap mask), 2 data gradient, strided (per-lane
+// tap validity mask).
+template <int TAPS, int MS, int NS, int WM, int WN>
+struct Tile2 {
+  static constexpr int BM = 32 * MS * WM;
+  static constexpr int WROWS = TAPS * KC2;
+  static constexpr int WRPP = 1024 / BM;
+  static constexpr int WIT = (WROWS + WRPP - 1) / WRPP;
+  static constexpr int WPAD = ((WROWS + 3) / 4) * 4;
+  static constexpr int RWMAX = (TAPS == 1 ? 512 : 640);       // staged elements per src channel row (bound)
+  static constexpr int SJ = RWMAX / 64;
+  static constexpr int SSTR = RWMAX + 8;
+  static constexpr int BUF = WPAD * BM + KC2 * SSTR;
+};
+
+template <int TR, int KH, int KW, int MS, int NS, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
   constexpr int TAPS = KH * KW;
-  constexpr int BM = 32 * MS * WM;
-  constexpr int WROWS = TAPS * KC2;
-  constexpr int WRPP = 1024 / BM;
-  constexpr int WIT = (WROWS + WRPP - 1) / WRPP;
-  constexpr int SLPR = 256 / KC2;
-  constexpr int SJMAX = (TAPS == 1 ? 512 : 640) / SLPR;     // staged elements per src channel row (bound)
-  static_assert(WM * WN == 4, "4 waves");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TRANSPOSED = TR != 0;
+  using TC = Tile2<TAPS, MS, NS, WM, WN>;
+  constexpr int BM = TC::BM, WROWS = TC::WROWS, WRPP = TC::WRPP, WIT = TC::WIT, SJ = TC::SJ, SSTR = TC::SSTR;
+  constexpr int ZCOL = TC::RWMAX;
+  static_assert(WM * WN == 4 && KC2 == 4, "4 waves, one staged channel row per wave");
+  constexpr int PAREA = 4 * 16 * 65;
+  constexpr int ROWP_OFF = TC::BUF >= PAREA ? TC::BUF : (2 * TC::BUF > PAREA ? 2 * TC::BUF : PAREA);
+  constexpr int LDS_FLOATS = 2 * TC::BUF > ROWP_OFF + 4 * BM ? 2 * TC::BUF : ROWP_OFF + 4 * BM;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  float4* rowp = reinterpret_cast<float4*>(smem + ROWP_OFF);   // aux affine per output row (MASK epilogue)
   const sar_conv2d_desc& d = k.d;
-  float* Wl = smem;                    // [TAPS][KC2][BM]
-  float* S = smem + WROWS * BM;        // [KC2][SROW] padded image rows
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,10 +72,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
   if (!TRANSPOSED) row_lo = h0 * s - d.pad;
   else row_lo = floordiv(h0 + d.pad - (KH - 1), s);
 
+  // ---- per-lane column geometry; off-tile columns read the always-zero LDS column
   bool colok[NS];
   int64_t coln[NS];
-  int base[NS];
-  int off[TRANSPOSED ? TAPS : 1][NS];
+  int off[TAPS][NS];
   unsigned vmask[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
@@ -67,19 +86,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
     if (!colok[ns]) { hl = 0; wo = 0; }
     coln[ns] = ((int64_t)b * d.H_out + (h0 + hl)) * d.W_out + wo;
     vmask[ns] = 0;
-    base[ns] = hl * s * k.Wq + wo * s;
-    if (TRANSPOSED) {
 #pragma unroll
-      for (int tp = 0; tp < TAPS; ++tp) {
-        const int kh = tp / KW, kw = tp % KW;
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const int kh = tp / KW, kw = tp % KW;
+      if (!TRANSPOSED) {
+        off[tp][ns] = (hl * s + kh) * k.Wq + wo * s + kw;
+      } else {
         const int qh = h0 + hl + d.pad - kh, qw = wo + d.pad - kw;
         const int ho = floordiv(qh, s), ws = floordiv(qw, s);
         const bool ok = (qh - ho * s == 0) && (qw - ws * s == 0);
         vmask[ns] |= (ok ? 1u : 0u) << tp;
         off[tp][ns] = (ho - row_lo) * k.Wq + (ws - k.col_lo);
       }
+      if (!colok[ns]) off[tp][ns] = ZCOL;
     }
   }
+  if (tid < 2 * KC2) smem[(tid / KC2) * TC::BUF + TC::WPAD * BM + (tid % KC2) * SSTR + ZCOL] = 0.f;
 
   f32x16 acc[MS][NS];
 #pragma unroll
@@ -89,119 +111,257 @@ __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
+  // ---- staging (everything stage-invariant is computed here once)
   const int img = d.H_src * d.W_src;
   const float* src_b = d.src + (int64_t)b * img;
-  const bool has_pro = d.pro_scale != nullptr;
-  const int w_m4 = (tid % (BM / 4)) * 4, w_r0 = tid / (BM / 4);
-  const bool w_vec = k.w_vec != 0;
-  const int s_row = tid / SLPR, s_c0 = tid % SLPR;
-  float4 wreg[WIT];
-  float sreg[SJMAX];
-  float psc = 1.f, psh = 0.f;
-
-  // staged element e of a channel row -> (r, q) = (e / Wq, e % Wq) -> src pixel (row_lo + r, col_lo + q)
-  auto src_index = [&](int e, bool& ok) -> int {
-    const int r = (int)(((float)e + 0.5f) * k.invWq);
-    const int q = e - r * k.Wq;
+  int svo[SJ];
+  bool sok[SJ];
+#pragma unroll
+  for (int j = 0; j < SJ; ++j) {
+    const int e = lane + 64 * j;                       // staged element -> (r, q) -> src pixel (row_lo + r, col_lo + q)
+    const int r = e / k.Wq, q = e - r * k.Wq;
     const int hs = row_lo + r, ws = k.col_lo + q;
-    ok = e < k.RW && (unsigned)hs < (unsigned)d.H_src && (unsigned)ws < (unsigned)d.W_src;
-    return hs * d.W_src + ws;
-  };
+    sok[j] = e < k.RW && (unsigned)hs < (unsigned)d.H_src && (unsigned)ws < (unsigned)d.W_src;   // else zero padding
+    svo[j] = sok[j] ? (hs * d.W_src + ws) * 4 : 0;
+  }
+  const bool w_vec = k.w_vec != 0;
+  const int w_m4 = (tid % (BM / 4)) * 4, w_r0 = tid / (BM / 4);
+  int wvo[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int row = w_r0 + i * WRPP;
+    const int tp = row / KC2, c = row % KC2;
+    const bool ok = row < WROWS && (m0 + w_m4) < d.M;
+    wvo[i] = ok ? (int)(((int64_t)tp * d.w_stride_tap + (int64_t)c * d.w_stride_c + m0 + w_m4) * 4) : 0;
+  }
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  float4 wreg[WIT];
+  float sreg[SJ];
+  float psc = 1.f, psh = 0.f;
 
   auto issue_loads = [&](int c0) {
     if (w_vec) {
+      const __amdgpu_buffer_rsrc_t rw =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(d.W + (int64_t)c0 * d.w_stride_c), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
       for (int i = 0; i < WIT; ++i) {
-        const int row = w_r0 + i * WRPP;
-        const int tp = row / KC2, c = row % KC2;
-        const int cg = c0 + c, mg = m0 + w_m4;
-        const bool ok = row < WROWS && cg < d.Kc && mg < d.M;
-        const float* wp = ok ? d.W + (int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg : d.W;
-        wreg[i] = *reinterpret_cast<const float4*>(wp);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], 0, 0);
+        wreg[i] = *reinterpret_cast<const float4*>(&v);
       }
     }
-    const int cg = c0 + s_row;
-    const bool rowok = cg < d.Kc;
-    const float* sp = src_b + (int64_t)(rowok ? cg : 0) * d.ld_src;
+    const int cg = (c0 + wave < d.Kc) ? c0 + wave : 0;   // wave-uniform
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, img * 4, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < SJMAX; ++j) {
-      bool ok;
-      const int idx = src_index(s_c0 + SLPR * j, ok);
-      sreg[j] = sp[(ok && rowok) ? idx : 0];
-    }
-    if (has_pro) {
-      psc = d.pro_scale[rowok ? cg : 0];
-      psh = d.pro_shift[rowok ? cg : 0];
+    for (int j = 0; j < SJ; ++j) sreg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo[j], 0, 0));
+    if (d.pro_scale) {
+      psc = d.pro_scale[cg];
+      psh = d.pro_shift[cg];
     }
   };
 
-  auto store_lds = [&](int c0) {
+  auto store_lds = [&](int c0, float* buf) {
+    float* Wl = buf;
+    float* S = buf + TC::WPAD * BM;
     if (w_vec) {
 #pragma unroll
       for (int i = 0; i < WIT; ++i) {
         const int row = w_r0 + i * WRPP;
-        const int c = row % KC2;
-        const bool ok = (c0 + c) < d.Kc && (m0 + w_m4) < d.M;
-        if (row < WROWS) *reinterpret_cast<float4*>(Wl + row * BM + w_m4) = ok ? wreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((i + 1) * WRPP <= TC::WPAD || row < TC::WPAD) *reinterpret_cast<float4*>(Wl + row * BM + w_m4) = wreg[i];
       }
-    } else {
+    } else {   // unaligned weights or a Kc tail: plain strided copy with zero fill
       for (int idx = tid; idx < WROWS * BM; idx += 256) {
         const int m = idx % BM, row = idx / BM;
         const int tp = row / KC2, cg = c0 + row % KC2, mg = m0 + m;
         Wl[idx] = (cg < d.Kc && mg < d.M) ? d.W[(int64_t)tp * d.w_stride_tap + (int64_t)cg * d.w_stride_c + mg] : 0.f;
       }
     }
-    const bool rowok = (c0 + s_row) < d.Kc;
+    const bool rowok = (c0 + wave) < d.Kc;
 #pragma unroll
-    for (int j = 0; j < SJMAX; ++j) {
-      const int e = s_c0 + SLPR * j;
-      if (e < k.RW) {
-        bool ok;
-        (void)src_index(e, ok);
-        float val = sreg[j];
-        if (has_pro) {
-          val = fmaf(val, psc, psh);
-          if (d.pro_relu) val = fmaxf(val, 0.f);
-        }
-        S[s_row * k.SROW + e] = (ok && rowok) ? val : 0.f;   // zero padding on all four sides
-      }
+    for (int j = 0; j < SJ; ++j) {
+      const float val = fmaxf(fmaf(sreg[j], psc, psh), relu_lo);
+      S[wave * SSTR + lane + 64 * j] = (sok[j] && rowok) ? val : 0.f;   // zero padding on all four sides
     }
   };
 
   issue_loads(0);
-  for (int c0 = 0; c0 < d.Kc; c0 += KC2) {
-    store_lds(c0);
-    __syncthreads();
-    if (c0 + KC2 < d.Kc) issue_loads(c0 + KC2);
+  store_lds(0, smem);
+  __syncthreads();
+  auto stage = [&](int c0, auto IT) {
+    constexpr int it = decltype(IT)::value;
+    const bool more = c0 + KC2 < d.Kc;
+    if (more) issue_loads(c0 + KC2);
+    const float* Wl = smem + it * TC::BUF;
+    const float* S = Wl + TC::WPAD * BM;
+    constexpr int HS = KC2 / 2;
+    const float* Sh = S + hi * SSTR;
+    typedef const float __attribute__((address_space(3))) * lds_cptr;
+    lds_cptr Wa[MS];
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
-      const int tapoff = (tp / KW) * k.Wq + (tp % KW);
+    for (int ms = 0; ms < MS; ++ms) {
+      unsigned a = (unsigned)(uintptr_t)(Wl + hi * BM + (wm * MS + ms) * 32 + l31);   // LDS byte address, kept opaque
+      asm volatile("" : "+v"(a));
+      Wa[ms] = (lds_cptr)(uintptr_t)a;
+    }
+    auto fetch = [&](int st, float (&a)[MS], float (&r)[NS]) {
+      const int tp = st / HS, cc = (st % HS) * 2;
 #pragma unroll
-      for (int cc = 0; cc < KC2; cc += 2) {
-        float a[MS], bv[NS];
+      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[ms][(tp * KC2 + cc) * BM];
+      const float* Srow = Sh + cc * SSTR;
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) a[ms] = Wl[(tp * KC2 + cc + hi) * BM + (wm * MS + ms) * 32 + l31];
-        const float* Srow = S + (cc + hi) * k.SROW;
+      for (int ns = 0; ns < NS; ++ns) r[ns] = Srow[off[tp][ns]];
+    };
+    auto mma = [&](int st, const float (&a)[MS], const float (&r)[NS], bool have_next) {
+      const int tp = st / HS;
+      float bv[NS];
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) {
-          if (!TRANSPOSED) {
-            bv[ns] = Srow[base[ns] + tapoff];
-          } else {
-            const float x = Srow[off[tp][ns]];
-            bv[ns] = ((vmask[ns] >> tp) & 1u) ? x : 0.f;
-          }
+      for (int ns = 0; ns < NS; ++ns) bv[ns] = (TR == 2) ? (((vmask[ns] >> tp) & 1u) ? r[ns] : 0.f) : r[ns];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
+      constexpr int NM = MS * NS, RD = MS + NS;
+      int done = 0;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        const int n = have_next ? (RD - done + (NM - i) - 1) / (NM - i) : 0;
+        if (n == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (n == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        done += n;
+      }
+    };
+    constexpr int NSTEP = TAPS * HS;
+    {
+      float a0[MS], r0[NS], a1[MS], r1[NS];
+      fetch(0, a0, r0);
+#pragma unroll
+      for (int st = 0; st < NSTEP; st += 2) {
+        if (st + 1 < NSTEP) fetch(st + 1, a1, r1);
+        mma(st, a0, r0, st + 1 < NSTEP);
+        if (st + 1 < NSTEP) {
+          if (st + 2 < NSTEP) fetch(st + 2, a0, r0);
+          mma(st + 1, a1, r1, st + 2 < NSTEP);
         }
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns)
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
       }
     }
+    if (more) store_lds(c0 + KC2, smem + (it ^ 1) * TC::BUF);
     __syncthreads();
+  };
+  for (int c0 = 0; c0 < d.Kc; c0 += 2 * KC2) {
+    stage(c0, std::integral_constant<int, 0>());
+    if (c0 + KC2 < d.Kc) stage(c0 + KC2, std::integral_constant<int, 1>());
   }
 
+  // ---- epilogue (see conv_gemm.hip): off-tile columns hold exact zeros
   const int part = tile * WN + wn;
+  auto fast_epilogue = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
+    if (EPI == SAR_EPI_MASK) {
+      if (tid < BM) {
+        const int row = m0 + tid;
+        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < d.M) {
+          ap.x = d.aux_scale[row];
+          ap.y = d.aux_shift[row];
+          if (d.aux_mean) ap.z = d.aux_mean[row];
+        }
+        rowp[tid] = ap;
+      }
+      __syncthreads();
+    }
+    const int rows_w = m0 + wm * MS * 32;
+    // num_records = bytes up to the end of the tensor (rows >= M of a partial row block must not be touched: the
+    // range check sees voffset + soffset), capped at 2^31 so that the off-tile marker offset stays out of range
+    auto rows_bytes = [&](int64_t ld) {
+      const int64_t n = (int64_t)(d.M - rows_w) * ld * 4;
+      return (unsigned)(n <= 0 ? 0 : (n > 0x80000000ll ? 0x80000000ll : n));
+    };
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, rows_bytes(d.ld_out), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, has_aux ? rows_bytes(d.ld_aux) : 0u, 0x00020000);
+    unsigned vo_out[NS], vo_aux[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
+      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+    }
+    const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
+    float* P = smem + wave * (16 * 65);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float ax[NS][16];
+        if (has_aux) {
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const int r = rb * 8 + r8;
+              ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+            }
+        }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = rb * 8 + r8;
+          const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;
+          float s1 = 0.f, s2 = 0.f;
+          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            float val = acc[ms][ns][r];
+            if (EPI == SAR_EPI_STATS) {
+              s1 += val;
+              s2 = fmaf(val, val, s2);
+            } else if (EPI == SAR_EPI_MASK) {
+              val = (fmaf(ax[ns][r], ap.x, ap.y) > 0.f) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ax[ns][r] - ap.z, s2);
+            } else if (EPI == SAR_EPI_ADD) {
+              val += ax[ns][r];
+            }
+            if (grp_ok)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
+                                                    (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_out, 0);
+          }
+          if (stats) {
+            P[(2 * r8) * 65 + lane] = s1;
+            P[(2 * r8 + 1) * 65 + lane] = s2;
+          }
+        }
+        if (stats) {
+          __builtin_amdgcn_wave_barrier();
+          const int q = lane & 15, sub = (lane >> 4) & 1;
+          const float* pr = P + q * 65 + hi * 32 + sub * 16;
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t += pr[i];
+          t += __shfl_xor(t, 16);
+          __builtin_amdgcn_wave_barrier();
+          const int r = rb * 8 + (q >> 1);
+          const int row = rows_w + ms * 32 + mfma_row(r, hi);
+          if (sub == 0 && row < d.M) d.partials[((int64_t)row * k.nparts + part) * 2 + (q & 1)] = t;
+        }
+      }
+    }
+  };
+  if ((d.M & 7) == 0) {
+    switch (d.epi) {
+      case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
+      case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
+      case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
+      default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
+    }
+    return;
+  }
+  // generic path (M % 8 != 0)
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
@@ -660,12 +820,12 @@ int gemm_geometry(const sar_conv2d_desc& d, int tile_n, int wn, C2K& k, int rwma
   k.SROW = k.RW;
   k.invWq = 1.0f / (float)k.Wq;
   k.nparts = d.B * k.TPI * wn;
-  k.w_vec = ((d.M & 3) == 0 && (d.w_stride_c & 3) == 0 && (d.w_stride_tap & 3) == 0 && ((uintptr_t)d.W & 15) == 0) ? 1 : 0;
+  k.w_vec = ((d.Kc % KC2) == 0 && (d.M & 3) == 0 && (d.w_stride_c & 3) == 0 && (d.w_stride_tap & 3) == 0 && ((uintptr_t)d.W & 15) == 0) ? 1 : 0;
   return 0;
 }
 
-template <int TRANSPOSED, int KH, int KW>
-int launch_gemm(const sar_conv2d_desc& d, hipStream_t st, bool query, int* nparts_out) {
+template <int TR, int KH, int KW>
+int launch_gemm_tr(const sar_conv2d_desc& d, hipStream_t st, bool query, int* nparts_out) {
   C2K k;
   k.d = d;
   constexpr int TAPS = KH * KW;
@@ -676,20 +836,25 @@ int launch_gemm(const sar_conv2d_desc& d, hipStream_t st, bool query, int* npart
     if (nparts_out) *nparts_out = k.nparts;
     if (query) return 0;
     if (k.RW > rwmax) return -2;
-    const size_t lds = sizeof(float) * ((size_t)TAPS * KC2 * 32 * MS * WM + (size_t)KC2 * k.SROW);
     dim3 grid(d.B * k.TPI, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
-    hipLaunchKernelGGL((conv2d_gemm_kernel<TRANSPOSED, KH, KW, MS, NS, WM, WN>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv2d_gemm_kernel<TR, KH, KW, MS, NS, WM, WN>), grid, dim3(256), 0, st, k);
   } else {
     constexpr int MS = 2, NS = 2, WM = 1, WN = 4;
     if (int g = gemm_geometry(d, 32 * NS * WN, WN, k, rwmax)) return g;
     if (nparts_out) *nparts_out = k.nparts;
     if (query) return 0;
     if (k.RW > rwmax) return -2;
-    const size_t lds = sizeof(float) * ((size_t)TAPS * KC2 * 32 * MS * WM + (size_t)KC2 * k.SROW);
     dim3 grid(d.B * k.TPI, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
-    hipLaunchKernelGGL((conv2d_gemm_kernel<TRANSPOSED, KH, KW, MS, NS, WM, WN>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv2d_gemm_kernel<TR, KH, KW, MS, NS, WM, WN>), grid, dim3(256), 0, st, k);
   }
   return 0;
+}
+
+template <int TRANSPOSED, int KH, int KW>
+int launch_gemm(const sar_conv2d_desc& d, hipStream_t st, bool query, int* nparts_out) {
+  if (!TRANSPOSED) return launch_gemm_tr<0, KH, KW>(d, st, query, nparts_out);
+  if (d.stride == 1) return launch_gemm_tr<1, KH, KW>(d, st, query, nparts_out);
+  return launch_gemm_tr<2, KH, KW>(d, st, query, nparts_out);
 }
 
 int launch_stem(const sar_conv2d_desc& d, hipStream_t st, bool query, int* nparts_out) {

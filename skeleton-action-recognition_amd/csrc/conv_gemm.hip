@@ -443,10 +443,16 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
       __syncthreads();
     }
     const int rows_w = m0 + wm * MS * 32;   // first row of this wave
+    // num_records = bytes up to the end of the tensor (rows >= M of a partial row block must not be touched: the
+    // range check sees voffset + soffset), capped at 2^31 so that the off-tile marker offset stays out of range
+    auto rows_bytes = [&](int64_t ld) {
+      const int64_t n = (int64_t)(d.M - rows_w) * ld * 4;
+      return (unsigned)(n <= 0 ? 0 : (n > 0x80000000ll ? 0x80000000ll : n));
+    };
     const __amdgpu_buffer_rsrc_t ro =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, 0x80000000u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, rows_bytes(d.ld_out), 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, 0x80000000u, 0x00020000);
+        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, has_aux ? rows_bytes(d.ld_aux) : 0u, 0x00020000);
     unsigned vo_out[NS], vo_aux[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {   // off-tile columns: an offset the range check rejects
