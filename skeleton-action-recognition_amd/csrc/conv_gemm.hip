@@ -29,9 +29,12 @@ namespace {
 
 constexpr int KC = 4;  // src channels staged per main-loop iteration (2 MFMA k-steps); one S row per wave
 
+#ifndef SAR_XCD_MAP
+#define SAR_XCD_MAP 1
+#endif
 struct ConvK {
   sar_conv_desc d;
-  int FT, TPS, NF, RW, nparts;
+  int FT, TPS, NF, RW, nparts, ntiles, ny;
   int w_vec;   // weight rows may be read as aligned float4
 };
 
@@ -89,10 +92,22 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
   const int l31 = lane & 31, hi = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int V = d.V;
-  const int tile = blockIdx.x;
+  // Workgroup -> (tile, row block).  Dispatch order is 1-D: consecutive ids go to consecutive XCDs (8, each with
+  // its own L2).  The row blocks of one tile are adjacent ids' worth of work on the SAME XCD (they share the staged
+  // src rows), and each XCD walks a contiguous range of tiles, so the temporal halo a tile shares with its
+  // neighbour is an L2 hit instead of a second HBM fetch.  id = slot*8 + xcd ; work item w = xcd*per + slot.
+  const int ny = k.ny, nwork = k.ntiles * ny;
+  int w = blockIdx.x;
+  if (SAR_XCD_MAP) {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;   // the padded tail of the id space (whole workgroup: before any barrier)
+  }
+  const int tile = w / ny;
   const int b = tile / k.TPS;
   const int t0 = (tile - b * k.TPS) * k.FT;
-  const int m0 = blockIdx.y * BM;
+  const int m0 = (w - tile * ny) * BM;
 
   // ---- per-lane column geometry (fixed for the whole kernel)
   bool colok[NS];
@@ -613,7 +628,10 @@ int launch_cfg(const sar_conv_desc& d, hipStream_t st, bool query_only, int* npa
   if (nparts_out) *nparts_out = k.nparts;
   if (query_only) return 0;
   constexpr int BM = 32 * MS * WM;
-  dim3 grid(d.B * k.TPS, (d.M + BM - 1) / BM);
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + BM - 1) / BM;
+  const int nwork = k.ntiles * k.ny;
+  dim3 grid(SAR_XCD_MAP ? ((nwork + 7) / 8) * 8 : nwork);
   hipLaunchKernelGGL((conv_gemm_kernel<MODE, TR, TAPS, MS, NS, WM, WN, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
   return 0;
 }

@@ -24,7 +24,26 @@ namespace {
 struct WgradK {
   sar_wgrad_desc d;
   int FT, FP, TPS, NT, NF, RW, SP, NPOS, NP, DP;
+  int gy, gz;   // weight blocks along m and c (the launch is 1-D: see wg_decode)
 };
+
+// Workgroup id -> (split, m block, c block).  Ids are dispatched round-robin over the 8 XCDs (one L2 each): the
+// gy*gz weight blocks that reduce the SAME tiles (same split) get adjacent slots of ONE XCD, so the tile data is
+// fetched from HBM once per split instead of once per weight block.
+struct WgId { int split, y, z; bool live; };
+__device__ __forceinline__ WgId wg_decode(int id, int nsplit, int gy, int gz) {
+  const int nyz = gy * gz, nwork = nsplit * nyz;
+  const int per = (nwork + 7) / 8;
+  const int xcd = id & 7, slot = id >> 3;
+  const int w = xcd * per + slot;
+  WgId r;
+  r.live = slot < per && w < nwork;
+  r.split = w / nyz;
+  const int yz = w - r.split * nyz;
+  r.z = yz / gy;
+  r.y = yz - r.z * gy;
+  return r;
+}
 
 // One tile of the temporal reduction for a wave that owns NT consecutive taps starting at Sbase's tap.
 // No per-MFMA conditions: NT is a compile-time count, every address is lane-constant + uniform, and the
@@ -190,7 +209,9 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction
   const int l31 = lane & 31, hi = lane >> 5;
   const int wf = wave % WF, wc = (wave / WF) % WC, wt = wave / (WF * WC);
-  const int f0 = blockIdx.y * BF, c0 = blockIdx.z * CT;
+  const WgId wg = wg_decode(blockIdx.x, d.nsplit, k.gy, k.gz);
+  if (!wg.live) return;   // padded tail of the id space (whole workgroup, before any barrier)
+  const int f0 = wg.y * BF, c0 = wg.z * CT;
 
   if (MODE == SAR_CONV_GRAPH) {   // pack {joints[E], weights[E], colsum[3]} per joint
     using GT = GraphTab<NZ0, NZ1, NZ2>;
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
 
   const int seq_src = d.T_src * V, seq_out = d.T_out * V;
   const bool has_pro = d.pro_scale != nullptr;
-  const bool do_bias = (wc == 0) && (MODE == SAR_CONV_GRAPH || wt == 0) && blockIdx.z == 0;
+  const bool do_bias = (wc == 0) && (MODE == SAR_CONV_GRAPH || wt == 0) && wg.z == 0;
 
   // ---- register prefetch of the next tile (unconditional loads from clamped addresses; predicates are
   // applied when the registers are written to LDS, see conv_gemm.hip)
@@ -357,13 +378,13 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
 #ifndef SAR_ABLATE
 #define SAR_ABLATE 0   // diagnostic builds only (tools/ablate.sh): 2 = stage the first tile only
 #endif
-  int tile = blockIdx.x;
+  int tile = wg.split;
   if (tile < k.NT) issue_loads(tile);
-  for (; tile < k.NT; tile += gridDim.x) {
+  for (; tile < k.NT; tile += d.nsplit) {
     __syncthreads();  // previous tile's LDS reads done
-    if (!(SAR_ABLATE & 2) || tile == (int)blockIdx.x) store_lds(tile);
+    if (!(SAR_ABLATE & 2) || tile == wg.split) store_lds(tile);
     __syncthreads();
-    if (!(SAR_ABLATE & 2) && tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
+    if (!(SAR_ABLATE & 2) && tile + d.nsplit < k.NT) issue_loads(tile + d.nsplit);
 
     if constexpr (MODE == SAR_CONV_TEMPORAL) {
       // every wave runs TPW taps: taps beyond TAPS (last wave class when WT*TPW > TAPS) read the padded
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
   }
 
   // ---- write this split's slab
-  float* slab = d.slab + (int64_t)blockIdx.x * (d.wsize + d.bsize);
+  float* slab = d.slab + (int64_t)wg.split * (d.wsize + d.bsize);
   const int f = f0 + wf * 32 + l31;
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
@@ -434,9 +455,11 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_fixed_kernel(const WgradK 
   const int l31 = lane & 31, hi = lane >> 5;
   const int wf = wave & 1, wc = wave >> 1;
   const int r8 = tid >> 5, c32 = tid & 31;
-  const int f0 = blockIdx.y * BF, c0 = blockIdx.z * CT;
+  const WgId wg = wg_decode(blockIdx.x, d.nsplit, k.gy, k.gz);
+  if (!wg.live) return;
+  const int f0 = wg.y * BF, c0 = wg.z * CT;
   // the bias sums (sum_n dout * colsum(A_k)) are needed once per m: the c-block 0 waves of the z == 0 slice carry them
-  const bool do_bias = d.bsize > 0 && blockIdx.z == 0 && wc == 0;
+  const bool do_bias = d.bsize > 0 && wg.z == 0 && wc == 0;
   const int seq = d.T_src * VC;   // T_src == T_out
 
   if (tid < 3 * VC) CS[tid] = d.g_colsum ? d.g_colsum[tid] : 0.f;   // visible after the first tile barrier
@@ -616,13 +639,13 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_fixed_kernel(const WgradK 
     }
   };
 
-  int tile = blockIdx.x;
+  int tile = wg.split;
   if (tile < k.NT) issue_loads(tile);
-  for (; tile < k.NT; tile += gridDim.x) {
+  for (; tile < k.NT; tile += d.nsplit) {
     __syncthreads();   // previous tile's operand reads done
-    if (!(SAR_ABLATE_G & 2) || tile == (int)blockIdx.x) store_lds(tile);
+    if (!(SAR_ABLATE_G & 2) || tile == wg.split) store_lds(tile);
     __syncthreads();
-    if (!(SAR_ABLATE_G & 2) && tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
+    if (!(SAR_ABLATE_G & 2) && tile + d.nsplit < k.NT) issue_loads(tile + d.nsplit);
     float d0[MB], z0[3], d1[MB], z1[3];
     fetch(0, d0, z0);
 #pragma unroll
@@ -647,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_fixed_kernel(const WgradK 
   }
 
   // ---- write this split's slab
-  float* slab = d.slab + (int64_t)blockIdx.x * (d.wsize + d.bsize);
+  float* slab = d.slab + (int64_t)wg.split * (d.wsize + d.bsize);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int f = f0 + (wf * MB + mb) * 32 + l31;
@@ -747,7 +770,9 @@ int launch(const sar_wgrad_desc& d, hipStream_t st) {
       return (int)e;
     }
   }
-  dim3 grid(d.nsplit, (d.M + BF - 1) / BF, (d.Kc + CT - 1) / CT);
+  k.gy = (d.M + BF - 1) / BF;
+  k.gz = (d.Kc + CT - 1) / CT;
+  dim3 grid((unsigned)(((int64_t)d.nsplit * k.gy * k.gz + 7) / 8 * 8));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WF * WC * WT), lds, st, k);
   return 0;
 }
@@ -765,7 +790,10 @@ int launch_graph_fixed_mb(const sar_wgrad_desc& d, hipStream_t st) {
   k.TPS = (d.T_out + 1) / 2;
   k.NT = d.B * k.TPS;
   const int gy = (d.M + 64 * MB - 1) / (64 * MB), gz = (d.Kc + 63) / 64;
-  hipLaunchKernelGGL((graph_wgrad_fixed_kernel<NZ0, NZ1, NZ2, MB>), dim3(d.nsplit, gy, gz), dim3(256), 0, st, k);
+  k.gy = gy;
+  k.gz = gz;
+  hipLaunchKernelGGL((graph_wgrad_fixed_kernel<NZ0, NZ1, NZ2, MB>), dim3((unsigned)(((int64_t)d.nsplit * gy * gz + 7) / 8 * 8)),
+                     dim3(256), 0, st, k);
   return 0;
 }
 
