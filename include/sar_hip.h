@@ -63,6 +63,8 @@ const char* sar_last_error_string(void);
  *                  partial (sum val, sum val*(aux-aux_mean[m]))   (ReLU+BN backward reductions, centred)
  *   SAR_EPI_ADD    val += aux ; store               (residual gradient accumulation)
  * partials layout: [M][nparts][2] with nparts = sar_conv_gemm_nparts(desc).
+ * Limits (checked, SAR_E_ARG otherwise): ld_out, ld_aux < 2^22 columns, T_src*V < 2^28, the weight tensor within
+ * 2^28 floats (the kernels address rows with 32-bit byte offsets through buffer descriptors); V <= 64.
  * ------------------------------------------------------------------------------------------------ */
 enum { SAR_CONV_GRAPH = 0, SAR_CONV_TEMPORAL = 1 };
 enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3 };
