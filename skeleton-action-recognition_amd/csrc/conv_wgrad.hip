@@ -189,7 +189,6 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
   static_assert(WT * TPW >= TAPS, "taps must be covered");
   constexpr int BF = 32 * WF, CT = 32 * WC;
   constexpr int NZMAX = 4;
-  constexpr int NZ[3] = {NZ0, NZ1, NZ2};
   // staging maps: a half-wave owns one row and reads 32 consecutive columns per pass (128-B segments)
   constexpr int DI = (BF + NHW - 1) / NHW, DJ = 4;             // dout tile: BF rows x <=128 positions
   constexpr int SI = (CT + NHW - 1) / NHW;                     // src tile: CT rows x RW columns
