@@ -87,7 +87,10 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
             ft, bf = 2, (128 if M > 64 else 64)
         ntiles = B * ((T_out + ft - 1) // ft)
         wgs = ((M + bf - 1) // bf) * ((Kc + ct - 1) // ct)
-        nsplit = max(1, min(ntiles, (1024 + wgs - 1) // wgs))
+        # workgroups in flight: two rounds of the 512 resident slots for the temporal kernels, one for the graph kernel
+        # (tools/nsplit_sweep.py)
+        target = 512 if (mode == L.SAR_CONV_GRAPH and ft == 2) else 1024
+        nsplit = max(1, min(ntiles, (target + wgs - 1) // wgs))
     d.nsplit = nsplit
     _f32(src), _f32(dout)
     d.src, d.ld_src, d.dout, d.ld_dout = ptr(src), src.stride(0), ptr(dout), dout.stride(0)
