@@ -34,7 +34,8 @@ def _A():
     return torch.tensor(spatial_adjacency().astype(np.float32))
 
 
-@pytest.mark.parametrize("B,cin,f,T", [(3, 3, 64, 13), (2, 64, 64, 10), (2, 64, 128, 7), (1, 128, 256, 5), (4, 256, 256, 3)])
+@pytest.mark.parametrize("B,cin,f,T", [(3, 3, 64, 13), (2, 64, 64, 10), (2, 64, 128, 7), (1, 128, 256, 5), (4, 256, 256, 3),
+                                       (2, 40, 72, 9), (1, 12, 200, 5), (2, 64, 44, 6), (1, 30, 50, 4)])   # ragged row / channel blocks
 def test_graph_conv_forward_and_stats(dev, B, cin, f, T):
     from sar_amd import ops, _lib as L
     g = torch.Generator().manual_seed(B * 1000 + cin)
@@ -64,7 +65,8 @@ def test_graph_conv_forward_and_stats(dev, B, cin, f, T):
     assert rel_err(rv.cpu(), 0.99 + 0.01 * v_ref * n / (n - 1)) < TOL
 
 
-@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (3, 64, 14, 2), (2, 128, 9, 2), (1, 256, 6, 1), (2, 128, 300, 2)])
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (3, 64, 14, 2), (2, 128, 9, 2), (1, 256, 6, 1), (2, 128, 300, 2),
+                                     (2, 72, 11, 1), (1, 200, 9, 2), (2, 44, 7, 1), (1, 50, 10, 2)])
 def test_temporal_conv_forward_fused_bn_relu(dev, B, f, T, s):
     from sar_amd import ops, _lib as L
     g = torch.Generator().manual_seed(f + T + s)
@@ -102,7 +104,8 @@ def test_residual_conv_forward(dev, B, cin, f, T, s):
     assert rel_err(from_cn(out.cpu(), B, To, 25), ref) < TOL
 
 
-@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9), (4, 256, 256, 75)])
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9), (4, 256, 256, 75),
+                                       (2, 40, 72, 9), (1, 72, 200, 5), (2, 44, 40, 6)])
 def test_graph_conv_gradients(dev, B, cin, f, T):
     """data gradient (A^T gather lists + W^T) and weight/bias gradients of GraphConvTD."""
     from sar_amd import ops, _lib as L
@@ -133,7 +136,8 @@ def test_graph_conv_gradients(dev, B, cin, f, T):
     assert rel_err(flat[cin * 3 * f:].cpu(), gb) < TOL
 
 
-@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2), (4, 256, 75, 1), (3, 128, 150, 2)])
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2), (4, 256, 75, 1), (3, 128, 150, 2),
+                                     (2, 72, 11, 1), (1, 200, 9, 2), (2, 44, 12, 2)])
 def test_temporal_conv_gradients(dev, B, f, T, s):
     """weight/bias gradient (with the folded BN+ReLU operand) and the transposed-conv data gradient with the
     fused ReLU mask + BN-backward reductions."""
