@@ -8,8 +8,9 @@ checkpoint every --save-freq epochs (main_gnn.py:359-428).
 
 Launch:  python main_gnn.py --model stgcn ...                      (1 GPU)
          python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main_gnn.py --model stgcn ...
-Data: --train-data-path / --test-data-path point at `<prefix>` for which `<prefix>.npy` and the sibling
-`*_label.pkl` exist (output of the reference's data_gen/gen_joint_data.py), or pass --synthetic.
+Data: --train-data-path / --test-data-path point at a directory of `*.tfrecord` shards (the reference's
+data_gen/gen_tfrecord_data.py output, read without TensorFlow by sar_amd/tfrecord.py) or at `<prefix>` for which
+`<prefix>.npy` and the sibling `*_label.pkl` exist (data_gen/gen_joint_data.py), or pass --synthetic.
 TensorBoard is not available in this image: scalars go to <log-dir>/scalars.jsonl with the reference's tags.
 """
 import argparse
@@ -94,8 +95,14 @@ def main():
         train_data = SyntheticSkeletonData(arg.synthetic_size, arg.num_classes)
         test_data = SyntheticSkeletonData(max(arg.batch_size * 4, 256), arg.num_classes)
     else:
-        train_data = NpySkeletonData(arg.train_data_path + ".npy", _label_path(arg.train_data_path))
-        test_data = NpySkeletonData(arg.test_data_path + ".npy", _label_path(arg.test_data_path))
+        def open_data(prefix):
+            # a directory of *.tfrecord shards (data_gen/gen_tfrecord_data.py, what the reference's main_gnn.py reads)
+            # or the <prefix>.npy + label pkl pair of data_gen/gen_joint_data.py
+            if os.path.isdir(prefix) and any(f.endswith("tfrecord") for f in os.listdir(prefix)):
+                from sar_amd.tfrecord import TFRecordSkeletonData
+                return TFRecordSkeletonData(prefix)
+            return NpySkeletonData(prefix + ".npy", _label_path(prefix))
+        train_data, test_data = open_data(arg.train_data_path), open_data(arg.test_data_path)
 
     model = model_mod.Model(num_classes=arg.num_classes, device=dev)
     eng = model.engine

@@ -2,7 +2,7 @@
 
 Formats: the reference's `*_data_joint.npy` (N,3,T,25,M) float32 + `*_label.pkl` pair
 (data_gen/gen_joint_data.py:138-151), memory-mapped; or synthetic NTU-like clips generated on the device.
-(The TFRecord shards of data_gen/gen_tfrecord_data.py are a SURVEY section 8(f) 'next' item.)
+(The TFRecord shards of data_gen/gen_tfrecord_data.py are read by sar_amd/tfrecord.py.)
 Sharding follows main_gnn.py:290-301 under MirroredStrategy: a global batch of batch_size*world clips per step,
 rank r takes elements r::world, remainder dropped; the reference shuffles with a buffer of 1000 BATCHES
 (main_gnn.py:189-194) -- here the clip order is a seeded permutation per epoch, identical on every rank.

@@ -1,0 +1,119 @@
+"""TFRecord reader / writer (SURVEY 8(f) input formats) without TensorFlow.  The hand-written protobuf codec is pinned
+against the real protobuf runtime: Example / Feature / TensorProto message classes are built at test time from
+descriptors that restate TensorFlow's .proto field numbers, serialized by google.protobuf, and must parse identically
+(and vice versa)."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "skeleton-action-recognition_amd"))
+from sar_amd import tfrecord as T  # noqa: E402
+
+
+def _tf_messages():
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="sar_tf_subset.proto", package="sartf", syntax="proto3")
+
+    def msg(name):
+        m = fd.message_type.add()
+        m.name = name
+        return m
+
+    def field(m, name, number, ftype, label=1, type_name=None, packed=None):
+        f = m.field.add()
+        f.name, f.number, f.type, f.label = name, number, ftype, label
+        if type_name:
+            f.type_name = type_name
+        return f
+    F = descriptor_pb2.FieldDescriptorProto
+    m = msg("BytesList"); field(m, "value", 1, F.TYPE_BYTES, 3)
+    m = msg("FloatList"); field(m, "value", 1, F.TYPE_FLOAT, 3)
+    m = msg("Int64List"); field(m, "value", 1, F.TYPE_INT64, 3)
+    m = msg("Feature")
+    field(m, "bytes_list", 1, F.TYPE_MESSAGE, 1, ".sartf.BytesList")
+    field(m, "float_list", 2, F.TYPE_MESSAGE, 1, ".sartf.FloatList")
+    field(m, "int64_list", 3, F.TYPE_MESSAGE, 1, ".sartf.Int64List")
+    m = msg("FeatureEntry")          # map<string, Feature> is a repeated {key=1, value=2} message on the wire
+    field(m, "key", 1, F.TYPE_STRING); field(m, "value", 2, F.TYPE_MESSAGE, 1, ".sartf.Feature")
+    m = msg("Features"); field(m, "feature", 1, F.TYPE_MESSAGE, 3, ".sartf.FeatureEntry")
+    m = msg("Example"); field(m, "features", 1, F.TYPE_MESSAGE, 1, ".sartf.Features")
+    m = msg("Dim"); field(m, "size", 1, F.TYPE_INT64); field(m, "name", 2, F.TYPE_STRING)
+    m = msg("TensorShapeProto"); field(m, "dim", 2, F.TYPE_MESSAGE, 3, ".sartf.Dim")
+    m = msg("TensorProto")
+    field(m, "dtype", 1, F.TYPE_INT32); field(m, "tensor_shape", 2, F.TYPE_MESSAGE, 1, ".sartf.TensorShapeProto")
+    field(m, "version_number", 3, F.TYPE_INT32); field(m, "tensor_content", 4, F.TYPE_BYTES)
+    field(m, "float_val", 5, F.TYPE_FLOAT, 3)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("sartf." + n))  # noqa: E731
+    return {n: get(n) for n in ("Example", "FeatureEntry", "Feature", "TensorProto", "Dim")}
+
+
+def test_crc32c_known_answers_and_mask():
+    assert T.crc32c(b"123456789") == 0xE3069283          # the CRC-32C check value
+    assert T.crc32c(b"") == 0
+    c = T.crc32c(b"123456789")
+    assert T.masked_crc(b"123456789") == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_codec_against_the_protobuf_runtime():
+    M = _tf_messages()
+    rng = np.random.default_rng(0)
+    clip = rng.standard_normal((3, 7, 25, 2)).astype(np.float32)
+    # protobuf runtime -> our parser
+    tp = M["TensorProto"](dtype=1, tensor_content=clip.tobytes())
+    for d in clip.shape:
+        tp.tensor_shape.dim.add(size=d)
+    ex = M["Example"]()
+    e = ex.features.feature.add(key="features"); e.value.bytes_list.value.append(tp.SerializeToString())
+    e = ex.features.feature.add(key="label"); e.value.int64_list.value.append(41)
+    data, label = T.parse_example(ex.SerializeToString())
+    assert label == 41 and data.dtype == np.float32 and np.array_equal(data, clip)
+    # our writer -> protobuf runtime
+    ex2 = M["Example"].FromString(T.serialize_example(clip, 59))
+    feats = {f.key: f.value for f in ex2.features.feature}
+    assert list(feats["label"].int64_list.value) == [59]
+    tp2 = M["TensorProto"].FromString(feats["features"].bytes_list.value[0])
+    assert tp2.dtype == 1 and [d.size for d in tp2.tensor_shape.dim] == list(clip.shape)
+    assert np.array_equal(np.frombuffer(tp2.tensor_content, dtype="<f4").reshape(clip.shape), clip)
+    # float_val form (what TensorFlow emits for small / constant tensors) and a negative label
+    tp3 = M["TensorProto"](dtype=1, float_val=[1.5, -2.0, 3.25, 0.0])
+    tp3.tensor_shape.dim.add(size=2); tp3.tensor_shape.dim.add(size=2)
+    assert np.array_equal(T.parse_tensor(tp3.SerializeToString()), np.array([[1.5, -2.0], [3.25, 0.0]], dtype=np.float32))
+    assert T.parse_example(T.serialize_example(clip, -3))[1] == -3
+
+
+def test_shards_roundtrip_interleave_and_corruption(tmp_path):
+    rng = np.random.default_rng(1)
+    n = 23
+    data = rng.standard_normal((n, 3, 5, 25, 2)).astype(np.float32)
+    labels = rng.integers(0, 60, n)
+    paths = T.write_shards(data, labels, str(tmp_path / "train_data_joint"), "train_data_joint", 4)
+    assert len(paths) == 5                               # 23 // 4 = 5 clips per shard -> 5 shards (the reference's rule)
+    ds = T.TFRecordSkeletonData(str(tmp_path / "train_data_joint"))
+    assert len(ds) == n
+    got = list(ds._interleaved())
+    # cyclic interleave: record j of shard s comes out at position j*n_shards + s while every shard is alive
+    order = [s * 5 + j for j in range(5) for s in range(5) if s * 5 + j < n]
+    assert [lab for _, lab in got] == [int(labels[i]) for i in order]
+    assert all(np.array_equal(x, data[i]) for (x, _), i in zip(got, order))
+    import torch
+    seen = []
+    for rank in range(2):
+        for x, y in ds.batches(4, rank, 2, torch.device("cpu"), shuffle=True, epoch=3):
+            assert x.shape == (4, 3, 5, 25, 2) and x.dtype == torch.float32
+            seen.extend(y.tolist())
+    assert len(seen) == 16                               # 2 global batches of 8, remainder dropped
+    # a flipped byte is caught by the data CRC
+    raw = bytearray(open(paths[0], "rb").read())
+    raw[40] ^= 0x01
+    open(paths[0], "wb").write(bytes(raw))
+    with pytest.raises(IOError):
+        list(T.read_records(paths[0]))
+    # the length CRC of an intact shard follows the masked CRC-32C rule
+    h = open(paths[1], "rb").read(12)
+    assert T.masked_crc(h[:8]) == struct.unpack("<I", h[8:])[0]
