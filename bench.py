@@ -134,7 +134,7 @@ def main_spectrogram(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     bs = 32 if args.batch == 64 else args.batch
-    model = Model(num_classes=args.classes, num_filters=64, device=dev)
+    model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=args.num_pad_frames)
     eng = model.base_model.engine
     batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
 
@@ -201,7 +201,9 @@ def main_spectrogram(args):
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VirtualRadar -> (B,1,256,256) log-spectrogram -> resnet18 fp32 training step (fwd+bwd+Adam), "
-                                   "synthetic NTU clips (3,300,25,2), %d classes, bs=%d/GPU" % (args.classes, bs),
+                                   "synthetic NTU clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
+                                   % (" up-sampled x%d on the GPU" % args.num_pad_frames if args.num_pad_frames else "",
+                                      args.classes, bs),
                        "global_batch": bs * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -228,6 +230,8 @@ def main():
     ap.add_argument("--classes", type=int, default=60)
     ap.add_argument("--workload", default="stgcn", choices=["stgcn", "spectrogram"],
                     help="stgcn = BASELINE.json's headline (configs[1]); spectrogram = Path B (configs[3] shape per GPU)")
+    ap.add_argument("--num-pad-frames", type=int, default=0,
+                    help="spectrogram workload: GPU-side frame up-sampling factor (the reference's loader default is 250)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="clips in the CPU-baseline sample batch")
     args = ap.parse_args()

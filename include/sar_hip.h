@@ -239,6 +239,25 @@ int sar_vr_signal_bwd_f32(const float* x, int B, int T, int V, int M, const int3
                           int E, const float* loc, const float* wavelength, const float* dz_re, const float* dz_im,
                           float* partials, sar_stream_t s);
 
+/* Frame-rate up-sampling of utils.py:134-140 (Dataset.pad_frames, what main_spectrogram.py feeds the radar:
+ * gaussian_filter1d(sigma) along T, then interp1d 'cubic' evaluated at np.linspace(0, 1, P*T), P = num_pad_frames = 250)
+ * fused with the radar signal: the (B,3,P*T,V,M) tensor is never materialised.
+ * sar_upsample_prepare_f64: x (B,3,T,V,M) -> per-interval cubic pieces coef [B][T-1][3][V*M][4] (float64;
+ *   sar_upsample_coef_doubles elements).  weights = the radius+1 one-sided Gaussian weights w[0..radius] (float64,
+ *   device; scipy's _gaussian_kernel1d, normalised), workspace of sar_upsample_workspace_bytes(...) bytes.  T >= 5.
+ * sar_vr_signal_upsampled_f32 / _bwd_f32: sar_vr_signal_f32 / sar_vr_signal_bwd_f32 on the up-sampled clip (P*T frames;
+ *   nparts = sar_vr_signal_bwd_nparts(B, P*T)), each frame evaluated from coef in float64 and rounded to float32. */
+int64_t sar_upsample_workspace_bytes(int B, int T, int V, int M);
+int64_t sar_upsample_coef_doubles(int B, int T, int V, int M);
+int sar_upsample_prepare_f64(const float* x, int B, int T, int V, int M, const double* weights, int radius,
+                             void* workspace, double* coef, sar_stream_t s);
+int sar_vr_signal_upsampled_f32(const double* coef, int B, int T, int P, int V, int M, const int32_t* e_src,
+                                const int32_t* e_dst, int E, const float* loc, const float* wavelength, float* z_re,
+                                float* z_im, sar_stream_t s);
+int sar_vr_signal_upsampled_bwd_f32(const double* coef, int B, int T, int P, int V, int M, const int32_t* e_src,
+                                    const int32_t* e_dst, int E, const float* loc, const float* wavelength,
+                                    const float* dz_re, const float* dz_im, float* partials, sar_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * ResNet-18 of the spectrogram path, models/resnet18.py:131-254 (torch Conv2d bias=False / BatchNorm2d /
  * MaxPool2d / Linear) on the CN layout: an image batch (B,C,H,W) is the matrix [C][B*H*W].

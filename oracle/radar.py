@@ -192,3 +192,15 @@ def radar_param_grads(x, weights, loc, lam, **kw):
     out = spectrogram_torch(x, loc_t, lam_t, **kw)
     (out * torch.as_tensor(weights).to(out.dtype)).sum().backward()
     return loc_t.grad.numpy(), lam_t.grad.numpy()
+
+
+def pad_frames(data, num_pad_frames=250, sigma=3):
+    """utils.py:134-140 (Dataset.pad_frames) with the reference's own scipy calls: Gaussian smoothing along T then cubic
+    interpolation to num_pad_frames*T frames.  data (..., T, V, M) float32 with T at axis -3 -> float32 (the
+    reference's `.type(torch.FloatTensor)`)."""
+    from scipy.interpolate import interp1d
+    from scipy.ndimage import gaussian_filter1d
+    data = np.asarray(data)
+    T = data.shape[-3]
+    f = interp1d(np.linspace(0, 1, T), gaussian_filter1d(data, sigma, axis=-3), 'cubic', axis=-3)
+    return f(np.linspace(0, 1, num_pad_frames * T)).astype(f32)

@@ -19,7 +19,45 @@ namespace {
 
 constexpr int FRAMES = 64;
 
-__global__ __launch_bounds__(FRAMES) void vr_signal_kernel(const float* __restrict__ x, int T, int V, int M,
+// Slab fill shared by the forward and backward signal kernels.  SPLINE == 0: frames t0.. of the clip itself.
+// SPLINE == 1: frame j of the UP-SAMPLED clip (utils.py:134-140: cubic interpolation of the Gaussian-smoothed clip
+// at np.linspace(0, 1, P*T)) evaluated on the fly from the per-interval cubic pieces of sar_upsample_prepare_f64 --
+// the (B,3,P*T,V,M) tensor (45 MB per clip at P = 250) is never materialised.  Evaluation in float64, rounded once
+// to float32 like the reference's `.type(torch.FloatTensor)`.
+template <int SPLINE>
+__device__ __forceinline__ void fill_slab(float* xs, int RS, const float* __restrict__ x, const double* __restrict__ coef,
+                                          int b, int T, int Tup, int VM, int t0, int nt) {
+  if (!SPLINE) {
+    for (int c = 0; c < 3; ++c) {
+      const float* g = x + (((int64_t)b * 3 + c) * T + t0) * VM;   // nt*VM contiguous floats
+      for (int i = threadIdx.x; i < nt * VM; i += FRAMES) {
+        const int tt = i / VM;
+        xs[(c * FRAMES + tt) * RS + (i - tt * VM)] = g[i];
+      }
+    }
+  } else {
+    const int tt = threadIdx.x;
+    if (tt < nt) {
+      const int j = t0 + tt;
+      // x_new = j / (Tup - 1) on knots i / (T - 1): interval i = floor(x_new (T-1)), local dx in knot units / (T-1)
+      const double xn = (double)j / (double)(Tup - 1);
+      int i = (int)floor(xn * (double)(T - 1));
+      if (i > T - 2) i = T - 2;
+      const double dx = xn - (double)i / (double)(T - 1);
+      const double* cf = coef + ((int64_t)b * (T - 1) + i) * (3 * VM * 4);
+      for (int c = 0; c < 3; ++c)
+        for (int vm = 0; vm < VM; ++vm) {
+          const double* q = cf + (c * VM + vm) * 4;
+          const double v = q[0] + dx * (q[1] + dx * (q[2] + dx * q[3]));
+          xs[(c * FRAMES + tt) * RS + vm] = (float)v;
+        }
+    }
+  }
+}
+
+template <int SPLINE>
+__global__ __launch_bounds__(FRAMES) void vr_signal_kernel(const float* __restrict__ x, const double* __restrict__ coef,
+                                                           int T, int Tup, int V, int M,
                                                            const int* __restrict__ e_src, const int* __restrict__ e_dst,
                                                            int E, const float* __restrict__ loc_p,
                                                            const float* __restrict__ lam_p, float* __restrict__ z_re,
@@ -32,14 +70,9 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_kernel(const float* __restri
   int* ed = es + E;                          // [E] dst joints
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * FRAMES;
-  const int nt = min(FRAMES, T - t0);
-  for (int c = 0; c < 3; ++c) {
-    const float* g = x + (((int64_t)b * 3 + c) * T + t0) * VM;   // nt*VM contiguous floats
-    for (int i = threadIdx.x; i < nt * VM; i += FRAMES) {
-      const int tt = i / VM;
-      xs[(c * FRAMES + tt) * RS + (i - tt * VM)] = g[i];
-    }
-  }
+  const int To = SPLINE ? Tup : T;           // frames of the signal
+  const int nt = min(FRAMES, To - t0);
+  fill_slab<SPLINE>(xs, RS, x, coef, b, T, Tup, VM, t0, nt);
   for (int i = threadIdx.x; i < E; i += FRAMES) {
     es[i] = e_src[i];
     ed[i] = e_dst[i];
@@ -91,8 +124,8 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_kernel(const float* __restri
       zi = zi + amp * sinf(psi);
     }
   }
-  z_re[(int64_t)b * T + t0 + tt] = zr;
-  z_im[(int64_t)b * T + t0 + tt] = zi;
+  z_re[(int64_t)b * To + t0 + tt] = zr;
+  z_im[(int64_t)b * To + t0 + tt] = zi;
 }
 
 __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ z_re, const float* __restrict__ z_im,
@@ -263,7 +296,9 @@ __global__ __launch_bounds__(256) void stft_logmag_bwd_gather_kernel(const float
 
 // Signal stage: partials[block][4] = sum over the block's frames of Re(conj(dz) . d z / d p), p = (loc_x, loc_y,
 // loc_z, lambda).  Same slab staging as the forward kernel.
-__global__ __launch_bounds__(FRAMES) void vr_signal_bwd_kernel(const float* __restrict__ x, int T, int V, int M,
+template <int SPLINE>
+__global__ __launch_bounds__(FRAMES) void vr_signal_bwd_kernel(const float* __restrict__ x, const double* __restrict__ coef,
+                                                               int T, int Tup, int V, int M,
                                                                const int* __restrict__ e_src,
                                                                const int* __restrict__ e_dst, int E,
                                                                const float* __restrict__ loc_p,
@@ -279,14 +314,9 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_bwd_kernel(const float* __re
   int* ed = es + E;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * FRAMES;
-  const int nt = min(FRAMES, T - t0);
-  for (int c = 0; c < 3; ++c) {
-    const float* g = x + (((int64_t)b * 3 + c) * T + t0) * VM;
-    for (int i = threadIdx.x; i < nt * VM; i += FRAMES) {
-      const int tt = i / VM;
-      xs[(c * FRAMES + tt) * RS + (i - tt * VM)] = g[i];
-    }
-  }
+  const int To = SPLINE ? Tup : T;
+  const int nt = min(FRAMES, To - t0);
+  fill_slab<SPLINE>(xs, RS, x, coef, b, T, Tup, VM, t0, nt);
   for (int i = threadIdx.x; i < E; i += FRAMES) {
     es[i] = e_src[i];
     ed[i] = e_dst[i];
@@ -302,7 +332,7 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_bwd_kernel(const float* __re
     const float* X2 = xs + (2 * FRAMES + tt) * RS;
     const float PI_F = 3.14159274101257324f;
     const float FOURPI_F = 12.5663706143591725f;
-    const float ur = dz_re[(int64_t)b * T + t0 + tt], ui = dz_im[(int64_t)b * T + t0 + tt];
+    const float ur = dz_re[(int64_t)b * To + t0 + tt], ui = dz_im[(int64_t)b * To + t0 + tt];
     float cm[4];
     for (int m = 0; m < M; ++m) {
       float acc = 0.f;
@@ -382,6 +412,72 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_bwd_kernel(const float* __re
   }
 }
 
+// Up-sampling preparation (utils.py:134-140, Dataset.pad_frames): per series (clip, coordinate, joint, body) along T
+//   1. scipy.ndimage.gaussian_filter1d(sigma, mode='reflect', truncate=4): symmetric FIR of radius int(4 sigma + .5),
+//      accumulated in float64 in scipy's order (centre, then the farthest pair inwards), stored as float32 (the
+//      filter keeps the input dtype);
+//   2. scipy.interpolate.interp1d(np.linspace(0,1,T), y, 'cubic') = the C2 cubic spline with not-a-knot end
+//      conditions on uniform knots, in float64: second derivatives by the Thomas algorithm
+//      (m[1] = r[1]/6, m[T-2] = r[T-2]/6 from the not-a-knot conditions, m[0] = 2 m[1] - m[2], ...), then the
+//      per-interval cubic pieces  a + b dx + c dx^2 + d dx^3  (dx in units of x, knot spacing h = 1/(T-1)).
+// One thread per series (150 per clip); scratch [T][nseries] so that neighbouring threads touch neighbouring words.
+__global__ __launch_bounds__(64) void upsample_prepare_kernel(const float* __restrict__ x, int B, int T, int VM,
+                                                              const double* __restrict__ w, int radius,
+                                                              float* __restrict__ sm, double* __restrict__ m2,
+                                                              double* __restrict__ cp, double* __restrict__ coef) {
+  const int nser = B * 3 * VM;
+  const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= nser) return;
+  const int vm = sidx % VM, c = (sidx / VM) % 3, b = sidx / (3 * VM);
+  const float* xs = x + ((int64_t)(b * 3 + c) * T) * VM + vm;        // element t at xs[t * VM]
+  auto refl = [&](int t) {                                          // scipy 'reflect': (d c b a | a b c d | d c b a)
+    while (t < 0 || t >= T) {
+      if (t < 0) t = -t - 1;
+      if (t >= T) t = 2 * T - 1 - t;
+    }
+    return t;
+  };
+  for (int t = 0; t < T; ++t) {
+    double tmp = (double)xs[(int64_t)t * VM] * w[0];
+    for (int k = radius; k >= 1; --k)
+      tmp += ((double)xs[(int64_t)refl(t - k) * VM] + (double)xs[(int64_t)refl(t + k) * VM]) * w[k];
+    sm[(int64_t)t * nser + sidx] = (float)tmp;
+  }
+  const int n = T - 1;                       // intervals
+  const double h = 1.0 / (double)n, ih2 = 6.0 / (h * h);
+  auto y = [&](int t) { return (double)sm[(int64_t)t * nser + sidx]; };
+  auto r = [&](int i) { return ih2 * (y(i - 1) - 2.0 * y(i) + y(i + 1)); };
+  auto M2 = [&](int i) -> double& { return m2[(int64_t)i * nser + sidx]; };
+  auto CP = [&](int i) -> double& { return cp[(int64_t)i * nser + sidx]; };
+  M2(1) = r(1) / 6.0;
+  M2(n - 1) = r(n - 1) / 6.0;
+  if (n - 2 >= 2) {   // interior unknowns m[2..n-2]: m[i-1] + 4 m[i] + m[i+1] = r[i]
+    double cprev = 0.0, dprev = 0.0;
+    for (int i = 2; i <= n - 2; ++i) {
+      double rhs = r(i);
+      if (i == 2) rhs -= M2(1);
+      if (i == n - 2) rhs -= M2(n - 1);
+      const double lower = (i == 2) ? 0.0 : 1.0;
+      const double denom = 4.0 - lower * cprev;
+      cprev = ((i == n - 2) ? 0.0 : 1.0) / denom;
+      dprev = (rhs - lower * dprev) / denom;
+      CP(i) = cprev;
+      M2(i) = dprev;
+    }
+    for (int i = n - 3; i >= 2; --i) M2(i) = M2(i) - CP(i) * M2(i + 1);
+  }
+  M2(0) = 2.0 * M2(1) - M2(2);
+  M2(n) = 2.0 * M2(n - 1) - M2(n - 2);
+  for (int i = 0; i < n; ++i) {
+    const double mi = M2(i), mj = M2(i + 1), yi = y(i), yj = y(i + 1);
+    double* q = coef + ((int64_t)b * n + i) * (3 * VM * 4) + (c * VM + vm) * 4;
+    q[0] = yi;
+    q[1] = (yj - yi) / h - h * (2.0 * mi + mj) / 6.0;
+    q[2] = mi / 2.0;
+    q[3] = (mj - mi) / (6.0 * h);
+  }
+}
+
 }  // namespace
 
 extern "C" int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, const int32_t* e_src, const int32_t* e_dst,
@@ -392,9 +488,51 @@ extern "C" int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, con
   const size_t lds = sizeof(float) * 3 * FRAMES * ((V * M) | 1) + sizeof(int) * 2 * E;
   SAR_REQUIRE(lds <= 64 * 1024, "sar_vr_signal: V*M = %d too large for the LDS slab", V * M);
   dim3 grid((T + FRAMES - 1) / FRAMES, B);
-  hipLaunchKernelGGL(vr_signal_kernel, grid, dim3(FRAMES), lds, as_stream(s), x, T, V, M, e_src, e_dst, E, loc,
-                     wavelength, z_re, z_im);
+  hipLaunchKernelGGL(vr_signal_kernel<0>, grid, dim3(FRAMES), lds, as_stream(s), x, nullptr, T, T, V, M, e_src, e_dst, E,
+                     loc, wavelength, z_re, z_im);
   SAR_LAUNCH_CHECK("sar_vr_signal_f32");
+  return 0;
+}
+
+extern "C" int64_t sar_upsample_workspace_bytes(int B, int T, int V, int M) {
+  if (B <= 0 || T < 5 || V <= 0 || M <= 0) return -1;
+  const int64_t nser = (int64_t)B * 3 * V * M;
+  return nser * T * (4 + 8 + 8);
+}
+
+extern "C" int64_t sar_upsample_coef_doubles(int B, int T, int V, int M) {
+  if (B <= 0 || T < 5 || V <= 0 || M <= 0) return -1;
+  return (int64_t)B * (T - 1) * 3 * V * M * 4;
+}
+
+extern "C" int sar_upsample_prepare_f64(const float* x, int B, int T, int V, int M, const double* weights, int radius,
+                                        void* workspace, double* coef, sar_stream_t s) {
+  SAR_REQUIRE(x && weights && workspace && coef, "sar_upsample_prepare: null pointer");
+  SAR_REQUIRE(B > 0 && T >= 5 && V > 0 && M > 0 && radius >= 0, "sar_upsample_prepare: bad sizes (T >= 5)");
+  const int64_t nser = (int64_t)B * 3 * V * M;
+  SAR_REQUIRE(nser < (1ll << 31), "sar_upsample_prepare: too many series");
+  float* sm = (float*)workspace;
+  double* m2 = (double*)((char*)workspace + (((nser * T * 4) + 7) / 8) * 8);
+  double* cp = m2 + nser * T;
+  hipLaunchKernelGGL(upsample_prepare_kernel, dim3((unsigned)((nser + 63) / 64)), dim3(64), 0, as_stream(s), x, B, T, V * M,
+                     weights, radius, sm, m2, cp, coef);
+  SAR_LAUNCH_CHECK("sar_upsample_prepare_f64");
+  return 0;
+}
+
+extern "C" int sar_vr_signal_upsampled_f32(const double* coef, int B, int T, int P, int V, int M, const int32_t* e_src,
+                                           const int32_t* e_dst, int E, const float* loc, const float* wavelength,
+                                           float* z_re, float* z_im, sar_stream_t s) {
+  SAR_REQUIRE(coef && e_src && e_dst && loc && wavelength && z_re && z_im, "sar_vr_signal_upsampled: null pointer");
+  SAR_REQUIRE(B > 0 && T >= 5 && P >= 1 && V > 0 && M > 0 && M <= 4 && E > 0, "sar_vr_signal_upsampled: bad sizes");
+  SAR_REQUIRE((int64_t)T * P < (1ll << 31), "sar_vr_signal_upsampled: T*P too large");
+  const size_t lds = sizeof(float) * 3 * FRAMES * ((V * M) | 1) + sizeof(int) * 2 * E;
+  SAR_REQUIRE(lds <= 64 * 1024, "sar_vr_signal_upsampled: V*M = %d too large for the LDS slab", V * M);
+  const int Tup = T * P;
+  dim3 grid((Tup + FRAMES - 1) / FRAMES, B);
+  hipLaunchKernelGGL(vr_signal_kernel<1>, grid, dim3(FRAMES), lds, as_stream(s), nullptr, coef, T, Tup, V, M, e_src, e_dst,
+                     E, loc, wavelength, z_re, z_im);
+  SAR_LAUNCH_CHECK("sar_vr_signal_upsampled_f32");
   return 0;
 }
 
@@ -448,8 +586,23 @@ extern "C" int sar_vr_signal_bwd_f32(const float* x, int B, int T, int V, int M,
   const size_t lds = sizeof(float) * 3 * FRAMES * ((V * M) | 1) + sizeof(int) * 2 * E;
   SAR_REQUIRE(lds <= 64 * 1024, "sar_vr_signal_bwd: V*M = %d too large for the LDS slab", V * M);
   dim3 grid((T + FRAMES - 1) / FRAMES, B);
-  hipLaunchKernelGGL(vr_signal_bwd_kernel, grid, dim3(FRAMES), lds, as_stream(s), x, T, V, M, e_src, e_dst, E, loc,
-                     wavelength, dz_re, dz_im, partials);
+  hipLaunchKernelGGL(vr_signal_bwd_kernel<0>, grid, dim3(FRAMES), lds, as_stream(s), x, nullptr, T, T, V, M, e_src, e_dst,
+                     E, loc, wavelength, dz_re, dz_im, partials);
   SAR_LAUNCH_CHECK("sar_vr_signal_bwd_f32");
+  return 0;
+}
+
+extern "C" int sar_vr_signal_upsampled_bwd_f32(const double* coef, int B, int T, int P, int V, int M, const int32_t* e_src,
+                                               const int32_t* e_dst, int E, const float* loc, const float* wavelength,
+                                               const float* dz_re, const float* dz_im, float* partials, sar_stream_t s) {
+  SAR_REQUIRE(coef && e_src && e_dst && loc && wavelength && dz_re && dz_im && partials, "sar_vr_signal_upsampled_bwd: null pointer");
+  SAR_REQUIRE(B > 0 && T >= 5 && P >= 1 && V > 0 && M > 0 && M <= 4 && E > 0, "sar_vr_signal_upsampled_bwd: bad sizes");
+  const size_t lds = sizeof(float) * 3 * FRAMES * ((V * M) | 1) + sizeof(int) * 2 * E;
+  SAR_REQUIRE(lds <= 64 * 1024, "sar_vr_signal_upsampled_bwd: V*M = %d too large for the LDS slab", V * M);
+  const int Tup = T * P;
+  dim3 grid((Tup + FRAMES - 1) / FRAMES, B);
+  hipLaunchKernelGGL(vr_signal_bwd_kernel<1>, grid, dim3(FRAMES), lds, as_stream(s), nullptr, coef, T, Tup, V, M, e_src,
+                     e_dst, E, loc, wavelength, dz_re, dz_im, partials);
+  SAR_LAUNCH_CHECK("sar_vr_signal_upsampled_bwd_f32");
   return 0;
 }

@@ -27,13 +27,23 @@ _CHAINS = [(0, 1, 20, 2, 3), (20, 4, 5, 6, 7, 21), (7, 22), (20, 8, 9, 10, 11, 2
 edges = [(c[i], c[i + 1]) for c in _CHAINS for i in range(len(c) - 1)]
 
 
+def gaussian_weights(sigma, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius): one-sided weights w[0..radius], float64."""
+    radius = int(truncate * float(sigma) + 0.5)
+    k = np.arange(-radius, radius + 1, dtype=np.float64)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * k ** 2)
+    phi = phi / phi.sum()
+    return phi[radius:].copy(), radius
+
+
 class _RadarFunction(torch.autograd.Function):
     """log|STFT(z(x; loc, lambda))| with gradients for radar_location and wavelength."""
 
     @staticmethod
-    def forward(ctx, loc, wavelength, mod, x, out_cols):
-        zr, zi = mod.signal(x)
-        ctx.mod, ctx.out_cols = mod, out_cols
+    def forward(ctx, loc, wavelength, mod, x, out_cols, num_pad_frames, sigma):
+        coef = mod.spline_pieces(x, sigma) if num_pad_frames else None
+        zr, zi = mod.signal(x, num_pad_frames, coef)
+        ctx.mod, ctx.out_cols, ctx.P, ctx.coef = mod, out_cols, num_pad_frames, coef
         ctx.save_for_backward(x, zr, zi)
         return mod._stft(zr, zi, out_cols)
 
@@ -52,11 +62,17 @@ class _RadarFunction(torch.autograd.Function):
                                           ptr(dout), ptr(ws), ptr(dzr), ptr(dzi), stream_ptr()), "sar_stft_logmag_bwd_f32")
         nparts = lib.sar_vr_signal_bwd_nparts(B, T)
         part = torch.empty((nparts, 4), dtype=torch.float32, device=x.device)
-        check(lib.sar_vr_signal_bwd_f32(ptr(x), B, T, V, M, ptr(mod._src), ptr(mod._dst), len(mod.src),
-                                        ptr(mod.radar_location.data), ptr(mod.wavelength.data.reshape(1)), ptr(dzr), ptr(dzi),
-                                        ptr(part), stream_ptr()), "sar_vr_signal_bwd_f32")
+        if ctx.P:
+            check(lib.sar_vr_signal_upsampled_bwd_f32(ptr(ctx.coef), B, x.shape[2], ctx.P, V, M, ptr(mod._src), ptr(mod._dst),
+                                                      len(mod.src), ptr(mod.radar_location.data),
+                                                      ptr(mod.wavelength.data.reshape(1)), ptr(dzr), ptr(dzi), ptr(part),
+                                                      stream_ptr()), "sar_vr_signal_upsampled_bwd_f32")
+        else:
+            check(lib.sar_vr_signal_bwd_f32(ptr(x), B, T, V, M, ptr(mod._src), ptr(mod._dst), len(mod.src),
+                                            ptr(mod.radar_location.data), ptr(mod.wavelength.data.reshape(1)), ptr(dzr),
+                                            ptr(dzi), ptr(part), stream_ptr()), "sar_vr_signal_bwd_f32")
         g = part.double().sum(0).float()          # fixed-order reduction of the per-block partial sums
-        return g[:3].clone(), g[3].reshape(mod.wavelength.shape), None, None, None
+        return g[:3].clone(), g[3].reshape(mod.wavelength.shape), None, None, None, None, None
 
 
 class VirtualRadar(torch.nn.Module):
@@ -80,24 +96,52 @@ class VirtualRadar(torch.nn.Module):
         self.register_buffer("_dst", torch.tensor(self.dst, dtype=torch.int32), persistent=False)
         self.to(device)
 
-    def signal(self, x):
-        """Complex baseband signal z[b, t] (layers/virtual_radar.py:93-123) as (z_re, z_im)."""
+    def spline_pieces(self, x, sigma=3):
+        """Gaussian smoothing + not-a-knot cubic spline of every coordinate series along T (utils.py:134-140), as
+        per-interval cubic pieces [B][T-1][3][V*M][4] float64 for the fused up-sampled signal kernel."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 3
         x = x.contiguous()
         B, _, T, V, M = x.shape
-        zr = torch.empty((B, T), dtype=torch.float32, device=x.device)
+        lib = L.load()
+        w, radius = gaussian_weights(sigma)
+        w_dev = torch.from_numpy(w).to(x.device)
+        ws = torch.empty(lib.sar_upsample_workspace_bytes(B, T, V, M), dtype=torch.uint8, device=x.device)
+        coef = torch.empty(lib.sar_upsample_coef_doubles(B, T, V, M), dtype=torch.float64, device=x.device)
+        check(lib.sar_upsample_prepare_f64(ptr(x), B, T, V, M, ptr(w_dev), radius, ptr(ws), ptr(coef), stream_ptr()),
+              "sar_upsample_prepare_f64")
+        return coef
+
+    def signal(self, x, num_pad_frames=0, coef=None, sigma=3):
+        """Complex baseband signal z[b, t] (layers/virtual_radar.py:93-123) as (z_re, z_im); with num_pad_frames = P
+        the signal of the clip up-sampled to P*T frames (utils.py:134-140), frames evaluated on the fly."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 3
+        x = x.contiguous()
+        B, _, T, V, M = x.shape
+        Tz = T * num_pad_frames if num_pad_frames else T
+        zr = torch.empty((B, Tz), dtype=torch.float32, device=x.device)
         zi = torch.empty_like(zr)
-        check(L.load().sar_vr_signal_f32(ptr(x), B, T, V, M, ptr(self._src), ptr(self._dst), len(self.src),
-                                         ptr(self.radar_location.data), ptr(self.wavelength.data.reshape(1)), ptr(zr),
-                                         ptr(zi), stream_ptr()), "sar_vr_signal_f32")
+        if num_pad_frames:
+            coef = coef if coef is not None else self.spline_pieces(x, sigma)
+            check(L.load().sar_vr_signal_upsampled_f32(ptr(coef), B, T, num_pad_frames, V, M, ptr(self._src), ptr(self._dst),
+                                                       len(self.src), ptr(self.radar_location.data),
+                                                       ptr(self.wavelength.data.reshape(1)), ptr(zr), ptr(zi), stream_ptr()),
+                  "sar_vr_signal_upsampled_f32")
+        else:
+            check(L.load().sar_vr_signal_f32(ptr(x), B, T, V, M, ptr(self._src), ptr(self._dst), len(self.src),
+                                             ptr(self.radar_location.data), ptr(self.wavelength.data.reshape(1)), ptr(zr),
+                                             ptr(zi), stream_ptr()), "sar_vr_signal_f32")
         return zr, zi
 
-    def forward(self, x, out_cols=0):
+    def forward(self, x, out_cols=0, num_pad_frames=0, sigma=3):
         """out_cols > 0 produces only the frames a nearest-neighbour F.interpolate(..., out_cols) would read
-        (models/resnet.py:26 fused as a column select) -> (B, n_fft, out_cols)."""
+        (models/resnet.py:26 fused as a column select) -> (B, n_fft, out_cols).
+        num_pad_frames = P > 0: x is the RAW (B,3,T,V,M) clip and the result is what the reference computes from
+        utils.Dataset.pad_frames(x) (Gaussian smoothing sigma + cubic interpolation to P*T frames, utils.py:134-140) --
+        the up-sampled tensor is never built."""
         if torch.is_grad_enabled() and (self.radar_location.requires_grad or self.wavelength.requires_grad):
-            return _RadarFunction.apply(self.radar_location, self.wavelength, self, x.contiguous(), out_cols)
-        zr, zi = self.signal(x)
+            return _RadarFunction.apply(self.radar_location, self.wavelength, self, x.contiguous(), out_cols, num_pad_frames,
+                                        sigma)
+        zr, zi = self.signal(x, num_pad_frames, None, sigma)
         return self._stft(zr, zi, out_cols)
 
     def _stft(self, zr, zi, out_cols=0):

@@ -34,6 +34,10 @@ def get_parser():
     parser.add_argument('--lr_cycle', type=int, default=10, help='number of epochs for the cyclic LR cycle')
     parser.add_argument('--lambda-train-epoch', type=int, default=1000, help='epoch to training the radar_lambda')
     parser.add_argument('--loc-train-epoch', type=int, default=1000, help='epoch to training the radar_loc')
+    parser.add_argument('--num-pad-frames', type=int, default=250,
+                        help='frame-rate up-sampling factor of utils.Dataset (utils.py:105, default 250), applied on the GPU inside '
+                             'the radar layer (Gaussian smoothing + cubic interpolation, never materialised); 0 = feed the clips as they are')
+    parser.add_argument('--sigma', type=int, default=3, help='sigma of the Gaussian smoothing before up-sampling (utils.py:105)')
     parser.add_argument('--synthetic', action='store_true')
     parser.add_argument('--synthetic-size', type=int, default=2048)
     parser.add_argument('--max-iters', type=int, default=0)
@@ -78,7 +82,8 @@ def main():
                 "val": SyntheticSkeletonData(max(arg.batch_size * 2, 64), arg.num_classes)}
     else:
         data = {x: NpySkeletonData(arg.data_path.format(x), arg.label_path.format(x)) for x in ['train', 'val']}
-    model = Model(num_classes=arg.num_classes, num_filters=arg.num_filters, device=dev)
+    model = Model(num_classes=arg.num_classes, num_filters=arg.num_filters, device=dev, num_pad_frames=arg.num_pad_frames,
+                  sigma=arg.sigma)
     eng = model.base_model.engine
     radar_params = list(model.virtual_radar.parameters())
     radar_opt = torch.optim.Adam(radar_params, lr=arg.base_lr)   # same Adam hyper-parameters as main_spectrogram.py:106

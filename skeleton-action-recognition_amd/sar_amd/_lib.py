@@ -99,6 +99,11 @@ SIGNATURES = {
     "sar_stft_logmag_bwd_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_vr_signal_bwd_nparts": (_i, [_i, _i]),
     "sar_vr_signal_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "sar_upsample_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "sar_upsample_coef_doubles": (_i64, [_i, _i, _i, _i]),
+    "sar_upsample_prepare_f64": (_i, [_fp, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp]),
+    "sar_vr_signal_upsampled_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
+    "sar_vr_signal_upsampled_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_conv2d_stem_dgrad_f32": (_i, [_fp, _i64, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
 }
 

@@ -109,6 +109,52 @@ def test_full_length_upsampled_clip_properties(dev):
     assert ((mb - 2 * ma).abs().max() / mb.max()).item() < 1e-5
 
 
+def test_fused_upsampling_matches_the_reference_pipeline(dev, golden_dir):
+    """utils.Dataset.pad_frames (Gaussian smoothing + cubic interpolation to 250*T frames, the reference's CPU data-loader
+    step) fused into the radar signal kernel: signal against the oracle on the scipy-up-sampled clip (2e-5 of its scale,
+    like the plain signal test -- the up-sampled coordinates must agree to the float32 bit almost everywhere for that),
+    spectrogram columns against the reference's own pipeline output."""
+    from layers.virtual_radar import VirtualRadar
+    g = np.load(os.path.join(golden_dir, "upsample_reference.npz"))
+    x = g["x"][None]
+    up = R.pad_frames(g["x"], 250, 3)[None]
+    for lam in (1e-1, 5e-4):
+        vr = VirtualRadar(wavelength=lam, device=dev)
+        zr, zi = vr.signal(torch.from_numpy(x).to(dev), num_pad_frames=250)
+        torch.cuda.synchronize()
+        rr, ri = R.radar_signal(up, wavelength=lam)
+        scale = max(np.abs(rr).max(), np.abs(ri).max())
+        e = max(np.abs(zr.cpu().numpy() - rr).max(), np.abs(zi.cpu().numpy() - ri).max()) / scale
+        print("lambda %g: up-sampled signal error %.2e of scale" % (lam, e))
+        assert zr.shape == (1, 75000) and e < (2e-5 if lam >= 1e-2 else 2e-3)
+        out = vr(torch.from_numpy(x).to(dev), out_cols=256, num_pad_frames=250).cpu().numpy()[0]
+        gold = g["spec_lam%g" % lam]
+        tol = 1e-4 if lam >= 1e-2 else 5e-3
+        assert out.shape == gold.shape == (256, 256)
+        assert np.abs(_mag(out[None]) - _mag(gold[None])).max() / _mag(gold[None]).max() < tol
+    # the zero-padded tail of the clip (frames >= 260 of 300) up-samples to exact silence where the reference's does
+    silent = gold == np.float32(np.log(np.float32(1e-6)))
+    assert silent.any() and (out[silent] == gold[silent]).all()
+
+
+def test_upsampled_radar_gradient_is_consistent(dev):
+    """radar_location gradient through the fused up-sampling path equals the gradient through the plain path applied to
+    a clip that was up-sampled beforehand by the oracle (same frames, same arithmetic after the slab fill)."""
+    from layers.virtual_radar import VirtualRadar
+    g = torch.Generator().manual_seed(5)
+    x = (0.12 * torch.randn((1, 3, 40, 25, 2), generator=g)).clamp(-1.1, 0.75)
+    up = torch.from_numpy(R.pad_frames(x[0].numpy(), 8, 3))[None]
+    grads = []
+    for inp, P in ((x, 8), (up, 0)):
+        vr = VirtualRadar(wavelength=0.1, radar_location=[0.4, -0.3, 1.0], train_radar_location=True, n_fft=64, hop_length=8,
+                          device=dev)
+        out = vr(inp.to(dev), num_pad_frames=P)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+        (out * w).sum().backward()
+        grads.append(vr.radar_location.grad.cpu())
+    assert (grads[0] - grads[1]).abs().max() <= 1e-4 * grads[1].abs().max()
+
+
 def test_trainable_stft_kernels_are_refused(dev):
     from layers.virtual_radar import VirtualRadar
     with pytest.raises(NotImplementedError):

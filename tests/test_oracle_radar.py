@@ -99,3 +99,12 @@ def test_parameter_gradients_match_the_reference_autograd(golden_dir, lam, loc):
     assert np.abs(dloc - g[key + "_dloc_f64"]).max() <= 2e-5 * np.abs(g[key + "_dloc_f64"]).max()
     assert abs(dlam - g[key + "_dlam_f64"]) <= 2e-5 * abs(g[key + "_dlam_f64"])
     assert g["ntu_dloc_is_nan"].all()     # the reference's own gradient is NaN on clips with an absent body / zero padding
+
+
+def test_pad_frames_restatement_equals_the_reference(golden_dir):
+    """utils.py:134-140 (Gaussian smoothing + cubic up-sampling x250): the oracle's scipy calls against the reference's
+    own Dataset.pad_frames output at ~1 000 of the 75 000 frames (tests/golden/make_golden_upsample.py)."""
+    g = np.load(os.path.join(golden_dir, "upsample_reference.npz"))
+    up = R.pad_frames(g["x"], 250, 3)
+    assert up.shape == (3, 75000, 25, 2) and up.dtype == np.float32
+    assert np.array_equal(up[:, g["frame_idx"]], g["up_frames"])
