@@ -153,13 +153,14 @@ int sar_bn_bwd_finalize_f32(const float* partials, int nparts, int64_t chan_stri
 
 /* data_bn, models/stgcn.py:142-147: x (N,C,T,V,M) contiguous -> CN activation [C][ld] with
  * b = n*M+m; BN channel = v*C+c, statistics over (n,m,t).  Optional fused joint->bone transform
- * (data_gen/gen_bone_data.py:36-41): bone_parent[v] = v2 (or -1 for none) subtracts joint v2. */
-int sar_data_bn_stats_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+ * (data_gen/gen_bone_data.py:36-41): bone_parent[v] = v2 (or -1 for none) subtracts joint v2.  motion != 0 feeds
+ * the motion stream (data_gen/gen_motion_data.py:24-27): frame t+1 minus frame t of the joint / bone data, last frame 0. */
+int sar_data_bn_stats_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent, int motion,
                           float* partials /* [V*C][N][2] */, sar_stream_t s);
-int sar_data_bn_apply_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+int sar_data_bn_apply_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent, int motion,
                           const float* scale, const float* shift, float* out, int64_t ld_out, sar_stream_t s);
 /* backward: partials [V*C][N][2] = (sum dy, sum dy*(x_raw - mean[ch])) from dy in CN layout (mean may be NULL). */
-int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent, int motion,
                                const float* dy, int64_t ld_dy, const float* mean, float* partials, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------ data_bn
 // One workgroup per (n, c) slab x[n][c][T][V][M] (contiguous, M fastest).
-__device__ __forceinline__ float load_joint(const float* slab, int t, int v, int m, int V, int M, const int* bone_parent) {
+__device__ __forceinline__ float load_frame(const float* slab, int t, int v, int m, int V, int M, const int* bone_parent) {
   float val = slab[(t * V + v) * M + m];
   if (bone_parent) {
     const int v2 = bone_parent[v];
@@ -135,10 +135,18 @@ __device__ __forceinline__ float load_joint(const float* slab, int t, int v, int
   }
   return val;
 }
+// optional motion stream (data_gen/gen_motion_data.py:24-27): frame t+1 minus frame t of the joint OR bone data
+// (each a float32 value, so the two roundings of the offline passes are reproduced), last frame 0
+__device__ __forceinline__ float load_joint(const float* slab, int t, int v, int m, int V, int M, const int* bone_parent,
+                                            int motion, int T) {
+  if (!motion) return load_frame(slab, t, v, m, V, M, bone_parent);
+  if (t >= T - 1) return 0.f;
+  return load_frame(slab, t + 1, v, m, V, M, bone_parent) - load_frame(slab, t, v, m, V, M, bone_parent);
+}
 
 template <bool BWD>
 __global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __restrict__ x, int N, int C, int T, int V, int M,
-                                                             const int* __restrict__ bone_parent,
+                                                             const int* __restrict__ bone_parent, int motion,
                                                              const float* __restrict__ dy, int64_t ld_dy,
                                                              const float* __restrict__ mean,
                                                              float* __restrict__ partials) {
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __rest
   const float mu = (BWD && mean && rg < groups) ? mean[v * C + c] : 0.f;
   if (rg < groups) {
     for (int t = rg; t < T; t += groups) {
-      const float val = load_joint(slab, t, v, m, V, M, bone_parent) - mu;
+      const float val = load_joint(slab, t, v, m, V, M, bone_parent, motion, T) - mu;
       if (BWD) {
         const float g = dy[(int64_t)c * ld_dy + ((int64_t)(n * M + m) * T + t) * V + v];
         s1 += g;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(TPB) void data_bn_apply_kernel(const float* __restrict__ x, int N, int C, int T, int V, int M,
-                                                            const int* __restrict__ bone_parent,
+                                                            const int* __restrict__ bone_parent, int motion,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ out, int64_t ld_out) {
   const int n = blockIdx.x / C, c = blockIdx.x - n * C;
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(TPB) void data_bn_apply_kernel(const float* __restr
   for (int e = threadIdx.x; e < total; e += TPB) {
     const int t = e / VM, r = e - t * VM;
     const int v = r / M, m = r - v * M;
-    const float val = load_joint(slab, t, v, m, V, M, bone_parent);
+    const float val = load_joint(slab, t, v, m, V, M, bone_parent, motion, T);
     const int ch = v * C + c;
     out[(int64_t)c * ld_out + ((int64_t)(n * M + m) * T + t) * V + v] = fmaf(val, scale[ch], shift[ch]);
   }
@@ -485,34 +493,34 @@ static int data_bn_check(const float* x, int N, int C, int T, int V, int M) {
 }
 
 extern "C" int sar_data_bn_stats_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
-                                     float* partials, sar_stream_t s) {
+                                     int motion, float* partials, sar_stream_t s) {
   int rc = data_bn_check(x, N, C, T, V, M);
   if (rc) return rc;
   SAR_REQUIRE(partials, "sar_data_bn_stats: null partials");
   hipLaunchKernelGGL(data_bn_reduce_kernel<false>, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M,
-                     bone_parent, (const float*)nullptr, (int64_t)0, (const float*)nullptr, partials);
+                     bone_parent, motion, (const float*)nullptr, (int64_t)0, (const float*)nullptr, partials);
   SAR_LAUNCH_CHECK("sar_data_bn_stats_f32");
   return 0;
 }
 
 extern "C" int sar_data_bn_apply_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
-                                     const float* scale, const float* shift, float* out, int64_t ld_out, sar_stream_t s) {
+                                     int motion, const float* scale, const float* shift, float* out, int64_t ld_out, sar_stream_t s) {
   int rc = data_bn_check(x, N, C, T, V, M);
   if (rc) return rc;
   SAR_REQUIRE(scale && shift && out && ld_out >= (int64_t)N * M * T * V, "sar_data_bn_apply: bad arguments");
-  hipLaunchKernelGGL(data_bn_apply_kernel, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent, scale,
-                     shift, out, ld_out);
+  hipLaunchKernelGGL(data_bn_apply_kernel, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent, motion,
+                     scale, shift, out, ld_out);
   SAR_LAUNCH_CHECK("sar_data_bn_apply_f32");
   return 0;
 }
 
 extern "C" int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
-                                          const float* dy, int64_t ld_dy, const float* mean, float* partials, sar_stream_t s) {
+                                          int motion, const float* dy, int64_t ld_dy, const float* mean, float* partials, sar_stream_t s) {
   int rc = data_bn_check(x, N, C, T, V, M);
   if (rc) return rc;
   SAR_REQUIRE(dy && partials && ld_dy >= (int64_t)N * M * T * V, "sar_data_bn_bwd_reduce: bad arguments");
   hipLaunchKernelGGL(data_bn_reduce_kernel<true>, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent,
-                     dy, ld_dy, mean, partials);
+                     motion, dy, ld_dy, mean, partials);
   SAR_LAUNCH_CHECK("sar_data_bn_bwd_reduce_f32");
   return 0;
 }

@@ -31,6 +31,9 @@ def get_parser():
     parser = argparse.ArgumentParser(
         description='Graph Convolutional Neural Network for Skeleton-Based Action Recognition')
     parser.add_argument('--model', required=True, help='model used to train')
+    parser.add_argument('--stream', default='joint', choices=['joint', 'bone', 'joint_motion', 'bone_motion'],
+                        help='input stream computed on the fly from JOINT data (data_gen/gen_bone_data.py, gen_motion_data.py); '
+                             'the reference trains each stream from its own pre-computed file')
     parser.add_argument('--base-lr', type=float, default=1e-1, help='initial learning rate')
     parser.add_argument('--num-classes', type=int, default=60, help='number of classes in dataset')
     parser.add_argument('--batch-size', type=int, default=64, help='training batch size')
@@ -104,7 +107,7 @@ def main():
             return NpySkeletonData(prefix + ".npy", _label_path(prefix))
         train_data, test_data = open_data(arg.train_data_path), open_data(arg.test_data_path)
 
-    model = model_mod.Model(num_classes=arg.num_classes, device=dev)
+    model = model_mod.Model(num_classes=arg.num_classes, device=dev, stream=arg.stream)
     eng = model.engine
     trainer = Trainer(eng, batch_size=arg.batch_size, base_lr=arg.base_lr, steps=arg.steps, world_size=world)
     log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None

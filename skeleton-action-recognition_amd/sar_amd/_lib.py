@@ -72,9 +72,9 @@ SIGNATURES = {
     "sar_bn_finalize_f32": (_i, [_fp, _i, _i, _d, _f, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_bn_eval_affine_f32": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _fp]),
     "sar_bn_bwd_finalize_f32": (_i, [_fp, _i, _i64, _i64, _i, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "sar_data_bn_stats_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp]),
-    "sar_data_bn_apply_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i64, _fp]),
-    "sar_data_bn_bwd_reduce_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i64, _fp, _fp, _fp]),
+    "sar_data_bn_stats_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp]),
+    "sar_data_bn_apply_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _i64, _fp]),
+    "sar_data_bn_bwd_reduce_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _i64, _fp, _fp, _fp]),
     "sar_bn_add_relu_fwd_f32": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_reduce_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_apply_f32": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),

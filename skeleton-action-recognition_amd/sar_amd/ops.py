@@ -132,21 +132,21 @@ def bn_bwd_finalize(partials, nparts, chan_stride, part_stride, off1, off2, C_, 
                                            ptr(k3), stream_ptr()), "sar_bn_bwd_finalize_f32")
 
 
-def data_bn_stats(x, bone_parent, partials):
+def data_bn_stats(x, bone_parent, partials, motion=False):
     N, C_, T, V, M = x.shape
-    check(L.load().sar_data_bn_stats_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(partials), stream_ptr()),
+    check(L.load().sar_data_bn_stats_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), int(motion), ptr(partials), stream_ptr()),
           "sar_data_bn_stats_f32")
 
 
-def data_bn_apply(x, bone_parent, scale, shift, out):
+def data_bn_apply(x, bone_parent, scale, shift, out, motion=False):
     N, C_, T, V, M = x.shape
-    check(L.load().sar_data_bn_apply_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(scale), ptr(shift), ptr(out),
+    check(L.load().sar_data_bn_apply_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), int(motion), ptr(scale), ptr(shift), ptr(out),
                                          out.stride(0), stream_ptr()), "sar_data_bn_apply_f32")
 
 
-def data_bn_bwd_reduce(x, bone_parent, dy, mean, partials):
+def data_bn_bwd_reduce(x, bone_parent, dy, mean, partials, motion=False):
     N, C_, T, V, M = x.shape
-    check(L.load().sar_data_bn_bwd_reduce_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), ptr(dy), dy.stride(0), ptr(mean),
+    check(L.load().sar_data_bn_bwd_reduce_f32(ptr(x), N, C_, T, V, M, ptr(bone_parent), int(motion), ptr(dy), dy.stride(0), ptr(mean),
                                               ptr(partials), stream_ptr()), "sar_data_bn_bwd_reduce_f32")
 
 

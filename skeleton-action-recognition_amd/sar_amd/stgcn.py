@@ -53,7 +53,7 @@ class _BN:
 
 class STGCN:
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
-                 blocks=None):
+                 blocks=None, motion=False):
         L.load()  # fail loudly if the HIP library is missing
         self.device = torch.device(device)
         self.num_classes, self.C_in, self.V = num_classes, in_channels, num_node
@@ -66,6 +66,7 @@ class STGCN:
         self.tab_bwd = ops.GraphTables(self.A_host, self.device, transpose=True)
         self._side = (torch.cuda.Stream(device=self.device)
                       if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "0") == "1" else None)
+        self.motion = bool(motion)   # motion stream (data_gen/gen_motion_data.py:24-27) of the joint / bone data, on the fly
         self.bone_parent = None
         if bone_pairs is not None:
             bp = np.full(num_node, -1, dtype=np.int32)
@@ -188,13 +189,13 @@ class STGCN:
         nch = V * Cin
         if training:
             part = torch.empty((nch, N, 2), dtype=torch.float32, device=dev)
-            ops.data_bn_stats(x, self.bone_parent, part)
+            ops.data_bn_stats(x, self.bone_parent, part, self.motion)
             self._bn_forward_stats("data_bn", part, N, N * M * T, True, False)
         else:
             self._bn_eval("data_bn")
         dbn = self.bn["data_bn"]
         h = torch.empty((Cin, B * T * V), dtype=torch.float32, device=dev)
-        ops.data_bn_apply(x, self.bone_parent, dbn.scale, dbn.shift, h)
+        ops.data_bn_apply(x, self.bone_parent, dbn.scale, dbn.shift, h, self.motion)
         if keep is not None:
             keep["x0"] = h
         Tc, cin = T, Cin
@@ -299,7 +300,7 @@ class STGCN:
         nch = V * self.C_in
         part = torch.empty((nch, N, 2), dtype=torch.float32, device=dev)
         dbn = self.bn["data_bn"]
-        ops.data_bn_bwd_reduce(x, self.bone_parent, dY, dbn.mean, part)
+        ops.data_bn_bwd_reduce(x, self.bone_parent, dY, dbn.mean, part, self.motion)
         ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, nch, N * M * sv["T"], self.p["data_bn.gamma"], dbn.mean, dbn.rstd,
                             self.g["data_bn.gamma"], self.g["data_bn.beta"])
         if self._side is not None:

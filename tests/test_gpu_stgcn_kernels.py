@@ -302,6 +302,42 @@ def test_bone_transform_is_bit_exact(dev, golden_dir):
     assert torch.equal(got, bone)
 
 
+def test_motion_stream_is_bit_exact(dev, golden_dir):
+    """data_gen/gen_motion_data.py:24-27 (frame t+1 minus frame t, last frame 0) of the joint and of the bone data, fused
+    into the data_bn prologue: float32 subtractions in the offline passes' order -> bit-exact; and a motion-stream train
+    step of the engine on joints equals the oracle fed the motion tensor."""
+    import os
+    from oracle import stgcn as O
+    from sar_amd import ops
+    from sar_amd.bone import NTU_BONE_PAIRS, bone_parent_array
+    from sar_amd.stgcn import STGCN
+    x = torch.from_numpy(np.load(os.path.join(golden_dir, "ntu_clips_0_2.npy")))[:, :, :40].contiguous()
+    N, C, T, V, M = x.shape
+    bone = x.clone()
+    for v1, v2 in NTU_BONE_PAIRS:
+        bone[:, :, :, v1 - 1, :] = x[:, :, :, v1 - 1, :] - x[:, :, :, v2 - 1, :]
+    one = torch.ones(V * C, device=dev); zero = torch.zeros(V * C, device=dev)
+    for src, parent in ((x, None), (bone, torch.from_numpy(bone_parent_array(V)).to(dev))):
+        motion = torch.zeros_like(src)
+        motion[:, :, :T - 1] = src[:, :, 1:] - src[:, :, :-1]
+        out = torch.empty((C, N * M * T * V), device=dev)
+        ops.data_bn_apply(x.to(dev), parent, one, zero, out, motion=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu().view(C, N, M, T, V).permute(1, 0, 3, 4, 2), motion)
+    blocks = [(64, 1, False), (64, 1, True)]
+    p = O.randomize_affine(O.init_params(10, seed=3, dtype=torch.float64, blocks=blocks), seed=4)
+    xs, ys = O.synthetic_batch(2, seed=3, T=16, num_classes=10)
+    mo = torch.zeros_like(xs)
+    mo[:, :, :15] = xs[:, :, 1:] - xs[:, :, :-1]
+    eng = STGCN(num_classes=10, device=dev, blocks=blocks, motion=True)
+    eng.load_params(p)
+    logits, loss = eng.loss_and_grad(xs.to(dev), ys.to(dev))
+    lref, loss_ref, gref, _, _ = O.loss_and_grads(p, mo.double(), ys, blocks=blocks)
+    assert rel_err(logits.cpu(), lref) < 1e-4
+    for k in ("data_bn.gamma", "data_bn.beta"):
+        assert rel_err(eng.g[k].cpu(), gref[k]) < 1e-3, k
+
+
 def test_head_loss_and_sgd(dev):
     from sar_amd import ops
     g = torch.Generator().manual_seed(9)
