@@ -17,6 +17,8 @@ import argparse
 import inspect
 import json
 import os
+
+import numpy as np
 import shutil
 import time
 
@@ -34,6 +36,11 @@ def get_parser():
     parser.add_argument('--stream', default='joint', choices=['joint', 'bone', 'joint_motion', 'bone_motion'],
                         help='input stream computed on the fly from JOINT data (data_gen/gen_bone_data.py, gen_motion_data.py); '
                              'the reference trains each stream from its own pre-computed file')
+    parser.add_argument('--resume', default='', help='checkpoint (ckpt-N.pt of a previous run) to restore model, optimizer '
+                                                    'velocity, iteration and epoch from (the reference only saves)')
+    parser.add_argument('--save-scores', action='store_true',
+                        help='write the test-set class probabilities of every checkpointed epoch (scores-N.npy, for score fusion '
+                             'of separately trained streams with tools/fuse_scores.py)')
     parser.add_argument('--base-lr', type=float, default=1e-1, help='initial learning rate')
     parser.add_argument('--num-classes', type=int, default=60, help='number of classes in dataset')
     parser.add_argument('--batch-size', type=int, default=64, help='training batch size')
@@ -80,7 +87,8 @@ def main():
     global_batch_size = arg.batch_size * world                # main_gnn.py:258
 
     run_params = {k: v for k, v in vars(arg).items()
-                  if k not in ("train_data_path", "test_data_path", "log_dir", "save_freq", "freeze_graph_until", "gpus")}
+                  if k not in ("train_data_path", "test_data_path", "log_dir", "save_freq", "freeze_graph_until", "gpus", "resume",
+                               "save_scores")}
     run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
     if arg.notes:
         run_name += "-" + arg.notes
@@ -117,7 +125,17 @@ def main():
             log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
 
     train_iter = test_iter = 0
-    for epoch in range(arg.num_epochs):
+    start_epoch = 0
+    if arg.resume:
+        ck = torch.load(arg.resume, map_location="cpu")
+        eng.load_params(ck["model"])
+        eng.velocity.copy_(ck["velocity"].to(dev))
+        trainer.iteration = int(ck["iteration"])
+        start_epoch = int(ck["epoch"])
+        train_iter = trainer.iteration
+        if rank == 0:
+            print("Resumed from {} (epoch {}, iteration {})".format(arg.resume, start_epoch, trainer.iteration), flush=True)
+    for epoch in range(start_epoch, arg.num_epochs):
         if rank == 0:
             print("Epoch: {}".format(epoch + 1), flush=True)
         t0 = time.time()
@@ -142,9 +160,16 @@ def main():
         # ---- test (main_gnn.py:381-408), un-distributed like the reference: rank 0 evaluates
         if rank == 0:
             c1 = c5 = n = 0
+            checkpointing = (epoch + 1) % arg.save_freq == 0 or epoch + 1 == arg.num_epochs
+            cm = torch.zeros((arg.num_classes, arg.num_classes), dtype=torch.int64, device=dev)
+            all_probs = []
             for it, (x, y) in enumerate(test_data.batches(arg.batch_size, 0, 1, dev, shuffle=False,
                                                           drop_remainder=False)):
                 probs = eng.predict(x)
+                if checkpointing:      # main_gnn.py:410-416: confusion matrix of the test set (rows = true class)
+                    cm.view(-1).index_add_(0, y * arg.num_classes + probs.argmax(1), torch.ones_like(y))
+                    if arg.save_scores:
+                        all_probs.append(probs.cpu())
                 b1, b5 = topk_correct(probs, y, 1).item(), topk_correct(probs, y, 5).item()
                 scalar("test_acc", b1 / len(y), test_iter)
                 scalar("test_acc_top_5", b5 / len(y), test_iter)
@@ -155,7 +180,10 @@ def main():
             scalar("epoch_test_acc", c1 / n, epoch)
             scalar("epoch_test_acc_top_5", c5 / n, epoch)
             print("  test: top1 %.4f top5 %.4f" % (c1 / n, c5 / n), flush=True)
-            if (epoch + 1) % arg.save_freq == 0 or epoch + 1 == arg.num_epochs:
+            if checkpointing:
+                np.save(os.path.join(arg.log_dir, "confusion_matrix-%d.npy" % (epoch + 1)), cm.cpu().numpy())
+                if arg.save_scores:
+                    np.save(os.path.join(arg.log_dir, "scores-%d.npy" % (epoch + 1)), torch.cat(all_probs).numpy())
                 path = os.path.join(ckpt_dir, "ckpt-%d.pt" % (epoch + 1))
                 torch.save({"model": eng.state_dict(), "velocity": eng.velocity.cpu(), "iteration": trainer.iteration,
                             "epoch": epoch + 1}, path)

@@ -2,6 +2,8 @@
 main_gnn.py command line on synthetic data."""
 import json
 import os
+
+import numpy as np
 import subprocess
 import sys
 
@@ -59,3 +61,15 @@ def test_main_gnn_cli_trains_on_synthetic_data(tmp_path):
     assert {"config.yaml", "stgcn.py", "scalars.jsonl", "checkpoints"} <= set(files)
     tags = {json.loads(line)["tag"] for line in open(os.path.join(tmp_path, runs[0], "scalars.jsonl"))}
     assert {"cross_entropy_loss", "train_acc", "train_acc_top_5", "epoch_test_acc", "epoch_test_acc_top_5"} <= tags
+    # confusion matrix of the test set (main_gnn.py:410-416) and the class scores for stream fusion
+    run = os.path.join(tmp_path, runs[0])
+    cm = np.load(os.path.join(run, "confusion_matrix-2.npy"))
+    assert cm.shape == (60, 60) and cm.sum() == 24
+    # resume from the first checkpoint with another stream option: continues at epoch 2, iteration counter restored
+    cmd2 = cmd + ["--resume", os.path.join(run, "checkpoints", "ckpt-1.pt"), "--save-scores"]
+    out2 = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    assert "Resumed from" in out2.stdout and "Epoch: 2" in out2.stdout and "Epoch: 1\n" not in out2.stdout
+    assert os.listdir(tmp_path) == runs                  # same run directory (resume / save-scores are not part of its name)
+    scores = np.load(os.path.join(run, "scores-2.npy"))
+    assert scores.shape == (24, 60) and np.allclose(scores.sum(1), 1, atol=1e-4)
