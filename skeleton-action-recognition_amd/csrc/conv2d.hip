@@ -511,7 +511,54 @@ struct W2K {
 };
 
 // STEM: the A-operand rows are the TAPS of the single input channel (lane-constant tap offset), one MFMA tile per wave.
-template <int KH, int KW, int STEM, int WF, int WC, int WT, int TPW, int DJ, int SJMAX>
+// Fixed-geometry reduction of one tile (compile-time output width WO, row pairs RPC, conv stride STRIDEC, padded
+// source width WQ): fully unrolled, every LDS address is per-lane base + immediate, operands of step s+1 are read
+// while the MFMAs of step s issue (see temporal_tile_fixed in conv_wgrad.hip).  Tap i of this wave is tap t0 + i.
+template <int TPW, int KW, int WO, int STRIDEC, int RPC, int WQ>
+__device__ __forceinline__ void wgrad2d_tile_fixed(f32x16 (&acc)[TPW], const float* Dbase, const float* Sbase, int t0) {
+  constexpr int NSTEP = RPC * WO;
+  // the tap offsets depend on the wave's first tap (wave-uniform, two values): fold it into the base pointer
+  auto fetch = [&](int st, float& dv, float (&sv)[TPW], const float* const (&Sb)[TPW]) {
+    const int rp = st / WO, w = st % WO;
+    dv = Dbase[rp * 2 * WO + w];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) sv[i] = Sb[i][rp * 2 * STRIDEC * WQ + w * STRIDEC];
+  };
+  const float* Sb[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tp = t0 + i;
+    Sb[i] = Sbase + (tp / KW) * WQ + (tp % KW);
+  }
+  auto mma = [&](float dv, const float (&sv)[TPW], bool have_next) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i], dv, acc[i], 0, 0, 0);
+    int done = 0;
+    const int rd = have_next ? TPW + 1 : 0;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      const int n = (rd - done + (TPW - i) - 1) / (TPW - i);
+      if (n == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      else if (n == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      done += n;
+    }
+  };
+  float d0, s0[TPW], d1, s1[TPW];
+  fetch(0, d0, s0, Sb);
+#pragma unroll
+  for (int st = 0; st < NSTEP; st += 2) {
+    if (st + 1 < NSTEP) fetch(st + 1, d1, s1, Sb);
+    mma(d0, s0, st + 1 < NSTEP);
+    if (st + 1 < NSTEP) {
+      if (st + 2 < NSTEP) fetch(st + 2, d0, s0, Sb);
+      mma(d1, s1, st + 2 < NSTEP);
+    }
+  }
+}
+
+// WO / STRIDEC / RPC != 0: output width, conv stride and row pairs per tile are compile-time (resnet18's layer shapes)
+template <int KH, int KW, int STEM, int WF, int WC, int WT, int TPW, int DJ, int SJMAX, int WO = 0, int STRIDEC = 0, int RPC = 0>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const W2K k) {
   constexpr int TAPS = KH * KW;
   constexpr int BF = 32 * WF, CT = STEM ? 1 : 32 * WC;
@@ -639,6 +686,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const W2K k) {
     store_lds(tile);
     __syncthreads();
     if (tile + (int)gridDim.x < k.NT) issue_loads(tile + gridDim.x);
+    if constexpr (WO != 0 && !STEM) {
+      constexpr int WQ = WO * STRIDEC + 2 * (KH / 2);
+      wgrad2d_tile_fixed<TPW, KW, WO, STRIDEC, RPC, WQ>(acc, Dbase, Sbase, wt * TPW);
+      continue;
+    }
     for (int rp = 0; rp < k.RP; ++rp) {
       const float* Dq = Dbase + rp * 2 * d.W_out;
       const float* Sq = Sbase + rp * 2 * sfs;
@@ -888,7 +940,7 @@ int check_common(const sar_conv2d_desc* d, const char* who) {
   return 0;
 }
 
-template <int KH, int KW, int STEM, int WF, int WC, int WT, int TPW, int DJ, int SJMAX>
+template <int KH, int KW, int STEM, int WF, int WC, int WT, int TPW, int DJ, int SJMAX, int WO = 0, int STRIDEC = 0, int RPC = 0>
 int launch_wgrad(const sar_conv2d_desc& d, hipStream_t st) {
   constexpr int TAPS = KH * KW, BF = 32 * WF, CT = STEM ? 1 : 32 * WC;
   W2K k;
@@ -916,7 +968,11 @@ int launch_wgrad(const sar_conv2d_desc& d, hipStream_t st) {
   k.invWq = 1.0f / (float)k.Wq;
   k.invWo = 1.0f / (float)d.W_out;
   if (k.NPOS > 32 * DJ || k.RW > (STEM ? 256 : 32) * SJMAX || lds > 150 * 1024) return -2;
-  auto kern = conv2d_wgrad_kernel<KH, KW, STEM, WF, WC, WT, TPW, DJ, SJMAX>;
+  if constexpr (WO != 0) {   // the fixed-geometry loop needs exactly this tile shape, else the generic loop
+    if (d.W_out != WO || d.stride != STRIDEC || k.RP != RPC || d.pad != KH / 2 || d.W_src + 2 * d.pad != WO * STRIDEC + 2 * (KH / 2))
+      return launch_wgrad<KH, KW, STEM, WF, WC, WT, TPW, DJ, SJMAX>(d, st);
+  }
+  auto kern = conv2d_wgrad_kernel<KH, KW, STEM, WF, WC, WT, TPW, DJ, SJMAX, WO, STRIDEC, RPC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -996,7 +1052,18 @@ extern "C" int sar_conv2d_wgrad_f32(const sar_conv2d_desc* d, sar_stream_t s) {
   SAR_REQUIRE(d->ld_dout >= (int64_t)d->B * d->H_out * d->W_out, "sar_conv2d_wgrad: bad dout leading dimension");
   hipStream_t st = as_stream(s);
   if (d->KH == 7 && d->KW == 7 && d->Kc == 1) rc = launch_wgrad<7, 7, 1, 2, 2, 1, 1, 8, 10>(*d, st);
-  else if (d->KH == 3 && d->KW == 3) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12>(*d, st);
+  else if (d->KH == 3 && d->KW == 3) {
+    // resnet18's 3x3 layers at 256x256 input: (W_out, stride, row pairs per tile)
+    const int wo = d->W_out, sd = d->stride;
+    if (wo == 64 && sd == 1) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12, 64, 1, 1>(*d, st);
+    else if (wo == 32 && sd == 1) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12, 32, 1, 2>(*d, st);
+    else if (wo == 32 && sd == 2) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12, 32, 2, 1>(*d, st);
+    else if (wo == 16 && sd == 1) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12, 16, 1, 4>(*d, st);
+    else if (wo == 16 && sd == 2) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12, 16, 2, 2>(*d, st);
+    else if (wo == 8 && sd == 1) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12, 8, 1, 4>(*d, st);
+    else if (wo == 8 && sd == 2) rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12, 8, 2, 4>(*d, st);
+    else rc = launch_wgrad<3, 3, 0, 2, 1, 2, 5, 4, 12>(*d, st);
+  }
   else if (d->KH == 1 && d->KW == 1) rc = launch_wgrad<1, 1, 0, 2, 2, 1, 1, 4, 8>(*d, st);
   else rc = -2;
   if (rc == -2) {
