@@ -307,6 +307,7 @@ int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, const float*
                                 int W, int64_t ld_x, int64_t ld_y, sar_stream_t s);
 /* its backward: dz[c,n] = gradient w.r.t. the BatchNorm output (ReLU mask applied, max routed to the first
  * maximal element of each window like torch); partials[C][nparts][2] = (sum dz, sum dz*(x-mean[c])). */
+int sar_bn_relu_maxpool_bwd_nparts(int B, int H, int W);   /* partial sums per channel written by the backward */
 int sar_bn_relu_maxpool_bwd_f32(const float* x, const float* scale, const float* shift, const float* mean,
                                 const float* dy, float* dz, float* partials, int nparts, int C, int B, int H, int W,
                                 int64_t ld_x, int64_t ld_y, sar_stream_t s);

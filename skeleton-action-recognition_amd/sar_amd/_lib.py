@@ -91,6 +91,7 @@ SIGNATURES = {
     "sar_conv2d_wgrad_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
     "sar_permute3_f32": (_i, [_fp, _fp, _i, _i, _i, _i64, _i64, _i64, _fp]),
     "sar_bn_relu_maxpool_fwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_relu_maxpool_bwd_nparts": (_i, [_i, _i, _i]),
     "sar_bn_relu_maxpool_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i64, _i64, _fp]),
     "sar_adam_f32": (_i, [_fp, _fp, _fp, _fp, _i64, _fp, _fp, _f, _f, _f, _fp]),
     "sar_vr_signal_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),

@@ -285,7 +285,7 @@ def bn_relu_maxpool_fwd(x, scale, shift, y, B, H, W):
 
 def bn_relu_maxpool_bwd(x, scale, shift, mean, dy, dz, B, H, W):
     Cc = x.shape[0]
-    nparts = max(1, min(256, (B * H * W + 8191) // 8192))
+    nparts = L.load().sar_bn_relu_maxpool_bwd_nparts(B, H, W)
     partials = torch.empty((Cc, nparts, 2), dtype=torch.float32, device=x.device)
     check(L.load().sar_bn_relu_maxpool_bwd_f32(ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(dy), ptr(dz), ptr(partials),
                                                nparts, Cc, B, H, W, x.stride(0), dy.stride(0), stream_ptr()),
