@@ -21,6 +21,7 @@ constexpr int KC2 = 4;   // src channels per main-loop stage
 struct C2K {
   sar_conv2d_desc d;
   int TH, TPI, NR, Wq, RW, SROW, nparts, w_vec, col_lo;
+  int NI, IRW, ntiles;   // images per tile (small feature maps: several whole images share a tile), staged elements per image
   float invWq;
 };
 
@@ -63,10 +64,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
   const int l31 = lane & 31, hi = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int tile = blockIdx.x;
-  const int b = tile / k.TPI;
-  const int h0 = (tile - b * k.TPI) * k.TH;
+  // NI == 1: the tile is TH output rows of image b.  NI > 1 (feature maps of <= half a tile): NI whole images
+  // b .. b + NI - 1, each with its own padded region of IRW staged elements.
+  const int b = k.NI > 1 ? tile * k.NI : tile / k.TPI;
+  const int h0 = k.NI > 1 ? 0 : (tile - b * k.TPI) * k.TH;
   const int m0 = blockIdx.y * BM;
   const int s = d.stride;
+  const int opix = d.H_out * d.W_out;
 
   int row_lo;
   if (!TRANSPOSED) row_lo = h0 * s - d.pad;
@@ -80,23 +84,25 @@ __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const int p = (wn * NS + ns) * 32 + l31;
-    int hl = p / d.W_out;
-    int wo = p - hl * d.W_out;
-    colok[ns] = hl < k.TH && (h0 + hl) < d.H_out;
+    const int im = k.NI > 1 ? p / opix : 0;            // image inside the tile
+    const int pp = p - im * opix;
+    int hl = pp / d.W_out;
+    int wo = pp - hl * d.W_out;
+    colok[ns] = im < k.NI && (b + im) < d.B && hl < k.TH && (h0 + hl) < d.H_out;
     if (!colok[ns]) { hl = 0; wo = 0; }
-    coln[ns] = ((int64_t)b * d.H_out + (h0 + hl)) * d.W_out + wo;
+    coln[ns] = ((int64_t)(b + (colok[ns] ? im : 0)) * d.H_out + (h0 + hl)) * d.W_out + wo;
     vmask[ns] = 0;
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) {
       const int kh = tp / KW, kw = tp % KW;
       if (!TRANSPOSED) {
-        off[tp][ns] = (hl * s + kh) * k.Wq + wo * s + kw;
+        off[tp][ns] = im * k.IRW + (hl * s + kh) * k.Wq + wo * s + kw;
       } else {
         const int qh = h0 + hl + d.pad - kh, qw = wo + d.pad - kw;
         const int ho = floordiv(qh, s), ws = floordiv(qw, s);
         const bool ok = (qh - ho * s == 0) && (qw - ws * s == 0);
         vmask[ns] |= (ok ? 1u : 0u) << tp;
-        off[tp][ns] = (ho - row_lo) * k.Wq + (ws - k.col_lo);
+        off[tp][ns] = im * k.IRW + (ho - row_lo) * k.Wq + (ws - k.col_lo);
       }
       if (!colok[ns]) off[tp][ns] = ZCOL;
     }
@@ -118,11 +124,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
   bool sok[SJ];
 #pragma unroll
   for (int j = 0; j < SJ; ++j) {
-    const int e = lane + 64 * j;                       // staged element -> (r, q) -> src pixel (row_lo + r, col_lo + q)
-    const int r = e / k.Wq, q = e - r * k.Wq;
+    const int e = lane + 64 * j;                       // staged element -> image, (r, q) -> src pixel (row_lo + r, col_lo + q)
+    const int im = e / k.IRW, ei = e - im * k.IRW;
+    const int r = ei / k.Wq, q = ei - r * k.Wq;
     const int hs = row_lo + r, ws = k.col_lo + q;
-    sok[j] = e < k.RW && (unsigned)hs < (unsigned)d.H_src && (unsigned)ws < (unsigned)d.W_src;   // else zero padding
-    svo[j] = sok[j] ? (hs * d.W_src + ws) * 4 : 0;
+    sok[j] = e < k.RW && (b + im) < d.B && (unsigned)hs < (unsigned)d.H_src && (unsigned)ws < (unsigned)d.W_src;   // else zero padding
+    svo[j] = sok[j] ? (im * img + hs * d.W_src + ws) * 4 : 0;
   }
   const bool w_vec = k.w_vec != 0;
   const int w_m4 = (tid % (BM / 4)) * 4, w_r0 = tid / (BM / 4);
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const C2K k) {
     }
     const int cg = (c0 + wave < d.Kc) ? c0 + wave : 0;   // wave-uniform
     const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, img * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, k.NI * img * 4, 0x00020000);
 #pragma unroll
     for (int j = 0; j < SJ; ++j) sreg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo[j], 0, 0));
     if (d.pro_scale) {
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-int gemm_geometry(const sar_conv2d_desc& d, int tile_n, int wn, C2K& k, int rwmax = 1 << 30) {
+int gemm_geometry(const sar_conv2d_desc& d, int tile_n, int wn, C2K& k, int rwmax = 1 << 30, bool multi_image = false) {
   if (d.W_out > tile_n) return -2;
   int th = tile_n / d.W_out;
   if (th > d.H_out) th = d.H_out;
@@ -896,9 +903,19 @@ int gemm_geometry(const sar_conv2d_desc& d, int tile_n, int wn, C2K& k, int rwma
     if (k.RW <= rwmax || th == 1) break;
   }
   k.TPI = (d.H_out + k.TH - 1) / k.TH;
+  k.IRW = k.RW;
+  k.NI = 1;
+  if (multi_image && k.TH == d.H_out && 2 * d.H_out * d.W_out <= tile_n) {   // several whole images per tile
+    int ni = tile_n / (d.H_out * d.W_out);
+    if (ni > d.B) ni = d.B;
+    while (ni > 1 && ni * k.IRW > rwmax) --ni;
+    k.NI = ni;
+    k.RW = ni * k.IRW;
+  }
+  k.ntiles = k.NI > 1 ? (d.B + k.NI - 1) / k.NI : d.B * k.TPI;
   k.SROW = k.RW;
   k.invWq = 1.0f / (float)k.Wq;
-  k.nparts = d.B * k.TPI * wn;
+  k.nparts = k.ntiles * wn;
   k.w_vec = ((d.Kc % KC2) == 0 && (d.M & 3) == 0 && (d.w_stride_c & 3) == 0 && (d.w_stride_tap & 3) == 0 && ((uintptr_t)d.W & 15) == 0) ? 1 : 0;
   return 0;
 }
@@ -909,21 +926,49 @@ int launch_gemm_tr(const sar_conv2d_desc& d, hipStream_t st, bool query, int* np
   k.d = d;
   constexpr int TAPS = KH * KW;
   const int rwmax = (TAPS == 1 ? 512 : 640);
-  if (d.M > 64) {
-    constexpr int MS = 2, NS = 2, WM = 2, WN = 2;
-    if (int g = gemm_geometry(d, 32 * NS * WN, WN, k, rwmax)) return g;
+  bool small_grid = false;
+  if (d.M > 64) {   // the deep resnet layers at small batch: 128 x 128 tiles would leave most CUs without a workgroup
+    C2K kk;
+    kk.d = d;
+    if (gemm_geometry(d, 128, 2, kk, rwmax, true) == 0) small_grid = (int64_t)kk.ntiles * ((d.M + 127) / 128) < 384;
+  }
+  bool tiny_grid = false;
+  if (small_grid) {
+    C2K kk;
+    kk.d = d;
+    if (gemm_geometry(d, 128, 4, kk, rwmax, true) == 0) tiny_grid = (int64_t)kk.ntiles * ((d.M + 63) / 64) < 192;
+  }
+  if (d.M > 64 && tiny_grid) {
+    constexpr int MS = 1, NS = 1, WM = 1, WN = 4;   // 32 x 128 tile: four times the workgroups
+    if (int g = gemm_geometry(d, 32 * NS * WN, WN, k, rwmax, true)) return g;
     if (nparts_out) *nparts_out = k.nparts;
     if (query) return 0;
     if (k.RW > rwmax) return -2;
-    dim3 grid(d.B * k.TPI, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
+    dim3 grid(k.ntiles, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
+    hipLaunchKernelGGL((conv2d_gemm_kernel<TR, KH, KW, MS, NS, WM, WN>), grid, dim3(256), 0, st, k);
+  } else if (d.M > 64 && small_grid) {
+    constexpr int MS = 2, NS = 1, WM = 1, WN = 4;   // 64 x 128 tile: twice the workgroups
+    if (int g = gemm_geometry(d, 32 * NS * WN, WN, k, rwmax, true)) return g;
+    if (nparts_out) *nparts_out = k.nparts;
+    if (query) return 0;
+    if (k.RW > rwmax) return -2;
+    dim3 grid(k.ntiles, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
+    hipLaunchKernelGGL((conv2d_gemm_kernel<TR, KH, KW, MS, NS, WM, WN>), grid, dim3(256), 0, st, k);
+  } else if (d.M > 64) {
+    constexpr int MS = 2, NS = 2, WM = 2, WN = 2;
+    if (int g = gemm_geometry(d, 32 * NS * WN, WN, k, rwmax, true)) return g;
+    if (nparts_out) *nparts_out = k.nparts;
+    if (query) return 0;
+    if (k.RW > rwmax) return -2;
+    dim3 grid(k.ntiles, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
     hipLaunchKernelGGL((conv2d_gemm_kernel<TR, KH, KW, MS, NS, WM, WN>), grid, dim3(256), 0, st, k);
   } else {
     constexpr int MS = 2, NS = 2, WM = 1, WN = 4;
-    if (int g = gemm_geometry(d, 32 * NS * WN, WN, k, rwmax)) return g;
+    if (int g = gemm_geometry(d, 32 * NS * WN, WN, k, rwmax, true)) return g;
     if (nparts_out) *nparts_out = k.nparts;
     if (query) return 0;
     if (k.RW > rwmax) return -2;
-    dim3 grid(d.B * k.TPI, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
+    dim3 grid(k.ntiles, (d.M + 32 * MS * WM - 1) / (32 * MS * WM));
     hipLaunchKernelGGL((conv2d_gemm_kernel<TR, KH, KW, MS, NS, WM, WN>), grid, dim3(256), 0, st, k);
   }
   return 0;
