@@ -232,6 +232,9 @@ def main():
                     help="stgcn = BASELINE.json's headline (configs[1]); spectrogram = Path B (configs[3] shape per GPU)")
     ap.add_argument("--num-pad-frames", type=int, default=0,
                     help="spectrogram workload: GPU-side frame up-sampling factor (the reference's loader default is 250)")
+    ap.add_argument("--mfma", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = BASELINE.json configs[1] (default, the headline); bf16 = configs[2]'s arithmetic for the temporal "
+                         "convolutions (bf16 MFMA operands, fp32 storage / accumulation / master weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="clips in the CPU-baseline sample batch")
     args = ap.parse_args()
@@ -254,7 +257,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
 
-    eng = STGCN(num_classes=args.classes, device=dev, seed=0)  # identical init on every rank
+    eng = STGCN(num_classes=args.classes, device=dev, seed=0, mfma=args.mfma)  # identical init on every rank
     trainer = Trainer(eng, batch_size=args.batch, world_size=world)
     # a few distinct batches resident in HBM, cycled (per-rank seeds: each rank trains on its own shard)
     nb = 4
@@ -296,13 +299,16 @@ def main():
         traffic, traffic_src = measured_traffic()
         kern_ms = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())}
         kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
+        bf16 = args.mfma == "bf16"
         out = {
             "metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ST-GCN fp32 training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
-                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (args.classes, args.batch),
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
+                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (
+                                       "bf16-MFMA-operand (temporal convs; fp32 storage, accumulation, graph conv, weight grads)"
+                                       if bf16 else "fp32", args.classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -313,6 +319,14 @@ def main():
                          "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
             "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),
         }
+        if bf16:   # the bf16 temporal kernels are bound by moving the fp32 activations, not by the matrix pipe
+            by = sum(summ[k]["bytes"] for k in fam)
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": "conv_gemm_bf16_kernel<9 taps> (fwd + data-grad launches)",
+                               "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                               "traffic": None, "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
+                               "avg_launch_ms": round(ms / max(calls, 1), 4),
+                               "mfma_tflops": round(achieved, 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out))

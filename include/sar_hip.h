@@ -98,6 +98,12 @@ typedef struct sar_conv_desc {
 int sar_struct_size(int which);
 int sar_conv_gemm_nparts(const sar_conv_desc* d);                 /* host query, no GPU work */
 int sar_conv_gemm_f32(const sar_conv_desc* d, sar_stream_t s);
+/* The TEMPORAL operator with bf16 MFMA operands: W and pro(src) are rounded to bfloat16
+ * (nearest-even) as they are staged, products are exact, accumulation / bias / epilogue / BatchNorm sums are fp32;
+ * src, out and W stay fp32 in memory.  Needs M % 8 == 0.  workspace: sar_conv_gemm_bf16_workspace_bytes(d) bytes,
+ * 16-byte aligned (holds the packed bf16 weights, rewritten by every call).  Partial-sum layout: sar_conv_gemm_nparts. */
+int64_t sar_conv_gemm_bf16_workspace_bytes(const sar_conv_desc* d);
+int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_stream_t s);
 
 /* Weight gradient of the same operator (reduction over all positions n):
  *   dW[tap][c][m] = sum_n dout[m, n] * OP_tap(pro(src))[c, n]        (tf.GradientTape of the conv,

@@ -1,0 +1,479 @@
+// conv_gemm_bf16.hip -- the temporal convolution / its data gradient with bf16 MFMA operands (gfx950).
+//
+//   out[m, n] = sum_tap sum_c bf16(W[tap][c][m]) * bf16(pro(src))[c, n + shift(tap)] (+ bias) ; epilogue
+//
+// Same operator, tiling, prologue and epilogue as conv_gemm.hip (models/stgcn.py:27-36,47-54 and their data
+// gradients); the difference is the arithmetic of the contraction: both operands are rounded to bfloat16
+// (round-to-nearest-even) when they are staged, products are exact and are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Activations stay fp32 in HBM, BatchNorm statistics are
+// reduced from the fp32 accumulators, the parameters are the caller's fp32 master copy.
+//
+// Design (MI355X):
+//  * The bf16 MFMA takes 8 consecutive k (= src channels) per lane, so the LDS image is k-innermost: one 16-byte
+//    unit holds 8 channels of ONE column.  A temporal tap is a shift by whole units: every operand read is one
+//    aligned ds_read_b128 whatever the tap (V = 25 makes the shifts odd, which rules out both a [c][n] bf16 image
+//    read by ds_read_b64_tr_b16 -- 8-byte alignment -- and packed pairs along n).
+//  * The stager does the transposition for free: a lane owns a column and loads it from 8 channel rows (each load
+//    is a coalesced row segment across the wave), applies the folded BatchNorm + ReLU, converts
+//    (v_cvt_pk_bf16_f32) and writes one ds_write_b128.
+//  * The weights are packed once per call by a small kernel into the exact LDS image ([tap][c/8][m][8] bf16), so
+//    their staging is a straight 16-byte copy.
+//  * The bf16 MFMA is 16x faster than the fp32 one: the kernel is bound by HBM (fp32 activations in and out) and
+//    by the L2 -> LDS traffic of the weights, not by the matrix pipe; one LDS buffer, two workgroups per CU.
+#include "sar_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KC16 = 16;   // src channels per main-loop stage = one MFMA k-step
+
+struct ConvKB {
+  sar_conv_desc d;
+  const uint4* wp;   // packed weights [taps][G][M] units of 8 bf16
+  int G;             // channel groups of 8 (even)
+  int FT, TPS, NF, RW, nparts, ntiles, ny;
+};
+
+template <int TAPS, int MS, int NS, int WM, int WN>
+struct TileCfgB {
+  static constexpr int BM = 32 * MS * WM;
+  static constexpr int TN = 32 * NS * WN;
+  static constexpr int RWMAX = (TN == 128 ? 448 : 704);   // staged columns (as conv_gemm.hip)
+  static constexpr int SCOLS = RWMAX + 8;                 // + the always-zero column
+  static constexpr int WUNITS = TAPS * 2 * BM;            // [tap][h][m]
+  static constexpr int SUNITS = 2 * SCOLS;                // [h][col]
+  static constexpr int CJ = (RWMAX + 255) / 256;          // S columns per lane
+  static constexpr int WIT = (WUNITS + 255) / 256;        // W units per lane
+  static constexpr int UNITS = WUNITS + SUNITS;
+};
+
+// fp32 weights (element (tap,c,m) at tap*st + c*sc + m) -> bf16 units [tap][g][m][8], zero beyond Kc
+__global__ void pack_weights_kernel(const float* __restrict__ W, int64_t st, int64_t sc, int taps, int Kc, int M, int G,
+                                    uint4* __restrict__ out) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= (int64_t)taps * G * M) return;
+  const int m = (int)(u % M);
+  const int g = (int)((u / M) % G);
+  const int tp = (int)(u / ((int64_t)M * G));
+  bf16x8 p;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 8 * g + j;
+    p[j] = (__bf16)(c < Kc ? W[tp * st + c * sc + m] : 0.f);
+  }
+  out[u] = *reinterpret_cast<uint4*>(&p);
+}
+
+// TR: 0 forward; 1 data gradient, stride 1; 2 data gradient, generic stride (tap validity mask); 3 data gradient,
+// stride 2, parity-split column map (see conv_gemm.hip)
+template <int TR, int TAPS, int MS, int NS, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvKB k) {
+  using TC = TileCfgB<TAPS, MS, NS, WM, WN>;
+  constexpr int TRANSPOSED = TR != 0;
+  constexpr int PAR = (TR == 3);
+  constexpr int JT = PAR ? (TAPS + 1) / 2 : TAPS;
+  constexpr int BM = TC::BM, SCOLS = TC::SCOLS, CJ = TC::CJ, WIT = TC::WIT;
+  constexpr int ZCOL = TC::RWMAX;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area (floats / 4), aliases the operand image
+  constexpr int IMG_U = TC::UNITS > PAREA_U ? TC::UNITS : PAREA_U;
+  __shared__ uint4 smem_u[IMG_U + BM];       // image | per-row parameters (float4 per row)
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + TC::WUNITS;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int V = d.V;
+  // workgroup -> (tile, row block), XCD-aware (conv_gemm.hip)
+  const int ny = k.ny, nwork = k.ntiles * ny;
+  int w = blockIdx.x;
+  {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;
+  }
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+
+  // ---- per-lane column geometry
+  bool colok[NS];
+  int64_t coln[NS];
+  int off[JT][NS];
+  unsigned vmask[NS];
+  int t_lo;
+  if (!TRANSPOSED) t_lo = t0 * d.stride - d.pad;
+  else t_lo = floordiv(t0 + d.pad - (TAPS - 1), d.stride);
+  constexpr int HALFC = 16 * NS * WN;
+  const int par = PAR ? (wn * NS * 32 >= HALFC ? 1 : 0) : 0;
+  const int tp0 = PAR ? ((par + d.pad) & 1) : 0;
+  const int ntap_w = PAR ? (TAPS - tp0 + 1) / 2 : TAPS;
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    int fo, v;
+    if (PAR) {
+      const int pp = p - par * HALFC;
+      const int fh = pp / V;
+      v = pp - fh * V;
+      fo = 2 * fh + par;
+    } else {
+      fo = p / V;
+      v = p - fo * V;
+    }
+    colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
+    if (!colok[ns]) fo = par;
+    coln[ns] = ((int64_t)b * d.T_out + (t0 + fo)) * V + v;
+    vmask[ns] = 0;
+#pragma unroll
+    for (int tp = 0; tp < JT; ++tp) {
+      if (!TRANSPOSED) {
+        off[tp][ns] = (fo * d.stride + tp) * V + v;
+      } else if (PAR) {
+        const int to = (t0 + fo + d.pad - (tp0 + 2 * tp)) >> 1;
+        off[tp][ns] = (to - t_lo) * V + v;
+      } else {
+        const int q = t0 + fo + d.pad - tp;
+        const int to = floordiv(q, d.stride);
+        const bool ok = (q - to * d.stride) == 0;
+        vmask[ns] |= (ok ? 1u : 0u) << tp;
+        off[tp][ns] = (to - t_lo) * V + v;
+      }
+      if (!colok[ns]) off[tp][ns] = ZCOL;
+      off[tp][ns] += hi * SCOLS;   // this lane's k half
+    }
+  }
+
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) bp.x = d.bias[row];
+    rowp[tid] = bp;
+  }
+  if (tid < 2) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16 acc[MS][NS];
+
+  const int seq_len = d.T_src * V;
+  const float* src_b = d.src + (int64_t)b * seq_len;
+
+  // ---- staging: per-lane offsets and masks once, scalar arithmetic per stage
+  int svo[CJ];
+  bool sok[CJ];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int col = tid + 256 * j;
+    const int rabs = t_lo * V + col;
+    sok[j] = col < k.RW && (unsigned)rabs < (unsigned)seq_len;
+    svo[j] = sok[j] ? rabs * 4 : 0;
+  }
+  unsigned wvo[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int u = tid + 256 * i;
+    const int m = u % BM, h = (u / BM) & 1, tp = u / (2 * BM);
+    const bool ok = u < TC::WUNITS && (m0 + m) < d.M;
+    wvo[i] = ok ? (unsigned)((((int64_t)tp * k.G + h) * d.M + m0 + m) * 16) : 0x80000000u;   // rejected by the range check -> 0
+  }
+  const unsigned wbytes = (unsigned)((int64_t)TAPS * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  uint4 wreg[WIT];
+  float sreg[2][CJ][8];
+
+  auto issue_loads = [&](int c0) {
+    const int wso = (c0 / 8) * d.M * 16;   // scalar: first channel group of the stage
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], wso, 0);
+      wreg[i] = *reinterpret_cast<const uint4*>(&v);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + 8 * h + q;
+        const int cg = c < d.Kc ? c : 0;   // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq_len * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) sreg[h][j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo[j], 0, 0));
+      }
+  };
+
+  auto store_lds = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < WIT; ++i)
+      if ((i + 1) * 256 <= TC::WUNITS || tid + 256 * i < TC::WUNITS) Wl[tid + 256 * i] = wreg[i];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float psc[8], psh[8];
+      bool rok[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + 8 * h + q;
+        rok[q] = c < d.Kc;
+        const int cg = rok[q] ? c : 0;
+        psc[q] = d.pro_scale ? d.pro_scale[cg] : 1.f;
+        psh[q] = d.pro_scale ? d.pro_shift[cg] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) {
+        bf16x8 p;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float val = fmaxf(fmaf(sreg[h][j][q], psc[q], psh[q]), relu_lo);
+          p[q] = (__bf16)((sok[j] && rok[q]) ? val : 0.f);
+        }
+        if ((j + 1) * 256 <= TC::RWMAX || tid + 256 * j < TC::RWMAX) Sl[h * SCOLS + tid + 256 * j] = *reinterpret_cast<uint4*>(&p);
+      }
+    }
+  };
+
+  issue_loads(0);
+  __syncthreads();   // rowp
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = colok[ns] ? bp.x : 0.f;
+    }
+
+  const uint4* Wa = Wl + (tp0 * 2 + hi) * BM + wm * MS * 32 + l31;
+  auto taps_mma = [&](int j) {
+    const int tpw = PAR ? 2 * j : j;
+    uint4 a[MS], bq[NS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tpw * 2 * BM + ms * 32];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      bq[ns] = Sl[off[j][ns]];
+      if (TR == 2 && !((vmask[ns] >> j) & 1u)) bq[ns] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[ms]),
+                                                              *reinterpret_cast<bf16x8*>(&bq[ns]), acc[ms][ns], 0, 0, 0);
+  };
+
+  for (int c0 = 0; c0 < d.Kc; c0 += KC16) {
+    store_lds(c0);
+    __syncthreads();
+    if (c0 + KC16 < d.Kc) issue_loads(c0 + KC16);   // in flight during the MFMA phase
+    constexpr int JSURE = PAR ? JT - 1 : JT;
+#pragma unroll
+    for (int j = 0; j < JSURE; ++j) taps_mma(j);
+    if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
+    __syncthreads();   // every wave is done with the image (next store / the epilogue's transpose area)
+  }
+
+  // ---- epilogue (as conv_gemm.hip): mask / add, store, BatchNorm partial sums
+  const int part = tile * WN + wn;
+  const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK;
+  auto fast_epilogue = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
+    if (EPI == SAR_EPI_MASK) {
+      if (tid < BM) {
+        const int row = m0 + tid;
+        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < d.M) {
+          ap.x = d.aux_scale[row];
+          ap.y = d.aux_shift[row];
+          if (d.aux_mean) ap.z = d.aux_mean[row];
+        }
+        rowp[tid] = ap;
+      }
+      __syncthreads();
+    }
+    const int rows_w = m0 + wm * MS * 32;
+    auto rows_bytes = [&](int64_t ld) {
+      const int64_t n = (int64_t)(d.M - rows_w) * ld * 4;
+      return (unsigned)(n <= 0 ? 0 : (n > 0x80000000ll ? 0x80000000ll : n));
+    };
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, rows_bytes(d.ld_out), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, has_aux ? rows_bytes(d.ld_aux) : 0u, 0x00020000);
+    unsigned vo_out[NS], vo_aux[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
+      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+    }
+    const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
+    float* P = smem + wave * (16 * 65);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float ax[NS][16];
+        if (has_aux) {
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const int r = rb * 8 + r8;
+              ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+            }
+        }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = rb * 8 + r8;
+          const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;
+          float s1 = 0.f, s2 = 0.f;
+          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            float val = acc[ms][ns][r];
+            if (EPI == SAR_EPI_STATS) {
+              s1 += val;
+              s2 = fmaf(val, val, s2);
+            } else if (EPI == SAR_EPI_MASK) {
+              val = (fmaf(ax[ns][r], ap.x, ap.y) > 0.f) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ax[ns][r] - ap.z, s2);
+            } else if (EPI == SAR_EPI_ADD) {
+              val += ax[ns][r];
+            }
+            if (grp_ok)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
+                                                    (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_out, 0);
+          }
+          if (stats) {
+            P[(2 * r8) * 65 + lane] = s1;
+            P[(2 * r8 + 1) * 65 + lane] = s2;
+          }
+        }
+        if (stats) {
+          __builtin_amdgcn_wave_barrier();
+          const int q = lane & 15, sub = (lane >> 4) & 1;
+          const float* pr = P + q * 65 + hi * 32 + sub * 16;
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t += pr[i];
+          t += __shfl_xor(t, 16);
+          __builtin_amdgcn_wave_barrier();
+          const int r = rb * 8 + (q >> 1);
+          const int row = rows_w + ms * 32 + mfma_row(r, hi);
+          if (sub == 0 && row < d.M) d.partials[((int64_t)row * k.nparts + part) * 2 + (q & 1)] = t;
+        }
+      }
+    }
+  };
+  (void)stats;
+  switch (d.epi) {   // M % 8 == 0 is a precondition of this kernel (checked by the host)
+    case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
+    case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
+    case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
+    default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
+  }
+}
+
+template <int WN>
+int tile_geometry_b(const sar_conv_desc& d, int NSv, bool parity, ConvKB& k) {
+  const int tile_n = 32 * NSv * WN;
+  if (parity) {
+    k.FT = 2 * ((tile_n / 2) / d.V);
+    const int t_even = d.T_out + (d.T_out & 1);
+    if (k.FT > t_even) k.FT = t_even;
+  } else {
+    k.FT = tile_n / d.V;
+    if (k.FT > d.T_out) k.FT = d.T_out;
+  }
+  if (k.FT < 1) return -1;
+  k.TPS = (d.T_out + k.FT - 1) / k.FT;
+  if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
+  else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
+  k.RW = k.NF * d.V;
+  k.nparts = d.B * k.TPS * WN;
+  const int rwmax = (NSv * WN == 4 ? 448 : 704);
+  if (k.RW > rwmax) return -2;
+  return 0;
+}
+
+template <int TR, int TAPS, int MS, int NS, int WM, int WN>
+int launch_cfg_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
+  ConvKB k;
+  k.d = d;
+  k.wp = wp;
+  k.G = 2 * ((d.Kc + 15) / 16);
+  if (int g = tile_geometry_b<WN>(d, NS, TR == 3, k)) {
+    sar_set_error("sar_conv_gemm_bf16: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
+  }
+  constexpr int BM = 32 * MS * WM;
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + BM - 1) / BM;
+  const int nwork = k.ntiles * k.ny;
+  const int64_t units = (int64_t)d.taps * k.G * d.M;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, d.W, d.w_stride_tap,
+                     d.w_stride_c, d.taps, d.Kc, d.M, k.G, wp);
+  hipLaunchKernelGGL((conv_gemm_bf16_kernel<TR, TAPS, MS, NS, WM, WN>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
+  return 0;
+}
+
+// the same tile choice as conv_gemm.hip's launch_by_m: the partial-sum layout (sar_conv_gemm_nparts) is shared
+template <int TR, int TAPS>
+int launch_by_m_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
+  if constexpr (TR != 3)
+    if (d.M > 64) return launch_cfg_b<TR, TAPS, 2, 2, 2, 2>(d, wp, st);
+  if (d.M > 32) return launch_cfg_b<TR, TAPS, 2, 2, 1, 4>(d, wp, st);
+  return launch_cfg_b<TR, TAPS, 1, 2, 1, 4>(d, wp, st);
+}
+
+int dispatch_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
+  if (!d.transposed) return d.taps == 9 ? launch_by_m_b<0, 9>(d, wp, st) : launch_by_m_b<0, 1>(d, wp, st);
+  if (d.stride == 1) return d.taps == 9 ? launch_by_m_b<1, 9>(d, wp, st) : launch_by_m_b<1, 1>(d, wp, st);
+  if (d.taps == 9) return d.stride == 2 ? launch_by_m_b<3, 9>(d, wp, st) : launch_by_m_b<2, 9>(d, wp, st);
+  return launch_by_m_b<2, 1>(d, wp, st);
+}
+
+}  // namespace
+
+extern "C" int64_t sar_conv_gemm_bf16_workspace_bytes(const sar_conv_desc* d) {
+  if (!d || d->Kc <= 0 || d->M <= 0 || d->taps <= 0) return SAR_E_ARG;
+  return (int64_t)d->taps * 2 * ((d->Kc + 15) / 16) * d->M * 16;
+}
+
+extern "C" int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_stream_t s) {
+  SAR_REQUIRE(d != nullptr && workspace != nullptr, "sar_conv_gemm_bf16: null descriptor / workspace");
+  SAR_REQUIRE(((uintptr_t)workspace & 15) == 0, "sar_conv_gemm_bf16: workspace must be 16-byte aligned");
+  SAR_REQUIRE(d->mode == SAR_CONV_TEMPORAL, "sar_conv_gemm_bf16: temporal mode only (the graph contraction runs in fp32)");
+  SAR_REQUIRE(d->B > 0 && d->V > 0 && d->V <= 64 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0,
+              "sar_conv_gemm_bf16: bad sizes");
+  SAR_REQUIRE((d->M & 7) == 0, "sar_conv_gemm_bf16: M must be a multiple of 8 (got %d)", d->M);
+  SAR_REQUIRE(d->src && d->out && d->W, "sar_conv_gemm_bf16: null src/out/W");
+  SAR_REQUIRE(d->taps == 9 || d->taps == 1, "sar_conv_gemm_bf16: temporal kernel size %d not built (1 and 9 are)", d->taps);
+  SAR_REQUIRE(d->stride >= 1 && d->pad >= 0, "sar_conv_gemm_bf16: bad stride/pad");
+  SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_out >= (int64_t)d->B * d->T_out * d->V,
+              "sar_conv_gemm_bf16: leading dimension smaller than B*T*V");
+  SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_gemm_bf16: pro_scale/pro_shift mismatch");
+  SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 28), "sar_conv_gemm_bf16: sequence row too long");
+  SAR_REQUIRE(d->ld_out < (1 << 22) && d->ld_aux < (1 << 22), "sar_conv_gemm_bf16: leading dimension too large (2^22 columns)");
+  SAR_REQUIRE(sar_conv_gemm_bf16_workspace_bytes(d) < (1ll << 31), "sar_conv_gemm_bf16: weight tensor too large");
+  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm_bf16: bad epilogue %d", d->epi);
+  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm_bf16: partials required");
+  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
+    SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm_bf16: aux required");
+  if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->aux_scale && d->aux_shift, "sar_conv_gemm_bf16: aux affine required");
+  int rc = dispatch_b(*d, (uint4*)workspace, as_stream(s));
+  if (rc) return rc;
+  SAR_LAUNCH_CHECK("sar_conv_gemm_bf16");
+  return 0;
+}

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sar_struct_size": (_i, [_i]),
     "sar_conv_gemm_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),
+    "sar_conv_gemm_bf16_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
+    "sar_conv_gemm_bf16": (_i, [C.POINTER(ConvDesc), _fp, _fp]),
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),
     "sar_bn_finalize_f32": (_i, [_fp, _i, _i, _d, _f, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -32,8 +32,10 @@ class GraphTables:
 
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
-              aux_affine=None, aux_mean=None):
-    """Launch sar_conv_gemm_f32.  Returns (partials, nparts) when the epilogue reduces, else None."""
+              aux_affine=None, aux_mean=None, bf16=False):
+    """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (TEMPORAL mode, M % 8 == 0, Kc >= 16: bf16
+    MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel).  Returns (partials, nparts) when the
+    epilogue reduces, else None."""
     lib = L.load()
     d = ConvDesc()
     d.mode, d.transposed, d.B, d.V = mode, int(transposed), B, V
@@ -67,8 +69,14 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     n_conv = B * (T_src if transposed else T_out) * V
     flops = 2.0 * M * Kc * taps * n_conv
     tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else "")))
-    with profiler.region(tag, flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
-        check(lib.sar_conv_gemm_f32(C.byref(d), stream_ptr()), "sar_conv_gemm_f32")
+    bf16 = bf16 and mode == L.SAR_CONV_TEMPORAL and M % 8 == 0 and Kc >= 16
+    if bf16:
+        ws = torch.empty(lib.sar_conv_gemm_bf16_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=src.device)
+        with profiler.region(tag + "_bf16", flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+            check(lib.sar_conv_gemm_bf16(C.byref(d), ptr(ws), stream_ptr()), "sar_conv_gemm_bf16")
+    else:
+        with profiler.region(tag, flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+            check(lib.sar_conv_gemm_f32(C.byref(d), stream_ptr()), "sar_conv_gemm_f32")
     return (partials, nparts) if partials is not None else None
 
 

@@ -53,8 +53,13 @@ class _BN:
 
 class STGCN:
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
-                 blocks=None, motion=False):
+                 blocks=None, motion=False, mfma="fp32"):
         L.load()  # fail loudly if the HIP library is missing
+        # mfma="bf16" (SURVEY.md 8d config 3): the temporal / residual convolutions and their data gradients round both
+        # MFMA operands to bfloat16 (sar_conv_gemm_bf16); activations, accumulation, BatchNorm statistics, weight gradients,
+        # master weights and the optimizer stay fp32.  "fp32" (default) is the reference's arithmetic.
+        assert mfma in ("fp32", "bf16")
+        self.bf16 = mfma == "bf16"
         self.device = torch.device(device)
         self.num_classes, self.C_in, self.V = num_classes, in_channels, num_node
         self.blocks = list(blocks if blocks is not None else BLOCKS)
@@ -233,7 +238,7 @@ class STGCN:
         u = torch.empty((f, n_out), dtype=torch.float32, device=dev)
         r2 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, g, u, self.p[pre + "tcn.kernel"], f * f, f, B=B, V=V, T_src=T, T_out=To,
                            Kc=f, M=f, taps=KT, stride=s, pad=pad, bias=self.p[pre + "tcn.bias"],
-                           pro=(bn1.scale, bn1.shift), pro_relu=True, epi=epi)
+                           pro=(bn1.scale, bn1.shift), pro_relu=True, epi=epi, bf16=self.bf16)
         if training:
             self._bn_forward_stats(pre + "bn2", r2[0], r2[1], n_out, True, True)
         else:
@@ -244,7 +249,7 @@ class STGCN:
         if kind == "conv":  # models/stgcn.py:47-56
             r = torch.empty((f, n_out), dtype=torch.float32, device=dev)
             r3 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, X, r, self.p[pre + "res.kernel"], 0, f, B=B, V=V, T_src=T, T_out=To,
-                               Kc=cin, M=f, taps=1, stride=s, pad=0, bias=self.p[pre + "res.bias"], epi=epi)
+                               Kc=cin, M=f, taps=1, stride=s, pad=0, bias=self.p[pre + "res.bias"], epi=epi, bf16=self.bf16)
             if training:
                 self._bn_forward_stats(pre + "res_bn", r3[0], r3[1], n_out, True, True)
             else:
@@ -341,7 +346,7 @@ class STGCN:
         dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
         pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, du, dz1, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=KT,
                            stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g,
-                           aux_affine=(bn1.scale, bn1.shift), aux_mean=bn1.mean)
+                           aux_affine=(bn1.scale, bn1.shift), aux_mean=bn1.mean, bf16=self.bf16)
         ops.bn_bwd_finalize(pm[0], pm[1], pm[1] * 2, 2, 0, 1, f, n_in, self.p[pre + "bn1.gamma"], bn1.mean, bn1.rstd,
                             self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
         dg = dz1
@@ -362,7 +367,7 @@ class STGCN:
             ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
             dXres = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
             ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
-                          stride=s, pad=0, transposed=True)
+                          stride=s, pad=0, transposed=True, bf16=self.bf16)
         # ---- graph conv data gradient (+ skip-path gradient)
         gT = torch.empty((KS * f, cin), dtype=torch.float32, device=dev)
         ops.transpose(self.p[pre + "gcn.kernel"], gT, 1, cin, KS * f)    # [c][k*F+f] -> [k][f][c]

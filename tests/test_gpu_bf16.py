@@ -1,0 +1,159 @@
+"""bf16-operand temporal convolution (sar_conv_gemm_bf16) against its exact definition:
+both operands rounded to bfloat16 (nearest-even) after the folded BatchNorm + ReLU, exact products, fp32 accumulation.
+The reference below rounds the operands the same way and contracts in float64, so the tolerance only has to cover
+the fp32 accumulation order (1e-5 of the output scale), not the bf16 rounding itself; the distance to the
+un-rounded fp32 operator is asserted separately at bf16 scale."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import stgcn as O
+from util import to_cn, from_cn, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5          # vs the bf16-operand definition (accumulation order only)
+TOL_F32 = 1e-2      # vs the fp32 operator: 2^-9 relative per operand, averaged over the contraction
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _bf(t):
+    return t.float().bfloat16().double()
+
+
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (3, 64, 14, 2), (2, 128, 9, 2), (1, 256, 6, 1), (2, 128, 300, 2),
+                                     (2, 72, 11, 1), (1, 200, 9, 2), (2, 40, 7, 1), (1, 48, 10, 2), (2, 24, 30, 1)])
+def test_temporal_conv_forward_bf16(dev, B, f, T, s):
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(f + T + s)
+    x = torch.randn(B, f, T, 25, generator=g)
+    sc = 1 + 0.2 * torch.randn(f, generator=g); sh = 0.3 * torch.randn(f, generator=g)
+    kernel = torch.randn(9, 1, f, f, generator=g) * 0.05
+    bias = torch.randn(f, generator=g) * 0.1
+    h = torch.relu((x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float())
+    ref = O.temporal_conv(_bf(h), _bf(kernel), bias.double(), s)
+    ref32 = O.temporal_conv(h.double(), kernel.double(), bias.double(), s)
+    To, pad, _ = O.same_pad(T, 9, s)
+    out = torch.empty((f, B * To * 25), device=dev)
+    r = ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), out, kernel.to(dev), f * f, f, B=B, V=25, T_src=T, T_out=To,
+                      Kc=f, M=f, taps=9, stride=s, pad=pad, bias=bias.to(dev), pro=(sc.to(dev), sh.to(dev)),
+                      pro_relu=True, epi=L.SAR_EPI_STATS, bf16=True)
+    torch.cuda.synchronize()
+    got = from_cn(out.cpu(), B, To, 25)
+    assert rel_err(got, ref) < TOL
+    assert 1e-6 < rel_err(got, ref32) < TOL_F32          # it really is the bf16 operator, and no worse than bf16
+    part = r[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], ref.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (ref * ref).sum(dim=(0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2), (1, 64, 64, 7, 1)])
+def test_residual_conv_forward_bf16(dev, B, cin, f, T, s):
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(cin + f)
+    x = torch.randn(B, cin, T, 25, generator=g)
+    kernel = torch.randn(1, 1, cin, f, generator=g) * 0.1
+    bias = torch.randn(f, generator=g) * 0.1
+    ref = F.conv2d(_bf(x), O.hwio_to_oihw(_bf(kernel)), bias.double(), stride=(s, 1))
+    To = ref.shape[2]
+    out = torch.empty((f, B * To * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), out, kernel.to(dev), 0, f, B=B, V=25, T_src=T, T_out=To, Kc=cin, M=f,
+                  taps=1, stride=s, pad=0, bias=bias.to(dev), bf16=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), B, To, 25), ref) < TOL
+
+
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2), (4, 256, 75, 1),
+                                     (3, 128, 150, 2), (2, 72, 11, 1), (1, 200, 9, 2), (2, 40, 12, 2)])
+def test_temporal_conv_data_gradient_bf16(dev, B, f, T, s):
+    """transposed conv of the bf16-rounded output gradient with the bf16-rounded weights, fused ReLU mask (decided on the
+    fp32 pre-activation) and BatchNorm-backward reductions."""
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(11 * f + T + s)
+    gx = torch.randn(B, f, T, 25, generator=g).double()
+    sc = (1 + 0.2 * torch.randn(f, generator=g)).double(); sh = (0.3 * torch.randn(f, generator=g)).double()
+    kernel = (torch.randn(9, 1, f, f, generator=g) * 0.05)
+    To, pad, _ = O.same_pad(T, 9, s)
+    du = torch.randn(B, f, To, 25, generator=g)
+    h = torch.zeros(B, f, T, 25, dtype=torch.float64, requires_grad=True)
+    y = O.temporal_conv(h, _bf(kernel), None, s)
+    dh, = torch.autograd.grad(y, h, _bf(du))
+    pre = gx * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    g_pre = dh * (pre.float() > 0)
+    n_in = B * T * 25
+    scd, shd = sc.float().to(dev), sh.float().to(dev)
+    wT = torch.empty((9, f, f), device=dev)
+    ops.transpose(kernel.to(dev).contiguous(), wT, 9, f, f)
+    dz1 = torch.empty((f, n_in), device=dev)
+    gcn_d = to_cn(gx.float()).to(dev)
+    pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(du).to(dev), dz1, wT, f * f, f, B=B, V=25, T_src=To, T_out=T, Kc=f, M=f,
+                       taps=9, stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=gcn_d, aux_affine=(scd, shd),
+                       bf16=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(dz1.cpu(), B, T, 25), g_pre) < TOL
+    part = pm[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], g_pre.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (g_pre * gx).sum(dim=(0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2)])
+def test_residual_conv_data_gradient_bf16(dev, B, cin, f, T, s):
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(cin * 3 + f)
+    kernel = (torch.randn(1, 1, cin, f, generator=g) * 0.1)
+    x = torch.zeros(B, cin, T, 25, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, O.hwio_to_oihw(_bf(kernel)), None, stride=(s, 1))
+    To = y.shape[2]
+    dr = torch.randn(B, f, To, 25, generator=g)
+    gx, = torch.autograd.grad(y, x, _bf(dr))
+    rT = torch.empty((f, cin), device=dev)
+    ops.transpose(kernel.to(dev).contiguous(), rT, 1, cin, f)
+    dx = torch.empty((cin, B * T * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(dr).to(dev), dx, rT, 0, cin, B=B, V=25, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
+                  stride=s, pad=0, transposed=True, bf16=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(dx.cpu(), B, T, 25), gx) < TOL
+
+
+def test_bf16_argument_errors(dev):
+    from sar_amd import _lib as L
+    import ctypes as C
+    lib = L.load()
+    d = L.ConvDesc()
+    d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M, d.taps, d.stride = L.SAR_CONV_GRAPH, 1, 25, 4, 4, 16, 16, 9, 1
+    ws = torch.empty(1 << 16, dtype=torch.uint8, device=dev)
+    assert lib.sar_conv_gemm_bf16(C.byref(d), ws.data_ptr(), None) < 0        # graph mode is fp32 only
+    assert b"temporal" in lib.sar_last_error_string()
+    d.mode, d.M = L.SAR_CONV_TEMPORAL, 12
+    assert lib.sar_conv_gemm_bf16(C.byref(d), ws.data_ptr(), None) < 0        # M % 8
+    assert lib.sar_conv_gemm_bf16(C.byref(d), None, None) < 0                 # no workspace
+
+
+def test_train_step_bf16_close_to_fp32(dev):
+    """SURVEY.md 8c tolerance for the bf16 config: logits within ~1e-2 relative of the fp32 path; the gradients of the
+    large tensors point the same way (cosine > 0.99).  The fp32 engine is the one pinned to the oracle at 1e-4."""
+    from sar_amd.stgcn import STGCN
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True), (128, 1, True)]
+    p = O.randomize_affine(O.init_params(10, seed=0, dtype=torch.float64, blocks=blocks))
+    x, y = O.synthetic_batch(4, seed=0, T=40, num_classes=10)
+    out = {}
+    for mode in ("fp32", "bf16"):
+        eng = STGCN(num_classes=10, device=dev, blocks=blocks, mfma=mode)
+        eng.load_params(p)
+        logits, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+        torch.cuda.synchronize()
+        out[mode] = (logits.cpu().double(), loss.item(), {k: v.cpu().double().clone() for k, v in eng.g.items()})
+    l32, lb = out["fp32"][0], out["bf16"][0]
+    assert 1e-7 < rel_err(lb, l32) < 2e-2
+    assert abs(out["bf16"][1] - out["fp32"][1]) < 2e-2 * abs(out["fp32"][1])
+    for k, g32 in out["fp32"][2].items():
+        gb = out["bf16"][2][k]
+        if k.endswith(("gcn.bias", "tcn.bias", "res.bias")):
+            continue     # a bias in front of a BatchNorm has zero gradient analytically: both paths hold rounding noise
+        if g32.numel() >= 64 and g32.abs().max() > 1e-9:
+            cos = (g32 * gb).sum() / (g32.norm() * gb.norm())
+            assert cos > 0.99, (k, cos.item())

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--only", default="")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--bf16", action="store_true", help="temporal fwd/dgrad with bf16 MFMA operands (sar_conv_gemm_bf16)")
     a = ap.parse_args()
     only = set(a.only.split(",")) if a.only else None
     layers = set(int(x) for x in a.layers.split(",")) if a.layers else None
@@ -69,10 +70,10 @@ def main():
                     tables=tf_, epi=L.SAR_EPI_STATS)),
                 "tconv_fwd": (2.0 * f * f * 9 * n_out, lambda: ops.conv_gemm(
                     L.SAR_CONV_TEMPORAL, G, out_out, Wt, f * f, f, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s,
-                    pad=pad, bias=bt, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS)),
+                    pad=pad, bias=bt, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS, bf16=a.bf16)),
                 "tconv_dgrad": (2.0 * f * f * 9 * n_out, lambda: ops.conv_gemm(
                     L.SAR_CONV_TEMPORAL, U, out_in, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s,
-                    pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh))),
+                    pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh), bf16=a.bf16)),
                 "gcn_dgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_gemm(
                     L.SAR_CONV_GRAPH, G, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tb_,
                     epi=L.SAR_EPI_ADD, aux=X)),
