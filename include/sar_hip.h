@@ -130,6 +130,10 @@ typedef struct sar_wgrad_desc {
 } sar_wgrad_desc;
 
 int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s);
+/* The same slabs for the 9-tap TEMPORAL operator at stride 1 with bf16 MFMA operands (both operands rounded to
+ * bfloat16 as they are staged, exact products, fp32 accumulation; the bias gradient is summed from the fp32 values).
+ * Built for V = 25; other shapes: sar_conv_wgrad_f32. */
+int sar_conv_wgrad_bf16(const sar_wgrad_desc* d, sar_stream_t s);
 /* out[i] = sum_s slab[s*slab_stride + i] (i < n), summed in split order. */
 int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out, sar_stream_t s);
 

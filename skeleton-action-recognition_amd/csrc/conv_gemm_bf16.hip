@@ -66,6 +66,120 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int64_t st, int
   out[u] = *reinterpret_cast<uint4*>(&p);
 }
 
+// ---- epilogue (as conv_gemm.hip): mask / add, store, BatchNorm partial sums.  Every wave is past its last MFMA phase
+// and the closing barrier: the transpose area aliases the operand image.
+template <int MS, int NS, int WN, int BM>
+__device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, int tile, int wm, int wn, int m0,
+                                           const bool (&colok)[NS], const int64_t (&coln)[NS], f32x16 (&acc)[MS][NS],
+                                           float4* rowp, float* smem) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int part = tile * WN + wn;
+  const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK;
+  auto fast_epilogue = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
+    if (EPI == SAR_EPI_MASK) {
+      if (tid < BM) {
+        const int row = m0 + tid;
+        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < d.M) {
+          ap.x = d.aux_scale[row];
+          ap.y = d.aux_shift[row];
+          if (d.aux_mean) ap.z = d.aux_mean[row];
+        }
+        rowp[tid] = ap;
+      }
+      __syncthreads();
+    }
+    const int rows_w = m0 + wm * MS * 32;
+    auto rows_bytes = [&](int64_t ld) {
+      const int64_t n = (int64_t)(d.M - rows_w) * ld * 4;
+      return (unsigned)(n <= 0 ? 0 : (n > 0x80000000ll ? 0x80000000ll : n));
+    };
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, rows_bytes(d.ld_out), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, has_aux ? rows_bytes(d.ld_aux) : 0u, 0x00020000);
+    unsigned vo_out[NS], vo_aux[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
+      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+    }
+    const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
+    float* P = smem + wave * (16 * 65);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float ax[NS][16];
+        if (has_aux) {
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const int r = rb * 8 + r8;
+              ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+            }
+        }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = rb * 8 + r8;
+          const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;
+          float s1 = 0.f, s2 = 0.f;
+          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            float val = acc[ms][ns][r];
+            if (EPI == SAR_EPI_STATS) {
+              s1 += val;
+              s2 = fmaf(val, val, s2);
+            } else if (EPI == SAR_EPI_MASK) {
+              val = (fmaf(ax[ns][r], ap.x, ap.y) > 0.f) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ax[ns][r] - ap.z, s2);
+            } else if (EPI == SAR_EPI_ADD) {
+              val += ax[ns][r];
+            }
+            if (grp_ok)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
+                                                    (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_out, 0);
+          }
+          if (stats) {
+            P[(2 * r8) * 65 + lane] = s1;
+            P[(2 * r8 + 1) * 65 + lane] = s2;
+          }
+        }
+        if (stats) {
+          __builtin_amdgcn_wave_barrier();
+          const int q = lane & 15, sub = (lane >> 4) & 1;
+          const float* pr = P + q * 65 + hi * 32 + sub * 16;
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t += pr[i];
+          t += __shfl_xor(t, 16);
+          __builtin_amdgcn_wave_barrier();
+          const int r = rb * 8 + (q >> 1);
+          const int row = rows_w + ms * 32 + mfma_row(r, hi);
+          if (sub == 0 && row < d.M) d.partials[((int64_t)row * nparts + part) * 2 + (q & 1)] = t;
+        }
+      }
+    }
+  };
+  (void)stats;
+  switch (d.epi) {   // M % 8 == 0 is a precondition of this kernel (checked by the host)
+    case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
+    case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
+    case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
+    default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
+  }
+}
+
 // TR: 0 forward; 1 data gradient, stride 1; 2 data gradient, generic stride (tap validity mask); 3 data gradient,
 // stride 2, parity-split column map (see conv_gemm.hip)
 template <int TR, int TAPS, int MS, int NS, int WM, int WN>
@@ -279,110 +393,210 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvKB k) 
     __syncthreads();   // every wave is done with the image (next store / the epilogue's transpose area)
   }
 
-  // ---- epilogue (as conv_gemm.hip): mask / add, store, BatchNorm partial sums
-  const int part = tile * WN + wn;
-  const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK;
-  auto fast_epilogue = [&](auto EPI_) {
-    constexpr int EPI = decltype(EPI_)::value;
-    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
-    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
-    if (EPI == SAR_EPI_MASK) {
-      if (tid < BM) {
-        const int row = m0 + tid;
-        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < d.M) {
-          ap.x = d.aux_scale[row];
-          ap.y = d.aux_shift[row];
-          if (d.aux_mean) ap.z = d.aux_mean[row];
-        }
-        rowp[tid] = ap;
-      }
-      __syncthreads();
+  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, wm, wn, m0, colok, coln, acc, rowp, smem);
+}
+
+// ---- GraphConvTD (models/gcn.py:199-209) and its data gradient with bf16 MFMA operands:
+//   out[m, (t,w)] = sum_k sum_c bf16(W_k[c][m]) * bf16(z_k)[c, (t,w)] + sum_k b_k[m] colsum(A_k)[w],
+//   z_k[c, (t,w)] = sum_v pro(src)[c, (t,v)] A_k[v, w]      (fp32, <= 4 non-zeros per column of A_k)
+// The adjacency is applied on the src side in fp32 and the result rounded once.  Stage = 16 src channels:
+//   (1) raw fp32 rows -> LDS (coalesced row segments, folded BatchNorm/ReLU applied),
+//   (2) every thread builds the three k-innermost 16-byte units of its (channel half, column): 8 channels x NZ gather
+//       entries read back from the raw image, weighted in fp32, converted, one ds_write_b128 per slice,
+//   (3) 3 slices x MS x NS MFMAs.
+template <int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
+__global__ __launch_bounds__(256, 2) void conv_graph_bf16_kernel(const ConvKB k) {
+  constexpr int BM = 32 * MS * WM, TN = 32 * NS * WN;
+  constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  constexpr int XS = TN + 4;                 // raw row stride (floats)
+  constexpr int CPT = TN / 128;              // columns per thread in the unit builder (thread = (half, column))
+  constexpr int WUNITS = 3 * 2 * BM;         // [slice][h][m]
+  constexpr int ZUNITS = 3 * 2 * TN;         // [slice][h][col]
+  constexpr int WIT = (WUNITS + 255) / 256;
+  constexpr int XJ = TN / 64;                // raw columns per lane and row (wave w stages rows w, w+4, ..)
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;
+  constexpr int IMG_U = (WUNITS + ZUNITS) > PAREA_U ? (WUNITS + ZUNITS) : PAREA_U;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ uint4 smem_u[IMG_U + BM];
+  __shared__ float XR[KC16 * XS];
+  uint4* Wl = smem_u;
+  uint4* Zl = smem_u + WUNITS;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int V = d.V;
+  const int ny = k.ny, nwork = k.ntiles * ny;
+  int w = blockIdx.x;
+  {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;
+  }
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+  const int ncols = ((t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0) * V;   // live columns of this tile
+
+  bool colok[NS];
+  int64_t coln[NS];
+  float gcs[3][NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    colok[ns] = p < ncols;
+    const int pv = colok[ns] ? p : 0;
+    coln[ns] = ((int64_t)b * d.T_out + t0) * V + pv;
+    const int v = pv % V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) gcs[tp][ns] = (d.g_colsum && colok[ns]) ? d.g_colsum[tp * V + v] : 0.f;
+  }
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) {
+      bp.x = d.bias[row];
+      bp.y = d.bias[d.M + row];
+      bp.z = d.bias[2 * d.M + row];
     }
-    const int rows_w = m0 + wm * MS * 32;
-    auto rows_bytes = [&](int64_t ld) {
-      const int64_t n = (int64_t)(d.M - rows_w) * ld * 4;
-      return (unsigned)(n <= 0 ? 0 : (n > 0x80000000ll ? 0x80000000ll : n));
-    };
-    const __amdgpu_buffer_rsrc_t ro =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, rows_bytes(d.ld_out), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, has_aux ? rows_bytes(d.ld_aux) : 0u, 0x00020000);
-    unsigned vo_out[NS], vo_aux[NS];
+    rowp[tid] = bp;
+  }
+  // unit builder geometry: this thread's channel half and columns, gather offsets (floats inside a raw row) and weights
+  const int uh = tid >> 7;   // 0 / 1 (wave-uniform)
+  int go[CPT][3][4];
+  float gwt[CPT][3][4];
+  bool ulive[CPT];
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) {
-      vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
-      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+  for (int q = 0; q < CPT; ++q) {
+    const int col = (tid & 127) + 128 * q;
+    ulive[q] = col < ncols;
+    const int cc = ulive[q] ? col : 0;
+    const int fo = cc / V, v = cc - fo * V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < NZ[tp]) {
+          go[q][tp][j] = fo * V + d.g_idx[(tp * V + v) * 4 + j];
+          gwt[q][tp][j] = ulive[q] ? d.g_wt[(tp * V + v) * 4 + j] : 0.f;
+        }
+  }
+
+  f32x16 acc[MS][NS];
+  const int seq_len = d.T_src * V;
+  const float* src_b = d.src + ((int64_t)b * d.T_src + t0) * V;
+  int svo[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) svo[j] = (lane + 64 * j) < ncols ? (lane + 64 * j) * 4 : 0x7fffffff;   // rejected -> 0
+  unsigned wvo[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int u = tid + 256 * i;
+    const int m = u % BM, h = (u / BM) & 1, tp = u / (2 * BM);
+    const bool ok = u < WUNITS && (m0 + m) < d.M;
+    wvo[i] = ok ? (unsigned)((((int64_t)tp * k.G + h) * d.M + m0 + m) * 16) : 0x80000000u;
+  }
+  const unsigned wbytes = (unsigned)((int64_t)3 * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  uint4 wreg[WIT];
+  float sreg[4][XJ];
+
+  auto issue_loads = [&](int c0) {
+    const int wso = (c0 / 8) * d.M * 16;
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], wso, 0);
+      wreg[i] = *reinterpret_cast<const uint4*>(&v);
     }
-    const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
-    float* P = smem + wave * (16 * 65);
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + wave + 4 * r;
+      const int cg = c < d.Kc ? c : 0;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0,
+                                                                          (unsigned)(seq_len - t0 * V) * 4, 0x00020000);
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        float ax[NS][16];
-        if (has_aux) {
+      for (int j = 0; j < XJ; ++j) sreg[r][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo[j], 0, 0));
+    }
+  };
+  auto store_raw = [&](int c0) {
 #pragma unroll
-          for (int r8 = 0; r8 < 8; ++r8)
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + wave + 4 * r;
+      const bool rok = c < d.Kc;
+      const int cg = rok ? c : 0;
+      const float psc = d.pro_scale ? d.pro_scale[cg] : 1.f, psh = d.pro_scale ? d.pro_shift[cg] : 0.f;
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-              const int r = rb * 8 + r8;
-              ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                  ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
-            }
-        }
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-          const int r = rb * 8 + r8;
-          const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;
-          float s1 = 0.f, s2 = 0.f;
-          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns) {
-            float val = acc[ms][ns][r];
-            if (EPI == SAR_EPI_STATS) {
-              s1 += val;
-              s2 = fmaf(val, val, s2);
-            } else if (EPI == SAR_EPI_MASK) {
-              val = (fmaf(ax[ns][r], ap.x, ap.y) > 0.f) ? val : 0.f;
-              s1 += val;
-              s2 = fmaf(val, ax[ns][r] - ap.z, s2);
-            } else if (EPI == SAR_EPI_ADD) {
-              val += ax[ns][r];
-            }
-            if (grp_ok)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
-                                                    (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_out, 0);
-          }
-          if (stats) {
-            P[(2 * r8) * 65 + lane] = s1;
-            P[(2 * r8 + 1) * 65 + lane] = s2;
-          }
-        }
-        if (stats) {
-          __builtin_amdgcn_wave_barrier();
-          const int q = lane & 15, sub = (lane >> 4) & 1;
-          const float* pr = P + q * 65 + hi * 32 + sub * 16;
-          float t = 0.f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) t += pr[i];
-          t += __shfl_xor(t, 16);
-          __builtin_amdgcn_wave_barrier();
-          const int r = rb * 8 + (q >> 1);
-          const int row = rows_w + ms * 32 + mfma_row(r, hi);
-          if (sub == 0 && row < d.M) d.partials[((int64_t)row * k.nparts + part) * 2 + (q & 1)] = t;
-        }
+      for (int j = 0; j < XJ; ++j) {
+        const float val = fmaxf(fmaf(sreg[r][j], psc, psh), relu_lo);
+        XR[(wave + 4 * r) * XS + lane + 64 * j] = (rok && (lane + 64 * j) < ncols) ? val : 0.f;
       }
     }
   };
-  (void)stats;
-  switch (d.epi) {   // M % 8 == 0 is a precondition of this kernel (checked by the host)
-    case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
-    case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
-    case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
-    default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
+  auto build_units = [&]() {
+#pragma unroll
+    for (int i = 0; i < WIT; ++i)
+      if ((i + 1) * 256 <= WUNITS || tid + 256 * i < WUNITS) Wl[tid + 256 * i] = wreg[i];
+    const float* Xh = XR + uh * 8 * XS;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) {
+        bf16x8 p;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float z = gwt[q][tp][0] * Xh[c * XS + go[q][tp][0]];
+#pragma unroll
+          for (int j = 1; j < 4; ++j)
+            if (j < NZ[tp]) z = fmaf(gwt[q][tp][j], Xh[c * XS + go[q][tp][j]], z);
+          p[c] = (__bf16)z;
+        }
+        Zl[(tp * 2 + uh) * TN + (tid & 127) + 128 * q] = *reinterpret_cast<uint4*>(&p);
+      }
+    }
+  };
+
+  issue_loads(0);
+  __syncthreads();   // rowp
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
+    }
+  const uint4* Wa = Wl + hi * BM + wm * MS * 32 + l31;
+  const uint4* Za = Zl + hi * TN + wn * NS * 32 + l31;
+  for (int c0 = 0; c0 < d.Kc; c0 += KC16) {
+    store_raw(c0);
+    __syncthreads();   // raw image complete; every wave is past the MFMA phase of the previous stage
+    build_units();
+    __syncthreads();
+    if (c0 + KC16 < d.Kc) issue_loads(c0 + KC16);
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      uint4 a[MS], bq[NS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tp * 2 * BM + ms * 32];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) bq[ns] = Za[tp * 2 * TN + ns * 32];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[ms]),
+                                                                *reinterpret_cast<bf16x8*>(&bq[ns]), acc[ms][ns], 0, 0, 0);
+    }
   }
+  __syncthreads();   // the epilogue's transpose area aliases the image
+  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, wm, wn, m0, colok, coln, acc, rowp, smem);
 }
 
 template <int WN>
@@ -398,11 +612,12 @@ int tile_geometry_b(const sar_conv_desc& d, int NSv, bool parity, ConvKB& k) {
   }
   if (k.FT < 1) return -1;
   k.TPS = (d.T_out + k.FT - 1) / k.FT;
-  if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
+  if (d.mode == SAR_CONV_GRAPH) k.NF = k.FT;
+  else if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
   else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
   k.RW = k.NF * d.V;
   k.nparts = d.B * k.TPS * WN;
-  const int rwmax = (NSv * WN == 4 ? 448 : 704);
+  const int rwmax = (d.mode == SAR_CONV_GRAPH) ? tile_n : (NSv * WN == 4 ? 448 : 704);
   if (k.RW > rwmax) return -2;
   return 0;
 }
@@ -428,6 +643,34 @@ int launch_cfg_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
   return 0;
 }
 
+template <int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
+int launch_graph_cfg_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
+  ConvKB k;
+  k.d = d;
+  k.wp = wp;
+  k.G = 2 * ((d.Kc + 15) / 16);
+  if (int g = tile_geometry_b<WN>(d, NS, false, k)) {
+    sar_set_error("sar_conv_gemm_bf16: unsupported tile geometry (V=%d)", d.V);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
+  }
+  constexpr int BM = 32 * MS * WM;
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + BM - 1) / BM;
+  const int nwork = k.ntiles * k.ny;
+  const int64_t units = (int64_t)3 * k.G * d.M;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, d.W, d.w_stride_tap,
+                     d.w_stride_c, 3, d.Kc, d.M, k.G, wp);
+  hipLaunchKernelGGL((conv_graph_bf16_kernel<MS, NS, WM, WN, NZ0, NZ1, NZ2>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
+  return 0;
+}
+
+template <int NZ0, int NZ1, int NZ2>
+int launch_graph_by_m_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
+  if (d.M > 64) return launch_graph_cfg_b<2, 2, 2, 2, NZ0, NZ1, NZ2>(d, wp, st);
+  if (d.M > 32) return launch_graph_cfg_b<2, 2, 1, 4, NZ0, NZ1, NZ2>(d, wp, st);
+  return launch_graph_cfg_b<1, 2, 1, 4, NZ0, NZ1, NZ2>(d, wp, st);
+}
+
 // the same tile choice as conv_gemm.hip's launch_by_m: the partial-sum layout (sar_conv_gemm_nparts) is shared
 template <int TR, int TAPS>
 int launch_by_m_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
@@ -438,6 +681,11 @@ int launch_by_m_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
 }
 
 int dispatch_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
+  if (d.mode == SAR_CONV_GRAPH) {
+    if (d.nz[0] == 1 && d.nz[1] == 1) return launch_graph_by_m_b<1, 1, 4>(d, wp, st);
+    if (d.nz[0] == 1 && d.nz[2] == 1) return launch_graph_by_m_b<1, 4, 1>(d, wp, st);
+    return launch_graph_by_m_b<4, 4, 4>(d, wp, st);
+  }
   if (!d.transposed) return d.taps == 9 ? launch_by_m_b<0, 9>(d, wp, st) : launch_by_m_b<0, 1>(d, wp, st);
   if (d.stride == 1) return d.taps == 9 ? launch_by_m_b<1, 9>(d, wp, st) : launch_by_m_b<1, 1>(d, wp, st);
   if (d.taps == 9) return d.stride == 2 ? launch_by_m_b<3, 9>(d, wp, st) : launch_by_m_b<2, 9>(d, wp, st);
@@ -454,13 +702,21 @@ extern "C" int64_t sar_conv_gemm_bf16_workspace_bytes(const sar_conv_desc* d) {
 extern "C" int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_stream_t s) {
   SAR_REQUIRE(d != nullptr && workspace != nullptr, "sar_conv_gemm_bf16: null descriptor / workspace");
   SAR_REQUIRE(((uintptr_t)workspace & 15) == 0, "sar_conv_gemm_bf16: workspace must be 16-byte aligned");
-  SAR_REQUIRE(d->mode == SAR_CONV_TEMPORAL, "sar_conv_gemm_bf16: temporal mode only (the graph contraction runs in fp32)");
+  SAR_REQUIRE(d->mode == SAR_CONV_TEMPORAL || d->mode == SAR_CONV_GRAPH, "sar_conv_gemm_bf16: bad mode %d", d->mode);
   SAR_REQUIRE(d->B > 0 && d->V > 0 && d->V <= 64 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0,
               "sar_conv_gemm_bf16: bad sizes");
   SAR_REQUIRE((d->M & 7) == 0, "sar_conv_gemm_bf16: M must be a multiple of 8 (got %d)", d->M);
   SAR_REQUIRE(d->src && d->out && d->W, "sar_conv_gemm_bf16: null src/out/W");
-  SAR_REQUIRE(d->taps == 9 || d->taps == 1, "sar_conv_gemm_bf16: temporal kernel size %d not built (1 and 9 are)", d->taps);
-  SAR_REQUIRE(d->stride >= 1 && d->pad >= 0, "sar_conv_gemm_bf16: bad stride/pad");
+  if (d->mode == SAR_CONV_GRAPH) {
+    SAR_REQUIRE(d->taps == 3 && d->T_src == d->T_out, "sar_conv_gemm_bf16: graph mode needs 3 adjacency slices and keeps T");
+    SAR_REQUIRE(d->g_idx && d->g_wt, "sar_conv_gemm_bf16: graph gather tables required");
+    SAR_REQUIRE(!d->bias || d->g_colsum, "sar_conv_gemm_bf16: graph bias needs g_colsum");
+    for (int i = 0; i < 3; ++i)
+      SAR_REQUIRE(d->nz[i] >= 1 && d->nz[i] <= 4, "sar_conv_gemm_bf16: adjacency slice %d needs %d gather entries (max 4)", i, d->nz[i]);
+  } else {
+    SAR_REQUIRE(d->taps == 9 || d->taps == 1, "sar_conv_gemm_bf16: temporal kernel size %d not built (1 and 9 are)", d->taps);
+    SAR_REQUIRE(d->stride >= 1 && d->pad >= 0, "sar_conv_gemm_bf16: bad stride/pad");
+  }
   SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_out >= (int64_t)d->B * d->T_out * d->V,
               "sar_conv_gemm_bf16: leading dimension smaller than B*T*V");
   SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_gemm_bf16: pro_scale/pro_shift mismatch");

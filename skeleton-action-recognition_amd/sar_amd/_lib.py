@@ -70,6 +70,7 @@ SIGNATURES = {
     "sar_conv_gemm_bf16_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_bf16": (_i, [C.POINTER(ConvDesc), _fp, _fp]),
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
+    "sar_conv_wgrad_bf16": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),
     "sar_bn_finalize_f32": (_i, [_fp, _i, _i, _d, _f, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_bn_eval_affine_f32": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _fp]),

@@ -33,7 +33,7 @@ class GraphTables:
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
               aux_affine=None, aux_mean=None, bf16=False):
-    """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (TEMPORAL mode, M % 8 == 0, Kc >= 16: bf16
+    """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (M % 8 == 0, Kc >= 16: bf16
     MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel).  Returns (partials, nparts) when the
     epilogue reduces, else None."""
     lib = L.load()
@@ -69,7 +69,7 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     n_conv = B * (T_src if transposed else T_out) * V
     flops = 2.0 * M * Kc * taps * n_conv
     tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else "")))
-    bf16 = bf16 and mode == L.SAR_CONV_TEMPORAL and M % 8 == 0 and Kc >= 16
+    bf16 = bf16 and M % 8 == 0 and Kc >= 16
     if bf16:
         ws = torch.empty(lib.sar_conv_gemm_bf16_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=src.device)
         with profiler.region(tag + "_bf16", flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
@@ -81,13 +81,19 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
 
 
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
-               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None):
-    """dW (and dbias, stored right behind it) -> dW_out[0 : wsize+bsize] (flat float32 view)."""
+               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, bf16=False):
+    """dW (and dbias, stored right behind it) -> dW_out[0 : wsize+bsize] (flat float32 view).  bf16=True routes the
+    9-tap temporal operator at stride 1 (V = 25) to sar_conv_wgrad_bf16 (bf16 MFMA operands, fp32 accumulation and bias
+    sums); every other shape stays on the fp32 kernel."""
     lib = L.load()
     d = WgradDesc()
     d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
     d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
     ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
+    bf16 = bf16 and mode == L.SAR_CONV_TEMPORAL and taps == 9 and stride == 1 and V == 25
+    if bf16 and nsplit is None:     # 64 x 64 weight blocks, 8-frame tiles; one round of the 512 resident workgroups
+        ntiles = B * ((T_out + 7) // 8)
+        nsplit = max(1, min(ntiles, 512 // (((M + 63) // 64) * ((Kc + 63) // 64))))
     if nsplit is None:
         ft = max(2, min((128 // V) & ~1, (T_out + 1) & ~1))
         bf = 64
@@ -112,8 +118,12 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
     d.slab = ptr(slab)
     tag = "wgrad_graph" if mode == L.SAR_CONV_GRAPH else "wgrad_temporal%d" % taps
-    with profiler.region(tag, 2.0 * M * Kc * taps * B * T_out * V, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
-        check(lib.sar_conv_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv_wgrad_f32")
+    with profiler.region(tag + ("_bf16" if bf16 else ""), 2.0 * M * Kc * taps * B * T_out * V,
+                         4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+        if bf16:
+            check(lib.sar_conv_wgrad_bf16(C.byref(d), stream_ptr()), "sar_conv_wgrad_bf16")
+        else:
+            check(lib.sar_conv_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv_wgrad_f32")
     assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
     check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, wsize + bsize, wsize + bsize, ptr(dW_out), stream_ptr()),
           "sar_slab_reduce_f32")

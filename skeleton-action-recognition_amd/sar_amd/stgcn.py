@@ -55,9 +55,10 @@ class STGCN:
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
                  blocks=None, motion=False, mfma="fp32"):
         L.load()  # fail loudly if the HIP library is missing
-        # mfma="bf16" (SURVEY.md 8d config 3): the temporal / residual convolutions and their data gradients round both
-        # MFMA operands to bfloat16 (sar_conv_gemm_bf16); activations, accumulation, BatchNorm statistics, weight gradients,
-        # master weights and the optimizer stay fp32.  "fp32" (default) is the reference's arithmetic.
+        # mfma="bf16" (SURVEY.md 8d config 3): the graph / temporal / residual convolutions, their data gradients and the
+        # stride-1 temporal weight gradients round both MFMA operands to bfloat16 (sar_conv_gemm_bf16, sar_conv_wgrad_bf16);
+        # activations in HBM, accumulation, BatchNorm statistics, the remaining weight gradients, master weights and the
+        # optimizer stay fp32.  "fp32" (default) is the reference's arithmetic.
         assert mfma in ("fp32", "bf16")
         self.bf16 = mfma == "bf16"
         self.device = torch.device(device)
@@ -228,7 +229,7 @@ class STGCN:
         # sgcn: GraphConvTD (models/gcn.py:199-209)
         g = torch.empty((f, n_in), dtype=torch.float32, device=dev)
         r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
-                           Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi)
+                           Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi, bf16=self.bf16)
         if training:
             self._bn_forward_stats(pre + "bn1", r1[0], r1[1], n_in, True, True)
         else:
@@ -340,7 +341,8 @@ class STGCN:
         flat_w = self.grad[self.offsets[pre + "tcn.kernel"]:self.offsets[pre + "tcn.bias"] + f]
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
-            pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f), g, du)
+            pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
+            bf16=self.bf16), g, du)
         wT = torch.empty((KT, f, f), dtype=torch.float32, device=dev)
         ops.transpose(self.p[pre + "tcn.kernel"], wT, KT, f, f)          # [tap][c][f] -> [tap][f][c]
         dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
@@ -374,7 +376,7 @@ class STGCN:
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
         ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
-                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux)
+                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux, bf16=self.bf16)
         return dX
 
     # ------------------------------------------------------------------ training step

@@ -124,13 +124,17 @@ def test_bf16_argument_errors(dev):
     import ctypes as C
     lib = L.load()
     d = L.ConvDesc()
-    d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M, d.taps, d.stride = L.SAR_CONV_GRAPH, 1, 25, 4, 4, 16, 16, 9, 1
+    d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M, d.taps, d.stride = L.SAR_CONV_TEMPORAL, 1, 25, 4, 4, 16, 12, 9, 1
     ws = torch.empty(1 << 16, dtype=torch.uint8, device=dev)
-    assert lib.sar_conv_gemm_bf16(C.byref(d), ws.data_ptr(), None) < 0        # graph mode is fp32 only
-    assert b"temporal" in lib.sar_last_error_string()
-    d.mode, d.M = L.SAR_CONV_TEMPORAL, 12
     assert lib.sar_conv_gemm_bf16(C.byref(d), ws.data_ptr(), None) < 0        # M % 8
+    assert b"multiple of 8" in lib.sar_last_error_string()
     assert lib.sar_conv_gemm_bf16(C.byref(d), None, None) < 0                 # no workspace
+    d.M = 16
+    assert lib.sar_conv_gemm_bf16(C.byref(d), ws.data_ptr(), None) < 0        # null tensors
+    w = L.WgradDesc()
+    w.mode, w.B, w.V, w.T_src, w.T_out, w.Kc, w.M, w.taps, w.stride, w.pad, w.nsplit = L.SAR_CONV_TEMPORAL, 1, 25, 8, 4, 16, 16, 9, 2, 3, 1
+    assert lib.sar_conv_wgrad_bf16(C.byref(w), None) < 0                      # stride 2 is not built in bf16
+    assert b"stride 1" in lib.sar_last_error_string()
 
 
 def test_train_step_bf16_close_to_fp32(dev):
@@ -157,3 +161,94 @@ def test_train_step_bf16_close_to_fp32(dev):
         if g32.numel() >= 64 and g32.abs().max() > 1e-9:
             cos = (g32 * gb).sum() / (g32.norm() * gb.norm())
             assert cos > 0.99, (k, cos.item())
+
+
+@pytest.mark.parametrize("B,f,T", [(2, 64, 13), (1, 64, 8), (2, 128, 20), (1, 256, 7), (4, 256, 75), (2, 72, 11), (1, 200, 9), (2, 40, 30),
+                                   (3, 24, 17)])
+def test_temporal_conv_weight_gradient_bf16(dev, B, f, T):
+    """dW from the bf16-rounded operand (after the folded BN + ReLU) and the bf16-rounded output gradient, fp32 accumulation;
+    the bias gradient from the fp32 values."""
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(7 * f + T)
+    gx = torch.randn(B, f, T, 25, generator=g)
+    sc = 1 + 0.2 * torch.randn(f, generator=g); sh = 0.3 * torch.randn(f, generator=g)
+    du = torch.randn(B, f, T, 25, generator=g)
+    h = torch.relu((gx.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float())
+    kernel = torch.zeros(9, 1, f, f, dtype=torch.float64, requires_grad=True)
+    y = O.temporal_conv(_bf(h), kernel, None, 1)
+    g_k, = torch.autograd.grad(y, kernel, _bf(du))
+    g_b = du.double().sum(dim=(0, 2, 3))
+    flat = torch.zeros(9 * f * f + f, device=dev)
+    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx).to(dev), to_cn(du).to(dev), flat, B=B, V=25, T_src=T, T_out=T, Kc=f,
+                   M=f, taps=9, stride=1, pad=4, pro=(sc.to(dev), sh.to(dev)), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
+                   wsize=9 * f * f, bsize=f, bf16=True)
+    torch.cuda.synchronize()
+    assert rel_err(flat[:9 * f * f].cpu().view(9, 1, f, f), g_k) < TOL
+    assert rel_err(flat[9 * f * f:].cpu(), g_b) < 1e-5
+    # several explicit split counts give the same sums (deterministic slab reduction)
+    flat2 = torch.zeros_like(flat)
+    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx).to(dev), to_cn(du).to(dev), flat2, B=B, V=25, T_src=T, T_out=T, Kc=f,
+                   M=f, taps=9, stride=1, pad=4, pro=(sc.to(dev), sh.to(dev)), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
+                   wsize=9 * f * f, bsize=f, bf16=True, nsplit=3)
+    torch.cuda.synchronize()
+    assert rel_err(flat2[:9 * f * f].cpu().view(9, 1, f, f), g_k) < TOL
+
+
+def _graph_operand(x, transpose=False):
+    """z_k = x . A_k exactly as the kernel forms it: fp32 weighted gather in table order (the NTU adjacency entries are
+    powers of two, so the fused multiply-adds round like separate operations), then one rounding to bfloat16."""
+    import numpy as np
+    from oracle.graph import spatial_adjacency
+    from sar_amd.graph_tables import gather_lists
+    idx, wt, nz, colsum = gather_lists(spatial_adjacency().astype(np.float32), transpose)
+    idx, wt = torch.from_numpy(idx).long(), torch.from_numpy(wt)
+    zs = []
+    for k in range(3):
+        z = wt[k, :, 0] * x[..., idx[k, :, 0]]
+        for j in range(1, nz[k]):
+            z = z + wt[k, :, j] * x[..., idx[k, :, j]]
+        zs.append(z.bfloat16().double())
+    return torch.stack(zs, 1), torch.from_numpy(colsum).double()        # (B, 3, C, T, V), (3, V)
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 10), (2, 64, 128, 7), (1, 128, 256, 5), (4, 256, 256, 3), (2, 40, 72, 9),
+                                       (1, 16, 200, 5), (2, 64, 40, 6), (2, 128, 128, 150)])
+def test_graph_conv_forward_bf16(dev, B, cin, f, T):
+    from sar_amd import ops, _lib as L
+    from test_gpu_stgcn_kernels import _tables
+    g = torch.Generator().manual_seed(B * 1000 + cin)
+    x = torch.randn(B, cin, T, 25, generator=g)
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    bias = torch.randn(3 * f, generator=g) * 0.1
+    z, colsum = _graph_operand(x)
+    Wk = _bf(kernel).view(cin, 3, f)                                     # channel k*F + m  (models/gcn.py:205)
+    ref = torch.einsum("bkctv,ckm->bmtv", z, Wk) + torch.einsum("km,kv->mv", bias.double().view(3, f), colsum)[None, :, None, :]
+    out = torch.empty((f, B * T * 25), device=dev)
+    r = ops.conv_gemm(L.SAR_CONV_GRAPH, to_cn(x).to(dev), out, kernel.to(dev), f, 3 * f, B=B, V=25, T_src=T, T_out=T, Kc=cin,
+                      M=f, taps=3, bias=bias.to(dev), tables=_tables(dev), epi=L.SAR_EPI_STATS, bf16=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), B, T, 25), ref) < TOL
+    part = r[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], ref.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (ref * ref).sum(dim=(0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (4, 256, 256, 75), (2, 40, 72, 9)])
+def test_graph_conv_data_gradient_bf16(dev, B, cin, f, T):
+    """dX = sum_k W_k^T (dg . A_k^T) (+ the skip gradient): the same kernel with the transposed gather lists."""
+    from sar_amd import ops, _lib as L
+    from test_gpu_stgcn_kernels import _tables
+    g = torch.Generator().manual_seed(B * 77 + f)
+    dg = torch.randn(B, f, T, 25, generator=g)
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    skip = torch.randn(B, cin, T, 25, generator=g)
+    z, _ = _graph_operand(dg, transpose=True)                            # (B, 3, f, T, V)
+    Wk = _bf(kernel).view(cin, 3, f)
+    ref = torch.einsum("bkmtv,ckm->bctv", z, Wk) + skip.double()
+    gT = torch.empty((3 * f, cin), device=dev)
+    ops.transpose(kernel.to(dev).contiguous(), gT, 1, cin, 3 * f)
+    dX = torch.empty((cin, B * T * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_GRAPH, to_cn(dg).to(dev), dX, gT, f * cin, cin, B=B, V=25, T_src=T, T_out=T, Kc=f, M=cin, taps=3,
+                  tables=_tables(dev, True), epi=L.SAR_EPI_ADD, aux=to_cn(skip).to(dev), bf16=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(dX.cpu(), B, T, 25), ref) < TOL

@@ -67,7 +67,7 @@ def main():
             cases = {
                 "gcn_fwd": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_gemm(
                     L.SAR_CONV_GRAPH, X, out_in, Wg, f, 3 * f, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, bias=bg,
-                    tables=tf_, epi=L.SAR_EPI_STATS)),
+                    tables=tf_, epi=L.SAR_EPI_STATS, bf16=a.bf16)),
                 "tconv_fwd": (2.0 * f * f * 9 * n_out, lambda: ops.conv_gemm(
                     L.SAR_CONV_TEMPORAL, G, out_out, Wt, f * f, f, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s,
                     pad=pad, bias=bt, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS, bf16=a.bf16)),
@@ -76,10 +76,10 @@ def main():
                     pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh), bf16=a.bf16)),
                 "gcn_dgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_gemm(
                     L.SAR_CONV_GRAPH, G, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tb_,
-                    epi=L.SAR_EPI_ADD, aux=X)),
+                    epi=L.SAR_EPI_ADD, aux=X, bf16=a.bf16)),
                 "tconv_wgrad": (2.0 * f * f * 9 * n_out, lambda: ops.conv_wgrad(
                     L.SAR_CONV_TEMPORAL, G, U, flat_t, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad,
-                    pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f)),
+                    pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f, bf16=a.bf16)),
                 "gcn_wgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_wgrad(
                     L.SAR_CONV_GRAPH, X, G, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tf_,
                     w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)),
