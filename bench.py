@@ -307,7 +307,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
                                    "(3,300,25,2), %d classes, bs=%d/GPU" % (
-                                       "bf16-MFMA-operand (temporal convs; fp32 storage, accumulation, graph conv, weight grads)"
+                                       "bf16-MFMA-operand (graph/temporal/residual convs, their data gradients, stride-1 temporal weight gradients; fp32 storage, accumulation, BatchNorm, remaining weight gradients, master weights)"
                                        if bf16 else "fp32", args.classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches)",

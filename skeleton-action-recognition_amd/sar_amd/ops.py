@@ -90,6 +90,8 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
     d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
     ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
+    # (a bf16 graph weight gradient was built and measured: with the adjacency gather in its stager it ran 1.7x SLOWER
+    # than the fp32 kernel -- 9.0 vs 5.4 ms per step -- so the graph weight gradient stays on the fp32 kernel)
     bf16 = bf16 and mode == L.SAR_CONV_TEMPORAL and taps == 9 and stride == 1 and V == 25
     if bf16 and nsplit is None:     # 64 x 64 weight blocks, 8-frame tiles; one round of the 512 resident workgroups
         ntiles = B * ((T_out + 7) // 8)

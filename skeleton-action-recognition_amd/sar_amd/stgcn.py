@@ -357,7 +357,7 @@ class STGCN:
         flat_g = self.grad[self.offsets[pre + "gcn.kernel"]:self.offsets[pre + "gcn.bias"] + KS * f]
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_GRAPH, X, dg, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS, tables=self.tab_fwd,
-            w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f), X, dg)
+            w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, bf16=self.bf16), X, dg)
         # ---- residual conv branch
         dXres = None
         if kind == "conv":

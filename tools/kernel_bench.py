@@ -82,7 +82,7 @@ def main():
                     pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f, bf16=a.bf16)),
                 "gcn_wgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_wgrad(
                     L.SAR_CONV_GRAPH, X, G, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tf_,
-                    w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)),
+                    w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f, bf16=a.bf16)),
             }
             for name, (flops, fn) in cases.items():
                 if only and name not in only:
