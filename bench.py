@@ -26,12 +26,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
 
 
-def measured_traffic():
+def measured_traffic(bf16=False):
     """HBM bytes per launch of the dominant kernel family from the committed PMC profile of this same workload
     (profiles/rNN_kernel_summary.json, written by tools/summarize_profiles.py from separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).  None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bf16_kernel_summary.json" if bf16
+                                          else "r[0-9][0-9]_kernel_summary.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -296,7 +297,7 @@ def main():
         fl = sum(summ[k]["flops"] for k in fam)
         calls = sum(summ[k]["calls"] for k in fam)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src = measured_traffic(args.mfma == "bf16")
         kern_ms = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())}
         kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
         bf16 = args.mfma == "bf16"
@@ -307,7 +308,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
                                    "(3,300,25,2), %d classes, bs=%d/GPU" % (
-                                       "bf16-MFMA-operand (graph/temporal/residual convs, their data gradients, stride-1 temporal weight gradients; fp32 storage, accumulation, BatchNorm, remaining weight gradients, master weights)"
+                                       "bf16-MFMA-operand (graph/temporal/residual convs, their data gradients, temporal weight gradients; fp32 storage, accumulation, BatchNorm, remaining weight gradients, master weights)"
                                        if bf16 else "fp32", args.classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches)",
@@ -324,7 +325,9 @@ def main():
             gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             out["roofline"] = {"bound": "hbm", "kernel": "conv_gemm_bf16_kernel<9 taps> (fwd + data-grad launches)",
                                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                               "traffic": None, "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
+                               "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
+                               "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
                                "avg_launch_ms": round(ms / max(calls, 1), 4),
                                "mfma_tflops": round(achieved, 1)}
         if world == 1 and not args.no_cpu_baseline:

@@ -98,10 +98,11 @@ typedef struct sar_conv_desc {
 int sar_struct_size(int which);
 int sar_conv_gemm_nparts(const sar_conv_desc* d);                 /* host query, no GPU work */
 int sar_conv_gemm_f32(const sar_conv_desc* d, sar_stream_t s);
-/* The TEMPORAL operator with bf16 MFMA operands: W and pro(src) are rounded to bfloat16
- * (nearest-even) as they are staged, products are exact, accumulation / bias / epilogue / BatchNorm sums are fp32;
- * src, out and W stay fp32 in memory.  Needs M % 8 == 0.  workspace: sar_conv_gemm_bf16_workspace_bytes(d) bytes,
- * 16-byte aligned (holds the packed bf16 weights, rewritten by every call).  Partial-sum layout: sar_conv_gemm_nparts. */
+/* The same operators with bf16 MFMA operands: W and the src-side operand -- pro(src) for
+ * TEMPORAL, z_k = pro(src) . A_k (formed in fp32) for GRAPH -- are rounded to bfloat16 (nearest-even) as they are
+ * staged, products are exact, accumulation / bias / epilogue / BatchNorm sums are fp32; src, out and W stay fp32 in
+ * memory.  Needs M % 8 == 0.  workspace: sar_conv_gemm_bf16_workspace_bytes(d) bytes, 16-byte aligned (holds the packed
+ * bf16 weights, rewritten by every call).  Partial-sum layout: sar_conv_gemm_nparts. */
 int64_t sar_conv_gemm_bf16_workspace_bytes(const sar_conv_desc* d);
 int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_stream_t s);
 
@@ -130,9 +131,9 @@ typedef struct sar_wgrad_desc {
 } sar_wgrad_desc;
 
 int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s);
-/* The same slabs for the 9-tap TEMPORAL operator at stride 1 with bf16 MFMA operands (both operands rounded to
- * bfloat16 as they are staged, exact products, fp32 accumulation; the bias gradient is summed from the fp32 values).
- * Built for V = 25; other shapes: sar_conv_wgrad_f32. */
+/* The same slabs for the 9-tap TEMPORAL operator with bf16 MFMA operands (both operands rounded to bfloat16 as they
+ * are staged, exact products, fp32 accumulation; the bias gradient is summed from the fp32 values).  Built for V = 25
+ * at stride 1, and at stride 2 with pad 3 (TF-SAME padding of an even T); other shapes: sar_conv_wgrad_f32. */
 int sar_conv_wgrad_bf16(const sar_wgrad_desc* d, sar_stream_t s);
 /* out[i] = sum_s slab[s*slab_stride + i] (i < n), summed in split order. */
 int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out, sar_stream_t s);

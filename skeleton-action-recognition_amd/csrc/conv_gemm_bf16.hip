@@ -676,6 +676,7 @@ template <int TR, int TAPS>
 int launch_by_m_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
   if constexpr (TR != 3)
     if (d.M > 64) return launch_cfg_b<TR, TAPS, 2, 2, 2, 2>(d, wp, st);
+  // (32-row blocks for M = 64 -- 3 workgroups per CU -- measured slower: 31.3 vs 30.5 ms per step)
   if (d.M > 32) return launch_cfg_b<TR, TAPS, 2, 2, 1, 4>(d, wp, st);
   return launch_cfg_b<TR, TAPS, 1, 2, 1, 4>(d, wp, st);
 }

@@ -41,6 +41,9 @@ def get_parser():
     parser.add_argument('--save-scores', action='store_true',
                         help='write the test-set class probabilities of every checkpointed epoch (scores-N.npy, for score fusion '
                              'of separately trained streams with tools/fuse_scores.py)')
+    parser.add_argument('--mfma', default='fp32', choices=['fp32', 'bf16'],
+                        help="arithmetic of the convolutions' matrix products: fp32 (the reference's) or bf16 operands with fp32 "
+                             "accumulation, storage and master weights (about 2x the clips/s)")
     parser.add_argument('--base-lr', type=float, default=1e-1, help='initial learning rate')
     parser.add_argument('--num-classes', type=int, default=60, help='number of classes in dataset')
     parser.add_argument('--batch-size', type=int, default=64, help='training batch size')
@@ -88,7 +91,7 @@ def main():
 
     run_params = {k: v for k, v in vars(arg).items()
                   if k not in ("train_data_path", "test_data_path", "log_dir", "save_freq", "freeze_graph_until", "gpus", "resume",
-                               "save_scores")}
+                               "save_scores") and not (k == "mfma" and v == "fp32")}
     run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
     if arg.notes:
         run_name += "-" + arg.notes
@@ -115,7 +118,7 @@ def main():
             return NpySkeletonData(prefix + ".npy", _label_path(prefix))
         train_data, test_data = open_data(arg.train_data_path), open_data(arg.test_data_path)
 
-    model = model_mod.Model(num_classes=arg.num_classes, device=dev, stream=arg.stream)
+    model = model_mod.Model(num_classes=arg.num_classes, device=dev, stream=arg.stream, mfma=arg.mfma)
     eng = model.engine
     trainer = Trainer(eng, batch_size=arg.batch_size, base_lr=arg.base_lr, steps=arg.steps, world_size=world)
     log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None

@@ -43,16 +43,17 @@ class _Variable:
 
 
 class Model(torch.nn.Module):
-    def __init__(self, num_classes=60, in_channels=3, device="cuda", seed=0, stream="joint"):
+    def __init__(self, num_classes=60, in_channels=3, device="cuda", seed=0, stream="joint", mfma="fp32"):
         """stream (not in the reference's constructor, which reads pre-computed files): 'joint', 'bone', 'joint_motion'
         or 'bone_motion' -- the bone (data_gen/gen_bone_data.py) and motion (data_gen/gen_motion_data.py) transforms are
-        applied on the fly to JOINT input inside the data_bn prologue, bit-exactly."""
+        applied on the fly to JOINT input inside the data_bn prologue, bit-exactly.
+        mfma: 'fp32' (the reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 everything else: sar_amd/stgcn.py)."""
         super().__init__()
         assert stream in ("joint", "bone", "joint_motion", "bone_motion"), stream
         from sar_amd.bone import NTU_BONE_PAIRS
         self.engine = STGCN(num_classes=num_classes, in_channels=in_channels, device=device, seed=seed,
                             bone_pairs=NTU_BONE_PAIRS if stream.startswith("bone") else None,
-                            motion=stream.endswith("motion"))
+                            motion=stream.endswith("motion"), mfma=mfma)
         # parameters are views into the engine's flat fp32 buffer (one all-reduce bucket, fused optimizer)
         self._names = list(self.engine.shapes)
         for k in self._names:

@@ -83,7 +83,7 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
                tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, bf16=False):
     """dW (and dbias, stored right behind it) -> dW_out[0 : wsize+bsize] (flat float32 view).  bf16=True routes the
-    9-tap temporal operator at stride 1 (V = 25) to sar_conv_wgrad_bf16 (bf16 MFMA operands, fp32 accumulation and bias
+    9-tap temporal operator (V = 25; stride 1, or stride 2 with the even-T SAME padding 3) to sar_conv_wgrad_bf16 (bf16 MFMA operands, fp32 accumulation and bias
     sums); every other shape stays on the fp32 kernel."""
     lib = L.load()
     d = WgradDesc()
@@ -92,10 +92,11 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
     # (a bf16 graph weight gradient was built and measured: with the adjacency gather in its stager it ran 1.7x SLOWER
     # than the fp32 kernel -- 9.0 vs 5.4 ms per step -- so the graph weight gradient stays on the fp32 kernel)
-    bf16 = bf16 and mode == L.SAR_CONV_TEMPORAL and taps == 9 and stride == 1 and V == 25
-    if bf16 and nsplit is None:     # 64 x 64 weight blocks, 8-frame tiles; one round of the 512 resident workgroups
+    bf16 = bf16 and mode == L.SAR_CONV_TEMPORAL and taps == 9 and V == 25 and (stride == 1 or (stride == 2 and pad == 3))
+    if bf16 and nsplit is None:     # 64 (m) x 64 / 32 (c, stride 1 / 2) weight blocks, 8-frame tiles; one round of the 512 resident workgroups
         ntiles = B * ((T_out + 7) // 8)
-        nsplit = max(1, min(ntiles, 512 // (((M + 63) // 64) * ((Kc + 63) // 64))))
+        cb = 64 if stride == 1 else 32
+        nsplit = max(1, min(ntiles, 512 // (((M + 63) // 64) * ((Kc + cb - 1) // cb))))
     if nsplit is None:
         ft = max(2, min((128 // V) & ~1, (T_out + 1) & ~1))
         bf = 64

@@ -56,8 +56,8 @@ class STGCN:
                  blocks=None, motion=False, mfma="fp32"):
         L.load()  # fail loudly if the HIP library is missing
         # mfma="bf16" (SURVEY.md 8d config 3): the graph / temporal / residual convolutions, their data gradients and the
-        # stride-1 temporal weight gradients round both MFMA operands to bfloat16 (sar_conv_gemm_bf16, sar_conv_wgrad_bf16);
-        # activations in HBM, accumulation, BatchNorm statistics, the remaining weight gradients, master weights and the
+        # temporal weight gradients round both MFMA operands to bfloat16 (sar_conv_gemm_bf16, sar_conv_wgrad_bf16);
+        # activations in HBM, accumulation, BatchNorm statistics, the graph / 1x1 weight gradients, master weights and the
         # optimizer stay fp32.  "fp32" (default) is the reference's arithmetic.
         assert mfma in ("fp32", "bf16")
         self.bf16 = mfma == "bf16"

@@ -132,8 +132,8 @@ def test_bf16_argument_errors(dev):
     d.M = 16
     assert lib.sar_conv_gemm_bf16(C.byref(d), ws.data_ptr(), None) < 0        # null tensors
     w = L.WgradDesc()
-    w.mode, w.B, w.V, w.T_src, w.T_out, w.Kc, w.M, w.taps, w.stride, w.pad, w.nsplit = L.SAR_CONV_TEMPORAL, 1, 25, 8, 4, 16, 16, 9, 2, 3, 1
-    assert lib.sar_conv_wgrad_bf16(C.byref(w), None) < 0                      # stride 2 is not built in bf16
+    w.mode, w.B, w.V, w.T_src, w.T_out, w.Kc, w.M, w.taps, w.stride, w.pad, w.nsplit = L.SAR_CONV_TEMPORAL, 1, 25, 8, 3, 16, 16, 9, 3, 3, 1
+    assert lib.sar_conv_wgrad_bf16(C.byref(w), None) < 0                      # stride 3 is not built in bf16
     assert b"stride 1" in lib.sar_last_error_string()
 
 
@@ -163,32 +163,34 @@ def test_train_step_bf16_close_to_fp32(dev):
             assert cos > 0.99, (k, cos.item())
 
 
-@pytest.mark.parametrize("B,f,T", [(2, 64, 13), (1, 64, 8), (2, 128, 20), (1, 256, 7), (4, 256, 75), (2, 72, 11), (1, 200, 9), (2, 40, 30),
-                                   (3, 24, 17)])
-def test_temporal_conv_weight_gradient_bf16(dev, B, f, T):
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (1, 64, 8, 1), (2, 128, 20, 1), (1, 256, 7, 1), (4, 256, 75, 1), (2, 72, 11, 1), (1, 200, 9, 1),
+                                     (2, 40, 30, 1), (3, 24, 17, 1), (2, 64, 14, 2), (2, 128, 20, 2), (1, 256, 38, 2), (3, 128, 150, 2),
+                                     (2, 72, 12, 2), (1, 40, 50, 2)])
+def test_temporal_conv_weight_gradient_bf16(dev, B, f, T, s):
     """dW from the bf16-rounded operand (after the folded BN + ReLU) and the bf16-rounded output gradient, fp32 accumulation;
     the bias gradient from the fp32 values."""
     from sar_amd import ops, _lib as L
     g = torch.Generator().manual_seed(7 * f + T)
     gx = torch.randn(B, f, T, 25, generator=g)
     sc = 1 + 0.2 * torch.randn(f, generator=g); sh = 0.3 * torch.randn(f, generator=g)
-    du = torch.randn(B, f, T, 25, generator=g)
+    To, pad, _ = O.same_pad(T, 9, s)
+    du = torch.randn(B, f, To, 25, generator=g)
     h = torch.relu((gx.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float())
     kernel = torch.zeros(9, 1, f, f, dtype=torch.float64, requires_grad=True)
-    y = O.temporal_conv(_bf(h), kernel, None, 1)
+    y = O.temporal_conv(_bf(h), kernel, None, s)
     g_k, = torch.autograd.grad(y, kernel, _bf(du))
     g_b = du.double().sum(dim=(0, 2, 3))
     flat = torch.zeros(9 * f * f + f, device=dev)
-    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx).to(dev), to_cn(du).to(dev), flat, B=B, V=25, T_src=T, T_out=T, Kc=f,
-                   M=f, taps=9, stride=1, pad=4, pro=(sc.to(dev), sh.to(dev)), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
+    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx).to(dev), to_cn(du).to(dev), flat, B=B, V=25, T_src=T, T_out=To, Kc=f,
+                   M=f, taps=9, stride=s, pad=pad, pro=(sc.to(dev), sh.to(dev)), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
                    wsize=9 * f * f, bsize=f, bf16=True)
     torch.cuda.synchronize()
     assert rel_err(flat[:9 * f * f].cpu().view(9, 1, f, f), g_k) < TOL
     assert rel_err(flat[9 * f * f:].cpu(), g_b) < 1e-5
     # several explicit split counts give the same sums (deterministic slab reduction)
     flat2 = torch.zeros_like(flat)
-    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx).to(dev), to_cn(du).to(dev), flat2, B=B, V=25, T_src=T, T_out=T, Kc=f,
-                   M=f, taps=9, stride=1, pad=4, pro=(sc.to(dev), sh.to(dev)), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
+    ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx).to(dev), to_cn(du).to(dev), flat2, B=B, V=25, T_src=T, T_out=To, Kc=f,
+                   M=f, taps=9, stride=s, pad=pad, pro=(sc.to(dev), sh.to(dev)), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
                    wsize=9 * f * f, bsize=f, bf16=True, nsplit=3)
     torch.cuda.synchronize()
     assert rel_err(flat2[:9 * f * f].cpu().view(9, 1, f, f), g_k) < TOL
