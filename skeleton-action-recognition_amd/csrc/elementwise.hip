@@ -45,12 +45,26 @@ __global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* __restric
                                                           float* running_mean, float* running_var, float* mean_o,
                                                           float* rstd_o, float* scale_o, float* shift_o) {
   const int c = blockIdx.x;
-  const float* p = partials + (int64_t)c * nparts * 2;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += TPB) {
-    s1 += (double)p[2 * i];
-    s2 += (double)p[2 * i + 1];
+  // (sum, sum of squares) pairs: 8-byte loads, four independent fp64 chains per thread so that the loads overlap
+  const float2* p = reinterpret_cast<const float2*>(partials) + (int64_t)c * nparts;
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+  int i = threadIdx.x;
+  for (; i + 3 * TPB < nparts; i += 4 * TPB) {
+    float2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = p[i + q * TPB];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a1[q] += (double)v[q].x;
+      a2[q] += (double)v[q].y;
+    }
   }
+  for (; i < nparts; i += TPB) {
+    const float2 v = p[i];
+    a1[0] += (double)v.x;
+    a2[0] += (double)v.y;
+  }
+  double s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   __shared__ double red[2][4];
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
@@ -96,11 +110,26 @@ __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* __res
                                                               float* dgamma, float* dbeta, float* k1, float* k2, float* k3) {
   const int c = blockIdx.x;
   const float* p = partials + (int64_t)c * chan_stride;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += TPB) {
-    s1 += (double)p[(int64_t)i * part_stride + off1];
-    s2 += (double)p[(int64_t)i * part_stride + off2];
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};   // four independent chains: the loads overlap
+  int i = threadIdx.x;
+  for (; i + 3 * TPB < nparts; i += 4 * TPB) {
+    float u[4], w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u[q] = p[(int64_t)(i + q * TPB) * part_stride + off1];
+      w[q] = p[(int64_t)(i + q * TPB) * part_stride + off2];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a1[q] += (double)u[q];
+      a2[q] += (double)w[q];
+    }
   }
+  for (; i < nparts; i += TPB) {
+    a1[0] += (double)p[(int64_t)i * part_stride + off1];
+    a2[0] += (double)p[(int64_t)i * part_stride + off2];
+  }
+  double s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   __shared__ double red[2][4];
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
@@ -340,24 +369,52 @@ inline int row_blocks(int64_t n, int vec) {
 }
 
 // ------------------------------------------------------------------------------------ head
+// one wave per (sample n, channel c): 4 independent partial sums per lane, no LDS, no barrier
 __global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__ y, int64_t ldm, int span, float inv,
-                                                       int C, float* __restrict__ feat) {
-  const int n = blockIdx.x, c = blockIdx.y;
+                                                       int C, int N, float* __restrict__ feat) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), c = blockIdx.y;
+  if (n >= N) return;
   const float* p = y + (int64_t)c * ldm + (int64_t)n * span;
-  float acc[1] = {0.f};
-  for (int i = threadIdx.x; i < span; i += TPB) acc[0] += p[i];
-  __shared__ float red[4];
-  block_sum<1>(acc, red);
-  if (threadIdx.x == 0) feat[(int64_t)n * C + c] = acc[0] * inv;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = lane;
+  for (; i + 192 < span; i += 256) {
+    a0 += p[i];
+    a1 += p[i + 64];
+    a2 += p[i + 128];
+    a3 += p[i + 192];
+  }
+  for (; i < span; i += 64) a0 += p[i];
+  const float t = wave_sum((a0 + a1) + (a2 + a3));
+  if (lane == 0) feat[(int64_t)n * C + c] = t * inv;
 }
 
-__global__ void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W, const float* __restrict__ bias,
-                              int C, int K, float* __restrict__ logits) {
+// one workgroup per sample: the channel range is split over the 4 waves (two chains per lane), partials combined in
+// a fixed order
+__global__ __launch_bounds__(TPB) void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, int C, int K, float* __restrict__ logits) {
   const int n = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float s = bias ? bias[k] : 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(feat[(int64_t)n * C + c], W[(int64_t)c * K + k], s);
-    logits[(int64_t)n * K + k] = s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* f = feat + (int64_t)n * C;
+  const int cq = (C + 3) / 4;
+  const int cb = wave * cq, ce = (cb + cq < C) ? cb + cq : C;
+  __shared__ float part[4][64];
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int k = k0 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (k < K) {
+      int c = cb;
+      for (; c + 1 < ce; c += 2) {
+        s0 = fmaf(f[c], W[(int64_t)c * K + k], s0);
+        s1 = fmaf(f[c + 1], W[(int64_t)(c + 1) * K + k], s1);
+      }
+      if (c < ce) s0 = fmaf(f[c], W[(int64_t)c * K + k], s0);
+    }
+    part[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && k < K)
+      logits[(int64_t)n * K + k] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + (bias ? bias[k] : 0.f);
+    __syncthreads();
   }
 }
 
@@ -592,8 +649,9 @@ extern "C" int sar_pool_fwd_f32(const float* y, int64_t ldm, int C, int B, int T
   SAR_REQUIRE(y && feat && C > 0 && B > 0 && TV > 0 && Mp > 0 && B % Mp == 0 && ldm >= (int64_t)B * TV,
               "sar_pool_fwd: bad arguments");
   const int span = Mp * TV;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B / Mp, C), dim3(TPB), 0, as_stream(s), y, ldm, span, 1.0f / (float)span, C,
-                     feat);
+  const int N = B / Mp;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3((N + TPB / 64 - 1) / (TPB / 64), C), dim3(TPB), 0, as_stream(s), y, ldm, span,
+                     1.0f / (float)span, C, N, feat);
   SAR_LAUNCH_CHECK("sar_pool_fwd_f32");
   return 0;
 }
@@ -601,7 +659,7 @@ extern "C" int sar_pool_fwd_f32(const float* y, int64_t ldm, int C, int B, int T
 extern "C" int sar_fc_fwd_f32(const float* feat, const float* W, const float* bias, int N, int C, int K, float* logits,
                               sar_stream_t s) {
   SAR_REQUIRE(feat && W && logits && N > 0 && C > 0 && K > 0, "sar_fc_fwd: bad arguments");
-  hipLaunchKernelGGL(fc_fwd_kernel, dim3(N), dim3(128), 0, as_stream(s), feat, W, bias, C, K, logits);
+  hipLaunchKernelGGL(fc_fwd_kernel, dim3(N), dim3(TPB), 0, as_stream(s), feat, W, bias, C, K, logits);
   SAR_LAUNCH_CHECK("sar_fc_fwd_f32");
   return 0;
 }
