@@ -1,0 +1,3 @@
+// part 10 of conv2d.hip (see the build note in its header)
+#define SAR_C2D_PART 10
+#include "conv2d.hip"

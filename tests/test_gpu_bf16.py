@@ -254,3 +254,26 @@ def test_graph_conv_data_gradient_bf16(dev, B, cin, f, T):
                   tables=_tables(dev, True), epi=L.SAR_EPI_ADD, aux=to_cn(skip).to(dev), bf16=True)
     torch.cuda.synchronize()
     assert rel_err(from_cn(dX.cpu(), B, T, 25), ref) < TOL
+
+
+def test_bf16_mode_trains_like_fp32(dev):
+    """40 Nesterov-SGD steps on one small fixed batch: both modes drive the loss down and stay close to each other (the
+    bf16 operands perturb each step by ~1e-2 relative; the trajectories must not drift apart)."""
+    from sar_amd.stgcn import STGCN
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True)]
+    p = O.init_params(10, seed=3, dtype=torch.float64, blocks=blocks)
+    x, y = O.synthetic_batch(8, seed=5, T=32, num_classes=10)
+    losses = {}
+    for mode in ("fp32", "bf16"):
+        eng = STGCN(num_classes=10, device=dev, blocks=blocks, mfma=mode)
+        eng.load_params(p)
+        hist = []
+        for _ in range(40):
+            _, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+            eng.sgd_step(0.05)
+            hist.append(loss.item())
+        losses[mode] = hist
+    f, b = losses["fp32"], losses["bf16"]
+    assert f[-1] < 0.5 * f[0] and b[-1] < 0.5 * b[0], (f[0], f[-1], b[0], b[-1])
+    assert abs(b[0] - f[0]) < 2e-2 * f[0]
+    assert abs(b[-1] - f[-1]) < 0.25 * f[0], (f[-1], b[-1])
