@@ -25,9 +25,15 @@ def short(n):
     return n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
+def newest(pattern):
+    """the most recent run only (gpurun_out accumulates the files of earlier calls)"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def pmc(sub, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for f in glob.glob(os.path.join(P, sub, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(P, sub, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 a = agg[short(r["Kernel_Name"])]
@@ -36,7 +42,7 @@ def pmc(sub, counter):
     return agg
 
 
-stats = glob.glob(os.path.join(P, "trace", "*", "*kernel_stats.csv"))[0]
+stats = newest(os.path.join(P, "trace", "*", "*kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(OUT, "%s_bench_kernel_stats.csv" % tag))
 dur = {}
 for r in csv.DictReader(open(stats)):
