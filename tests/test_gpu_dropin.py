@@ -73,3 +73,19 @@ def test_main_gnn_cli_trains_on_synthetic_data(tmp_path):
     assert os.listdir(tmp_path) == runs                  # same run directory (resume / save-scores are not part of its name)
     scores = np.load(os.path.join(run, "scores-2.npy"))
     assert scores.shape == (24, 60) and np.allclose(scores.sum(1), 1, atol=1e-4)
+
+
+def test_main_gnn_cli_bf16_mode(tmp_path):
+    """--mfma bf16 (not a reference flag): the same command line on the bf16-operand kernels; the flag is part of the
+    run name only when it is not the default."""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "skeleton-action-recognition_amd"))
+    cmd = [sys.executable, os.path.join(ROOT, "skeleton-action-recognition_amd", "main_gnn.py"), "--model", "stgcn",
+           "--synthetic", "--synthetic-size", "32", "--batch-size", "8", "--num-epochs", "1", "--save-freq", "1",
+           "--max-iters", "2", "--mfma", "bf16", "--log-dir", str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    runs = os.listdir(tmp_path)
+    assert len(runs) == 1 and "mfma:bf16" in runs[0]
+    losses = [json.loads(line)["value"] for line in open(os.path.join(tmp_path, runs[0], "scalars.jsonl"))
+              if json.loads(line)["tag"] == "cross_entropy_loss"]
+    assert len(losses) == 2 and all(np.isfinite(losses))
