@@ -105,6 +105,17 @@ int sar_conv_gemm_f32(const sar_conv_desc* d, sar_stream_t s);
  * bf16 weights, rewritten by every call).  Partial-sum layout: sar_conv_gemm_nparts. */
 int64_t sar_conv_gemm_bf16_workspace_bytes(const sar_conv_desc* d);
 int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_stream_t s);
+/* Packing many weight tensors in ONE launch (a training step packs every layer, in both orientations, from the flat
+ * parameter buffer): item i reads element (tap, c, m) at base[src_off + tap*st + c*sc + m*sm] -- a data gradient is the
+ * same tensor with sc and sm exchanged, no transposed copy needed -- and writes the image sar_conv_gemm_bf16 expects
+ * at out + 16*dst_unit bytes (taps * G * M units, G = 2*ceil(Kc/16)).  A descriptor with W == NULL makes
+ * sar_conv_gemm_bf16 take `workspace` as such an already packed image.  `items` is a DEVICE array. */
+typedef struct sar_pack_item {
+  int64_t src_off, st, sc, sm, dst_unit;
+  int32_t taps, Kc, M, G;
+} sar_pack_item;
+int sar_pack_weights_bf16_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units, void* out,
+                                sar_stream_t s);
 
 /* Weight gradient of the same operator (reduction over all positions n):
  *   dW[tap][c][m] = sum_n dout[m, n] * OP_tap(pro(src))[c, n]        (tf.GradientTape of the conv,

@@ -66,6 +66,25 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int64_t st, int
   out[u] = *reinterpret_cast<uint4*>(&p);
 }
 
+// the same for many tensors at once (blockIdx.y = item): sar_pack_weights_bf16_batch
+__global__ void pack_weights_batch_kernel(const float* __restrict__ base, const sar_pack_item* __restrict__ items,
+                                          uint4* __restrict__ out) {
+  const sar_pack_item it = items[blockIdx.y];
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= (int64_t)it.taps * it.G * it.M) return;
+  const int m = (int)(u % it.M);
+  const int g = (int)((u / it.M) % it.G);
+  const int tp = (int)(u / ((int64_t)it.M * it.G));
+  const float* W = base + it.src_off + tp * it.st + m * it.sm;
+  bf16x8 p;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 8 * g + j;
+    p[j] = (__bf16)(c < it.Kc ? W[c * it.sc] : 0.f);
+  }
+  out[it.dst_unit + u] = *reinterpret_cast<uint4*>(&p);
+}
+
 // ---- epilogue (as conv_gemm.hip): mask / add, store, BatchNorm partial sums.  Every wave is past its last MFMA phase
 // and the closing barrier: the transpose area aliases the operand image.
 template <int MS, int NS, int WN, int BM>
@@ -637,8 +656,9 @@ int launch_cfg_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
   k.ny = (d.M + BM - 1) / BM;
   const int nwork = k.ntiles * k.ny;
   const int64_t units = (int64_t)d.taps * k.G * d.M;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, d.W, d.w_stride_tap,
-                     d.w_stride_c, d.taps, d.Kc, d.M, k.G, wp);
+  if (d.W)   // else: `wp` already holds the packed image (sar_pack_weights_bf16_batch)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, d.W, d.w_stride_tap,
+                       d.w_stride_c, d.taps, d.Kc, d.M, k.G, wp);
   hipLaunchKernelGGL((conv_gemm_bf16_kernel<TR, TAPS, MS, NS, WM, WN>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
   return 0;
 }
@@ -658,8 +678,9 @@ int launch_graph_cfg_b(const sar_conv_desc& d, uint4* wp, hipStream_t st) {
   k.ny = (d.M + BM - 1) / BM;
   const int nwork = k.ntiles * k.ny;
   const int64_t units = (int64_t)3 * k.G * d.M;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, d.W, d.w_stride_tap,
-                     d.w_stride_c, 3, d.Kc, d.M, k.G, wp);
+  if (d.W)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, d.W, d.w_stride_tap,
+                       d.w_stride_c, 3, d.Kc, d.M, k.G, wp);
   hipLaunchKernelGGL((conv_graph_bf16_kernel<MS, NS, WM, WN, NZ0, NZ1, NZ2>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
   return 0;
 }
@@ -707,7 +728,7 @@ extern "C" int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_s
   SAR_REQUIRE(d->B > 0 && d->V > 0 && d->V <= 64 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0,
               "sar_conv_gemm_bf16: bad sizes");
   SAR_REQUIRE((d->M & 7) == 0, "sar_conv_gemm_bf16: M must be a multiple of 8 (got %d)", d->M);
-  SAR_REQUIRE(d->src && d->out && d->W, "sar_conv_gemm_bf16: null src/out/W");
+  SAR_REQUIRE(d->src && d->out, "sar_conv_gemm_bf16: null src/out");   /* W == NULL: workspace is already packed */
   if (d->mode == SAR_CONV_GRAPH) {
     SAR_REQUIRE(d->taps == 3 && d->T_src == d->T_out, "sar_conv_gemm_bf16: graph mode needs 3 adjacency slices and keeps T");
     SAR_REQUIRE(d->g_idx && d->g_wt, "sar_conv_gemm_bf16: graph gather tables required");
@@ -732,5 +753,16 @@ extern "C" int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_s
   int rc = dispatch_b(*d, (uint4*)workspace, as_stream(s));
   if (rc) return rc;
   SAR_LAUNCH_CHECK("sar_conv_gemm_bf16");
+  return 0;
+}
+
+extern "C" int sar_pack_weights_bf16_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units,
+                                           void* out, sar_stream_t s) {
+  SAR_REQUIRE(base && items && out && nitems > 0 && max_units > 0, "sar_pack_weights_bf16_batch: bad arguments");
+  SAR_REQUIRE(((uintptr_t)out & 15) == 0, "sar_pack_weights_bf16_batch: out must be 16-byte aligned");
+  SAR_REQUIRE(nitems <= 65535 && (max_units + 255) / 256 < (1ll << 31), "sar_pack_weights_bf16_batch: too many items / units");
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)((max_units + 255) / 256), nitems), dim3(256), 0, as_stream(s),
+                     base, items, (uint4*)out);
+  SAR_LAUNCH_CHECK("sar_pack_weights_bf16_batch");
   return 0;
 }

@@ -69,6 +69,7 @@ SIGNATURES = {
     "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),
     "sar_conv_gemm_bf16_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_bf16": (_i, [C.POINTER(ConvDesc), _fp, _fp]),
+    "sar_pack_weights_bf16_batch": (_i, [_fp, _fp, _i, _i64, _fp, _fp]),
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_conv_wgrad_bf16": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),

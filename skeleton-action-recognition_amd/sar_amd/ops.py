@@ -30,9 +30,44 @@ class GraphTables:
         self.K, self.V = idx.shape[0], idx.shape[1]
 
 
+class PackedWeights:
+    """bf16 operand images of many weight tensors, refreshed from the flat parameter buffer by ONE launch
+    (sar_pack_weights_bf16_batch).  add() registers element (tap, c, m) at base[src_off + tap*st + c*sc + m*sm]; a data
+    gradient registers the same tensor with the roles of c and m exchanged (no transposed copy)."""
+
+    ITEM = [("src_off", "<i8"), ("st", "<i8"), ("sc", "<i8"), ("sm", "<i8"), ("dst_unit", "<i8"),
+            ("taps", "<i4"), ("Kc", "<i4"), ("M", "<i4"), ("G", "<i4")]
+
+    def __init__(self):
+        self.items, self.index, self.units = [], {}, 0
+
+    def add(self, key, src_off, st, sc, sm, taps, Kc, M):
+        G = 2 * ((Kc + 15) // 16)
+        n = taps * G * M
+        self.index[key] = (self.units, n)
+        self.items.append((src_off, st, sc, sm, self.units, taps, Kc, M, G))
+        self.units += n
+
+    def finalize(self, device):
+        import numpy as np
+        tab = np.array(self.items, dtype=np.dtype(self.ITEM, align=True))
+        assert tab.dtype.itemsize == 56          # sizeof(sar_pack_item)
+        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(device)
+        self.max_units = max(it[5] * it[8] * it[7] for it in self.items)
+        self.buf = torch.empty(self.units * 16, dtype=torch.uint8, device=device)
+
+    def refresh(self, flat):
+        check(L.load().sar_pack_weights_bf16_batch(ptr(flat), ptr(self.table), len(self.items), self.max_units, ptr(self.buf),
+                                                   stream_ptr()), "sar_pack_weights_bf16_batch")
+
+    def image(self, key):
+        off, n = self.index[key]
+        return self.buf[off * 16:(off + n) * 16]
+
+
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
-              aux_affine=None, aux_mean=None, bf16=False):
+              aux_affine=None, aux_mean=None, bf16=False, packed=None):
     """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (M % 8 == 0, Kc >= 16: bf16
     MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel).  Returns (partials, nparts) when the
     epilogue reduces, else None."""
@@ -44,7 +79,9 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     _f32(src), _f32(out), _f32(W)
     d.src, d.ld_src = ptr(src), src.stride(0)
     d.out, d.ld_out = ptr(out), out.stride(0)
-    d.W, d.w_stride_tap, d.w_stride_c = ptr(W), w_stride_tap, w_stride_c
+    bf16 = bf16 and M % 8 == 0 and Kc >= 16
+    use_packed = bf16 and packed is not None      # packed: the operand image from PackedWeights (W is then not read)
+    d.W, d.w_stride_tap, d.w_stride_c = (None if use_packed else ptr(W)), w_stride_tap, w_stride_c
     d.bias = ptr(_f32(bias))
     if pro is not None:
         d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
@@ -69,9 +106,9 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     n_conv = B * (T_src if transposed else T_out) * V
     flops = 2.0 * M * Kc * taps * n_conv
     tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else "")))
-    bf16 = bf16 and M % 8 == 0 and Kc >= 16
     if bf16:
-        ws = torch.empty(lib.sar_conv_gemm_bf16_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=src.device)
+        ws = packed if use_packed else torch.empty(lib.sar_conv_gemm_bf16_workspace_bytes(C.byref(d)), dtype=torch.uint8,
+                                                   device=src.device)
         with profiler.region(tag + "_bf16", flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
             check(lib.sar_conv_gemm_bf16(C.byref(d), ptr(ws), stream_ptr()), "sar_conv_gemm_bf16")
     else:

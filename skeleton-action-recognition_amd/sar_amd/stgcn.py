@@ -116,6 +116,30 @@ class STGCN:
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.velocity = torch.zeros(total, dtype=torch.float32, device=dev)
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.packed = None
+        if self.bf16:      # bf16 operand images of every conv weight, both orientations, refreshed by one launch per forward
+            pk = ops.PackedWeights()
+            cin = in_channels
+            for i, (f, s_, res) in enumerate(self.blocks):
+                pre = "l%d." % i
+                og, ot = self.offsets[pre + "gcn.kernel"], self.offsets[pre + "tcn.kernel"]
+                if f % 8 == 0 and cin >= 16:
+                    pk.add(pre + "gcn.f", og, f, KS * f, 1, KS, cin, f)          # (k, c, m) = kernel[c][k*F + m]
+                if cin % 8 == 0 and f >= 16:
+                    pk.add(pre + "gcn.b", og, f, 1, KS * f, KS, f, cin)          # (k, c', m') = kernel[m'][k*F + c']
+                if f % 8 == 0 and f >= 16:
+                    pk.add(pre + "tcn.f", ot, f * f, f, 1, KT, f, f)             # (tap, c, m) = kernel[tap][c][m]
+                    pk.add(pre + "tcn.b", ot, f * f, 1, f, KT, f, f)             # (tap, c', m') = kernel[tap][m'][c']
+                if self.kinds[i] == "conv":
+                    orr = self.offsets[pre + "res.kernel"]
+                    if f % 8 == 0 and cin >= 16:
+                        pk.add(pre + "res.f", orr, 0, f, 1, 1, cin, f)
+                    if cin % 8 == 0 and f >= 16:
+                        pk.add(pre + "res.b", orr, 0, 1, f, 1, f, cin)
+                cin = f
+            if pk.items:
+                pk.finalize(dev)
+                self.packed = pk
         self.p = {k: self._view(self.flat, k) for k in self.shapes}
         self.g = {k: self._view(self.grad, k) for k in self.shapes}
         self.bn = {"data_bn": _BN(nch, dev)}
@@ -191,6 +215,8 @@ class STGCN:
         assert Cin == self.C_in and V == self.V
         dev, B = x.device, N * M
         saved = {"x": x, "N": N, "M": M, "T": T, "blocks": [], "training": training}
+        if self.packed is not None:
+            self.packed.refresh(self.flat)       # the parameters may have changed since the last step
         # ---- data_bn (models/stgcn.py:142-147)
         nch = V * Cin
         if training:
@@ -229,7 +255,8 @@ class STGCN:
         # sgcn: GraphConvTD (models/gcn.py:199-209)
         g = torch.empty((f, n_in), dtype=torch.float32, device=dev)
         r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
-                           Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi, bf16=self.bf16)
+                           Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi, bf16=self.bf16,
+                           packed=self._img(pre + "gcn.f"))
         if training:
             self._bn_forward_stats(pre + "bn1", r1[0], r1[1], n_in, True, True)
         else:
@@ -239,7 +266,7 @@ class STGCN:
         u = torch.empty((f, n_out), dtype=torch.float32, device=dev)
         r2 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, g, u, self.p[pre + "tcn.kernel"], f * f, f, B=B, V=V, T_src=T, T_out=To,
                            Kc=f, M=f, taps=KT, stride=s, pad=pad, bias=self.p[pre + "tcn.bias"],
-                           pro=(bn1.scale, bn1.shift), pro_relu=True, epi=epi, bf16=self.bf16)
+                           pro=(bn1.scale, bn1.shift), pro_relu=True, epi=epi, bf16=self.bf16, packed=self._img(pre + "tcn.f"))
         if training:
             self._bn_forward_stats(pre + "bn2", r2[0], r2[1], n_out, True, True)
         else:
@@ -250,7 +277,8 @@ class STGCN:
         if kind == "conv":  # models/stgcn.py:47-56
             r = torch.empty((f, n_out), dtype=torch.float32, device=dev)
             r3 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, X, r, self.p[pre + "res.kernel"], 0, f, B=B, V=V, T_src=T, T_out=To,
-                               Kc=cin, M=f, taps=1, stride=s, pad=0, bias=self.p[pre + "res.bias"], epi=epi, bf16=self.bf16)
+                               Kc=cin, M=f, taps=1, stride=s, pad=0, bias=self.p[pre + "res.bias"], epi=epi, bf16=self.bf16,
+                               packed=self._img(pre + "res.f"))
             if training:
                 self._bn_forward_stats(pre + "res_bn", r3[0], r3[1], n_out, True, True)
             else:
@@ -265,6 +293,10 @@ class STGCN:
         if keep is not None:
             keep[pre + "g"], keep[pre + "u"], keep[pre + "y"] = g, u, y
         return y, To
+
+    def _img(self, key):
+        """packed bf16 operand image of a conv weight (bf16 mode), else None"""
+        return self.packed.image(key) if self.packed is not None and key in self.packed.index else None
 
     # ------------------------------------------------------------------ backward
     def _off_critical_path(self, fn, *tensors):
@@ -343,12 +375,15 @@ class STGCN:
             L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
             pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
             bf16=self.bf16), g, du)
-        wT = torch.empty((KT, f, f), dtype=torch.float32, device=dev)
-        ops.transpose(self.p[pre + "tcn.kernel"], wT, KT, f, f)          # [tap][c][f] -> [tap][f][c]
+        wimg = self._img(pre + "tcn.b")
+        wT = None
+        if wimg is None:
+            wT = torch.empty((KT, f, f), dtype=torch.float32, device=dev)
+            ops.transpose(self.p[pre + "tcn.kernel"], wT, KT, f, f)      # [tap][c][f] -> [tap][f][c]
         dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
         pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, du, dz1, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=KT,
                            stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g,
-                           aux_affine=(bn1.scale, bn1.shift), aux_mean=bn1.mean, bf16=self.bf16)
+                           aux_affine=(bn1.scale, bn1.shift), aux_mean=bn1.mean, bf16=self.bf16, packed=wimg)
         ops.bn_bwd_finalize(pm[0], pm[1], pm[1] * 2, 2, 0, 1, f, n_in, self.p[pre + "bn1.gamma"], bn1.mean, bn1.rstd,
                             self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
         dg = dz1
@@ -365,18 +400,25 @@ class STGCN:
             self._off_critical_path(lambda: ops.conv_wgrad(
                 L.SAR_CONV_TEMPORAL, X, dr, flat_r, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
                 w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f), X, dr)
-            rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
-            ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
+            rimg = self._img(pre + "res.b")
+            rT = None
+            if rimg is None:
+                rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
+                ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
             dXres = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
             ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
-                          stride=s, pad=0, transposed=True, bf16=self.bf16)
+                          stride=s, pad=0, transposed=True, bf16=self.bf16, packed=rimg)
         # ---- graph conv data gradient (+ skip-path gradient)
-        gT = torch.empty((KS * f, cin), dtype=torch.float32, device=dev)
-        ops.transpose(self.p[pre + "gcn.kernel"], gT, 1, cin, KS * f)    # [c][k*F+f] -> [k][f][c]
+        gimg = self._img(pre + "gcn.b")
+        gT = None
+        if gimg is None:
+            gT = torch.empty((KS * f, cin), dtype=torch.float32, device=dev)
+            ops.transpose(self.p[pre + "gcn.kernel"], gT, 1, cin, KS * f)    # [c][k*F+f] -> [k][f][c]
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
         ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
-                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux, bf16=self.bf16)
+                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux, bf16=self.bf16,
+                      packed=gimg)
         return dX
 
     # ------------------------------------------------------------------ training step
