@@ -203,3 +203,26 @@ def test_bone_stream_120_classes(dev):
     for k, g in grads_ref.items():
         if g.abs().max().item() >= 1e-9:
             assert rel_err(eng.g[k].cpu(), g) < TOL, k
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_train_step_is_bitwise_deterministic(dev, mode):
+    """Full NTU shape (T = 300, 10 blocks): no atomics, every reduction in a fixed order => logits, loss and the whole
+    gradient buffer repeat bit for bit; a mismatch would mean a race in a kernel (LDS hazard, missing barrier).
+    tools/determinism_check.py runs the same check at the bench batch size."""
+    from sar_amd.stgcn import STGCN
+    from sar_amd.train import synthetic_clips
+    x, y = synthetic_clips(6, dev, seed=3, num_classes=60)
+    eng = STGCN(num_classes=60, device=dev, seed=0, mfma=mode)
+    state = {k: v.clone() for k, v in eng.state_dict().items()}
+    ref = None
+    for _ in range(3):
+        eng.load_params(state)
+        logits, loss = eng.loss_and_grad(x, y)
+        torch.cuda.synchronize()
+        cur = (logits.clone(), loss.clone(), eng.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(p, q) for p, q in zip(ref, cur))
+    assert torch.isfinite(ref[2]).all()
