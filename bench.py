@@ -50,34 +50,61 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(sample_clips, budget_s=25.0):
-    """Times the CPU oracle (oracle/stgcn.py: torch CPU ops, fp32) -- fwd + bwd + Nesterov SGD -- on a bounded
-    sample of the same workload.  The oracle is used here ONLY as the reported CPU baseline."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch=64, fallback_clips=8, budget_s=150.0):
+    """SURVEY.md 8(d) protocol: the CPU oracle (oracle/stgcn.py: torch CPU ops, fp32) -- fwd + bwd + Nesterov SGD -- on
+    the bs = `batch` synthetic batch, all physical cores.  One short warm-up step on `fallback_clips` clips (thread pool,
+    allocator) also predicts the cost of a full-batch step: if one would not fit `budget_s`, the small batch is timed
+    instead and the sample string says so.  Otherwise 1 untimed + up to 2 timed full-batch steps (the second only while
+    inside the budget).  The oracle is used here ONLY as the reported CPU baseline."""
     import torch
     from oracle import stgcn as O
     cores = physical_cores()
     torch.set_num_threads(cores)
     p = O.init_params(60, seed=0)
-    x, y = O.synthetic_batch(sample_clips, seed=0, T=300, num_classes=60)
     vel = {}
 
-    def one():
+    def one(x, y):
         _, _, grads, new, _ = O.loss_and_grads(p, x, y)
         O.sgd_nesterov_step(p, grads, vel, 0.1)
         p.update(new)
 
-    one()                                  # warm-up
+    xs, ys = O.synthetic_batch(fallback_clips, seed=0, T=300, num_classes=60)
+    one(xs, ys)                            # thread-pool / allocator warm-up
     t0 = time.time()
-    n = 0
-    while True:
-        one()
-        n += 1
-        if time.time() - t0 > budget_s or n >= 5:
-            break
-    dt = time.time() - t0
-    return {"value": round(sample_clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "%d timed steps of fwd+bwd+SGD on a %d-clip (3,300,25,2) fp32 batch, torch CPU ops, %d threads"
-                      % (n, sample_clips, cores)}
+    one(xs, ys)
+    small_rate = fallback_clips / (time.time() - t0)
+    full = batch / small_rate * 3 <= budget_s * 1.5          # 1 warm-up + 2 timed steps predicted to fit
+    if full:
+        x, y = O.synthetic_batch(batch, seed=0, T=300, num_classes=60)
+        one(x, y)                          # untimed
+        t0 = time.time()
+        n = 0
+        while n < 2 and (n == 0 or time.time() - t0 < budget_s / 2):
+            one(x, y)
+            n += 1
+        dt = time.time() - t0
+        clips, what = batch, "SURVEY 8(d) protocol: 1 warm-up + %d timed steps" % n
+    else:
+        t0 = time.time()
+        n = 0
+        while n < 5 and (n == 0 or time.time() - t0 < 25.0):
+            one(xs, ys)
+            n += 1
+        dt = time.time() - t0
+        clips, what = fallback_clips, "FALLBACK (a bs=%d step would exceed the %d s budget): %d timed steps" % (batch, budget_s, n)
+    return {"value": round(clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
+            "sample": "%s of fwd+bwd+SGD on a %d-clip (3,300,25,2) fp32 batch, torch CPU ops, %d threads"
+                      % (what, clips, cores)}
 
 
 def cpu_baseline_spectrogram(sample_clips, budget_s=25.0):
@@ -112,7 +139,7 @@ def cpu_baseline_spectrogram(sample_clips, budget_s=25.0):
         if time.time() - t0 > budget_s or n >= 5:
             break
     dt = time.time() - t0
-    return {"value": round(sample_clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+    return {"value": round(sample_clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
             "sample": "%d timed steps of VirtualRadar + resnet18 fwd+bwd+Adam on %d (3,300,25,2) clips, numpy / torch CPU ops, "
                       "%d threads" % (n, sample_clips, cores)}
 
@@ -123,32 +150,16 @@ def main_spectrogram(args):
     import torch
     import torch.distributed as dist
     from sar_amd import profiler
-    from sar_amd.train import allreduce_sum_, synthetic_clips
+    from sar_amd.train import SpectrogramTrainer, synthetic_clips
     from models.resnet import Model
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dev = rank_setup(args)
     bs = 32 if args.batch == 64 else args.batch
     model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=args.num_pad_frames)
-    eng = model.base_model.engine
+    trainer = SpectrogramTrainer(model, 1e-3, world_size=world)      # the product step of main_spectrogram.py
     batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
 
     def step(i):
-        x, y = batches[i % 4]
-        with torch.no_grad():
-            img = model.spectrogram(x)
-        _, loss = eng.loss_and_grad(img, y)
-        if world > 1:
-            allreduce_sum_(eng.grad)
-            eng.grad.div_(world)
-        eng.adam_step(1e-3)
-        return loss
+        return trainer.step(*batches[i % 4], 1e-3)[1]
 
     def sync():
         torch.cuda.synchronize()
@@ -184,10 +195,7 @@ def main_spectrogram(args):
     profiler.install(None)
     if graphs is not None:
         loss = step(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = max_over_ranks(dt, dev)
     if rank == 0:
         summ = timer.summary()
         fam = [k for k in summ if k.startswith("conv2d_3x3")]
@@ -198,7 +206,7 @@ def main_spectrogram(args):
         value = bs * world * args.steps / dt
         out = {
             "metric": "spectrogram clips/sec training (VirtualRadar + resnet18, bs=%d/GPU)" % bs,
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VirtualRadar -> (B,1,256,256) log-spectrogram -> resnet18 fp32 training step (fwd+bwd+Adam), "
@@ -222,6 +230,46 @@ def main_spectrogram(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through torch.distributed.run
+    and relay their output.  Called BEFORE this process imports torch or touches the GPU (a process that has initialised
+    the GPU must not be replaced, and the ranks must be fresh processes)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def rank_setup(args):
+    """(rank, world, device) of this process; joins the process group when world > 1 (backend nccl = RCCL over xGMI;
+    SAR_BENCH_SHARE_GPU=1 -- a test switch for one-GPU boxes -- puts every rank on cuda:0 over gloo)."""
+    import torch
+    from sar_amd.train import init_distributed
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    share = os.environ.get("SAR_BENCH_SHARE_GPU", "0") == "1"
+    local_rank = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    rank, world = init_distributed(dev, backend="gloo" if share else "nccl")
+    return rank, world, dev
+
+
+def max_over_ranks(dt, dev):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,8 +285,11 @@ def main():
                     help="fp32 = BASELINE.json configs[1] (default, the headline); bf16 = configs[2]'s arithmetic for the temporal "
                          "convolutions (bf16 MFMA operands, fp32 storage / accumulation / master weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="clips in the CPU-baseline sample batch")
+    ap.add_argument("--cpu-sample", type=int, default=8,
+                    help="clips in the CPU-baseline fallback batch (used only when a full --batch step does not fit the budget)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -248,15 +299,7 @@ def main():
 
     if args.workload == "spectrogram":
         return main_spectrogram(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+    rank, world, dev = rank_setup(args)
 
     eng = STGCN(num_classes=args.classes, device=dev, seed=0, mfma=args.mfma)  # identical init on every rank
     trainer = Trainer(eng, batch_size=args.batch, world_size=world)
@@ -281,10 +324,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     profiler.install(None)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = max_over_ranks(dt, dev)
     loss_val = float(loss.item())
     assert loss_val == loss_val, "loss is NaN"
 
@@ -303,7 +343,7 @@ def main():
         bf16 = args.mfma == "bf16"
         out = {
             "metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)",
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
@@ -331,7 +371,7 @@ def main():
                                "avg_launch_ms": round(ms / max(calls, 1), 4),
                                "mfma_tflops": round(achieved, 1)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -337,6 +337,26 @@ int sar_bn_relu_maxpool_bwd_f32(const float* x, const float* scale, const float*
 int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_t n, const float* lr_dev, const float* step_dev,
                  float beta1, float beta2, float eps, sar_stream_t s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host-side input helpers (HOST pointers, no stream, no device work): what tf.data.TFRecordDataset's native reader does
+ * for main_gnn.py:159-194 -- the reference's clips are tf.train.Example records written by
+ * data_gen/gen_tfrecord_data.py:25-33,76-85.
+ *   sar_crc32c          CRC-32C (Castagnoli, reflected 0x82F63B78, init/xorout 0xFFFFFFFF); SSE4.2 crc32 instruction when
+ *                       the CPU has it, slice-by-8 tables otherwise (sar_crc32c_sw = always the tables: self-test).
+ *   sar_masked_crc32c   TFRecord's mask: rotr(crc, 15) + 0xA282EAD8.
+ *   sar_tfrecord_index  walks a whole shard held in memory (uint64 length | uint32 masked crc(length) | data |
+ *                       uint32 masked crc(data)) and returns the number of records, writing the payload offset / length
+ *                       of the first max_records of them (offsets / lengths may be NULL to count only).
+ *                       verify: 0 = framing only, 1 = + length CRCs, 2 = + data CRCs.
+ *                       Error: -(code + 4*record_index), code 2 = truncated header, 3 = corrupt length CRC,
+ *                       4 = truncated record, 5 = corrupt data CRC; -1 = bad arguments.
+ * ------------------------------------------------------------------------------------------------ */
+uint32_t sar_crc32c(const void* data, int64_t n);
+uint32_t sar_crc32c_sw(const void* data, int64_t n);
+uint32_t sar_masked_crc32c(const void* data, int64_t n);
+int64_t sar_tfrecord_index(const void* file, int64_t nbytes, int verify, int64_t* offsets, int64_t* lengths,
+                           int64_t max_records);
+
 #ifdef __cplusplus
 }
 #endif

@@ -431,14 +431,18 @@ __global__ __launch_bounds__(TPB) void softmax_ce_kernel(const float* __restrict
     float se = 0.f;
     for (int k = lane; k < K; k += 64) se += expf(row[k] - mx);
     se = wave_sum(se);
-    const int lab = (int)labels[n];
+    // a label outside [0, K) (e.g. 120-class data with --num-classes 60) must not read out of bounds and must not
+    // pass silently: the loss (and this row's gradient) become NaN, which the host loops surface
+    const int64_t lab64 = labels[n];
+    const bool lab_ok = lab64 >= 0 && lab64 < K;
+    const int lab = lab_ok ? (int)lab64 : 0;
     const float lse = logf(se) + mx;
-    if (lane == 0) lsum += (lse - row[lab]);
+    if (lane == 0) lsum += lab_ok ? (lse - row[lab]) : NAN;
     const float inv = 1.f / se;
     for (int k = lane; k < K; k += 64) {
       const float p = expf(row[k] - mx) * inv;
       if (probs) probs[(int64_t)n * K + k] = p;
-      if (dlogits) dlogits[(int64_t)n * K + k] = (p - (k == lab ? 1.f : 0.f)) * inv_gbs;
+      if (dlogits) dlogits[(int64_t)n * K + k] = lab_ok ? (p - (k == lab ? 1.f : 0.f)) * inv_gbs : NAN;
     }
   }
   __shared__ float red[4];

@@ -81,11 +81,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SAR_DIST_BACKEND") == "gloo":       # ranks sharing one device (tests)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)        # RCCL over xGMI
+    from sar_amd.train import init_distributed
+    init_distributed(dev)                                   # RCCL over xGMI unless SAR_DIST_BACKEND says otherwise
     arg.gpus = world
     global_batch_size = arg.batch_size * world                # main_gnn.py:258
 
@@ -114,8 +115,8 @@ def main():
             # or the <prefix>.npy + label pkl pair of data_gen/gen_joint_data.py
             if os.path.isdir(prefix) and any(f.endswith("tfrecord") for f in os.listdir(prefix)):
                 from sar_amd.tfrecord import TFRecordSkeletonData
-                return TFRecordSkeletonData(prefix)
-            return NpySkeletonData(prefix + ".npy", _label_path(prefix))
+                return TFRecordSkeletonData(prefix, num_classes=arg.num_classes)
+            return NpySkeletonData(prefix + ".npy", _label_path(prefix), num_classes=arg.num_classes)
         train_data, test_data = open_data(arg.train_data_path), open_data(arg.test_data_path)
 
     model = model_mod.Model(num_classes=arg.num_classes, device=dev, stream=arg.stream, mfma=arg.mfma)
@@ -142,20 +143,26 @@ def main():
         if rank == 0:
             print("Epoch: {}".format(epoch + 1), flush=True)
         t0 = time.time()
+        it = -1
         # `train_adj` (epoch > freeze_graph_until, main_gnn.py:228-232,364) has no effect for models.stgcn: its
         # adjacency is a non-trainable variable (models/stgcn.py:105-109).
+        # per-iteration scalars stay on the device and are exchanged / read back once per epoch (no host sync per step)
+        pending = []
         for it, (x, y) in enumerate(train_data.batches(arg.batch_size, rank, world, dev, shuffle=True, epoch=epoch)):
             logits, loss = trainer.step(x, y)
-            stats = torch.stack([loss.reshape(()) * 1.0, topk_correct(logits, y, 1).float(),
-                                 topk_correct(logits, y, 5).float()])
-            stats[1:] /= global_batch_size
-            allreduce_sum_(stats)                              # loss is already divided by the global batch
-            scalar("cross_entropy_loss", stats[0], train_iter)
-            scalar("train_acc", stats[1], train_iter)
-            scalar("train_acc_top_5", stats[2], train_iter)
-            train_iter += 1
+            pending.append(torch.stack([loss.reshape(()) * 1.0, topk_correct(logits, y, 1).float() / global_batch_size,
+                                        topk_correct(logits, y, 5).float() / global_batch_size]))
             if arg.max_iters and it + 1 >= arg.max_iters:
                 break
+        if pending:
+            stats = allreduce_sum_(torch.stack(pending)).cpu()     # loss is already divided by the global batch
+            if not bool(torch.isfinite(stats[:, 0]).all()):
+                raise FloatingPointError("non-finite training loss in epoch %d (labels outside [0, --num-classes)?)" % (epoch + 1))
+            for row in stats.tolist():
+                scalar("cross_entropy_loss", row[0], train_iter)
+                scalar("train_acc", row[1], train_iter)
+                scalar("train_acc_top_5", row[2], train_iter)
+                train_iter += 1
         if rank == 0:
             torch.cuda.synchronize()
             print("  train: %d iters, %.1f clips/s" % (it + 1, (it + 1) * global_batch_size / (time.time() - t0)),

@@ -5,8 +5,12 @@ step_size_up=lr_cycle, cycle_momentum=False) stepped once per epoch, train / val
 The reference wraps the model in nn.DataParallel (main_spectrogram.py:118-119); here it is one process per GPU with
 one RCCL all-reduce of the flat gradient buffer (launch with torch.distributed.run).
 Data: `--data-path data/ntu/xview/{}_data_joint.npy --label-path data/ntu/xview/{}_label.pkl` as in the reference, or
---synthetic.  The reference's CPU-side 250x frame upsampling (utils.py:105,134-140) is a SURVEY 8(f) next item:
-clips are fed at their native T."""
+--synthetic.  The reference's CPU-side 250x frame up-sampling (utils.py:105,134-140: Gaussian smoothing + cubic
+interpolation in the loader) runs on the GPU, fused into the radar signal kernels (--num-pad-frames, default 250 as in
+the reference; 0 feeds the clips at their native T).
+Batch semantics under data parallelism: the reference's DataParallel SPLITS --batch-size across the GPUs; here every
+rank takes --batch-size clips (global batch = batch_size * world, gradients averaged), like main_gnn.py's
+MirroredStrategy.  Divide --batch-size by the number of ranks to reproduce the reference's effective batch."""
 import argparse
 import inspect
 import json
@@ -58,11 +62,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SAR_DIST_BACKEND") == "gloo":       # ranks sharing one device (tests)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    from sar_amd.train import init_distributed
+    init_distributed(dev)                                   # RCCL over xGMI unless SAR_DIST_BACKEND says otherwise
     arg.model_type = 'models.' + arg.model_type.strip() + '.Model'
     run_params = {k: v for k, v in vars(arg).items() if k not in ("data_path", "label_path", "log_dir")}
     run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
@@ -76,17 +81,17 @@ def main():
         shutil.copy2(os.path.abspath(__file__), arg.log_dir)
 
     from sar_amd.data import NpySkeletonData, SyntheticSkeletonData
-    from sar_amd.train import allreduce_sum_
+    from sar_amd.train import SpectrogramTrainer
     if arg.synthetic:
         data = {"train": SyntheticSkeletonData(arg.synthetic_size, arg.num_classes),
                 "val": SyntheticSkeletonData(max(arg.batch_size * 2, 64), arg.num_classes)}
     else:
-        data = {x: NpySkeletonData(arg.data_path.format(x), arg.label_path.format(x)) for x in ['train', 'val']}
+        data = {x: NpySkeletonData(arg.data_path.format(x), arg.label_path.format(x), num_classes=arg.num_classes)
+                for x in ['train', 'val']}
     model = Model(num_classes=arg.num_classes, num_filters=arg.num_filters, device=dev, num_pad_frames=arg.num_pad_frames,
                   sigma=arg.sigma)
     eng = model.base_model.engine
-    radar_params = list(model.virtual_radar.parameters())
-    radar_opt = torch.optim.Adam(radar_params, lr=arg.base_lr)   # same Adam hyper-parameters as main_spectrogram.py:106
+    trainer = SpectrogramTrainer(model, arg.base_lr, world_size=world)
     log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None
 
     def scalar(tag, value, step):
@@ -97,59 +102,47 @@ def main():
         if rank == 0:
             print('Epoch {}/{}'.format(epoch + 1, arg.num_epochs), flush=True)
         lr = cyclic_lr(epoch, 1e-4, arg.base_lr, arg.lr_cycle)
-        # main_spectrogram.py:127-136: parameters are un-frozen by NAME at the given epochs ('radar_lambda' matches no
+        # main_spectrogram.py:127-136: parameters are un-frozen by NAME while `epoch > ...` ('radar_lambda' matches no
         # parameter of the reference model either -- the wavelength is called `wavelength`)
-        if epoch == arg.lambda_train_epoch:
+        if epoch > arg.lambda_train_epoch:
             for name, param in model.named_parameters():
                 if 'radar_lambda' in name:
                     param.requires_grad = True
-        if epoch == arg.loc_train_epoch:
+        if epoch > arg.loc_train_epoch:
             for name, param in model.named_parameters():
                 if 'radar_loc' in name:
                     param.requires_grad = True
-        train_radar = any(p.requires_grad for p in radar_params)
-        for g in radar_opt.param_groups:
-            g['lr'] = lr
         for phase in ['train', 'val']:
-            run_loss = run_ok = n_seen = n_it = 0
+            # per-iteration loss / correct counts stay on the device (one small tensor per iteration) and are read back
+            # ONCE per phase: a .item() per iteration would serialise the host with the GPU on a ~8 ms step
+            stats, sizes = [], []
             for it, (x, y) in enumerate(data[phase].batches(arg.batch_size, rank if phase == 'train' else 0,
                                                             world if phase == 'train' else 1, dev, shuffle=True, epoch=epoch,
                                                             drop_remainder=phase == 'train')):
                 if phase == 'train':
-                    with torch.set_grad_enabled(train_radar):
-                        img = model.spectrogram(x)
-                    if train_radar:                                  # the image depends on trainable radar parameters
-                        logits, loss, dimg = eng.loss_and_grad(img.detach(), y, need_dx=True)
-                        radar_opt.zero_grad(set_to_none=False)
-                        img.backward(dimg)
-                    else:
-                        logits, loss = eng.loss_and_grad(img, y)
-                    if world > 1:
-                        allreduce_sum_(eng.grad)
-                        eng.grad.div_(world)                     # mean over the global batch, as DataParallel's gather+mean
-                        for p_ in radar_params:
-                            if p_.requires_grad and p_.grad is not None:
-                                allreduce_sum_(p_.grad)
-                                p_.grad.div_(world)
-                    eng.adam_step(lr)
-                    if train_radar:
-                        radar_opt.step()
+                    logits, loss = trainer.step(x, y, lr)
                 else:
                     with torch.no_grad():
                         img = model.spectrogram(x)
                     logits = eng.forward(img, training=False)
                     loss = torch.nn.functional.cross_entropy(logits, y).reshape(1)
-                ok = (logits.argmax(1) == y).sum()
-                scalar('{}_cross_entropy_loss'.format(phase), loss.item(), epoch * 100000 + it)
-                scalar('{}_acc'.format(phase), ok.item() / len(y), epoch * 100000 + it)
-                run_loss, run_ok, n_seen, n_it = run_loss + loss.item(), run_ok + ok.item(), n_seen + len(y), n_it + 1
+                stats.append(torch.stack([loss.reshape(()), (logits.argmax(1) == y).sum().float()]))
+                sizes.append(len(y))
                 if arg.max_iters and it + 1 >= arg.max_iters:
                     break
+            host = torch.stack(stats).cpu().tolist() if stats else []
+            for it, ((lo, ok), n) in enumerate(zip(host, sizes)):
+                scalar('{}_cross_entropy_loss'.format(phase), lo, epoch * 100000 + it)
+                scalar('{}_acc'.format(phase), ok / n, epoch * 100000 + it)
+            run_loss, run_ok = sum(h[0] for h in host), sum(h[1] for h in host)
+            n_it, n_seen = len(host), sum(sizes)
+            if run_loss != run_loss:
+                raise FloatingPointError("NaN loss in phase %s of epoch %d (labels outside [0, --num-classes)?)" % (phase, epoch + 1))
             if rank == 0:
                 scalar('{}_epoch_cross_entropy_loss'.format(phase), run_loss / max(n_it, 1), epoch)
                 scalar('{}_epoch_acc'.format(phase), run_ok / max(n_seen, 1), epoch)
                 print('{} Loss: {:.4f} Acc: {:.4f}'.format(phase, run_loss / max(n_it, 1), run_ok / max(n_seen, 1)), flush=True)
-        if rank == 0 and train_radar:
+        if rank == 0 and trainer.train_radar():
             print('radar_location {} wavelength {:.6g}'.format([round(v, 6) for v in model.virtual_radar.radar_location.tolist()],
                                                                model.virtual_radar.wavelength.item()), flush=True)
         if log:

@@ -110,6 +110,11 @@ SIGNATURES = {
     "sar_vr_signal_upsampled_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_vr_signal_upsampled_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_conv2d_stem_dgrad_f32": (_i, [_fp, _i64, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
+    # host-side input helpers (host pointers)
+    "sar_crc32c": (C.c_uint32, [_fp, _i64]),
+    "sar_crc32c_sw": (C.c_uint32, [_fp, _i64]),
+    "sar_masked_crc32c": (C.c_uint32, [_fp, _i64]),
+    "sar_tfrecord_index": (_i64, [_fp, _i64, _i, _fp, _fp, _i64]),
 }
 
 _lib = None

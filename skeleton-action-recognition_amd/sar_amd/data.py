@@ -1,4 +1,4 @@
-"""Input side of main_gnn.py for the HIP path.
+"""Input side of main_gnn.py / main_spectrogram.py for the HIP path.
 
 Formats: the reference's `*_data_joint.npy` (N,3,T,25,M) float32 + `*_label.pkl` pair
 (data_gen/gen_joint_data.py:138-151), memory-mapped; or synthetic NTU-like clips generated on the device.
@@ -6,8 +6,15 @@ Formats: the reference's `*_data_joint.npy` (N,3,T,25,M) float32 + `*_label.pkl`
 Sharding follows main_gnn.py:290-301 under MirroredStrategy: a global batch of batch_size*world clips per step,
 rank r takes elements r::world, remainder dropped; the reference shuffles with a buffer of 1000 BATCHES
 (main_gnn.py:189-194) -- here the clip order is a seeded permutation per epoch, identical on every rank.
+
+Host -> device: `prefetch_to_device` is the `dataset.prefetch(AUTOTUNE)` of main_gnn.py:193 / the
+`DataLoader(num_workers=10)` of main_spectrogram.py:94-101: a background thread builds the next batches in a small
+ring of PINNED host buffers while the GPU runs the current step, and the consumer enqueues the asynchronous
+H2D copies (11.5 MB per 64 clips) on the compute stream, so the step never waits for a page-able memcpy or a parse.
 """
 import pickle
+import queue
+import threading
 
 import numpy as np
 import torch
@@ -15,18 +22,86 @@ import torch
 from .train import shard_indices, synthetic_clips
 
 
+def prefetch_to_device(host_batches, device, depth=3):
+    """host_batches: iterator of (x float32 ndarray, y int64 ndarray).  Yields (x, y) device tensors.
+
+    The producer thread copies each batch into one of `depth + 1` pinned slots (file reads, memmap gathers, np.stack and
+    the CRC / protobuf work all release the GIL or are short); a slot is recycled only after the event recorded behind
+    its H2D copy has completed."""
+    device = torch.device(device)
+    cuda = device.type == "cuda"
+    free, ready = queue.Queue(), queue.Queue(maxsize=depth)
+    for _ in range(depth + 1):
+        free.put({"x": None, "y": None, "event": None})
+    stop = threading.Event()
+
+    def slot_buffer(slot, key, arr):
+        t = slot[key]
+        if t is None or t.numel() < arr.size or t.dtype != torch.from_numpy(arr[:0]).dtype:
+            t = torch.empty(arr.size, dtype=torch.from_numpy(arr[:0]).dtype, pin_memory=cuda)
+            slot[key] = t
+        v = t[:arr.size].view(arr.shape)
+        np.copyto(v.numpy(), arr)
+        return v
+
+    def producer():
+        try:
+            for x, y in host_batches:
+                slot = free.get()
+                if stop.is_set():
+                    return
+                if slot["event"] is not None:
+                    slot["event"].synchronize()          # the previous copy out of this slot has finished
+                ready.put((slot, slot_buffer(slot, "x", np.asarray(x, dtype=np.float32)),
+                           slot_buffer(slot, "y", np.asarray(y, dtype=np.int64))))
+                if stop.is_set():
+                    return
+            ready.put(None)
+        except BaseException as e:                        # surface loader errors in the training thread
+            ready.put(e)
+
+    th = threading.Thread(target=producer, name="sar-prefetch", daemon=True)
+    th.start()
+    try:
+        while True:
+            item = ready.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            slot, hx, hy = item
+            x = hx.to(device, non_blocking=True)
+            y = hy.to(device, non_blocking=True)
+            if cuda:
+                slot["event"] = torch.cuda.Event()
+                slot["event"].record()
+            free.put(slot)
+            yield x, y
+    finally:
+        stop.set()
+        try:                                              # unblock a producer waiting for a slot / queue space
+            while True:
+                ready.get_nowait()
+        except queue.Empty:
+            pass
+        free.put({"x": None, "y": None, "event": None})
+
+
 class NpySkeletonData:
-    def __init__(self, data_path, label_path):
+    def __init__(self, data_path, label_path, num_classes=None):
         self.data = np.load(data_path, mmap_mode="r")
         with open(label_path, "rb") as f:
             _, labels = pickle.load(f, encoding="latin1")
         self.labels = np.asarray(labels, dtype=np.int64)
         assert len(self.labels) == len(self.data)
+        if num_classes is not None and len(self.labels) and not (0 <= self.labels.min() and self.labels.max() < num_classes):
+            raise ValueError("%s: labels span [%d, %d] but --num-classes is %d" % (label_path, self.labels.min(),
+                                                                                   self.labels.max(), num_classes))
 
     def __len__(self):
         return len(self.data)
 
-    def batches(self, batch_size, rank, world, device, shuffle, epoch=0, drop_remainder=True):
+    def host_batches(self, batch_size, rank=0, world=1, shuffle=False, epoch=0, drop_remainder=True):
         n = len(self)
         perm = np.random.default_rng(1234 + epoch).permutation(n) if shuffle else np.arange(n)
         if drop_remainder:
@@ -35,9 +110,10 @@ class NpySkeletonData:
             shards = [perm[i:i + batch_size] for i in range(0, n, batch_size)]
         for idx in shards:
             idx = np.sort(np.asarray(idx))
-            x = torch.from_numpy(np.ascontiguousarray(self.data[idx])).to(device, non_blocking=True)
-            y = torch.from_numpy(self.labels[idx]).to(device, non_blocking=True)
-            yield x.float(), y
+            yield self.data[idx], self.labels[idx]
+
+    def batches(self, batch_size, rank, world, device, shuffle, epoch=0, drop_remainder=True):
+        return prefetch_to_device(self.host_batches(batch_size, rank, world, shuffle, epoch, drop_remainder), device)
 
 
 class SyntheticSkeletonData:

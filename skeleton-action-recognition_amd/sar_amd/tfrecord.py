@@ -23,31 +23,27 @@ _MASK_DELTA = 0xA282EAD8
 _DT_FLOAT = 1
 
 
-def _crc_table():
-    poly = 0x82F63B78        # CRC-32C (Castagnoli), reflected
-    tab = []
-    for i in range(256):
-        c = i
-        for _ in range(8):
-            c = (c >> 1) ^ poly if c & 1 else c >> 1
-        tab.append(c)
-    return np.array(tab, dtype=np.uint32)
+def _native():
+    """libsar_hip.so's host-side input helpers (include/sar_hip.h: sar_crc32c, sar_tfrecord_index).  No Python
+    fallback: a 180 KB clip per record needs a CRC at hundreds of MB/s to keep one GPU fed."""
+    from . import _lib
+    return _lib.load()
 
 
-_TAB = _crc_table()
+def _addr(buf):
+    """(address, keep-alive) of a bytes-like object without copying it."""
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    return arr.ctypes.data, arr
 
 
 def crc32c(data):
-    c = 0xFFFFFFFF
-    tab = _TAB
-    for b in bytes(data):
-        c = int(tab[(c ^ b) & 0xFF]) ^ (c >> 8)
-    return c ^ 0xFFFFFFFF
+    a, keep = _addr(data)
+    return int(_native().sar_crc32c(a, len(keep)))
 
 
 def masked_crc(data):
-    c = crc32c(data)
-    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + _MASK_DELTA) & 0xFFFFFFFF
+    a, keep = _addr(data)
+    return int(_native().sar_masked_crc32c(a, len(keep)))
 
 
 # ---------------------------------------------------------------- protobuf wire format
@@ -115,7 +111,7 @@ def parse_tensor(buf):
                             size = v3
                     dims.append(size)
         elif fno == 4:
-            content = bytes(val)
+            content = val                      # memoryview into the record: no copy
         elif fno == 5:
             if wt == 2:
                 fvals.extend(np.frombuffer(bytes(val), dtype="<f4").tolist())
@@ -184,24 +180,37 @@ def serialize_example(features, label):
 
 
 # ---------------------------------------------------------------- TFRecord files
+_ERRORS = {2: "truncated record header", 3: "corrupt length CRC", 4: "truncated record", 5: "corrupt data CRC"}
+
+
+def index_records(buf, verify=True):
+    """(offsets, lengths) int64 arrays of the record payloads of a whole shard held in `buf` (bytes / mmap / uint8
+    array); verify checks the masked CRC-32C of every length field and payload in native code."""
+    a, keep = _addr(buf)
+    lib = _native()
+    level = 2 if verify else 0
+    n = lib.sar_tfrecord_index(a, len(keep), 0, None, None, 0)           # framing pass: record count
+    if n >= 0:
+        off, ln = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        n = lib.sar_tfrecord_index(a, len(keep), level, off.ctypes.data, ln.ctypes.data, n)
+    if n < 0:
+        code, rec = 2 + (-n - 2) % 4, (-n - 2) // 4
+        raise IOError("%s (record %d)" % (_ERRORS.get(code, "bad arguments"), rec))
+    return off, ln
+
+
 def read_records(path, verify=True):
-    with open(path, "rb") as f:
-        while True:
-            head = f.read(12)
-            if not head:
-                return
-            if len(head) < 12:
-                raise IOError("%s: truncated record header" % path)
-            (length,), (lcrc,) = struct.unpack("<Q", head[:8]), struct.unpack("<I", head[8:])
-            if verify and masked_crc(head[:8]) != lcrc:
-                raise IOError("%s: corrupt length CRC" % path)
-            data = f.read(length)
-            tail = f.read(4)
-            if len(data) < length or len(tail) < 4:
-                raise IOError("%s: truncated record" % path)
-            if verify and masked_crc(data) != struct.unpack("<I", tail)[0]:
-                raise IOError("%s: corrupt data CRC" % path)
-            yield data
+    """yield the payload of every record of a shard as a zero-copy memoryview into the memory-mapped file"""
+    if os.path.getsize(path) == 0:
+        return
+    buf = np.memmap(path, dtype=np.uint8, mode="r")
+    try:
+        off, ln = index_records(buf, verify)
+    except IOError as e:
+        raise IOError("%s: %s" % (path, e)) from None
+    view = memoryview(buf)
+    for o, l in zip(off.tolist(), ln.tolist()):
+        yield view[o:o + l]
 
 
 def write_records(path, records):
@@ -224,59 +233,97 @@ def write_shards(data, labels, dest_folder, name, num_shards):
 
 
 class TFRecordSkeletonData:
-    """main_gnn.py:159-194 on a directory of shards: cyclic interleave of the files, batch, shuffle of BATCHES with a
-    bounded buffer (seeded here).  Clips are parsed on the host and moved to the device per batch; with world > 1 every
-    rank walks the same batch sequence and takes rows rank::world of each global batch."""
+    """main_gnn.py:159-194 on a directory of shards: cyclic interleave of the files (num_parallel_reads = all of them),
+    batch, shuffle of BATCHES with a bounded buffer (seeded here).
 
-    def __init__(self, directory, verify_crc=True):
+    Data parallel: when there are at least as many shards as ranks (and the split is balanced to 20 %), rank r reads ONLY
+    shards r::world (tf.data's FILE auto-shard policy) and forms its own per-rank batches; otherwise every rank walks
+    the record framing of all shards and keeps records r::world.  Either way a rank parses only the clips it trains on.  Every rank yields the same number of
+    batches (the shortest rank's count, computed from the record framing alone) so the collective in the train step
+    never deadlocks.  The shuffle buffer is counted in PER-RANK batches and capped by `shuffle_bytes` of host memory.
+    Parsing runs in a background thread into pinned buffers (sar_amd/data.py:prefetch_to_device)."""
+
+    def __init__(self, directory, verify_crc=True, num_classes=None):
         self.files = sorted(os.path.join(directory, f) for f in os.listdir(directory) if f.endswith("tfrecord"))
         if not self.files:
             raise FileNotFoundError("no *.tfrecord shard in %s" % directory)
         self.verify = verify_crc
-        self._n = None
+        self.num_classes = num_classes
+        self._counts = None
+
+    def counts(self):
+        if self._counts is None:
+            self._counts = [len(index_records(np.memmap(f, dtype=np.uint8, mode="r"), verify=False)[0])
+                            if os.path.getsize(f) else 0 for f in self.files]
+        return self._counts
 
     def __len__(self):
-        if self._n is None:
-            self._n = sum(1 for f in self.files for _ in read_records(f, verify=False))
-        return self._n
+        return sum(self.counts())
 
-    def _interleaved(self):
-        its = [read_records(f, self.verify) for f in self.files]
+    def _plan(self, rank, world):
+        """(files, record stride, record phase, clips this rank will see, min over ranks of that)"""
+        cnt = self.counts()
+        if world > 1 and len(self.files) >= world:
+            per_rank = [sum(cnt[r::world]) for r in range(world)]
+            if min(per_rank) * 10 >= max(per_rank) * 8:       # balanced enough: at most 20 % of a rank's clips go unused
+                return self.files[rank::world], 1, 0, per_rank[rank], min(per_rank)
+        total = sum(cnt)
+        per_rank = [len(range(r, total, world)) for r in range(world)]
+        return self.files, world, rank, per_rank[rank], min(per_rank)
+
+    @staticmethod
+    def _interleave(files, verify):
+        its = [read_records(f, verify) for f in files]
         while its:
             alive = []
             for it in its:
                 rec = next(it, None)
                 if rec is not None:
                     alive.append(it)
-                    yield parse_example(rec)
+                    yield rec
             its = alive
 
-    def batches(self, batch_size, rank, world, device, shuffle, epoch=0, drop_remainder=True, shuffle_size=1000):
-        import torch
-        gbs = batch_size * world
+    def host_batches(self, batch_size, rank=0, world=1, shuffle=False, epoch=0, drop_remainder=True, shuffle_size=1000,
+                     shuffle_bytes=2 << 30):
+        """numpy (x (n,C,T,V,M) float32, y (n,) int64) per-rank batches"""
+        files, stride, phase, mine, fewest = self._plan(rank, world)
+        n_batches = fewest // batch_size if drop_remainder else -(-mine // batch_size)
 
-        def global_batches():
-            xs, ys = [], []
-            for x, y in self._interleaved():
+        def batches():
+            xs, ys, made = [], [], 0
+            if n_batches == 0:
+                return
+            for i, rec in enumerate(self._interleave(files, self.verify)):
+                if i % stride != phase:
+                    continue
+                x, y = parse_example(rec)
+                if self.num_classes is not None and not 0 <= y < self.num_classes:
+                    raise ValueError("label %d outside [0, %d)" % (y, self.num_classes))
                 xs.append(x)
                 ys.append(y)
-                if len(xs) == gbs:
+                if len(xs) == batch_size:
                     yield np.stack(xs), np.asarray(ys, dtype=np.int64)
-                    xs, ys = [], []
-            if xs and not drop_remainder:
+                    xs, ys, made = [], [], made + 1
+                    if made == n_batches:
+                        return
+            if xs and made < n_batches:
                 yield np.stack(xs), np.asarray(ys, dtype=np.int64)
 
         def shuffled(gen):
-            rng = np.random.default_rng(4321 + epoch)
-            buf = []
+            rng = np.random.default_rng(4321 + epoch)      # same seed on every rank; each rank shuffles its own batches
+            buf, cap = [], None
             for item in gen:
+                if cap is None:
+                    cap = max(1, min(shuffle_size, shuffle_bytes // max(item[0].nbytes, 1)))
                 buf.append(item)
-                if len(buf) > shuffle_size:
+                if len(buf) > cap:
                     yield buf.pop(int(rng.integers(len(buf))))
             while buf:
                 yield buf.pop(int(rng.integers(len(buf))))
 
-        gen = shuffled(global_batches()) if shuffle else global_batches()
-        for x, y in gen:
-            x, y = x[rank::world], y[rank::world]
-            yield torch.from_numpy(np.ascontiguousarray(x)).to(device, non_blocking=True).float(), torch.from_numpy(y).to(device)
+        return shuffled(batches()) if shuffle else batches()
+
+    def batches(self, batch_size, rank, world, device, shuffle, epoch=0, drop_remainder=True, shuffle_size=1000):
+        from .data import prefetch_to_device
+        return prefetch_to_device(self.host_batches(batch_size, rank, world, shuffle, epoch, drop_remainder, shuffle_size),
+                                  device)

@@ -35,10 +35,37 @@ def shard_indices(perm, rank, world_size, global_batch):
 
 
 def allreduce_sum_(flat, group=None):
-    """Gradient exchange (the implicit NCCL all-reduce inside apply_gradients, main_gnn.py:234,239)."""
+    """Gradient exchange (the implicit NCCL all-reduce inside apply_gradients, main_gnn.py:234,239).
+
+    Backend "nccl" (= RCCL over xGMI) reduces the device buffer in place on torch's current stream, i.e. ordered after
+    the HIP kernels that produced it and before the optimizer kernel that consumes it (both are launched on that same
+    stream, sar_amd/_lib.py:stream_ptr).  Under "gloo" (ranks that share one GPU, CPU-only rendezvous) the bucket is
+    staged through host memory: the .cpu() copy synchronises with the producing stream."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+def init_distributed(device, backend=None):
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns
+    (rank, world).  backend: "nccl" (RCCL) by default; SAR_DIST_BACKEND / the argument select "gloo" for ranks that
+    share a device."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or os.environ.get("SAR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return rank, world
 
 
 class Trainer:
@@ -54,6 +81,52 @@ class Trainer:
         allreduce_sum_(self.engine.grad)
         self.engine.sgd_step(lr_schedule(self.iteration, self.base_lr, self.steps, self.batch_size), self.momentum)
         self.iteration += 1
+        return logits, loss
+
+
+class SpectrogramTrainer:
+    """Train step of main_spectrogram.py:124-189 on the HIP engines: VirtualRadar -> spectrogram image -> resnet18
+    forward / backward (mean CrossEntropyLoss) -> ONE all-reduce of the flat resnet gradient buffer and ONE of the
+    flat radar-parameter bucket (when radar parameters train) -> Adam on both.  Gradients are averaged over ranks
+    (each rank's loss is the mean over its own clips), like DataParallel's gather + mean (main_spectrogram.py:118-119)."""
+
+    def __init__(self, model, base_lr, world_size=1):
+        self.model, self.eng, self.world_size = model, model.base_model.engine, world_size
+        self.radar_params = list(model.virtual_radar.parameters())
+        self.radar_opt = torch.optim.Adam(self.radar_params, lr=base_lr)   # main_spectrogram.py:106 hyper-parameters
+
+    def train_radar(self):
+        return any(p.requires_grad for p in self.radar_params)
+
+    def step(self, x, labels, lr):
+        """Returns (logits, loss) device tensors; no host synchronisation."""
+        model, eng, world = self.model, self.eng, self.world_size
+        train_radar = self.train_radar()
+        with torch.set_grad_enabled(train_radar):
+            img = model.spectrogram(x)
+        if train_radar:                                  # the image depends on trainable radar parameters
+            logits, loss, dimg = eng.loss_and_grad(img.detach(), labels, need_dx=True)
+            self.radar_opt.zero_grad(set_to_none=False)
+            img.backward(dimg)
+        else:
+            logits, loss = eng.loss_and_grad(img, labels)
+        if world > 1:
+            allreduce_sum_(eng.grad)
+            eng.grad.div_(world)
+            live = [p for p in self.radar_params if p.requires_grad and p.grad is not None]
+            if live:                                     # one flat bucket for the (few) radar parameters
+                bucket = torch.cat([p.grad.reshape(-1) for p in live])
+                allreduce_sum_(bucket)
+                bucket.div_(world)
+                o = 0
+                for p in live:
+                    p.grad.copy_(bucket[o:o + p.numel()].view_as(p.grad))
+                    o += p.numel()
+        eng.adam_step(lr)
+        if train_radar:
+            for g in self.radar_opt.param_groups:
+                g['lr'] = lr
+            self.radar_opt.step()
         return logits, loss
 
 

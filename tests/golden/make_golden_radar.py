@@ -1,6 +1,7 @@
 """Generates tests/golden/radar_*.npz by running the REFERENCE's VirtualRadar.forward code
 (layers/virtual_radar.py, imported from /root/reference) with a restatement of nnAudio-0.1.1's STFT
-injected as `nnAudio.Spectrogram.STFT` (nnAudio itself is not installable here).  Build container only.
+injected as `nnAudio.Spectrogram.STFT` (nnAudio itself is not installable here).  Build container only.  Every configuration is run twice: as the reference
+runs it (float32) and with the module and the input converted to float64 (`*_f64` keys).
 Inputs are clips 0 and 2 of the reference's bundled data/NTU_preprocessed_skeleton_examples.npy.
 """
 import os
@@ -13,35 +14,9 @@ import torch
 here = os.path.dirname(os.path.abspath(__file__))
 
 
-class STFT(torch.nn.Module):
-    """nnAudio 0.1.1 Spectrogram.STFT semantics (freq_scale='no', hann, center, reflect, Complex)."""
+sys.path.insert(0, here)
+from make_golden_radar_grad import STFT  # noqa: E402,F401  (the nnAudio-0.1.1 STFT restatement; also injects the nnAudio stub)
 
-    def __init__(self, n_fft=2048, freq_bins=None, hop_length=512, window='hann', freq_scale='no', center=True,
-                 pad_mode='reflect', trainable=False, output_format='Magnitude', device='cpu', **kw):
-        super().__init__()
-        assert freq_bins == n_fft and output_format == 'Complex'
-        self.n_fft, self.stride = n_fft, hop_length
-        s = np.arange(0, n_fft, 1.)
-        n = np.arange(n_fft, dtype=np.float64)
-        w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)          # scipy get_window('hann', fftbins=True)
-        wsin = np.empty((n_fft, 1, n_fft)); wcos = np.empty((n_fft, 1, n_fft))
-        for k in range(n_fft):
-            wsin[k, 0, :] = w * np.sin(2 * np.pi * k * s / n_fft)
-            wcos[k, 0, :] = w * np.cos(2 * np.pi * k * s / n_fft)
-        self.wsin = torch.tensor(wsin, dtype=torch.float)
-        self.wcos = torch.tensor(wcos, dtype=torch.float)
-
-    def forward(self, x):
-        x = x[:, None, :]
-        x = torch.nn.ReflectionPad1d(self.n_fft // 2)(x)
-        spec_imag = torch.nn.functional.conv1d(x, self.wsin, stride=self.stride)
-        spec_real = torch.nn.functional.conv1d(x, self.wcos, stride=self.stride)
-        return torch.stack((spec_real, -spec_imag), -1)
-
-
-mod = types.ModuleType("nnAudio"); sub = types.ModuleType("nnAudio.Spectrogram"); sub.STFT = STFT
-mod.Spectrogram = sub
-sys.modules["nnAudio"] = mod; sys.modules["nnAudio.Spectrogram"] = sub
 sys.path.insert(0, "/root/reference")
 from layers.virtual_radar import VirtualRadar  # noqa: E402  (reference code, executed not copied)
 
@@ -55,7 +30,14 @@ for lam, loc in [(5e-4, [0., 0., 0.]), (1e-3, [0., 0., 0.]), (1e-1, [0., 0., 0.]
         y = vr(torch.from_numpy(x)).numpy()
     key = "lam%g_loc%g" % (lam, loc[2])
     out[key] = y.astype(np.float32)
-    print(key, y.shape, y.min(), y.max())
+    # the same reference code in float64 on the same float32 inputs / parameters: the yardstick for "how far is a float32
+    # evaluation allowed to be" at radar wavelengths, where the phase 4*pi*d/lambda ~ 1e4..1e5 rad loses 3-4 digits
+    vr64 = VirtualRadar(wavelength=lam, radar_location=loc, device='cpu').double()
+    with torch.no_grad():
+        y64 = vr64(torch.from_numpy(x).double()).numpy()
+    out[key + "_f64"] = y64.astype(np.float64)
+    m32, m64 = np.exp(y.astype(np.float64)) - 1e-6, np.exp(y64) - 1e-6
+    print(key, y.shape, y.min(), y.max(), "float32-vs-float64 |Z| distance / peak: %.3e" % (np.abs(m32 - m64).max() / m64.max()))
 np.savez_compressed(os.path.join(here, "radar_reference_outputs.npz"), **out)
 
 # notebook known answers (virtual_radar_example.ipynb cell 4: NTU clip, upsampled): shape only needs T

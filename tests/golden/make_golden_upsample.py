@@ -30,5 +30,18 @@ for lam in (1e-1, 5e-4):
     F = spec.shape[1]
     cols = np.minimum(np.floor(np.arange(256, dtype=np.float32) * (np.float32(F) / np.float32(256))).astype(np.int64), F - 1)
     out["spec_lam%g" % lam] = spec[:, cols].astype(np.float32)
-    print(lam, spec.shape, spec.min(), spec.max())
+    # float64 evaluation of the same reference code on the same float32 up-sampled input (yardstick, see make_golden_radar.py)
+    vr64 = VirtualRadar(wavelength=lam, radar_location=[0., 0., 0.], device='cpu').double()
+    with torch.no_grad():
+        spec64 = vr64(torch.from_numpy(up32)[None].double()).numpy()[0]
+    out["spec_lam%g_f64" % lam] = spec64[:, cols].astype(np.float64)
+    # ... and end to end in float64 (the up-sampled coordinates NOT rounded to float32): against this one the reference's
+    # own float32 pipeline error includes its float32 cast of the up-sampled clip (utils.py:130)
+    with torch.no_grad():
+        spec64e = vr64(torch.from_numpy(up)[None]).numpy()[0]
+    out["spec_lam%g_f64_e2e" % lam] = spec64e[:, cols].astype(np.float64)
+    print("   end-to-end float64: reference float32 pipeline distance / peak %.3e"
+          % (np.abs(np.exp(spec[:, cols].astype(np.float64)) - np.exp(spec64e[:, cols])).max() / np.exp(spec64e[:, cols]).max()))
+    m32, m64 = np.exp(spec[:, cols].astype(np.float64)) - 1e-6, np.exp(spec64[:, cols]) - 1e-6
+    print(lam, spec.shape, spec.min(), spec.max(), "float32-vs-float64 |Z| distance / peak: %.3e" % (np.abs(m32 - m64).max() / m64.max()))
 np.savez_compressed(os.path.join(here, "upsample_reference.npz"), **out)

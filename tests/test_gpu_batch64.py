@@ -1,0 +1,269 @@
+"""bs = 64 (B = N*M = 128 sequences) -- BASELINE.json configs[1]'s batch -- as a GPU TEST, not only a bench line.
+
+The CPU oracle cannot run 128 sequences of T = 300 in test time, so the full-size launches are checked through a
+size-independent property of the domain: no output column of the graph / temporal / residual convolutions, of their data
+gradients or of the element-wise passes depends on any OTHER sequence (a workgroup tile is whole frames of one sequence;
+BatchNorm enters only as per-channel scale / shift vectors), and the small sizes are pinned to the oracle by
+tests/test_gpu_stgcn_kernels.py.  Hence, for each of the six distinct layer geometries of models/stgcn.py:113-123:
+
+  * forward / data-gradient launches at B = 128 must equal BIT FOR BIT the same kernel launched on 2-sequence slices
+    (covers the XCD work map at 38 400 tiles, 32-bit offsets up to ld = 960 000 columns, ragged last tiles);
+  * weight / bias gradients and the BatchNorm partial sums reduce over all sequences: the B = 128 launch (nsplit slabs,
+    fixed-order slab reduce) must equal the float64 sum of the 64 slice launches to <= 2e-6 of the tensor's scale;
+  * eval-mode logits of the whole model at bs = 64 must equal bit for bit the logits of 2-clip chunks (moving statistics
+    => clips are independent).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+V, B = 25, 128
+# (cin, f, stride, T): the distinct (Cin -> F, s, T) of the ten blocks
+LAYERS = [(3, 64, 1, 300), (64, 64, 1, 300), (64, 128, 2, 300), (128, 128, 1, 150), (128, 256, 2, 150), (256, 256, 1, 75)]
+SLICES = [0, 1, 31, 62, 63]           # 2-sequence slices compared bit for bit (first, second, middle, last two)
+RED_TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from sar_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _tables(dev, transpose=False):
+    from sar_amd import ops
+    from graph.ntu_rgb_d import Graph
+    return ops.GraphTables(Graph().A.astype(np.float32), dev, transpose)
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.randn(shape, generator=g, device=dev) * scale
+
+
+def _cols(t, T, i, n=2):
+    """contiguous copy of the columns of sequences [n*i, n*i + n)"""
+    w = T * V
+    return t[:, n * i * w:(n * i + n) * w].contiguous()
+
+
+def _same_pad(T, k, s):
+    out = -(-T // s)
+    total = max((out - 1) * s + k - T, 0)
+    return out, total // 2
+
+
+def _partials_sum(r):
+    return r[0].double().sum(dim=1)            # [M][2]
+
+
+@pytest.mark.parametrize("cin,f,s,T", LAYERS)
+def test_forward_convs_at_bs64_equal_their_slices(dev, cin, f, s, T):
+    from sar_amd import ops, _lib as L
+    To, pad = _same_pad(T, 9, s)
+    X = _rand((cin, B * T * V), dev, 1)
+    Wg, bg = _rand((1, 1, cin, 3 * f), dev, 2, 0.1), _rand((3 * f,), dev, 3, 0.1)
+    Wt, bt = _rand((9, 1, f, f), dev, 4, 0.05), _rand((f,), dev, 5, 0.1)
+    Wr, br = _rand((1, 1, cin, f), dev, 6, 0.1), _rand((f,), dev, 7, 0.1)
+    sc, sh = 1 + 0.2 * _rand((f,), dev, 8), 0.3 * _rand((f,), dev, 9)
+    tab = _tables(dev)
+
+    def graph(x, nb, epi):
+        out = torch.empty((f, nb * T * V), device=dev)
+        r = ops.conv_gemm(L.SAR_CONV_GRAPH, x, out, Wg, f, 3 * f, B=nb, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, bias=bg,
+                          tables=tab, epi=epi)
+        return out, r
+
+    def temporal(g_, nb, epi):
+        out = torch.empty((f, nb * To * V), device=dev)
+        r = ops.conv_gemm(L.SAR_CONV_TEMPORAL, g_, out, Wt, f * f, f, B=nb, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s,
+                          pad=pad, bias=bt, pro=(sc, sh), pro_relu=True, epi=epi)
+        return out, r
+
+    def residual(x, nb, epi):
+        out = torch.empty((f, nb * To * V), device=dev)
+        r = ops.conv_gemm(L.SAR_CONV_TEMPORAL, x, out, Wr, 0, f, B=nb, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s,
+                          pad=0, bias=br, epi=epi)
+        return out, r
+
+    g_full, rg = graph(X, B, L.SAR_EPI_STATS)
+    u_full, ru = temporal(g_full, B, L.SAR_EPI_STATS)
+    r_full, rr = residual(X, B, L.SAR_EPI_STATS)
+    y_full = torch.empty_like(u_full)
+    ops.bn_add_relu_fwd(u_full, sc, sh, 2, r_full, sc, sh, y_full)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_full).all()
+    sums = {"g": torch.zeros((f, 2), dtype=torch.float64, device=dev), "u": torch.zeros((f, 2), dtype=torch.float64, device=dev),
+            "r": torch.zeros((f, 2), dtype=torch.float64, device=dev)}
+    for i in range(B // 2):
+        xs = _cols(X, T, i)
+        gs, r1 = graph(xs, 2, L.SAR_EPI_STATS)
+        us, r2 = temporal(_cols(g_full, T, i), 2, L.SAR_EPI_STATS)
+        rs, r3 = residual(xs, 2, L.SAR_EPI_STATS)
+        sums["g"] += _partials_sum(r1)
+        sums["u"] += _partials_sum(r2)
+        sums["r"] += _partials_sum(r3)
+        if i in SLICES:
+            ys = torch.empty_like(us)
+            ops.bn_add_relu_fwd(us, sc, sh, 2, rs, sc, sh, ys)
+            assert torch.equal(gs, _cols(g_full, T, i)), "graph conv, slice %d" % i
+            assert torch.equal(us, _cols(u_full, To, i)), "temporal conv, slice %d" % i
+            assert torch.equal(rs, _cols(r_full, To, i)), "residual conv, slice %d" % i
+            assert torch.equal(ys, _cols(y_full, To, i)), "block tail, slice %d" % i
+    torch.cuda.synchronize()
+    for key, r in (("g", rg), ("u", ru), ("r", rr)):
+        full = _partials_sum(r)
+        # (sum, sum of squares): sum is cancelled (mean ~ 0) -> measure both against the sum-of-squares scale
+        scale = sums[key][:, 1].abs().max().item()
+        err = (full - sums[key]).abs().max().item() / scale
+        print("BN partial sums %s: full-vs-slices %.2e of scale" % (key, err))
+        assert err < RED_TOL
+
+
+@pytest.mark.parametrize("cin,f,s,T", LAYERS)
+def test_backward_kernels_at_bs64_equal_their_slices(dev, cin, f, s, T):
+    from sar_amd import ops, _lib as L
+    To, pad = _same_pad(T, 9, s)
+    X = _rand((cin, B * T * V), dev, 11)
+    G = _rand((f, B * T * V), dev, 12)                 # graph-conv output (temporal conv input, pre-BN)
+    dU = _rand((f, B * To * V), dev, 13)               # gradient at the temporal conv output
+    dG = _rand((f, B * T * V), dev, 14)                # gradient at the graph conv output
+    Wt = _rand((9, 1, f, f), dev, 15, 0.05)
+    Wg = _rand((1, 1, cin, 3 * f), dev, 16, 0.1)
+    sc, sh, mean = 1 + 0.2 * _rand((f,), dev, 17), 0.3 * _rand((f,), dev, 18), 0.1 * _rand((f,), dev, 19)
+    tab, tabT = _tables(dev), _tables(dev, True)
+    WtT = torch.empty((9, f, f), device=dev)
+    ops.transpose(Wt, WtT, 9, f, f)
+    WgT = torch.empty((3 * f, cin), device=dev)
+    ops.transpose(Wg, WgT, 1, cin, 3 * f)
+
+    def t_dgrad(du, g_, nb):
+        out = torch.empty((f, nb * T * V), device=dev)
+        r = ops.conv_gemm(L.SAR_CONV_TEMPORAL, du, out, WtT, f * f, f, B=nb, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s,
+                          pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g_, aux_affine=(sc, sh), aux_mean=mean)
+        return out, r
+
+    def g_dgrad(dg, add, nb):
+        out = torch.empty((cin, nb * T * V), device=dev)
+        ops.conv_gemm(L.SAR_CONV_GRAPH, dg, out, WgT, f * cin, cin, B=nb, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tabT,
+                      epi=L.SAR_EPI_ADD, aux=add)
+        return out
+
+    def t_wgrad(g_, du, nb):
+        flat = torch.zeros(9 * f * f + f, device=dev)
+        ops.conv_wgrad(L.SAR_CONV_TEMPORAL, g_, du, flat, B=nb, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad,
+                       pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f)
+        return flat
+
+    def g_wgrad(x, dg, nb):
+        flat = torch.zeros(cin * 3 * f + 3 * f, device=dev)
+        ops.conv_wgrad(L.SAR_CONV_GRAPH, x, dg, flat, B=nb, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab,
+                       w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)
+        return flat
+
+    def r_wgrad(x, dr, nb):
+        flat = torch.zeros(cin * f + f, device=dev)
+        ops.conv_wgrad(L.SAR_CONV_TEMPORAL, x, dr, flat, B=nb, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
+                       w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f)
+        return flat
+
+    dz_full, rm = t_dgrad(dU, G, B)
+    dx_full = g_dgrad(dG, X, B)
+    wt_full, wg_full, wr_full = t_wgrad(G, dU, B), g_wgrad(X, dG, B), r_wgrad(X, dU, B)
+    torch.cuda.synchronize()
+    acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in (("wt", wt_full), ("wg", wg_full), ("wr", wr_full))}
+    msum = torch.zeros((f, 2), dtype=torch.float64, device=dev)
+    for i in range(B // 2):
+        du, g_, x, dg = _cols(dU, To, i), _cols(G, T, i), _cols(X, T, i), _cols(dG, T, i)
+        dzs, r = t_dgrad(du, g_, 2)
+        msum += _partials_sum(r)
+        acc["wt"] += t_wgrad(g_, du, 2).double()
+        acc["wg"] += g_wgrad(x, dg, 2).double()
+        acc["wr"] += r_wgrad(x, du, 2).double()
+        if i in SLICES:
+            assert torch.equal(dzs, _cols(dz_full, T, i)), "temporal data gradient, slice %d" % i
+            assert torch.equal(g_dgrad(dg, x, 2), _cols(dx_full, T, i)), "graph data gradient, slice %d" % i
+    torch.cuda.synchronize()
+    for key, full in (("wt", wt_full), ("wg", wg_full), ("wr", wr_full)):
+        err = rel_err(full, acc[key])
+        print("%s: B=128 launch vs float64 sum of the 64 slice launches: %.2e" % (key, err))
+        assert err < RED_TOL, key
+    full = _partials_sum(rm)
+    err = (full - msum).abs().max().item() / msum.abs().max().item()
+    print("ReLU/BN backward partial sums: %.2e" % err)
+    assert err < RED_TOL
+
+
+def test_elementwise_backward_at_bs64_equals_slices(dev):
+    from sar_amd import ops
+    f, To = 64, 300
+    n = B * To * V
+    dY, Y, U, R = _rand((f, n), dev, 21), _rand((f, n), dev, 22), _rand((f, n), dev, 23), _rand((f, n), dev, 24)
+    k = tuple(_rand((f,), dev, 25 + i, 0.5) for i in range(3))
+    rk = tuple(_rand((f,), dev, 28 + i, 0.5) for i in range(3))
+    mu, mr = 0.1 * _rand((f,), dev, 31), 0.1 * _rand((f,), dev, 32)
+    du, dr = torch.empty_like(U), torch.empty_like(R)
+    ops.bn_add_relu_bwd_apply(dY, Y, U, R, k, rk, du, dr, None)
+    part, nparts = ops.bn_add_relu_bwd_reduce(dY, Y, U, R, mu, mr)
+    a2 = torch.empty_like(U)
+    ops.affine2(dY, U, k, a2)
+    torch.cuda.synchronize()
+    acc = torch.zeros((f, 4), dtype=torch.float64, device=dev)
+    for i in range(B // 2):
+        sl = [_cols(t, To, i) for t in (dY, Y, U, R)]
+        p, _ = ops.bn_add_relu_bwd_reduce(*sl, mu, mr)
+        acc += p.double().sum(dim=1)
+        if i in SLICES:
+            dus, drs = torch.empty_like(sl[2]), torch.empty_like(sl[3])
+            ops.bn_add_relu_bwd_apply(*sl, k, rk, dus, drs, None)
+            a2s = torch.empty_like(sl[2])
+            ops.affine2(sl[0], sl[2], k, a2s)
+            assert torch.equal(dus, _cols(du, To, i)) and torch.equal(drs, _cols(dr, To, i)) and torch.equal(a2s, _cols(a2, To, i))
+    full = part.double().sum(dim=1)
+    err = (full - acc).abs().max().item() / acc.abs().max().item()
+    print("BN+add+ReLU backward reductions: %.2e" % err)
+    assert err < RED_TOL
+
+
+@pytest.mark.parametrize("classes,stream", [(60, "joint"), (120, "bone")])
+def test_eval_logits_bs64_equal_chunks(dev, classes, stream):
+    """Whole model, all 10 blocks, T = 300, bs = 64, inference mode (moving statistics): every clip's logits are
+    independent of its batch-mates, so bs = 64 must reproduce 2-clip chunks bit for bit (configs[1] and configs[4] shape)."""
+    from sar_amd.bone import NTU_BONE_PAIRS
+    from sar_amd.stgcn import STGCN
+    from sar_amd.train import synthetic_clips
+    eng = STGCN(num_classes=classes, device=dev, seed=3, bone_pairs=NTU_BONE_PAIRS if stream == "bone" else None)
+    g = torch.Generator(device=dev).manual_seed(5)
+    for name, bn in eng.bn.items():               # non-trivial moving statistics
+        bn.moving_mean.copy_(0.1 * torch.randn(bn.moving_mean.shape, generator=g, device=dev))
+        bn.moving_var.copy_(1 + 0.3 * torch.rand(bn.moving_var.shape, generator=g, device=dev))
+    x, _ = synthetic_clips(64, dev, seed=9, num_classes=classes)
+    full = eng.forward(x, training=False).clone()
+    torch.cuda.synchronize()
+    assert full.shape == (64, classes) and torch.isfinite(full).all() and full.std() > 0
+    for i in (0, 1, 15, 31):
+        part = eng.forward(x[2 * i:2 * i + 2].contiguous(), training=False)
+        assert torch.equal(part, full[2 * i:2 * i + 2]), "clips %d-%d" % (2 * i, 2 * i + 1)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_train_step_bs64_finite_and_deterministic(dev, mode):
+    """One full train step at the bench batch size (bs = 64, T = 300): finite loss / gradients, bitwise repeatable."""
+    from sar_amd.stgcn import STGCN
+    from sar_amd.train import synthetic_clips
+    x, y = synthetic_clips(64, dev, seed=4, num_classes=60)
+    eng = STGCN(num_classes=60, device=dev, seed=0, mfma=mode)
+    state = {k: v.clone() for k, v in eng.state_dict().items()}
+    outs = []
+    for _ in range(2):
+        eng.load_params(state)
+        logits, loss = eng.loss_and_grad(x, y)
+        torch.cuda.synchronize()
+        outs.append((logits.clone(), loss.clone(), eng.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert torch.isfinite(outs[0][2]).all() and abs(outs[0][1].item() - np.log(60)) < 1.0

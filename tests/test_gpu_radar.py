@@ -59,9 +59,20 @@ def test_spectrogram_matches_oracle_and_reference_golden(dev, clips, golden_dir,
     # tolerance: |Z| within 1e-4 of the spectrogram peak (assert on the magnitude, floor ~1e-3*max)
     assert np.abs(m - mo).max() / mo.max() < 1e-4
     assert np.array_equal(out[ora == ora.min()], ora[ora == ora.min()])        # exact log(1e-6)
-    gold = np.load(os.path.join(golden_dir, "radar_reference_outputs.npz"))["lam%g_loc0" % lam]
+    ref = np.load(os.path.join(golden_dir, "radar_reference_outputs.npz"))
+    gold = ref["lam%g_loc0" % lam]
     tol = 1e-4 if lam >= 1e-2 else 2e-3        # chaotic phase at radar wavelengths: see tests/test_oracle_radar.py
     assert np.abs(m - _mag(gold)).max() / _mag(gold).max() < tol
+    # Pinned to the reference at EVERY wavelength (also lambda = 5e-4, the one models/resnet.py:20 uses): the yardstick is
+    # the reference's own forward code run in float64 on the same inputs (`*_f64`, make_golden_radar.py).  At radar
+    # wavelengths a float32 evaluation -- the reference's included -- is 1.6e-4 .. 2.9e-4 of the peak away from it (a
+    # 1e4..1e5 rad phase rounded to float32); the HIP path must be no further from the truth than 3x the reference's own
+    # float32 run (and in absolute terms within 1e-3 of the peak).
+    m64 = np.exp(np.roll(ref["lam%g_loc0_f64" % lam], -128, axis=1)) - 1e-6
+    d_ref = np.abs(_mag(gold).astype(np.float64) - m64).max() / m64.max()
+    d_hip = np.abs(m.astype(np.float64) - m64).max() / m64.max()
+    print("lambda %g: |Z| distance to the float64 reference run / peak: HIP %.3e, reference float32 %.3e" % (lam, d_hip, d_ref))
+    assert d_hip <= 3 * d_ref and d_hip < 1e-3
 
 
 def test_stft_kernel_against_fft_and_column_select(dev):
@@ -132,6 +143,13 @@ def test_fused_upsampling_matches_the_reference_pipeline(dev, golden_dir):
         tol = 1e-4 if lam >= 1e-2 else 5e-3
         assert out.shape == gold.shape == (256, 256)
         assert np.abs(_mag(out[None]) - _mag(gold[None])).max() / _mag(gold[None]).max() < tol
+        # against the reference pipeline evaluated END TO END in float64 (scipy up-sampling not rounded to float32, radar in
+        # float64): no further from it than 3x the reference's own float32 pipeline
+        m64 = np.exp(np.roll(g["spec_lam%g_f64_e2e" % lam][None], -128, axis=1)) - 1e-6
+        d_ref = np.abs(_mag(gold[None]).astype(np.float64) - m64).max() / m64.max()
+        d_hip = np.abs(_mag(out[None]).astype(np.float64) - m64).max() / m64.max()
+        print("lambda %g up-sampled: distance to the float64 pipeline / peak: HIP %.3e, reference float32 %.3e" % (lam, d_hip, d_ref))
+        assert d_hip <= 3 * d_ref
     # the zero-padded tail of the clip (frames >= 260 of 300) up-samples to exact silence where the reference's does
     silent = gold == np.float32(np.log(np.float32(1e-6)))
     assert silent.any() and (out[silent] == gold[silent]).all()

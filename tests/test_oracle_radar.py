@@ -51,6 +51,20 @@ def test_matches_reference_statistically_at_radar_wavelengths(clips, gold, lam, 
     assert ref.min() == out.min() == np.float32(np.log(np.float32(1e-6)))
 
 
+@pytest.mark.parametrize("lam", [5e-4, 1e-3, 1e-1])
+def test_oracle_pinned_to_the_float64_reference_run(clips, gold, lam):
+    """The oracle is pinned at every wavelength by the reference's own forward code evaluated in float64 (`*_f64` in the
+    fixture, tests/golden/make_golden_radar.py): it must be no further from that truth than 1.5x the reference's own
+    float32 run (measured 0.84x / 1.05x / 0.91x) -- i.e. the oracle is as good a float32 evaluation of
+    layers/virtual_radar.py:93-133 as the reference itself, also where elementwise agreement between two float32
+    evaluations is impossible."""
+    out = R.virtual_radar(clips, wavelength=lam)
+    m64 = np.exp(np.roll(gold["lam%g_loc0_f64" % lam], -128, axis=1)) - 1e-6
+    d_ref = np.abs(_mag(gold["lam%g_loc0" % lam]).astype(np.float64) - m64).max() / m64.max()
+    d_ora = np.abs(_mag(out).astype(np.float64) - m64).max() / m64.max()
+    assert d_ora <= 1.5 * d_ref and d_ora < 5e-4, (d_ora, d_ref)
+
+
 def test_stft_restatement_equals_windowed_fft():
     rng = np.random.default_rng(0)
     u, v = rng.standard_normal((2, 300)).astype(np.float32), rng.standard_normal((2, 300)).astype(np.float32)

@@ -96,7 +96,7 @@ def test_shards_roundtrip_interleave_and_corruption(tmp_path):
     assert len(paths) == 5                               # 23 // 4 = 5 clips per shard -> 5 shards (the reference's rule)
     ds = T.TFRecordSkeletonData(str(tmp_path / "train_data_joint"))
     assert len(ds) == n
-    got = list(ds._interleaved())
+    got = [T.parse_example(r) for r in ds._interleave(ds.files, True)]
     # cyclic interleave: record j of shard s comes out at position j*n_shards + s while every shard is alive
     order = [s * 5 + j for j in range(5) for s in range(5) if s * 5 + j < n]
     assert [lab for _, lab in got] == [int(labels[i]) for i in order]
@@ -107,7 +107,9 @@ def test_shards_roundtrip_interleave_and_corruption(tmp_path):
         for x, y in ds.batches(4, rank, 2, torch.device("cpu"), shuffle=True, epoch=3):
             assert x.shape == (4, 3, 5, 25, 2) and x.dtype == torch.float32
             seen.extend(y.tolist())
-    assert len(seen) == 16                               # 2 global batches of 8, remainder dropped
+    # 5 shards >= 2 ranks: rank 0 reads shards 0,2,4 (13 clips), rank 1 shards 1,3 (10 clips); both yield the shorter
+    # rank's 2 full batches
+    assert len(seen) == 16
     # a flipped byte is caught by the data CRC
     raw = bytearray(open(paths[0], "rb").read())
     raw[40] ^= 0x01
@@ -117,3 +119,88 @@ def test_shards_roundtrip_interleave_and_corruption(tmp_path):
     # the length CRC of an intact shard follows the masked CRC-32C rule
     h = open(paths[1], "rb").read(12)
     assert T.masked_crc(h[:8]) == struct.unpack("<I", h[8:])[0]
+
+
+def test_crc32c_instruction_path_equals_table_path():
+    """sar_crc32c (SSE4.2 crc32 instruction when present) against sar_crc32c_sw (slice-by-8 tables) on every length /
+    alignment class, and against the bit-serial definition."""
+    from sar_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    buf = rng.integers(0, 256, 5000, dtype=np.uint8)
+
+    def bitwise(b):
+        c = 0xFFFFFFFF
+        for x in b:
+            c ^= int(x)
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        return c ^ 0xFFFFFFFF
+    for off in range(9):
+        for n in (0, 1, 7, 8, 9, 63, 64, 65, 1000, 4099):
+            a = buf[off:off + n]
+            hw, sw = lib.sar_crc32c(a.ctypes.data, n), lib.sar_crc32c_sw(a.ctypes.data, n)
+            assert hw == sw
+            if n <= 65:
+                assert hw == bitwise(a)
+
+
+def test_rank_sharding_disjoint_and_equal_batch_counts(tmp_path):
+    """Every clip a rank parses is one it trains on; ranks see disjoint clips and the same number of batches -- with
+    fewer shards than ranks (records r::world) and with at least as many (files r::world)."""
+    rng = np.random.default_rng(2)
+    n = 41
+    data = np.arange(n, dtype=np.float32)[:, None, None, None, None] + np.zeros((n, 3, 4, 25, 2), dtype=np.float32)
+    labels = rng.integers(0, 60, n)
+    for num_shards, world in ((1, 3), (2, 3), (8, 3), (4, 4)):
+        d = str(tmp_path / ("s%d_w%d" % (num_shards, world)))
+        T.write_shards(data, labels, d, "x", num_shards)
+        ds = T.TFRecordSkeletonData(d, num_classes=60)
+        per_rank = []
+        for r in range(world):
+            ids = []
+            for x, y in ds.host_batches(5, r, world, shuffle=True, epoch=1):
+                assert x.shape == (5, 3, 4, 25, 2)
+                ids.extend(int(v) for v in x[:, 0, 0, 0, 0])
+                assert all(int(labels[int(i)]) == int(l) for i, l in zip(x[:, 0, 0, 0, 0], y))
+            per_rank.append(ids)
+        assert len({len(p) for p in per_rank}) == 1 and len(per_rank[0]) > 0
+        flat = [i for p in per_rank for i in p]
+        assert len(flat) == len(set(flat))
+    with pytest.raises(ValueError):
+        list(T.TFRecordSkeletonData(d, num_classes=3).host_batches(5))
+
+
+def test_host_loaders_outrun_one_gpu(tmp_path):
+    """SURVEY 8(f)-2 / VERDICT r01 #7: the host side of the input pipeline (TFRecord shards WITH CRC verification, and the
+    .npy + .pkl pair), through the prefetch thread, must deliver well above one MI355X's ~1 000-2 000 clips/s of ST-GCN
+    training.  Full-size NTU clips (3,300,25,2) = 180 KB each."""
+    import pickle
+    import time
+
+    import torch
+    from sar_amd.data import NpySkeletonData
+    rng = np.random.default_rng(3)
+    n = 512
+    data = rng.standard_normal((n, 3, 300, 25, 2)).astype(np.float32)
+    labels = rng.integers(0, 60, n)
+    d = str(tmp_path / "shards")
+    T.write_shards(data, labels, d, "train_data_joint", 8)
+    np.save(str(tmp_path / "train_data_joint.npy"), data)
+    with open(str(tmp_path / "train_label.pkl"), "wb") as f:
+        pickle.dump((["s%d" % i for i in range(n)], labels.tolist()), f)
+    rates = {}
+    for name, ds in (("tfrecord", T.TFRecordSkeletonData(d, verify_crc=True, num_classes=60)),
+                     ("npy", NpySkeletonData(str(tmp_path / "train_data_joint.npy"), str(tmp_path / "train_label.pkl"), 60))):
+        best = 0.0
+        for rep in range(3):
+            t0 = time.perf_counter()
+            clips, checksum = 0, 0.0
+            for x, y in ds.batches(64, 0, 1, torch.device("cpu"), shuffle=True, epoch=rep):
+                clips += x.shape[0]
+                checksum += float(x[0, 0, 0, 0, 0])
+            best = max(best, clips / (time.perf_counter() - t0))
+        assert clips == n
+        rates[name] = best
+    print("host loader clips/s:", {k: round(v) for k, v in rates.items()})
+    assert rates["tfrecord"] >= 2500 and rates["npy"] >= 2500, rates

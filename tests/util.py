@@ -19,3 +19,11 @@ def rel_err(a, b):
     b = b.detach().double().cpu()
     denom = b.abs().max().item()
     return (a - b).abs().max().item() / (denom if denom > 0 else 1.0)
+
+
+def rel_err_fro(a, b):
+    """||a-b||_2 / ||b||_2 (Frobenius-relative error; b is the reference)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    denom = b.norm().item()
+    return (a - b).norm().item() / (denom if denom > 0 else 1.0)

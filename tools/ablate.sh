@@ -10,7 +10,9 @@ if [ "$1" = build ]; then
   for m in ${MODES:-1 2 3}; do
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSAR_ABLATE=$m -c $C/conv_gemm.hip -o tools/bin/conv_gemm_a$m.o
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSAR_ABLATE=$m -c $C/conv_wgrad.hip -o tools/bin/conv_wgrad_a$m.o
-    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libsar_a$m.so tools/bin/conv_gemm_a$m.o tools/bin/conv_wgrad_a$m.o $C/conv2d.o $C/elementwise.o $C/radar.o
+    # every other object of the regular build (make -C $C first): the loader requires every symbol of include/sar_hip.h
+    OTHERS=$(ls $C/*.o | grep -v -e "/conv_gemm.o" -e "/conv_wgrad.o")
+    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libsar_a$m.so tools/bin/conv_gemm_a$m.o tools/bin/conv_wgrad_a$m.o $OTHERS
   done
 else
   K=${KERNELS:-tconv_fwd,tconv_dgrad,gcn_fwd}
