@@ -207,6 +207,7 @@ def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None, masks
     g = graph_conv_td(x, p[pre + "gcn.kernel"], p[pre + "gcn.bias"], A)
     h = batch_norm(g, p[pre + "bn1.gamma"], p[pre + "bn1.beta"], p[pre + "bn1.moving_mean"],
                    p[pre + "bn1.moving_var"], training, (0, 2, 3), True, new_stats, pre + "bn1")
+    h_pre = h
     h = _relu(h, masks, pre + "h")
     u = temporal_conv(h, p[pre + "tcn.kernel"], p[pre + "tcn.bias"], s)
     z = batch_norm(u, p[pre + "bn2.gamma"], p[pre + "bn2.beta"], p[pre + "bn2.moving_mean"],
@@ -218,6 +219,8 @@ def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None, masks
         taps[pre + "g"] = g
         taps[pre + "u"] = u
         taps[pre + "y"] = y
+        taps[pre + "h_pre"] = h_pre      # the two ReLU inputs of the block (tests: activation-pattern ties)
+        taps[pre + "y_pre"] = z
     return y
 
 

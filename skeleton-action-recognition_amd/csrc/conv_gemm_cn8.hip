@@ -1,0 +1,741 @@
+// conv_gemm_cn8.hip -- graph / temporal / residual convolutions and their data gradients on bf16 CN8 activations
+// (cn8.h): SURVEY.md 8(d) config 3 -- bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation, fp32 BatchNorm
+// statistics (reduced from the accumulators), fp32 master weights.
+//
+//   out[m, n] = sum_tap sum_c bf16(W[tap][c][m]) * OP_tap(pro(src))[c, n] (+ bias) ; epilogue ; out rounded to bfloat16
+//
+// Operators, prologue and epilogue semantics are those of sar_conv_gemm_f32 (include/sar_hip.h; models/stgcn.py:27-36,
+// 47-54, models/gcn.py:199-209 and their data gradients).  What the layout buys (cn8.h):
+//  * src -> LDS is a straight copy of 16-byte units (8 channels of one column) into the k-innermost operand image of
+//    v_mfma_f32_32x32x16_bf16; TF-SAME zero padding and everything outside the sequence come from the hardware range
+//    check of a per-(sequence, channel group) buffer descriptor (a negative or past-the-end offset reads 0);
+//  * a folded BatchNorm + ReLU prologue (temporal forward) touches the unit in registers: unpack, fma, max, repack;
+//  * the graph gather z_k = x . A_k reads whole units (8 channels per ds_read_b128) of the raw tile;
+//  * the epilogue stores the 4 consecutive channels a lane holds in registers 4q .. 4q+3 as ONE 8-byte half unit:
+//    512 contiguous bytes per wave instruction, 4 stores per 32x32 accumulator tile (fp32 CN layout: 16).
+#include "cn8.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int KC16 = 16;   // src channels per main-loop stage = one MFMA k-step = two CN8 planes
+
+struct ConvK8 {
+  sar_conv_desc d;
+  const uint4* wp;   // packed weights [taps][G][M] units of 8 bf16 (sar_pack_weights_bf16_batch)
+  int G;             // channel groups of 8 in the packed weights (even)
+  int Gs, Go;        // CN8 planes of src / out (= aux)
+  int FT, TPS, NF, RW, nparts, ntiles, ny;
+};
+
+template <int TAPS, int MS, int NS, int WM, int WN>
+struct TileCfg8 {
+  static constexpr int BM = 32 * MS * WM;
+  static constexpr int TN = 32 * NS * WN;
+  static constexpr int RWMAX = (TN == 128 ? 448 : 704);   // staged columns: (FT - 1) * stride + taps frames of V joints
+  static constexpr int SCOLS = RWMAX + 8;                 // + the always-zero column
+  static constexpr int WUNITS = TAPS * 2 * BM;            // [tap][h][m]
+  static constexpr int SUNITS = 2 * SCOLS;                // [h][col]
+  static constexpr int CJ = (RWMAX + 255) / 256;          // S units per lane and plane
+  static constexpr int WIT = (WUNITS + 255) / 256;        // W units per lane
+  static constexpr int UNITS = WUNITS + SUNITS;
+};
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- epilogue: mask / add, BatchNorm partial sums from the fp32 accumulators, bf16 half-unit stores.  Every wave is
+// past its last MFMA phase and the closing barrier: the transpose area aliases the operand image.
+template <int MS, int NS, int WN, int BM>
+__device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int wn, int m0, const bool (&colok)[NS],
+                                          const int64_t (&coln)[NS], f32x16 (&acc)[MS][NS], float4* rowp, float* smem) {
+  const sar_conv_desc& d = k.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int part = tile * WN + wn;
+  auto run = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
+    if (EPI == SAR_EPI_MASK) {
+      if (tid < BM) {
+        const int row = m0 + tid;
+        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < d.M) {
+          ap.x = d.aux_scale[row];
+          ap.y = d.aux_shift[row];
+          if (d.aux_mean) ap.z = d.aux_mean[row];
+        }
+        rowp[tid] = ap;
+      }
+      __syncthreads();
+    }
+    const int rows_w = m0 + wm * MS * 32;          // first output row of this wave (multiple of 32)
+    const int g_w = rows_w >> 3;                   // its first CN8 plane
+    auto plane_bytes = [&](int64_t ld) {           // bytes from plane g_w to the end of the tensor (clamped to 2 GiB)
+      const int64_t n = (int64_t)(k.Go - g_w) * ld * 16;
+      return (unsigned)(n <= 0 ? 0 : (n > 0x7fffffffll ? 0x7fffffffll : n));
+    };
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)d.out + (int64_t)g_w * d.ld_out * 16), 0, plane_bytes(d.ld_out), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_aux ? (char*)d.aux + (int64_t)g_w * d.ld_aux * 16 : (char*)d.out), 0, has_aux ? plane_bytes(d.ld_aux) : 0u,
+        0x00020000);
+    unsigned vo[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) vo[ns] = colok[ns] ? (unsigned)(coln[ns] * 16 + 8 * hi) : 0x80000000u;
+    const int so_out = (int)(d.ld_out * 16), so_aux = (int)(d.ld_aux * 16);   // one plane
+    float* P = smem + wave * (16 * 65);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        // registers 8 rb .. 8 rb + 7 = two groups of 4 consecutive channels: planes 4 ms + 2 rb + {0, 1}
+        float ax[NS][8];
+        if (has_aux) {
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(ra, vo[ns], (4 * ms + 2 * rb + q2) * so_aux, 0);
+              float f[4];
+              cn8_unpack4(make_uint2(a[0], a[1]), f);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ax[ns][4 * q2 + i] = f[i];
+            }
+        }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = rb * 8 + r8;
+          float s1 = 0.f, s2 = 0.f;
+          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            float val = acc[ms][ns][r];
+            if (EPI == SAR_EPI_STATS) {
+              s1 += val;
+              s2 = fmaf(val, val, s2);
+            } else if (EPI == SAR_EPI_MASK) {
+              val = (fmaf(ax[ns][r8], ap.x, ap.y) > 0.f) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ax[ns][r8] - ap.z, s2);
+            } else if (EPI == SAR_EPI_ADD) {
+              val += ax[ns][r8];
+            }
+            acc[ms][ns][r] = val;
+          }
+          if (stats) {
+            P[(2 * r8) * 65 + lane] = s1;
+            P[(2 * r8 + 1) * 65 + lane] = s2;
+          }
+        }
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const int gq = 4 * ms + 2 * rb + q2;
+          if (g_w + gq < k.Go) {   // wave-uniform
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const int r0 = rb * 8 + 4 * q2;
+              u32x2 o;
+              o[0] = cn8_pack2(acc[ms][ns][r0], acc[ms][ns][r0 + 1]);
+              o[1] = cn8_pack2(acc[ms][ns][r0 + 2], acc[ms][ns][r0 + 3]);
+              __builtin_amdgcn_raw_buffer_store_b64(o, ro, vo[ns], gq * so_out, 0);
+            }
+          }
+        }
+        if (stats) {
+          __builtin_amdgcn_wave_barrier();
+          const int q = lane & 15, sub = (lane >> 4) & 1;
+          const float* pr = P + q * 65 + hi * 32 + sub * 16;
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t += pr[i];
+          t += __shfl_xor(t, 16);
+          __builtin_amdgcn_wave_barrier();
+          const int r = rb * 8 + (q >> 1);
+          const int row = rows_w + ms * 32 + mfma_row(r, hi);
+          if (sub == 0 && row < d.M) d.partials[((int64_t)row * k.nparts + part) * 2 + (q & 1)] = t;
+        }
+      }
+    }
+  };
+  switch (d.epi) {
+    case SAR_EPI_STATS: run(std::integral_constant<int, SAR_EPI_STATS>()); break;
+    case SAR_EPI_MASK: run(std::integral_constant<int, SAR_EPI_MASK>()); break;
+    case SAR_EPI_ADD: run(std::integral_constant<int, SAR_EPI_ADD>()); break;
+    default: run(std::integral_constant<int, SAR_EPI_NONE>()); break;
+  }
+}
+
+// workgroup id -> work item, XCD-aware (conv_gemm.hip): consecutive ids go to consecutive XCDs; each XCD walks a
+// contiguous range of tiles so that the temporal halo and the row blocks of a tile share one L2
+__device__ __forceinline__ int xcd_work(int nwork) {
+  const int per = (nwork + 7) / 8;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int w = xcd * per + slot;
+  return (w >= nwork || slot >= per) ? -1 : w;
+}
+
+// TR: 0 forward; 1 data gradient, stride 1; 2 data gradient, generic stride (tap validity mask); 3 data gradient,
+// stride 2, parity-split column map (see conv_gemm.hip)
+template <int TR, int TAPS, int MS, int NS, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
+  using TC = TileCfg8<TAPS, MS, NS, WM, WN>;
+  constexpr int TRANSPOSED = TR != 0;
+  constexpr int PAR = (TR == 3);
+  constexpr int JT = PAR ? (TAPS + 1) / 2 : TAPS;
+  constexpr int BM = TC::BM, SCOLS = TC::SCOLS, CJ = TC::CJ, WIT = TC::WIT;
+  constexpr int ZCOL = TC::RWMAX;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area (floats / 4), aliases the operand image
+  constexpr int IMG_U = TC::UNITS > PAREA_U ? TC::UNITS : PAREA_U;
+  __shared__ uint4 smem_u[IMG_U + BM];       // image | per-row parameters (float4 per row)
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + TC::WUNITS;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int V = d.V;
+  const int ny = k.ny;
+  const int w = xcd_work(k.ntiles * ny);
+  if (w < 0) return;
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+
+  // ---- per-lane column geometry
+  bool colok[NS];
+  int64_t coln[NS];
+  int off[JT][NS];
+  unsigned vmask[NS];
+  int t_lo;
+  if (!TRANSPOSED) t_lo = t0 * d.stride - d.pad;
+  else t_lo = floordiv(t0 + d.pad - (TAPS - 1), d.stride);
+  constexpr int HALFC = 16 * NS * WN;
+  const int par = PAR ? (wn * NS * 32 >= HALFC ? 1 : 0) : 0;
+  const int tp0 = PAR ? ((par + d.pad) & 1) : 0;
+  const int ntap_w = PAR ? (TAPS - tp0 + 1) / 2 : TAPS;
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    int fo, v;
+    if (PAR) {
+      const int pp = p - par * HALFC;
+      const int fh = pp / V;
+      v = pp - fh * V;
+      fo = 2 * fh + par;
+    } else {
+      fo = p / V;
+      v = p - fo * V;
+    }
+    colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
+    if (!colok[ns]) fo = par;
+    coln[ns] = ((int64_t)b * d.T_out + (t0 + fo)) * V + v;
+    vmask[ns] = 0;
+#pragma unroll
+    for (int tp = 0; tp < JT; ++tp) {
+      if (!TRANSPOSED) {
+        off[tp][ns] = (fo * d.stride + tp) * V + v;
+      } else if (PAR) {
+        const int to = (t0 + fo + d.pad - (tp0 + 2 * tp)) >> 1;
+        off[tp][ns] = (to - t_lo) * V + v;
+      } else {
+        const int q = t0 + fo + d.pad - tp;
+        const int to = floordiv(q, d.stride);
+        const bool ok = (q - to * d.stride) == 0;
+        vmask[ns] |= (ok ? 1u : 0u) << tp;
+        off[tp][ns] = (to - t_lo) * V + v;
+      }
+      if (!colok[ns]) off[tp][ns] = ZCOL;
+      off[tp][ns] += hi * SCOLS;   // this lane's k half
+    }
+  }
+
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) bp.x = d.bias[row];
+    rowp[tid] = bp;
+  }
+  if (tid < 2) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16 acc[MS][NS];
+
+  // ---- staging.  S: unit (h, col) <- plane c0/8 + h, column t_lo V + col of sequence b; the descriptor spans exactly the
+  // sequence, so the temporal zero padding (negative / past-the-end columns) is the range check's 0
+  const int seq_len = d.T_src * V;
+  const char* src_b = (const char*)d.src + (int64_t)b * seq_len * 16;
+  int svo[CJ];
+  bool sok[CJ];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int col = tid + 256 * j;
+    const int rabs = t_lo * V + col;
+    sok[j] = col < k.RW && (unsigned)rabs < (unsigned)seq_len;
+    svo[j] = col < k.RW ? rabs * 16 : 0x7fffffff;   // lanes beyond the staged width read 0 too
+  }
+  unsigned wvo[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int u = tid + 256 * i;
+    const int m = u % BM, h = (u / BM) & 1, tp = u / (2 * BM);
+    const bool ok = u < TC::WUNITS && (m0 + m) < d.M;
+    wvo[i] = ok ? (unsigned)((((int64_t)tp * k.G + h) * d.M + m0 + m) * 16) : 0x80000000u;   // rejected by the range check -> 0
+  }
+  const unsigned wbytes = (unsigned)((int64_t)TAPS * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const bool has_pro = d.pro_scale != nullptr;
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  uint4 wreg[WIT];
+  uint4 sreg[2][CJ];
+
+  auto issue_loads = [&](int c0) {
+    const int wso = (c0 / 8) * d.M * 16;   // scalar: first channel group of the stage
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], wso, 0);
+      wreg[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int g = c0 / 8 + h;   // wave-uniform
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(src_b + (int64_t)(g < k.Gs ? g : 0) * d.ld_src * 16), 0, g < k.Gs ? (unsigned)seq_len * 16u : 0u, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, svo[j], 0, 0);
+        sreg[h][j] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+
+  auto store_lds = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < WIT; ++i)
+      if ((i + 1) * 256 <= TC::WUNITS || tid + 256 * i < TC::WUNITS) Wl[tid + 256 * i] = wreg[i];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (has_pro) {   // uniform: BatchNorm + ReLU of the producer folded into the operand (models/stgcn.py:27-28)
+        float psc[8], psh[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = c0 + 8 * h + q;
+          const bool rok = c < d.Kc;
+          psc[q] = rok ? d.pro_scale[c] : 0.f;
+          psh[q] = rok ? d.pro_shift[c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+          float f[8];
+          cn8_unpack(sreg[h][j], f);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) f[q] = sok[j] ? fmaxf(fmaf(f[q], psc[q], psh[q]), relu_lo) : 0.f;   // padding stays exactly 0
+          sreg[h][j] = cn8_pack(f);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CJ; ++j)
+        if ((j + 1) * 256 <= TC::RWMAX || tid + 256 * j < TC::RWMAX) Sl[h * SCOLS + tid + 256 * j] = sreg[h][j];
+    }
+  };
+
+  issue_loads(0);
+  __syncthreads();   // rowp
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = colok[ns] ? bp.x : 0.f;
+    }
+
+  const uint4* Wa = Wl + (tp0 * 2 + hi) * BM + wm * MS * 32 + l31;
+  auto taps_mma = [&](int j) {
+    const int tpw = PAR ? 2 * j : j;
+    uint4 a[MS], bq[NS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tpw * 2 * BM + ms * 32];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      bq[ns] = Sl[off[j][ns]];
+      if (TR == 2 && !((vmask[ns] >> j) & 1u)) bq[ns] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[ms]),
+                                                              *reinterpret_cast<bf16x8*>(&bq[ns]), acc[ms][ns], 0, 0, 0);
+  };
+
+  for (int c0 = 0; c0 < d.Kc; c0 += KC16) {
+    store_lds(c0);
+    __syncthreads();
+    if (c0 + KC16 < d.Kc) issue_loads(c0 + KC16);   // in flight during the MFMA phase
+    constexpr int JSURE = PAR ? JT - 1 : JT;
+#pragma unroll
+    for (int j = 0; j < JSURE; ++j) taps_mma(j);
+    if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
+    __syncthreads();   // every wave is done with the image (next store / the epilogue's transpose area)
+  }
+
+  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, colok, coln, acc, rowp, smem);
+}
+
+// ---- GraphConvTD (models/gcn.py:199-209) and its data gradient:
+//   out[m, (t,w)] = sum_k sum_c bf16(W_k[c][m]) * bf16(z_k)[c, (t,w)] + sum_k b_k[m] colsum(A_k)[w],
+//   z_k[c, (t,w)] = sum_v src[c, (t,v)] A_k[v, w]      (fp32, <= 4 non-zeros per column of A_k)
+// Stage = 16 src channels: (1) the tile's raw units -> LDS (straight copy), (2) every thread builds the three z_k
+// units of its (channel half, column): NZ gather entries, each ONE ds_read_b128 of 8 channels, weighted in fp32 and
+// rounded once (an entry list {(v, 1.0)} is a plain copy), (3) 3 slices x MS x NS MFMAs.
+template <int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
+__global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) {
+  constexpr int BM = 32 * MS * WM, TN = 32 * NS * WN;
+  constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  constexpr int XS = TN + 1;                 // raw plane stride (units)
+  constexpr int CPT = TN / 128;              // columns per thread in the unit builder (thread = (half, column))
+  constexpr int WUNITS = 3 * 2 * BM;         // [slice][h][m]
+  constexpr int ZUNITS = 3 * 2 * TN;         // [slice][h][col]
+  constexpr int WIT = (WUNITS + 255) / 256;
+  constexpr int XJ = (2 * TN) / 256;         // raw units per thread and stage
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;
+  constexpr int IMG_U = (WUNITS + ZUNITS) > PAREA_U ? (WUNITS + ZUNITS) : PAREA_U;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ uint4 smem_u[IMG_U + BM + 2 * XS];
+  uint4* Wl = smem_u;
+  uint4* Zl = smem_u + WUNITS;
+  uint4* XR = smem_u + IMG_U + BM;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int V = d.V;
+  const int ny = k.ny;
+  const int w = xcd_work(k.ntiles * ny);
+  if (w < 0) return;
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+  const int ncols = ((t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0) * V;   // live columns of this tile
+
+  bool colok[NS];
+  int64_t coln[NS];
+  float gcs[3][NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    colok[ns] = p < ncols;
+    const int pv = colok[ns] ? p : 0;
+    coln[ns] = ((int64_t)b * d.T_out + t0) * V + pv;
+    const int v = pv % V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) gcs[tp][ns] = (d.g_colsum && colok[ns]) ? d.g_colsum[tp * V + v] : 0.f;
+  }
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) {
+      bp.x = d.bias[row];
+      bp.y = d.bias[d.M + row];
+      bp.z = d.bias[2 * d.M + row];
+    }
+    rowp[tid] = bp;
+  }
+  // unit builder geometry: this thread's channel half and columns, gather offsets (units inside a raw plane) and weights
+  const int uh = tid >> 7;   // 0 / 1 (wave-uniform)
+  int go[CPT][3][4];
+  float gwt[CPT][3][4];
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const int col = (tid & 127) + 128 * q;
+    const bool live = col < ncols;
+    const int cc = live ? col : 0;
+    const int fo = cc / V, v = cc - fo * V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < NZ[tp]) {
+          go[q][tp][j] = fo * V + d.g_idx[(tp * V + v) * 4 + j];
+          gwt[q][tp][j] = live ? d.g_wt[(tp * V + v) * 4 + j] : 0.f;
+        }
+  }
+
+  f32x16 acc[MS][NS];
+  const int seq_left = (d.T_src - t0) * V;   // columns from the tile start to the end of the sequence
+  const char* src_b = (const char*)d.src + ((int64_t)b * d.T_src + t0) * V * 16;
+  // raw stager: thread -> (plane xh, column xc) for XJ units
+  int xvo[XJ], xdst[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int u = tid + 256 * j;
+    const int xh = u / TN, xc = u - xh * TN;
+    xvo[j] = xc < ncols ? xc * 16 : 0x7fffffff;   // rejected -> 0
+    xdst[j] = xh * XS + xc;
+  }
+  unsigned wvo[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int u = tid + 256 * i;
+    const int m = u % BM, h = (u / BM) & 1, tp = u / (2 * BM);
+    const bool ok = u < WUNITS && (m0 + m) < d.M;
+    wvo[i] = ok ? (unsigned)((((int64_t)tp * k.G + h) * d.M + m0 + m) * 16) : 0x80000000u;
+  }
+  const unsigned wbytes = (unsigned)((int64_t)3 * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  uint4 wreg[WIT];
+  uint4 xreg[XJ];
+
+  auto issue_loads = [&](int c0) {
+    const int wso = (c0 / 8) * d.M * 16;
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], wso, 0);
+      wreg[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int g = c0 / 8 + (tid + 256 * j) / TN;   // wave-uniform (TN is a multiple of 64)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(src_b + (int64_t)(g < k.Gs ? g : 0) * d.ld_src * 16), 0, g < k.Gs ? (unsigned)seq_left * 16u : 0u, 0x00020000);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xvo[j], 0, 0);
+      xreg[j] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_raw = [&]() {
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) XR[xdst[j]] = xreg[j];
+  };
+  auto build_units = [&]() {
+#pragma unroll
+    for (int i = 0; i < WIT; ++i)
+      if ((i + 1) * 256 <= WUNITS || tid + 256 * i < WUNITS) Wl[tid + 256 * i] = wreg[i];
+    const uint4* Xh = XR + uh * XS;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) {
+        uint4 zu;
+        if (NZ[tp] == 1 && gwt[q][tp][0] == 1.0f) {
+          zu = Xh[go[q][tp][0]];                       // a {(v, 1.0)} list: bf16(1.0 * x) = x
+        } else {
+          float z[8], x[8];
+          cn8_unpack(Xh[go[q][tp][0]], x);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) z[c] = gwt[q][tp][0] * x[c];
+#pragma unroll
+          for (int j = 1; j < 4; ++j)
+            if (j < NZ[tp]) {
+              cn8_unpack(Xh[go[q][tp][j]], x);
+#pragma unroll
+              for (int c = 0; c < 8; ++c) z[c] = fmaf(gwt[q][tp][j], x[c], z[c]);
+            }
+          zu = cn8_pack(z);
+        }
+        Zl[(tp * 2 + uh) * TN + (tid & 127) + 128 * q] = zu;
+      }
+    }
+  };
+
+  issue_loads(0);
+  __syncthreads();   // rowp
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
+    }
+  const uint4* Wa = Wl + hi * BM + wm * MS * 32 + l31;
+  const uint4* Za = Zl + hi * TN + wn * NS * 32 + l31;
+  for (int c0 = 0; c0 < d.Kc; c0 += KC16) {
+    store_raw();
+    __syncthreads();   // raw image complete; every wave is past the MFMA phase of the previous stage
+    build_units();
+    __syncthreads();
+    if (c0 + KC16 < d.Kc) issue_loads(c0 + KC16);
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      uint4 a[MS], bq[NS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tp * 2 * BM + ms * 32];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) bq[ns] = Za[tp * 2 * TN + ns * 32];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[ms]),
+                                                                *reinterpret_cast<bf16x8*>(&bq[ns]), acc[ms][ns], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // the epilogue's transpose area aliases the image
+  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, colok, coln, acc, rowp, smem);
+}
+
+template <int WN>
+int tile_geometry8(const sar_conv_desc& d, int NSv, bool parity, ConvK8& k) {
+  const int tile_n = 32 * NSv * WN;
+  if (parity) {
+    k.FT = 2 * ((tile_n / 2) / d.V);
+    const int t_even = d.T_out + (d.T_out & 1);
+    if (k.FT > t_even) k.FT = t_even;
+  } else {
+    k.FT = tile_n / d.V;
+    if (k.FT > d.T_out) k.FT = d.T_out;
+  }
+  if (k.FT < 1) return -1;
+  k.TPS = (d.T_out + k.FT - 1) / k.FT;
+  if (d.mode == SAR_CONV_GRAPH) k.NF = k.FT;
+  else if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
+  else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
+  k.RW = k.NF * d.V;
+  k.nparts = d.B * k.TPS * WN;
+  const int rwmax = (d.mode == SAR_CONV_GRAPH) ? tile_n : (NSv * WN == 4 ? 448 : 704);
+  if (k.RW > rwmax) return -2;
+  return 0;
+}
+
+void fill_common(const sar_conv_desc& d, const uint4* wp, ConvK8& k) {
+  k.d = d;
+  k.wp = wp;
+  k.G = 2 * ((d.Kc + 15) / 16);
+  k.Gs = (d.Kc + 7) / 8;
+  k.Go = (d.M + 7) / 8;
+}
+
+template <int TR, int TAPS, int MS, int NS, int WM, int WN>
+int launch_cfg8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* nparts_only) {
+  ConvK8 k;
+  fill_common(d, wp, k);
+  if (int g = tile_geometry8<WN>(d, NS, TR == 3, k)) {
+    sar_set_error("sar_conv_gemm_cn8: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
+  }
+  if (nparts_only) {
+    *nparts_only = k.nparts;
+    return 0;
+  }
+  constexpr int BM = 32 * MS * WM;
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + BM - 1) / BM;
+  const int nwork = k.ntiles * k.ny;
+  hipLaunchKernelGGL((conv_gemm_cn8_kernel<TR, TAPS, MS, NS, WM, WN>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
+  return 0;
+}
+
+template <int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
+int launch_graph_cfg8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* nparts_only) {
+  ConvK8 k;
+  fill_common(d, wp, k);
+  if (int g = tile_geometry8<WN>(d, NS, false, k)) {
+    sar_set_error("sar_conv_gemm_cn8: unsupported tile geometry (V=%d)", d.V);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
+  }
+  if (nparts_only) {
+    *nparts_only = k.nparts;
+    return 0;
+  }
+  constexpr int BM = 32 * MS * WM;
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + BM - 1) / BM;
+  const int nwork = k.ntiles * k.ny;
+  hipLaunchKernelGGL((conv_graph_cn8_kernel<MS, NS, WM, WN, NZ0, NZ1, NZ2>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
+  return 0;
+}
+
+template <int NZ0, int NZ1, int NZ2>
+int launch_graph_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) {
+  if (d.M > 64) return launch_graph_cfg8<2, 2, 2, 2, NZ0, NZ1, NZ2>(d, wp, st, np);
+  if (d.M > 32) return launch_graph_cfg8<2, 2, 1, 4, NZ0, NZ1, NZ2>(d, wp, st, np);
+  return launch_graph_cfg8<1, 2, 1, 4, NZ0, NZ1, NZ2>(d, wp, st, np);
+}
+
+template <int TR, int TAPS>
+int launch_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) {
+  if constexpr (TR != 3)
+    if (d.M > 64) return launch_cfg8<TR, TAPS, 2, 2, 2, 2>(d, wp, st, np);
+  if (d.M > 32) return launch_cfg8<TR, TAPS, 2, 2, 1, 4>(d, wp, st, np);
+  return launch_cfg8<TR, TAPS, 1, 2, 1, 4>(d, wp, st, np);
+}
+
+int dispatch8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) {
+  if (d.mode == SAR_CONV_GRAPH) {
+    if (d.nz[0] == 1 && d.nz[1] == 1) return launch_graph_by_m8<1, 1, 4>(d, wp, st, np);
+    if (d.nz[0] == 1 && d.nz[2] == 1) return launch_graph_by_m8<1, 4, 1>(d, wp, st, np);
+    return launch_graph_by_m8<4, 4, 4>(d, wp, st, np);
+  }
+  if (!d.transposed) return d.taps == 9 ? launch_by_m8<0, 9>(d, wp, st, np) : launch_by_m8<0, 1>(d, wp, st, np);
+  if (d.stride == 1) return d.taps == 9 ? launch_by_m8<1, 9>(d, wp, st, np) : launch_by_m8<1, 1>(d, wp, st, np);
+  if (d.taps == 9) return d.stride == 2 ? launch_by_m8<3, 9>(d, wp, st, np) : launch_by_m8<2, 9>(d, wp, st, np);
+  return launch_by_m8<2, 1>(d, wp, st, np);
+}
+
+int check8(const sar_conv_desc* d) {
+  SAR_REQUIRE(d != nullptr, "sar_conv_gemm_cn8: null descriptor");
+  SAR_REQUIRE(d->mode == SAR_CONV_TEMPORAL || d->mode == SAR_CONV_GRAPH, "sar_conv_gemm_cn8: bad mode %d", d->mode);
+  SAR_REQUIRE(d->B > 0 && d->V > 0 && d->V <= 64 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0,
+              "sar_conv_gemm_cn8: bad sizes");
+  if (d->mode == SAR_CONV_GRAPH) {
+    SAR_REQUIRE(d->taps == 3 && d->T_src == d->T_out, "sar_conv_gemm_cn8: graph mode needs 3 adjacency slices and keeps T");
+    for (int i = 0; i < 3; ++i)
+      SAR_REQUIRE(d->nz[i] >= 1 && d->nz[i] <= 4, "sar_conv_gemm_cn8: adjacency slice %d needs %d gather entries (max 4)", i, d->nz[i]);
+  } else {
+    SAR_REQUIRE(d->taps == 9 || d->taps == 1, "sar_conv_gemm_cn8: temporal kernel size %d not built (1 and 9 are)", d->taps);
+    SAR_REQUIRE(d->stride >= 1 && d->pad >= 0, "sar_conv_gemm_cn8: bad stride/pad");
+  }
+  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm_cn8: bad epilogue %d", d->epi);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sar_conv_gemm_cn8_nparts(const sar_conv_desc* d) {
+  if (int rc = check8(d)) return rc;
+  int np = 0;
+  const int rc = dispatch8(*d, nullptr, nullptr, &np);
+  return rc ? rc : np;
+}
+
+extern "C" int sar_conv_gemm_cn8(const sar_conv_desc* d, const void* packed_w, sar_stream_t s) {
+  if (int rc = check8(d)) return rc;
+  SAR_REQUIRE(packed_w && ((uintptr_t)packed_w & 15) == 0, "sar_conv_gemm_cn8: packed weights must be 16-byte aligned");
+  SAR_REQUIRE(d->src && d->out && (((uintptr_t)d->src | (uintptr_t)d->out | (uintptr_t)d->aux) & 15) == 0,
+              "sar_conv_gemm_cn8: null / misaligned src, out or aux (CN8 tensors are 16-byte aligned)");
+  if (d->mode == SAR_CONV_GRAPH) {
+    SAR_REQUIRE(d->g_idx && d->g_wt, "sar_conv_gemm_cn8: graph gather tables required");
+    SAR_REQUIRE(!d->bias || d->g_colsum, "sar_conv_gemm_cn8: graph bias needs g_colsum");
+    if (d->pro_scale) {
+      sar_set_error("sar_conv_gemm_cn8: a folded prologue is not built for graph mode");
+      return SAR_E_UNSUP;
+    }
+  }
+  SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_out >= (int64_t)d->B * d->T_out * d->V,
+              "sar_conv_gemm_cn8: leading dimension smaller than B*T*V");
+  SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_gemm_cn8: pro_scale/pro_shift mismatch");
+  SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 26), "sar_conv_gemm_cn8: sequence row too long");
+  SAR_REQUIRE(d->ld_out < (1 << 26) && d->ld_aux < (1 << 26), "sar_conv_gemm_cn8: leading dimension too large (2^26 columns)");
+  SAR_REQUIRE((int64_t)d->taps * 2 * ((d->Kc + 15) / 16) * d->M * 16 < (1ll << 31), "sar_conv_gemm_cn8: weight tensor too large");
+  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm_cn8: partials required");
+  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
+    SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm_cn8: aux required");
+  if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->aux_scale && d->aux_shift, "sar_conv_gemm_cn8: aux affine required");
+  int rc = dispatch8(*d, (const uint4*)packed_w, as_stream(s), nullptr);
+  if (rc) return rc;
+  SAR_LAUNCH_CHECK("sar_conv_gemm_cn8");
+  return 0;
+}

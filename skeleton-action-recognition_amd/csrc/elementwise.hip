@@ -6,6 +6,7 @@
 // every reduction is deterministic).  Reference call sites are cited in include/sar_hip.h.
 #include <stdarg.h>
 #include "sar_common.h"
+#include "cn8.h"
 
 // ------------------------------------------------------------------------------------ error state
 static thread_local char g_err[512] = "no error";
@@ -173,7 +174,7 @@ __device__ __forceinline__ float load_joint(const float* slab, int t, int v, int
   return load_frame(slab, t + 1, v, m, V, M, bone_parent) - load_frame(slab, t, v, m, V, M, bone_parent);
 }
 
-template <bool BWD>
+template <bool BWD, bool DY_CN8 = false>
 __global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __restrict__ x, int N, int C, int T, int V, int M,
                                                              const int* __restrict__ bone_parent, int motion,
                                                              const float* __restrict__ dy, int64_t ld_dy,
@@ -191,7 +192,13 @@ __global__ __launch_bounds__(TPB) void data_bn_reduce_kernel(const float* __rest
     for (int t = rg; t < T; t += groups) {
       const float val = load_joint(slab, t, v, m, V, M, bone_parent, motion, T) - mu;
       if (BWD) {
-        const float g = dy[(int64_t)c * ld_dy + ((int64_t)(n * M + m) * T + t) * V + v];
+        float g;
+        if (DY_CN8) {   // unit 0 of the column holds channels 0..7 of the (C <= 8)-channel input gradient
+          const unsigned short h = reinterpret_cast<const unsigned short*>(dy)[(((int64_t)(n * M + m) * T + t) * V + v) * 8 + c];
+          g = __uint_as_float((unsigned)h << 16);
+        } else {
+          g = dy[(int64_t)c * ld_dy + ((int64_t)(n * M + m) * T + t) * V + v];
+        }
         s1 += g;
         s2 = fmaf(g, val, s2);
       } else {
@@ -230,6 +237,33 @@ __global__ __launch_bounds__(TPB) void data_bn_apply_kernel(const float* __restr
     const float val = load_joint(slab, t, v, m, V, M, bone_parent, motion, T);
     const int ch = v * C + c;
     out[(int64_t)c * ld_out + ((int64_t)(n * M + m) * T + t) * V + v] = fmaf(val, scale[ch], shift[ch]);
+  }
+}
+
+// CN8 output (cn8.h): one unit per column holds the C <= 8 input channels.  Workgroup = (sample n, frame chunk); a thread
+// owns one (t, v, m) position and reads its C channel values (each read is coalesced over positions).
+__global__ __launch_bounds__(TPB) void data_bn_apply_cn8_kernel(const float* __restrict__ x, int N, int C, int T, int V, int M,
+                                                                const int* __restrict__ bone_parent, int motion,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                uint4* __restrict__ out) {
+  const int n = blockIdx.x;
+  const int VM = V * M, total = T * VM;
+  const int per = (total + gridDim.y - 1) / gridDim.y;
+  const int e_lo = blockIdx.y * per, e_hi = (e_lo + per < total) ? e_lo + per : total;
+  for (int e = e_lo + threadIdx.x; e < e_hi; e += TPB) {
+    const int t = e / VM, r = e - t * VM;
+    const int v = r / M, m = r - v * M;
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      o[c] = 0.f;
+      if (c < C) {
+        const float* slab = x + (int64_t)(n * C + c) * T * VM;
+        const int ch = v * C + c;
+        o[c] = fmaf(load_joint(slab, t, v, m, V, M, bone_parent, motion, T), scale[ch], shift[ch]);
+      }
+    }
+    out[((int64_t)(n * M + m) * T + t) * V + v] = cn8_pack(o);
   }
 }
 
@@ -583,6 +617,30 @@ extern "C" int sar_data_bn_bwd_reduce_f32(const float* x, int N, int C, int T, i
   hipLaunchKernelGGL(data_bn_reduce_kernel<true>, dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent,
                      motion, dy, ld_dy, mean, partials);
   SAR_LAUNCH_CHECK("sar_data_bn_bwd_reduce_f32");
+  return 0;
+}
+
+extern "C" int sar_data_bn_apply_cn8(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent, int motion,
+                                     const float* scale, const float* shift, void* out, int64_t ld_out, sar_stream_t s) {
+  int rc = data_bn_check(x, N, C, T, V, M);
+  if (rc) return rc;
+  SAR_REQUIRE(scale && shift && out && C <= 8 && ld_out >= (int64_t)N * M * T * V && ((uintptr_t)out & 15) == 0,
+              "sar_data_bn_apply_cn8: bad arguments (C <= 8, 16-byte aligned output)");
+  hipLaunchKernelGGL(data_bn_apply_cn8_kernel, dim3(N, 16), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent, motion,
+                     scale, shift, (uint4*)out);
+  SAR_LAUNCH_CHECK("sar_data_bn_apply_cn8");
+  return 0;
+}
+
+extern "C" int sar_data_bn_bwd_reduce_cn8(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent,
+                                          int motion, const void* dy, int64_t ld_dy, const float* mean, float* partials,
+                                          sar_stream_t s) {
+  int rc = data_bn_check(x, N, C, T, V, M);
+  if (rc) return rc;
+  SAR_REQUIRE(dy && partials && C <= 8 && ld_dy >= (int64_t)N * M * T * V, "sar_data_bn_bwd_reduce_cn8: bad arguments");
+  hipLaunchKernelGGL((data_bn_reduce_kernel<true, true>), dim3(N * C), dim3(TPB), 0, as_stream(s), x, N, C, T, V, M, bone_parent,
+                     motion, (const float*)dy, ld_dy, mean, partials);
+  SAR_LAUNCH_CHECK("sar_data_bn_bwd_reduce_cn8");
   return 0;
 }
 

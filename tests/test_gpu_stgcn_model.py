@@ -109,17 +109,28 @@ def _compare(dev, blocks, N, T, classes, seed, tol=TOL, x=None, y=None, stream="
         second = m * v + (1 - m) * batch
         worst["stat " + k] = rel_err(got.cpu(), second)
     bad = {k: (v, tol) for k, v in worst.items() if not (v < tol)}
-    # UNCONDITIONED check (no knowledge of the engine's masks goes into the reference): every gradient tensor against the
-    # plain float64 oracle.  Two float32 evaluations cannot agree better than the float32 ORACLE agrees with the float64
-    # one (each ReLU tie that lands on the other side moves one channel's cancelled sums by ~1/sqrt(positions)), so the
-    # yardstick is that oracle-vs-oracle band:
-    #   * Frobenius-relative error of every tensor <= 2x the band's worst tensor (a tie perturbs a few entries; the norm
-    #     measures how much of the tensor is off),
-    #   * max-norm error <= 4x the band's max-norm (the max over ~80 tensors of a heavy-tailed per-tie perturbation: which
-    #     ties flip is luck of the rounding, measured 2.5-2.7x on the 10-block stack; the folded BN affine of the engine
-    #     rounds a pre-activation differently from F.batch_norm),
-    # both floored at the conditioned tolerance.  A mask convention that was wrong consistently in forward and backward
-    # would pass the conditioned test and fail here by orders of magnitude.
+    # UNCONDITIONED checks (no knowledge of the engine's masks goes into the reference):
+    # (1) the activation pattern itself: wherever the engine's ReLU decision differs from the plain float64 oracle's, the
+    #     oracle's pre-activation must be a rounding-level tie (|z| <= 1e-4 of that tensor's largest pre-activation; measured
+    #     ~1e-7).  A mask convention that was wrong consistently in forward and backward (wrong tensor, wrong affine, >= vs >)
+    #     would pass the conditioned gradient test above and fail HERE on ordinary elements.
+    # (2) every gradient tensor against the plain float64 oracle.  Two float32 evaluations cannot agree better than the
+    #     float32 ORACLE agrees with the float64 one (each tie that lands on the other side moves one channel's cancelled
+    #     sums by ~1/sqrt(positions)), so the yardstick is that oracle-vs-oracle band; which ties flip is luck of the
+    #     rounding (max over ~80 tensors of a heavy-tailed per-tie perturbation: measured 1.0-3.0x the band on the 10-block
+    #     stack, where the engine's folded BN affine flips 4-13 elements of ~1e8 and the float32 oracle 2-5), hence 4x.
+    #     With (1) and the conditioned 1e-4 this bound is implied; it is asserted as the end-to-end envelope.
+    worst_tie, n_flip = 0.0, 0
+    for i in range(len(blocks)):
+        for site in ("h", "y"):
+            pre64 = taps["l%d.%s_pre" % (i, site)]
+            diff = masks["l%d.%s" % (i, site)] != (pre64 > 0)
+            if diff.any():
+                n_flip += int(diff.sum())
+                worst_tie = max(worst_tie, (pre64[diff].abs().max() / pre64.abs().max()).item())
+    print("activation-pattern differences vs the float64 oracle: %d elements, largest |pre-activation| among them %.2e of "
+          "its tensor's max" % (n_flip, worst_tie))
+    assert worst_tie <= 1e-4, "the engine's ReLU pattern differs from the float64 oracle's away from ties (%.3e)" % worst_tie
     live = [k for k, g in grads_unc.items() if g.abs().max().item() >= 1e-9]
     unc = {k: rel_err(eng.g[k].cpu(), grads_unc[k]) for k in live}
     unc_fro = {k: rel_err_fro(eng.g[k].cpu(), grads_unc[k]) for k in live}
@@ -130,8 +141,6 @@ def _compare(dev, blocks, N, T, classes, seed, tol=TOL, x=None, y=None, stream="
     print("unconditioned gradient error vs float64 oracle: max-norm %.3e (%s) [float32-oracle band %.3e], Frobenius %.3e (%s) "
           "[band %.3e]; block-output ReLU flips vs float64: engine %d, float32 oracle %d"
           % (unc_max, unc_key, band_max, fro_max, fro_key, band_fro, flips, flips32))
-    assert fro_max <= max(2 * band_fro, tol), "unconditioned Frobenius error %.3e (%s) > 2x the float32-oracle band %.3e" % (
-        fro_max, fro_key, band_fro)
     assert unc_max <= max(4 * band_max, tol), "unconditioned max-norm error %.3e (%s) > 4x the float32-oracle band %.3e" % (
         unc_max, unc_key, band_max)
     print("float32-oracle gradient error band (unconditioned): max %.3e" % band_max)
