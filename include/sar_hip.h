@@ -338,6 +338,49 @@ int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_t n, const 
                  float beta1, float beta2, float eps, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * bf16 configuration (bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation, fp32
+ * BatchNorm statistics, fp32 master weights).
+ *
+ * Activation layout "CN8": an activation with C channels over n columns (column = (b*T + t)*V + v as in the CN layout)
+ * is G = ceil(C/8) planes of ld >= n 16-byte units; unit (g, col) = the 8 bfloat16 channels 8g..8g+7 of that column,
+ * channels >= C are zero.  Byte address of channel c, column n: 16*((c/8)*ld + n) + 2*(c%8).  All CN8 pointers are
+ * 16-byte aligned; `ld` counts units per plane.  (This is the k-innermost MFMA operand image: csrc/cn8.h.)
+ *
+ * sar_conv_gemm_cn8: the operators of sar_conv_gemm_f32 (same descriptor; src / out / aux are CN8 tensors passed through
+ * the float* fields, ld_* in units; W is ignored) with the weights given as the packed bf16 image of
+ * sar_pack_weights_bf16_batch ([taps][2*ceil(Kc/16)][M] units).  Products of bf16 operands are exact, accumulation is
+ * fp32, BatchNorm partial sums (sar_conv_gemm_cn8_nparts per row) are taken from the fp32 accumulators BEFORE the
+ * result is rounded to bfloat16 (nearest even).  SAR_EPI_MASK decides on the stored (bf16) aux value.  GRAPH mode
+ * forms z_k = src . A_k in fp32 from the bf16 src and rounds it once; no prologue in GRAPH mode.
+ * ------------------------------------------------------------------------------------------------ */
+int sar_conv_gemm_cn8_nparts(const sar_conv_desc* d);
+int sar_conv_gemm_cn8(const sar_conv_desc* d, const void* packed_w, sar_stream_t s);
+/* Block tail and BatchNorm-backward passes on CN8 tensors: semantics and partial layouts of the *_f32 functions of the
+ * same name (C = channels, n = columns, ld = units per plane). */
+int sar_bn_add_relu_fwd_cn8(const void* u, const float* scale, const float* shift, int res_kind, const void* r,
+                            const float* res_scale, const float* res_shift, void* y, int C, int64_t n, int64_t ld,
+                            sar_stream_t s);
+int sar_bn_add_relu_bwd_reduce_cn8(const void* dy, const void* y, const void* u, const void* r, const float* mean_u,
+                                   const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
+                                   sar_stream_t s);
+int sar_bn_add_relu_bwd_apply_cn8(const void* dy, const void* y, const void* u, const void* r, const float* k1,
+                                  const float* k2, const float* k3, const float* rk1, const float* rk2, const float* rk3,
+                                  void* du, void* dr, void* dz_out, int C, int64_t n, int64_t ld, sar_stream_t s);
+int sar_affine2_cn8(const void* a, const void* b, const float* k1, const float* k2, const float* k3, void* out, int C,
+                    int64_t n, int64_t ld, sar_stream_t s);
+/* data_bn (models/stgcn.py:136-147) writing / reading the (C <= 8)-channel CN8 input tensor (one plane) */
+int sar_data_bn_apply_cn8(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent, int motion,
+                          const float* scale, const float* shift, void* out, int64_t ld_out, sar_stream_t s);
+int sar_data_bn_bwd_reduce_cn8(const float* x, int N, int C, int T, int V, int M, const int32_t* bone_parent, int motion,
+                               const void* dy, int64_t ld_dy, const float* mean, float* partials, sar_stream_t s);
+/* GlobalAveragePooling2D + mean over bodies (models/stgcn.py:153-156) on a CN8 tensor, and its gradient */
+int sar_pool_fwd_cn8(const void* y, int64_t ld, int C, int B, int TV, int Mp, float* feat, sar_stream_t s);
+int sar_pool_bwd_cn8(const float* dfeat, int64_t ld, int C, int B, int TV, int Mp, void* dy, sar_stream_t s);
+/* layout conversion fp32 CN [C][ld] <-> CN8 (boundary of the bf16 engine, tests) */
+int sar_cn_to_cn8(const float* x, int64_t ld_x, void* out, int64_t ld_out, int C, int64_t n, sar_stream_t s);
+int sar_cn8_to_cn(const void* x, int64_t ld_x, float* out, int64_t ld_out, int C, int64_t n, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-side input helpers (HOST pointers, no stream, no device work): what tf.data.TFRecordDataset's native reader does
  * for main_gnn.py:159-194 -- the reference's clips are tf.train.Example records written by
  * data_gen/gen_tfrecord_data.py:25-33,76-85.

@@ -110,6 +110,19 @@ SIGNATURES = {
     "sar_vr_signal_upsampled_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_vr_signal_upsampled_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_conv2d_stem_dgrad_f32": (_i, [_fp, _i64, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
+    # bf16 configuration: CN8 activations
+    "sar_conv_gemm_cn8_nparts": (_i, [C.POINTER(ConvDesc)]),
+    "sar_conv_gemm_cn8": (_i, [C.POINTER(ConvDesc), _fp, _fp]),
+    "sar_bn_add_relu_fwd_cn8": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_reduce_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_apply_cn8": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),
+    "sar_affine2_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
+    "sar_data_bn_apply_cn8": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _i64, _fp]),
+    "sar_data_bn_bwd_reduce_cn8": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _i64, _fp, _fp, _fp]),
+    "sar_pool_fwd_cn8": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
+    "sar_pool_bwd_cn8": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
+    "sar_cn_to_cn8": (_i, [_fp, _i64, _fp, _i64, _i, _i64, _fp]),
+    "sar_cn8_to_cn": (_i, [_fp, _i64, _fp, _i64, _i, _i64, _fp]),
     # host-side input helpers (host pointers)
     "sar_crc32c": (C.c_uint32, [_fp, _i64]),
     "sar_crc32c_sw": (C.c_uint32, [_fp, _i64]),

@@ -1,0 +1,132 @@
+"""Tensor-level wrappers of the bf16 configuration's kernels (include/sar_hip.h, "CN8" section; csrc/cn8.h).
+
+A CN8 activation is a torch.bfloat16 tensor of shape (G, ld, 8): G = ceil(C/8) planes of ld 16-byte units, unit
+(g, col) = channels 8g..8g+7 of column col = (b*T + t)*V + v.  torch is used for device memory and the stream only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import profiler
+from ._lib import ConvDesc, check, ptr, stream_ptr
+
+
+def empty(channels, n, device):
+    return torch.empty(((channels + 7) // 8, n, 8), dtype=torch.bfloat16, device=device)
+
+
+def _cn8(t):
+    assert t is None or (t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous() and t.dim() == 3 and t.shape[2] == 8), \
+        "need a contiguous cuda CN8 tensor (G, ld, 8) of bfloat16"
+    return t
+
+
+def _f32(t):
+    assert t is None or (t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()), "need contiguous cuda float32"
+    return t
+
+
+def from_cn(x):
+    """fp32 CN matrix [C][n] -> CN8 (rounded to bfloat16, nearest even)"""
+    Cc, n = x.shape
+    out = empty(Cc, n, x.device)
+    check(L.load().sar_cn_to_cn8(ptr(_f32(x)), x.stride(0), ptr(out), n, Cc, n, stream_ptr()), "sar_cn_to_cn8")
+    return out
+
+
+def to_cn(x8, channels):
+    """CN8 -> fp32 CN matrix [channels][n]"""
+    n = x8.shape[1]
+    out = torch.empty((channels, n), dtype=torch.float32, device=x8.device)
+    check(L.load().sar_cn8_to_cn(ptr(_cn8(x8)), n, ptr(out), n, channels, n, stream_ptr()), "sar_cn8_to_cn")
+    return out
+
+
+def conv_gemm(mode, src, out, packed, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, transposed=False, bias=None,
+              pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None, aux_affine=None, aux_mean=None):
+    """sar_conv_gemm_cn8: src / out / aux CN8, `packed` the bf16 weight image (ops.PackedWeights.image).  Returns
+    (partials, nparts) when the epilogue reduces."""
+    lib = L.load()
+    d = ConvDesc()
+    d.mode, d.transposed, d.B, d.V = mode, int(transposed), B, V
+    d.T_src, d.T_out, d.Kc, d.M = T_src, T_out, Kc, M
+    d.taps, d.stride, d.pad, d.pro_relu, d.epi = taps, stride, pad, int(pro_relu), epi
+    _cn8(src), _cn8(out), _cn8(aux)
+    assert src.shape[0] == (Kc + 7) // 8 and out.shape[0] == (M + 7) // 8
+    d.src, d.ld_src = ptr(src), src.shape[1]
+    d.out, d.ld_out = ptr(out), out.shape[1]
+    d.bias = ptr(_f32(bias))
+    if pro is not None:
+        d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
+    if tables is not None:
+        d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
+        for i in range(3):
+            d.nz[i] = tables.nz[i]
+    if aux is not None:
+        assert aux.shape[0] == out.shape[0]
+        d.aux, d.ld_aux = ptr(aux), aux.shape[1]
+    if aux_affine is not None:
+        d.aux_scale, d.aux_shift = ptr(_f32(aux_affine[0])), ptr(_f32(aux_affine[1]))
+    d.aux_mean = ptr(_f32(aux_mean))
+    partials, nparts = None, 0
+    if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
+        nparts = lib.sar_conv_gemm_cn8_nparts(C.byref(d))
+        if nparts <= 0:
+            check(nparts or -1, "sar_conv_gemm_cn8_nparts")
+        partials = torch.empty((M, nparts, 2), dtype=torch.float32, device=src.device)
+        d.partials = ptr(partials)
+    n_conv = B * (T_src if transposed else T_out) * V
+    tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else ""))) + "_cn8"
+    with profiler.region(tag, 2.0 * M * Kc * taps * n_conv, 2.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+        check(lib.sar_conv_gemm_cn8(C.byref(d), ptr(packed), stream_ptr()), "sar_conv_gemm_cn8")
+    return (partials, nparts) if partials is not None else None
+
+
+def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, channels):
+    check(L.load().sar_bn_add_relu_fwd_cn8(ptr(_cn8(u)), ptr(sc), ptr(sh), res_kind, ptr(_cn8(r)), ptr(rsc), ptr(rsh), ptr(_cn8(y)),
+                                           channels, u.shape[1], u.shape[1], stream_ptr()), "sar_bn_add_relu_fwd_cn8")
+
+
+def bn_add_relu_bwd_reduce(dy, y, u, r, channels, mu=None, mr=None):
+    n = u.shape[1]
+    nparts = max(1, min(256, (n + 8191) // 8192))
+    partials = torch.empty((channels, nparts, 4), dtype=torch.float32, device=u.device)
+    check(L.load().sar_bn_add_relu_bwd_reduce_cn8(ptr(_cn8(dy)), ptr(_cn8(y)), ptr(_cn8(u)), ptr(_cn8(r)), ptr(mu), ptr(mr),
+                                                  ptr(partials), nparts, channels, n, n, stream_ptr()),
+          "sar_bn_add_relu_bwd_reduce_cn8")
+    return partials, nparts
+
+
+def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, channels):
+    rk = rk or (None, None, None)
+    n = u.shape[1]
+    check(L.load().sar_bn_add_relu_bwd_apply_cn8(ptr(_cn8(dy)), ptr(_cn8(y)), ptr(_cn8(u)), ptr(_cn8(r)), ptr(k[0]), ptr(k[1]),
+                                                 ptr(k[2]), ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(_cn8(du)), ptr(_cn8(dr)),
+                                                 ptr(_cn8(dz_out)), channels, n, n, stream_ptr()), "sar_bn_add_relu_bwd_apply_cn8")
+
+
+def affine2(a, b, k, out, channels):
+    n = a.shape[1]
+    check(L.load().sar_affine2_cn8(ptr(_cn8(a)), ptr(_cn8(b)), ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(_cn8(out)), channels, n, n,
+                                   stream_ptr()), "sar_affine2_cn8")
+
+
+def data_bn_apply(x, bone_parent, scale, shift, out, motion=False):
+    N, C_, T, V, M = x.shape
+    check(L.load().sar_data_bn_apply_cn8(ptr(x), N, C_, T, V, M, ptr(bone_parent), int(motion), ptr(scale), ptr(shift),
+                                         ptr(_cn8(out)), out.shape[1], stream_ptr()), "sar_data_bn_apply_cn8")
+
+
+def data_bn_bwd_reduce(x, bone_parent, dy, mean, partials, motion=False):
+    N, C_, T, V, M = x.shape
+    check(L.load().sar_data_bn_bwd_reduce_cn8(ptr(x), N, C_, T, V, M, ptr(bone_parent), int(motion), ptr(_cn8(dy)), dy.shape[1],
+                                              ptr(mean), ptr(partials), stream_ptr()), "sar_data_bn_bwd_reduce_cn8")
+
+
+def pool_fwd(y, channels, B, TV, Mp, feat):
+    check(L.load().sar_pool_fwd_cn8(ptr(_cn8(y)), y.shape[1], channels, B, TV, Mp, ptr(feat), stream_ptr()), "sar_pool_fwd_cn8")
+
+
+def pool_bwd(dfeat, channels, B, TV, Mp, dy):
+    check(L.load().sar_pool_bwd_cn8(ptr(dfeat), dy.shape[1], channels, B, TV, Mp, ptr(_cn8(dy)), stream_ptr()), "sar_pool_bwd_cn8")

@@ -1,0 +1,311 @@
+"""bf16 configuration, kernel level: the CN8 kernels (include/sar_hip.h "CN8" section) against
+their exact definitions -- inputs ARE bfloat16 (stored activations), weights are rounded to bfloat16 when packed, products
+exact, contraction in float64 here / fp32 on the GPU, outputs rounded to bfloat16 once.  Tolerances: BatchNorm partial
+sums (taken from the fp32 accumulators) 1e-4; stored outputs within one bfloat16 rounding (2^-8 relative per element plus
+1e-5 of the tensor scale for the accumulation order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import stgcn as O
+from util import to_cn, from_cn, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _bf(t):
+    return t.float().bfloat16().double()
+
+
+def _A():
+    from oracle.graph import spatial_adjacency
+    return torch.tensor(spatial_adjacency().astype(np.float32))
+
+
+def _tables(dev, transpose=False):
+    from sar_amd import ops
+    from oracle.graph import spatial_adjacency
+    return ops.GraphTables(spatial_adjacency().astype(np.float32), dev, transpose)
+
+
+def _pack(dev, W, st, sc, sm, taps, Kc, M):
+    from sar_amd import ops
+    pk = ops.PackedWeights()
+    pk.add("w", 0, st, sc, sm, taps, Kc, M)
+    pk.finalize(dev)
+    pk.refresh(W.to(dev).contiguous().reshape(-1))
+    return pk.image("w")
+
+
+def _cn8(x, dev):
+    """(B,C,T,V) float tensor whose values are bf16-representable -> CN8 on the device"""
+    from sar_amd import ops8
+    return ops8.from_cn(to_cn(x.float()).to(dev))
+
+
+def _back(x8, C, B, T):
+    from sar_amd import ops8
+    return from_cn(ops8.to_cn(x8, C).cpu(), B, T, 25)
+
+
+def assert_bf16_close(got, ref, what=""):
+    got, ref = got.double(), ref.double()
+    scale = ref.abs().max().item()
+    bad = (got - ref).abs() - (2.0 ** -8) * ref.abs() - 1e-5 * scale
+    assert bad.max().item() <= 0, "%s: worst excess %.3e (scale %.3e)" % (what, bad.max().item(), scale)
+
+
+def test_layout_roundtrip_and_padding(dev):
+    from sar_amd import ops8
+    g = torch.Generator().manual_seed(0)
+    for C in (3, 8, 20, 64):
+        x = torch.randn(C, 1000, generator=g).bfloat16().float().to(dev)
+        x8 = ops8.from_cn(x)
+        assert x8.shape == ((C + 7) // 8, 1000, 8)
+        assert torch.equal(ops8.to_cn(x8, C), x)
+        # the definition of the layout: unit (g, col)[j] = channel 8g + j, zero beyond C
+        ref = torch.zeros(((C + 7) // 8) * 8, 1000, device=dev)
+        ref[:C] = x
+        assert torch.equal(x8.float(), ref.view(-1, 8, 1000).permute(0, 2, 1))
+
+
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (3, 64, 14, 2), (2, 128, 9, 2), (1, 256, 6, 1), (2, 128, 300, 2),
+                                     (2, 72, 11, 1), (1, 200, 9, 2), (2, 40, 7, 1), (1, 48, 10, 2), (2, 24, 30, 1)])
+def test_temporal_conv_forward(dev, B, f, T, s):
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(f + T + s)
+    x = torch.randn(B, f, T, 25, generator=g).bfloat16()
+    sc = 1 + 0.2 * torch.randn(f, generator=g); sh = 0.3 * torch.randn(f, generator=g)
+    kernel = torch.randn(9, 1, f, f, generator=g) * 0.05
+    bias = torch.randn(f, generator=g) * 0.1
+    h = torch.relu(torch.addcmul(sh.view(1, -1, 1, 1), x.float(), sc.view(1, -1, 1, 1)))      # fp32 fma like the kernel
+    ref = O.temporal_conv(_bf(h), _bf(kernel), bias.double(), s)
+    To, pad, _ = O.same_pad(T, 9, s)
+    out = ops8.empty(f, B * To * 25, dev)
+    r = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, _cn8(x, dev), out, _pack(dev, kernel, f * f, f, 1, 9, f, f), B=B, V=25, T_src=T,
+                       T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad, bias=bias.to(dev), pro=(sc.to(dev), sh.to(dev)),
+                       pro_relu=True, epi=L.SAR_EPI_STATS)
+    torch.cuda.synchronize()
+    assert_bf16_close(_back(out, f, B, To), ref, "temporal conv")
+    part = r[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], ref.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (ref * ref).sum(dim=(0, 2, 3))) < 1e-4
+    if f % 8:
+        assert (out.float()[-1, :, f % 8:] == 0).all()       # channels beyond C stay zero
+
+
+@pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2), (1, 64, 64, 7, 1), (2, 24, 40, 9, 2)])
+def test_residual_conv_forward_and_data_gradient(dev, B, cin, f, T, s):
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(cin + f)
+    x = torch.randn(B, cin, T, 25, generator=g).bfloat16()
+    kernel = torch.randn(1, 1, cin, f, generator=g) * 0.1
+    bias = torch.randn(f, generator=g) * 0.1
+    xd = x.double().requires_grad_(True)
+    ref = F.conv2d(xd, O.hwio_to_oihw(_bf(kernel)), bias.double(), stride=(s, 1))
+    To = ref.shape[2]
+    out = ops8.empty(f, B * To * 25, dev)
+    r = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, _cn8(x, dev), out, _pack(dev, kernel, 0, f, 1, 1, cin, f), B=B, V=25, T_src=T, T_out=To,
+                       Kc=cin, M=f, taps=1, stride=s, pad=0, bias=bias.to(dev), epi=L.SAR_EPI_STATS)
+    torch.cuda.synchronize()
+    assert_bf16_close(_back(out, f, B, To), ref.detach(), "residual conv")
+    assert rel_err(r[0].cpu().double().sum(dim=1)[:, 1], (ref.detach() ** 2).sum(dim=(0, 2, 3))) < 1e-4
+    dr = torch.randn(B, f, To, 25, generator=g).bfloat16()
+    gx, = torch.autograd.grad(ref, xd, dr.double())
+    dx = ops8.empty(cin, B * T * 25, dev)
+    ops8.conv_gemm(L.SAR_CONV_TEMPORAL, _cn8(dr, dev), dx, _pack(dev, kernel, 0, 1, f, 1, f, cin), B=B, V=25, T_src=To, T_out=T,
+                   Kc=f, M=cin, taps=1, stride=s, pad=0, transposed=True)
+    torch.cuda.synchronize()
+    assert_bf16_close(_back(dx, cin, B, T), gx, "residual conv data gradient")
+
+
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2), (4, 256, 75, 1),
+                                     (3, 128, 150, 2), (2, 72, 11, 1), (1, 200, 9, 2), (2, 40, 12, 2), (2, 64, 12, 3)])
+def test_temporal_conv_data_gradient(dev, B, f, T, s):
+    """transposed conv of the stored (bf16) output gradient with the bf16 weights, fused ReLU mask (decided on the STORED
+    pre-BatchNorm activation through the folded affine) and the centred BatchNorm-backward reductions."""
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(11 * f + T + s)
+    gx = torch.randn(B, f, T, 25, generator=g).bfloat16()
+    sc = 1 + 0.2 * torch.randn(f, generator=g); sh = 0.3 * torch.randn(f, generator=g); mean = 0.1 * torch.randn(f, generator=g)
+    kernel = torch.randn(9, 1, f, f, generator=g) * 0.05
+    To, pad, _ = O.same_pad(T, 9, s)
+    du = torch.randn(B, f, To, 25, generator=g).bfloat16()
+    h = torch.zeros(B, f, T, 25, dtype=torch.float64, requires_grad=True)
+    dh, = torch.autograd.grad(O.temporal_conv(h, _bf(kernel), None, s), h, du.double())
+    pre = torch.addcmul(sh.view(1, -1, 1, 1), gx.float(), sc.view(1, -1, 1, 1))
+    g_pre = dh * (pre > 0)
+    dz1 = ops8.empty(f, B * T * 25, dev)
+    pm = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, _cn8(du, dev), dz1, _pack(dev, kernel, f * f, 1, f, 9, f, f), B=B, V=25, T_src=To,
+                        T_out=T, Kc=f, M=f, taps=9, stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=_cn8(gx, dev),
+                        aux_affine=(sc.to(dev), sh.to(dev)), aux_mean=mean.to(dev))
+    torch.cuda.synchronize()
+    assert_bf16_close(_back(dz1, f, B, T), g_pre, "temporal data gradient")
+    part = pm[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], g_pre.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (g_pre * (gx.double() - mean.double().view(1, -1, 1, 1))).sum(dim=(0, 2, 3))) < 1e-4
+
+
+def _graph_ref(x, kernel, bias, A, dev_tables):
+    """exact definition: z_k = bf16(fp32 gather of the bf16 src in table order), W rounded to bf16, float64 contraction"""
+    idx, wt = dev_tables.idx.cpu(), dev_tables.wt.cpu()                   # [3][V][4]
+    Bq, cin, T, V = x.shape
+    f = kernel.shape[3] // 3
+    xs = x.float()
+    out = torch.zeros(Bq, f, T, V, dtype=torch.float64)
+    Wk = _bf(kernel)[0, 0]                                                 # (cin, 3f)
+    for k in range(3):
+        z = torch.zeros(Bq, cin, T, V)
+        for w in range(V):
+            acc = None
+            for j in range(dev_tables.nz[k]):
+                term = wt[k, w, j] * xs[:, :, :, idx[k, w, j]]
+                acc = term if acc is None else torch.addcmul(acc, xs[:, :, :, idx[k, w, j]], wt[k, w, j])   # fp32 fma chain
+            z[:, :, :, w] = acc
+        zb = _bf(z)
+        out += torch.einsum("bctv,cm->bmtv", zb, Wk[:, k * f:(k + 1) * f])
+        if bias is not None:
+            out += bias.double()[k * f:(k + 1) * f].view(1, -1, 1, 1) * A[k].double().sum(dim=0).view(1, 1, 1, -1)
+    return out
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(3, 3, 64, 13), (2, 64, 64, 10), (2, 64, 128, 7), (1, 128, 256, 5), (4, 256, 256, 3),
+                                       (2, 40, 72, 9), (1, 12, 200, 5), (2, 64, 44, 6), (2, 64, 64, 300)])
+def test_graph_conv_forward(dev, B, cin, f, T):
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(B * 1000 + cin)
+    x = torch.randn(B, cin, T, 25, generator=g).bfloat16()
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    bias = torch.randn(3 * f, generator=g) * 0.1
+    tab = _tables(dev)
+    ref = _graph_ref(x, kernel, bias, _A(), tab)
+    out = ops8.empty(f, B * T * 25, dev)
+    r = ops8.conv_gemm(L.SAR_CONV_GRAPH, _cn8(x, dev), out, _pack(dev, kernel, f, 3 * f, 1, 3, cin, f), B=B, V=25, T_src=T, T_out=T,
+                       Kc=cin, M=f, taps=3, bias=bias.to(dev), tables=tab, epi=L.SAR_EPI_STATS)
+    torch.cuda.synchronize()
+    assert_bf16_close(_back(out, f, B, T), ref, "graph conv")
+    part = r[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 1], (ref * ref).sum(dim=(0, 2, 3))) < 1e-4
+    # and it is the reference operator up to bf16 rounding of the operands
+    full = O.graph_conv_td(x.double(), kernel.double(), bias.double(), _A().double())
+    assert rel_err(_back(out, f, B, T), full) < 2e-2
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9), (4, 256, 256, 75),
+                                       (2, 40, 72, 9)])
+def test_graph_conv_data_gradient(dev, B, cin, f, T):
+    """A^T gather lists + the (k, c', m') view of the kernel; SAR_EPI_ADD accumulates the skip-path gradient (CN8 aux)"""
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(7 * cin + f)
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    dout = torch.randn(B, f, T, 25, generator=g).bfloat16()
+    add = torch.randn(B, cin, T, 25, generator=g).bfloat16()
+    tabT = _tables(dev, True)
+    # data gradient = graph conv of dout with A^T tables and kernel^T: reuse the forward definition on the transposed problem
+    kT = kernel[0, 0].view(cin, 3, f).permute(2, 1, 0).reshape(1, 1, f, 3 * cin)      # [m][k*cin + c]
+    ref = _graph_ref(dout, kT, None, _A().transpose(1, 2), tabT) + add.double()
+    dx = ops8.empty(cin, B * T * 25, dev)
+    ops8.conv_gemm(L.SAR_CONV_GRAPH, _cn8(dout, dev), dx, _pack(dev, kernel, f, 1, 3 * f, 3, f, cin), B=B, V=25, T_src=T, T_out=T,
+                   Kc=f, M=cin, taps=3, tables=tabT, epi=L.SAR_EPI_ADD, aux=_cn8(add, dev))
+    torch.cuda.synchronize()
+    assert_bf16_close(_back(dx, cin, B, T), ref, "graph data gradient")
+    x = torch.zeros(B, cin, T, 25, dtype=torch.float64, requires_grad=True)
+    gx, = torch.autograd.grad(O.graph_conv_td(x, kernel.double(), None, _A().double()), x, dout.double())
+    assert rel_err(_back(dx, cin, B, T) - add.double(), gx) < 2e-2
+
+
+@pytest.mark.parametrize("C,n,kind", [(64, 5000, 1), (128, 3001, 2), (20, 777, 0), (256, 9375, 2)])
+def test_block_tail_forward_backward(dev, C, n, kind):
+    """y = relu(bn2(u) + res) and its backward passes (sar_bn_add_relu_*_cn8, sar_affine2_cn8) against float64 arithmetic on
+    the same bf16 inputs."""
+    from sar_amd import ops8
+    g = torch.Generator().manual_seed(C + n)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    u, r, dy = rnd(C, n).bfloat16(), rnd(C, n).bfloat16(), rnd(C, n).bfloat16()
+    sc, sh, rsc, rsh = 1 + 0.2 * rnd(C), 0.3 * rnd(C), 1 + 0.2 * rnd(C), 0.3 * rnd(C)
+    k = [0.5 * rnd(C) for _ in range(3)]
+    rk = [0.5 * rnd(C) for _ in range(3)]
+    mu, mr = 0.1 * rnd(C), 0.1 * rnd(C)
+    D = lambda t: t.double()
+    col = lambda t: D(t).view(-1, 1)
+    z = D(u) * col(sc) + col(sh)
+    if kind == 1:
+        z = z + D(r)
+    elif kind == 2:
+        z = z + D(r) * col(rsc) + col(rsh)
+    yref = torch.relu(z)
+    u8, r8, dy8 = ops8.from_cn(u.float().to(dev)), ops8.from_cn(r.float().to(dev)), ops8.from_cn(dy.float().to(dev))
+    y8 = ops8.empty(C, n, dev)
+    ops8.bn_add_relu_fwd(u8, sc.to(dev), sh.to(dev), kind, r8 if kind else None, rsc.to(dev) if kind == 2 else None,
+                         rsh.to(dev) if kind == 2 else None, y8, C)
+    torch.cuda.synchronize()
+    assert_bf16_close(ops8.to_cn(y8, C).cpu(), yref, "block tail forward")
+    ystored = ops8.to_cn(y8, C).cpu().double()
+    dz = D(dy) * (ystored > 0)
+    conv = kind == 2
+    part, nparts = ops8.bn_add_relu_bwd_reduce(dy8, y8, u8, r8 if conv else None, C, mu.to(dev), mr.to(dev) if conv else None)
+    du8, dr8, dz8 = ops8.empty(C, n, dev), (ops8.empty(C, n, dev) if conv else None), ops8.empty(C, n, dev)
+    ops8.bn_add_relu_bwd_apply(dy8, y8, u8, r8 if conv else None, [t.to(dev) for t in k], [t.to(dev) for t in rk] if conv else None,
+                               du8, dr8, dz8, C)
+    a8 = ops8.empty(C, n, dev)
+    ops8.affine2(dy8, u8, [t.to(dev) for t in k], a8, C)
+    torch.cuda.synchronize()
+    p = part.cpu().double().sum(dim=1)
+    assert rel_err(p[:, 0], dz.sum(dim=1)) < 1e-4
+    assert rel_err(p[:, 1], (dz * (D(u) - col(mu))).sum(dim=1)) < 1e-4
+    if conv:
+        assert rel_err(p[:, 2], (dz * (D(r) - col(mr))).sum(dim=1)) < 1e-4
+        assert_bf16_close(ops8.to_cn(dr8, C).cpu(), col(rk[0]) * dz + col(rk[1]) * D(r) + col(rk[2]), "dr")
+    assert_bf16_close(ops8.to_cn(du8, C).cpu(), col(k[0]) * dz + col(k[1]) * D(u) + col(k[2]), "du")
+    assert torch.equal(ops8.to_cn(dz8, C).cpu().double(), dz)
+    assert_bf16_close(ops8.to_cn(a8, C).cpu(), col(k[0]) * D(dy) + col(k[1]) * D(u) + col(k[2]), "affine2")
+
+
+def test_pooling_and_data_bn(dev):
+    from sar_amd import ops, ops8
+    g = torch.Generator().manual_seed(3)
+    C, B, TV, Mp = 40, 6, 75, 2
+    y = torch.randn(C, B * TV, generator=g).bfloat16()
+    y8 = ops8.from_cn(y.float().to(dev))
+    feat = torch.empty((B // Mp, C), device=dev)
+    ops8.pool_fwd(y8, C, B, TV, Mp, feat)
+    ref = y.double().view(C, B // Mp, Mp * TV).mean(dim=2).t()
+    dfeat = torch.randn(B // Mp, C, generator=g).to(dev)
+    dy8 = ops8.empty(C, B * TV, dev)
+    ops8.pool_bwd(dfeat, C, B, TV, Mp, dy8)
+    torch.cuda.synchronize()
+    assert rel_err(feat.cpu(), ref) < 1e-5
+    dref = (dfeat.cpu().double().t() / (Mp * TV)).view(C, B // Mp, 1).expand(C, B // Mp, Mp * TV).reshape(C, -1)
+    assert_bf16_close(ops8.to_cn(dy8, C).cpu(), dref, "pool backward")
+    # data_bn apply: identical values (rounded) to the fp32 kernel, incl. the fused bone transform; backward reduce too
+    from sar_amd.bone import NTU_BONE_PAIRS
+    N, T, M = 3, 9, 2
+    x = (0.3 * torch.randn(N, 3, T, 25, M, generator=g)).to(dev)
+    bp = np.full(25, -1, dtype=np.int32)
+    for v1, v2 in NTU_BONE_PAIRS:
+        bp[v1 - 1] = v2 - 1
+    bone = torch.from_numpy(bp).to(dev)
+    scale, shift = (1 + 0.1 * torch.randn(75, generator=g)).to(dev), (0.1 * torch.randn(75, generator=g)).to(dev)
+    n = N * M * T * 25
+    for parent in (None, bone):
+        h32 = torch.empty((3, n), device=dev)
+        ops.data_bn_apply(x, parent, scale, shift, h32)
+        h8 = ops8.empty(3, n, dev)
+        ops8.data_bn_apply(x, parent, scale, shift, h8)
+        torch.cuda.synchronize()
+        assert torch.equal(ops8.to_cn(h8, 3), h32.bfloat16().float())
+        assert (h8.float()[0, :, 3:] == 0).all()
+        dy = torch.randn(3, n, generator=g).bfloat16().float().to(dev)
+        mean = (0.05 * torch.randn(75, generator=g)).to(dev)
+        p32, p8 = torch.empty((75, N, 2), device=dev), torch.empty((75, N, 2), device=dev)
+        ops.data_bn_bwd_reduce(x, parent, dy, mean, p32)
+        ops8.data_bn_bwd_reduce(x, parent, ops8.from_cn(dy), mean, p8)
+        torch.cuda.synchronize()
+        assert torch.equal(p32, p8)
