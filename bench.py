@@ -24,6 +24,7 @@ for _p in (ROOT, os.path.join(ROOT, "skeleton-action-recognition_amd")):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
+BYTES_PER_CLIP_TRAIN_BF16 = 427.3e6   # block-fused algorithmic HBM traffic per clip and train step, bf16 storage
 
 
 def measured_traffic(bf16=False):
@@ -281,9 +282,10 @@ def main():
                     help="stgcn = BASELINE.json's headline (configs[1]); spectrogram = Path B (configs[3] shape per GPU)")
     ap.add_argument("--num-pad-frames", type=int, default=0,
                     help="spectrogram workload: GPU-side frame up-sampling factor (the reference's loader default is 250)")
-    ap.add_argument("--mfma", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = BASELINE.json configs[1] (default, the headline); bf16 = configs[2]'s arithmetic for the temporal "
-                         "convolutions (bf16 MFMA operands, fp32 storage / accumulation / master weights)")
+    ap.add_argument("--mfma", default="fp32", choices=["fp32", "bf16", "bf16_operands"],
+                    help="fp32 = BASELINE.json configs[1] (default, the headline); bf16 = configs[2]: bf16 activations in HBM (CN8 "
+                         "layout) + bf16 MFMA operands, fp32 accumulation / BatchNorm statistics / master weights; bf16_operands = "
+                         "the round-1 intermediate (bf16 MFMA operands, fp32 activations in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8,
                     help="clips in the CPU-baseline fallback batch (used only when a full --batch step does not fit the budget)")
@@ -337,19 +339,22 @@ def main():
         fl = sum(summ[k]["flops"] for k in fam)
         calls = sum(summ[k]["calls"] for k in fam)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(args.mfma == "bf16")
+        traffic, traffic_src = measured_traffic(args.mfma != "fp32")
         kern_ms = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())}
         kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
-        bf16 = args.mfma == "bf16"
+        bf16 = args.mfma != "fp32"
+        desc = {"fp32": "fp32",
+                "bf16": "bf16 (bf16 CN8 activations in HBM, bf16 MFMA operands; fp32 accumulation, BatchNorm statistics, master "
+                        "weights, optimizer)",
+                "bf16_operands": "bf16-MFMA-operand (fp32 activations in HBM)"}[args.mfma]
         out = {
             "metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)",
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
-                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (
-                                       "bf16-MFMA-operand (graph/temporal/residual convs, their data gradients, temporal weight gradients; fp32 storage, accumulation, BatchNorm, remaining weight gradients, master weights)"
-                                       if bf16 else "fp32", args.classes, args.batch),
+                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (desc, args.classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -360,16 +365,20 @@ def main():
                          "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
             "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),
         }
-        if bf16:   # the bf16 temporal kernels are bound by moving the fp32 activations, not by the matrix pipe
+        if bf16:   # the bf16 kernels are bound by moving activations, not by the matrix pipe (2.5 PFLOP/s dense bf16)
             by = sum(summ[k]["bytes"] for k in fam)
             gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "hbm", "kernel": "conv_gemm_bf16_kernel<9 taps> (fwd + data-grad launches)",
+            step_bytes = BYTES_PER_CLIP_TRAIN_BF16 if args.mfma == "bf16" else 2 * BYTES_PER_CLIP_TRAIN_BF16
+            out["roofline"] = {"bound": "hbm", "kernel": "9-tap temporal conv GEMMs (fwd + data-grad launches)",
                                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                                "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
                                "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
                                "avg_launch_ms": round(ms / max(calls, 1), 4),
-                               "mfma_tflops": round(achieved, 1)}
+                               "mfma_tflops": round(achieved, 1),
+                               # whole step in SURVEY.md 8(d)'s convention: clips/s/GPU x algorithmic bytes per clip / 8 TB/s
+                               "step_frac_of_hbm_roof": round(value / world * step_bytes / 8.0e12, 4),
+                               "step_algorithmic_bytes_per_clip": step_bytes}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample)
         print(json.dumps(out))

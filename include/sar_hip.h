@@ -355,6 +355,14 @@ int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_t n, const 
  * ------------------------------------------------------------------------------------------------ */
 int sar_conv_gemm_cn8_nparts(const sar_conv_desc* d);
 int sar_conv_gemm_cn8(const sar_conv_desc* d, const void* packed_w, sar_stream_t s);
+/* Weight / bias gradients with CN8 src / dout (passed through the float* fields of sar_wgrad_desc, ld_* in units): the
+ * operators and the slab contract of sar_conv_wgrad_f32, bf16 products accumulated in fp32, bias sums in fp32 from the
+ * stored values.  Built for V = 25: GRAPH (3 slices; slice0_identity != 0 promises that slice 0's gather list is
+ * {(v, 1.0)}, i.e. A_0 = I, and lets the kernel read that operand straight from the staged tile), TEMPORAL with 9 taps
+ * (stride 1; stride 2 with the TF-SAME pads 3 (even T) or 4 (odd T)) and 1 tap (stride 1 or 2, pad 0).  Tiles are sar_conv_wgrad_cn8_tile_frames(mode)
+ * frames of one sequence; nsplit slabs as for sar_conv_wgrad_f32. */
+int sar_conv_wgrad_cn8_tile_frames(int mode);
+int sar_conv_wgrad_cn8(const sar_wgrad_desc* d, int slice0_identity, sar_stream_t s);
 /* Block tail and BatchNorm-backward passes on CN8 tensors: semantics and partial layouts of the *_f32 functions of the
  * same name (C = channels, n = columns, ld = units per plane). */
 int sar_bn_add_relu_fwd_cn8(const void* u, const float* scale, const float* shift, int res_kind, const void* r,

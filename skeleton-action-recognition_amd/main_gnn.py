@@ -41,9 +41,9 @@ def get_parser():
     parser.add_argument('--save-scores', action='store_true',
                         help='write the test-set class probabilities of every checkpointed epoch (scores-N.npy, for score fusion '
                              'of separately trained streams with tools/fuse_scores.py)')
-    parser.add_argument('--mfma', default='fp32', choices=['fp32', 'bf16'],
-                        help="arithmetic of the convolutions' matrix products: fp32 (the reference's) or bf16 operands with fp32 "
-                             "accumulation, storage and master weights (about 2x the clips/s)")
+    parser.add_argument('--mfma', default='fp32', choices=['fp32', 'bf16', 'bf16_operands'],
+                        help="arithmetic of the convolutions' matrix products: fp32 (the reference's); bf16 = bf16 activations in HBM + bf16 operands, fp32 "
+                             "accumulation, BatchNorm statistics and master weights; bf16_operands = bf16 operands only")
     parser.add_argument('--base-lr', type=float, default=1e-1, help='initial learning rate')
     parser.add_argument('--num-classes', type=int, default=60, help='number of classes in dataset')
     parser.add_argument('--batch-size', type=int, default=64, help='training batch size')

@@ -113,6 +113,8 @@ SIGNATURES = {
     # bf16 configuration: CN8 activations
     "sar_conv_gemm_cn8_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_cn8": (_i, [C.POINTER(ConvDesc), _fp, _fp]),
+    "sar_conv_wgrad_cn8_tile_frames": (_i, [_i]),
+    "sar_conv_wgrad_cn8": (_i, [C.POINTER(WgradDesc), _i, _fp]),
     "sar_bn_add_relu_fwd_cn8": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_reduce_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_apply_cn8": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),

@@ -28,6 +28,9 @@ class GraphTables:
         self.colsum = torch.from_numpy(colsum).to(device)
         self.nz = nz
         self.K, self.V = idx.shape[0], idx.shape[1]
+        # slice 0 is the identity (the 'spatial' strategy's self-links, graph/tools.py:22-30): gather list {(v, 1.0)}
+        import numpy as np
+        self.slice0_identity = bool(nz[0] == 1 and np.array_equal(idx[0, :, 0], np.arange(self.V)) and np.all(wt[0, :, 0] == 1.0))
 
 
 class PackedWeights:

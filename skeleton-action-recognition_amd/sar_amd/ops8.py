@@ -9,7 +9,7 @@ import torch
 
 from . import _lib as L
 from . import profiler
-from ._lib import ConvDesc, check, ptr, stream_ptr
+from ._lib import ConvDesc, WgradDesc, check, ptr, stream_ptr
 
 
 def empty(channels, n, device):
@@ -81,6 +81,41 @@ def conv_gemm(mode, src, out, packed, *, B, V, T_src, T_out, Kc, M, taps, stride
     with profiler.region(tag, 2.0 * M * Kc * taps * n_conv, 2.0 * (Kc * B * T_src * V + M * B * T_out * V)):
         check(lib.sar_conv_gemm_cn8(C.byref(d), ptr(packed), stream_ptr()), "sar_conv_gemm_cn8")
     return (partials, nparts) if partials is not None else None
+
+
+def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
+               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None):
+    """sar_conv_wgrad_cn8 + sar_slab_reduce_f32: dW (and dbias right behind it) -> dW_out[0 : wsize + bsize] (flat fp32)."""
+    lib = L.load()
+    d = WgradDesc()
+    d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
+    d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
+    ft = lib.sar_conv_wgrad_cn8_tile_frames(mode)
+    ntiles = B * ((T_out + ft - 1) // ft)
+    cb = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
+    blocks = ((M + 63) // 64) * ((Kc + cb - 1) // cb)
+    if nsplit is None:           # two resident workgroups per CU
+        nsplit = max(1, min(ntiles, (512 + blocks - 1) // blocks))
+    d.nsplit = nsplit
+    _cn8(src), _cn8(dout)
+    d.src, d.ld_src, d.dout, d.ld_dout = ptr(src), src.shape[1], ptr(dout), dout.shape[1]
+    if pro is not None:
+        d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
+    ident = 0
+    if tables is not None:
+        d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
+        for i in range(3):
+            d.nz[i] = tables.nz[i]
+        ident = int(getattr(tables, "slice0_identity", False))
+    d.w_stride_tap, d.w_stride_c, d.wsize, d.bsize = w_stride_tap, w_stride_c, wsize, bsize
+    slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
+    d.slab = ptr(slab)
+    tag = ("wgrad_graph" if mode == L.SAR_CONV_GRAPH else "wgrad_temporal%d" % taps) + "_cn8"
+    with profiler.region(tag, 2.0 * M * Kc * taps * B * T_out * V, 2.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+        check(lib.sar_conv_wgrad_cn8(C.byref(d), ident, stream_ptr()), "sar_conv_wgrad_cn8")
+    assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
+    check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, wsize + bsize, wsize + bsize, ptr(dW_out), stream_ptr()),
+          "sar_slab_reduce_f32")
 
 
 def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, channels):

@@ -55,12 +55,15 @@ class STGCN:
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
                  blocks=None, motion=False, mfma="fp32"):
         L.load()  # fail loudly if the HIP library is missing
-        # mfma="bf16" (SURVEY.md 8d config 3): the graph / temporal / residual convolutions, their data gradients and the
-        # temporal weight gradients round both MFMA operands to bfloat16 (sar_conv_gemm_bf16, sar_conv_wgrad_bf16);
-        # activations in HBM, accumulation, BatchNorm statistics, the graph / 1x1 weight gradients, master weights and the
-        # optimizer stay fp32.  "fp32" (default) is the reference's arithmetic.
-        assert mfma in ("fp32", "bf16")
-        self.bf16 = mfma == "bf16"
+        # mfma="fp32" (default) is the reference's arithmetic.
+        # mfma="bf16" is SURVEY.md 8d config 3: activations and activation gradients are stored in HBM as bfloat16 (CN8
+        # layout, csrc/cn8.h), every convolution / data gradient / weight gradient multiplies bf16 operands with fp32
+        # accumulation (sar_conv_gemm_cn8, sar_conv_wgrad_cn8); BatchNorm statistics, master weights, gradients and the
+        # optimizer stay fp32 (sar_amd/stgcn8.py holds the step).
+        # mfma="bf16_operands" is the round-1 intermediate kept for A/B runs: bf16 MFMA operands, fp32 activations in HBM.
+        assert mfma in ("fp32", "bf16", "bf16_operands")
+        self.cn8 = mfma == "bf16"
+        self.bf16 = mfma == "bf16_operands"
         self.device = torch.device(device)
         self.num_classes, self.C_in, self.V = num_classes, in_channels, num_node
         self.blocks = list(blocks if blocks is not None else BLOCKS)
@@ -117,6 +120,23 @@ class STGCN:
         self.velocity = torch.zeros(total, dtype=torch.float32, device=dev)
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.packed = None
+        if self.cn8:       # bf16 operand images of EVERY conv weight, both orientations, refreshed by one launch per forward
+            pk = ops.PackedWeights()
+            cin = in_channels
+            for i, (f, s_, res) in enumerate(self.blocks):
+                pre = "l%d." % i
+                og, ot = self.offsets[pre + "gcn.kernel"], self.offsets[pre + "tcn.kernel"]
+                pk.add(pre + "gcn.f", og, f, KS * f, 1, KS, cin, f)          # (k, c, m) = kernel[c][k*F + m]
+                pk.add(pre + "gcn.b", og, f, 1, KS * f, KS, f, cin)          # (k, c', m') = kernel[m'][k*F + c']
+                pk.add(pre + "tcn.f", ot, f * f, f, 1, KT, f, f)             # (tap, c, m) = kernel[tap][c][m]
+                pk.add(pre + "tcn.b", ot, f * f, 1, f, KT, f, f)             # (tap, c', m') = kernel[tap][m'][c']
+                if self.kinds[i] == "conv":
+                    orr = self.offsets[pre + "res.kernel"]
+                    pk.add(pre + "res.f", orr, 0, f, 1, 1, cin, f)
+                    pk.add(pre + "res.b", orr, 0, 1, f, 1, f, cin)
+                cin = f
+            pk.finalize(dev)
+            self.packed = pk
         if self.bf16:      # bf16 operand images of every conv weight, both orientations, refreshed by one launch per forward
             pk = ops.PackedWeights()
             cin = in_channels
@@ -209,6 +229,9 @@ class STGCN:
     def forward(self, x, training=True, keep=None):
         """x: (N, C, T, V, M) float32 cuda -> logits (N, classes).  keep: optional dict receiving
         intermediate activations (tests)."""
+        if self.cn8:
+            from . import stgcn8
+            return stgcn8.forward(self, x, training, keep)
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
         x = x.contiguous()
         N, Cin, T, V, M = x.shape
@@ -319,6 +342,9 @@ class STGCN:
 
     def backward(self, dlogits):
         """dlogits (N, classes) -> fills self.grad (every trainable parameter).  main_gnn.py:233."""
+        if self.cn8:
+            from . import stgcn8
+            return stgcn8.backward(self, dlogits)
         sv = self._saved
         assert sv is not None, "backward() needs a preceding forward(training=True)"
         dev, V = dlogits.device, self.V

@@ -309,3 +309,86 @@ def test_pooling_and_data_bn(dev):
         ops8.data_bn_bwd_reduce(x, parent, ops8.from_cn(dy), mean, p8)
         torch.cuda.synchronize()
         assert torch.equal(p32, p8)
+
+
+@pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 22, 2), (4, 256, 75, 1),
+                                     (3, 128, 150, 2), (2, 72, 11, 1), (1, 200, 10, 2), (2, 40, 12, 2), (2, 64, 300, 1)])
+def test_temporal_conv_weight_gradient(dev, B, f, T, s):
+    """dW / dbias of BN -> ReLU -> Conv2D[9,1] (stride 1, and stride 2 with the even-T SAME padding 3): the src operand is
+    bf16(relu(fma(g, scale, shift))) of the STORED g, dout the stored du; float64 contraction of those bf16 values."""
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(13 * f + T + s)
+    x = torch.randn(B, f, T, 25, generator=g).bfloat16()
+    sc = 1 + 0.2 * torch.randn(f, generator=g); sh = 0.3 * torch.randn(f, generator=g)
+    To, pad, _ = O.same_pad(T, 9, s)
+    du = torch.randn(B, f, To, 25, generator=g).bfloat16()
+    h = _bf(torch.relu(torch.addcmul(sh.view(1, -1, 1, 1), x.float(), sc.view(1, -1, 1, 1))))
+    kernel = torch.zeros(9, 1, f, f, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(f, dtype=torch.float64, requires_grad=True)
+    gk, gb = torch.autograd.grad(O.temporal_conv(h, kernel, bias, s), (kernel, bias), du.double())
+    flat = torch.zeros(9 * f * f + f, device=dev)
+    ops8.conv_wgrad(L.SAR_CONV_TEMPORAL, _cn8(x, dev), _cn8(du, dev), flat, B=B, V=25, T_src=T, T_out=To, Kc=f, M=f, taps=9,
+                    stride=s, pad=pad, pro=(sc.to(dev), sh.to(dev)), pro_relu=True, w_stride_tap=f * f, w_stride_c=f,
+                    wsize=9 * f * f, bsize=f)
+    torch.cuda.synchronize()
+    assert rel_err(flat[:9 * f * f].cpu().view(9, 1, f, f), gk) < 1e-5
+    assert rel_err(flat[9 * f * f:].cpu(), gb) < 1e-5
+
+
+@pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2), (1, 64, 64, 7, 1), (2, 24, 40, 9, 2), (2, 64, 128, 300, 2)])
+def test_residual_conv_weight_gradient(dev, B, cin, f, T, s):
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(5 * cin + f)
+    x = torch.randn(B, cin, T, 25, generator=g).bfloat16()
+    kernel = torch.zeros(1, 1, cin, f, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(f, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), O.hwio_to_oihw(kernel), bias, stride=(s, 1))
+    To = y.shape[2]
+    dr = torch.randn(B, f, To, 25, generator=g).bfloat16()
+    gk, gb = torch.autograd.grad(y, (kernel, bias), dr.double())
+    flat = torch.zeros(cin * f + f, device=dev)
+    ops8.conv_wgrad(L.SAR_CONV_TEMPORAL, _cn8(x, dev), _cn8(dr, dev), flat, B=B, V=25, T_src=T, T_out=To, Kc=cin, M=f, taps=1,
+                    stride=s, pad=0, w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f)
+    torch.cuda.synchronize()
+    assert rel_err(flat[:cin * f].cpu().view(1, 1, cin, f), gk) < 1e-5
+    assert rel_err(flat[cin * f:].cpu(), gb) < 1e-5
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9), (4, 256, 256, 75),
+                                       (2, 40, 72, 9), (2, 64, 64, 300)])
+def test_graph_conv_weight_gradient(dev, B, cin, f, T):
+    """dW[c][k F + m] = sum z_k[c, n] dg[m, n] with z_k = bf16(fp32 gather of the stored x), dbias[k][m] = sum dg colsum(A_k)"""
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(17 * cin + f)
+    x = torch.randn(B, cin, T, 25, generator=g).bfloat16()
+    dg = torch.randn(B, f, T, 25, generator=g).bfloat16()
+    tab = _tables(dev)
+    assert tab.slice0_identity
+    idx, wt = tab.idx.cpu(), tab.wt.cpu()
+    xs = x.float()
+    gk = torch.zeros(cin, 3 * f, dtype=torch.float64)
+    gb = torch.zeros(3 * f, dtype=torch.float64)
+    A = _A()
+    for k in range(3):
+        z = torch.zeros(B, cin, T, 25)
+        for w in range(25):
+            acc = wt[k, w, 0] * xs[:, :, :, idx[k, w, 0]]
+            for j in range(1, tab.nz[k]):
+                acc = torch.addcmul(acc, xs[:, :, :, idx[k, w, j]], wt[k, w, j])
+            z[:, :, :, w] = acc
+        gk[:, k * f:(k + 1) * f] = torch.einsum("bctv,bmtv->cm", _bf(z), dg.double())
+        gb[k * f:(k + 1) * f] = torch.einsum("bmtv,v->m", dg.double(), A[k].double().sum(dim=0))
+    flat = torch.zeros(cin * 3 * f + 3 * f, device=dev)
+    ops8.conv_wgrad(L.SAR_CONV_GRAPH, _cn8(x, dev), _cn8(dg, dev), flat, B=B, V=25, T_src=T, T_out=T, Kc=cin, M=f, taps=3,
+                    tables=tab, w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)
+    torch.cuda.synchronize()
+    assert rel_err(flat[:cin * 3 * f].cpu().view(cin, 3 * f), gk) < 1e-5
+    assert rel_err(flat[cin * 3 * f:].cpu(), gb) < 1e-5
+    # the slice-0 shortcut (identity read from the raw tile) equals the general path bit for bit
+    tab2 = _tables(dev)
+    tab2.slice0_identity = False
+    flat2 = torch.zeros_like(flat)
+    ops8.conv_wgrad(L.SAR_CONV_GRAPH, _cn8(x, dev), _cn8(dg, dev), flat2, B=B, V=25, T_src=T, T_out=T, Kc=cin, M=f, taps=3,
+                    tables=tab2, w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, flat2)
