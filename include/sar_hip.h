@@ -33,6 +33,9 @@ extern "C" {
 typedef void* sar_stream_t;
 
 int sar_version(void);
+/* diagnostic: fills 64 KiB of LDS on every CU with `pattern` (tests: a kernel whose result depends on LDS it never
+ * wrote becomes visible); sink: 4 device bytes */
+int sar_debug_poison_lds(unsigned pattern, void* sink, sar_stream_t s);
 /* diagnostic: workgroups/CU the runtime predicts for the temporal GEMM at a dynamic-LDS size */
 int sar_debug_occupancy(int which, int lds_bytes);
 const char* sar_last_error_string(void);
@@ -324,6 +327,15 @@ int sar_conv2d_stem_dgrad_f32(const float* dout, int64_t ld_dout, const float* w
 /* out[i][j][k] (contiguous [d0][d1][d2]) = in[i*s0 + j*s1 + k*s2]: weight repacking OIHW <-> (tap, c, m). */
 int sar_permute3_f32(const float* in, float* out, int d0, int d1, int d2, int64_t s0, int64_t s1, int64_t s2,
                      sar_stream_t s);
+/* The same for many tensors in ONE launch (a training step re-packs every conv weight of the resnet into both operand
+ * layouts, and every weight gradient back into OIHW): item i copies d0*d1*d2 elements, out[dst_off + (a*d1 + b)*d2 + c] =
+ * in[src_off + a*s0 + b*s1 + c*s2].  `items` is a DEVICE array; max_elems = the largest d0*d1*d2. */
+typedef struct sar_permute_item {
+  int64_t src_off, dst_off, s0, s1, s2;
+  int32_t d0, d1, d2, reserved;
+} sar_permute_item;
+int sar_permute3_batch_f32(const float* in, float* out, const sar_permute_item* items, int nitems, int64_t max_elems,
+                           sar_stream_t s);
 /* stem tail, models/resnet18.py:236-239: y = MaxPool2d(3,2,1)(relu(x*scale[c]+shift[c])); x [C][B*H*W] -> y [C][B*Ho*Wo]. */
 int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, const float* shift, float* y, int C, int B, int H,
                                 int W, int64_t ld_x, int64_t ld_y, sar_stream_t s);

@@ -544,9 +544,32 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     if (c + j < Cc && r < R) out[boff + (int64_t)(c + j) * R + r] = tile[threadIdx.x][threadIdx.y + j];
 }
 
+// many 3-d re-layouts in one launch (blockIdx.y = item): out[dst_off + (i*d1 + j)*d2 + k] = in[src_off + i*s0 + j*s1 + k*s2]
+__global__ __launch_bounds__(TPB) void permute3_batch_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const sar_permute_item* __restrict__ items) {
+  const sar_permute_item it = items[blockIdx.y];
+  const int64_t n = (int64_t)it.d0 * it.d1 * it.d2;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int kk = (int)(i % it.d2);
+    const int64_t r = i / it.d2;
+    const int j = (int)(r % it.d1), ii = (int)(r / it.d1);
+    out[it.dst_off + i] = in[it.src_off + ii * it.s0 + j * it.s1 + kk * it.s2];
+  }
+}
+
 }  // namespace
 
 // ====================================================================================== C ABI
+extern "C" int sar_permute3_batch_f32(const float* in, float* out, const sar_permute_item* items, int nitems, int64_t max_elems,
+                                      sar_stream_t s) {
+  SAR_REQUIRE(in && out && items && nitems > 0 && nitems <= 65535 && max_elems > 0, "sar_permute3_batch: bad arguments");
+  int64_t blocks = (max_elems + TPB - 1) / TPB;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(permute3_batch_kernel, dim3((unsigned)blocks, nitems), dim3(TPB), 0, as_stream(s), in, out, items);
+  SAR_LAUNCH_CHECK("sar_permute3_batch_f32");
+  return 0;
+}
+
 extern "C" int sar_bn_finalize_f32(const float* partials, int nparts, int C, double count, float eps, float momentum,
                                    int unbiased_running, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, float* mean, float* rstd, float* scale, float* shift,

@@ -219,6 +219,14 @@ __global__ __launch_bounds__(TPB) void cn8_to_cn_kernel(const uint4* __restrict_
   }
 }
 
+// diagnostic: leave a known pattern in the LDS of every CU (a kernel that reads LDS it never wrote then shows it)
+__global__ __launch_bounds__(TPB) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+  extern __shared__ unsigned dyn[];
+  for (int i = threadIdx.x; i < 16384; i += TPB) dyn[i] = pattern;
+  __syncthreads();
+  if (dyn[(threadIdx.x * 61) & 16383] != pattern) sink[0] = 1;   // keeps the stores alive
+}
+
 inline bool al16(std::initializer_list<const void*> ptrs) {
   for (const void* p : ptrs)
     if (p && ((uintptr_t)p & 15)) return false;
@@ -295,6 +303,13 @@ extern "C" int sar_pool_bwd_cn8(const float* dfeat, int64_t ld, int C, int B, in
   hipLaunchKernelGGL(pool_bwd_cn8_kernel, dim3(B / Mp, CN8_G(C)), dim3(TPB), 0, as_stream(s), dfeat, ld, span,
                      1.0f / (float)span, C, (uint4*)dy);
   SAR_LAUNCH_CHECK("sar_pool_bwd_cn8");
+  return 0;
+}
+
+extern "C" int sar_debug_poison_lds(unsigned pattern, void* sink, sar_stream_t s) {
+  SAR_REQUIRE(sink, "sar_debug_poison_lds: sink required");
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(TPB), 65536, as_stream(s), pattern, (unsigned*)sink);
+  SAR_LAUNCH_CHECK("sar_debug_poison_lds");
   return 0;
 }
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sar_version": (_i, []),
     "sar_last_error_string": (C.c_char_p, []),
     "sar_debug_occupancy": (_i, [_i, _i]),
+    "sar_debug_poison_lds": (C.c_int, [C.c_uint32, _fp, _fp]),
     "sar_struct_size": (_i, [_i]),
     "sar_conv_gemm_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     "sar_conv2d_gemm_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
     "sar_conv2d_wgrad_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
     "sar_permute3_f32": (_i, [_fp, _fp, _i, _i, _i, _i64, _i64, _i64, _fp]),
+    "sar_permute3_batch_f32": (_i, [_fp, _fp, _fp, _i, _i64, _fp]),
     "sar_bn_relu_maxpool_fwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i64, _i64, _fp]),
     "sar_bn_relu_maxpool_bwd_nparts": (_i, [_i, _i, _i]),
     "sar_bn_relu_maxpool_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i64, _i64, _fp]),

@@ -339,6 +339,30 @@ def permute3(inp, out, d0, d1, d2, s0, s1, s2):
     check(L.load().sar_permute3_f32(ptr(inp), ptr(out), d0, d1, d2, s0, s1, s2, stream_ptr()), "sar_permute3_f32")
 
 
+class PermuteBatch:
+    """Many 3-d re-layouts between two flat fp32 buffers in ONE launch (sar_permute3_batch_f32)."""
+
+    ITEM = [("src_off", "<i8"), ("dst_off", "<i8"), ("s0", "<i8"), ("s1", "<i8"), ("s2", "<i8"),
+            ("d0", "<i4"), ("d1", "<i4"), ("d2", "<i4"), ("reserved", "<i4")]
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, src_off, dst_off, d0, d1, d2, s0, s1, s2):
+        self.items.append((src_off, dst_off, s0, s1, s2, d0, d1, d2, 0))
+
+    def finalize(self, device):
+        import numpy as np
+        tab = np.array(self.items, dtype=np.dtype(self.ITEM, align=True))
+        assert tab.dtype.itemsize == 56          # sizeof(sar_permute_item)
+        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(device)
+        self.max_elems = max(it[5] * it[6] * it[7] for it in self.items)
+
+    def run(self, src, dst):
+        check(L.load().sar_permute3_batch_f32(ptr(_f32(src)), ptr(_f32(dst)), ptr(self.table), len(self.items), self.max_elems,
+                                              stream_ptr()), "sar_permute3_batch_f32")
+
+
 def bn_relu_maxpool_fwd(x, scale, shift, y, B, H, W):
     check(L.load().sar_bn_relu_maxpool_fwd_f32(ptr(x), ptr(scale), ptr(shift), ptr(y), x.shape[0], B, H, W, x.stride(0),
                                                y.stride(0), stream_ptr()), "sar_bn_relu_maxpool_fwd_f32")

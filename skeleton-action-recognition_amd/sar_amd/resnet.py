@@ -79,8 +79,25 @@ class ResNet18:
         self.g = {k: self._view(self.grad, k) for k in self.shapes}
         self.bn = {name: _BN(c, dev) for name, c in self.bn_names}
         self._init_params(seed)
-        self._packed = {}
         self._saved = None
+        # Operand layouts of every conv weight, refreshed by ONE launch per step (and one more for the data-gradient
+        # layouts when training): forward (tap, c, m), data gradient (tap, m, c); the weight-gradient kernels write
+        # (tap, c, m) tensors into one scratch buffer that ONE launch re-lays into the OIHW gradient views.
+        self._woff, off = {}, 0
+        pf, pb, pg = ops.PermuteBatch(), ops.PermuteBatch(), ops.PermuteBatch()
+        for name, cv in self.convs.items():
+            n = cv.taps * cv.cin * cv.cout
+            src = self.offsets[name + ".weight"]
+            self._woff[name] = (off, n)
+            pf.add(src, off, cv.taps, cv.cin, cv.cout, 1, cv.taps, cv.cin * cv.taps)
+            if name != "conv1":
+                pb.add(src, off, cv.taps, cv.cout, cv.cin, 1, cv.cin * cv.taps, cv.taps)
+            pg.add(off, src, cv.cout, cv.cin, cv.taps, 1, cv.cout, cv.cin * cv.cout)      # (tap, c, m) -> OIHW
+            off += (n + 3) // 4 * 4
+        for pk in (pf, pb, pg):
+            pk.finalize(dev)
+        self._perm_fwd, self._perm_bwd, self._perm_grad = pf, pb, pg
+        self._wf, self._wb, self._gw = z(off), z(off), z(off)
 
     def _view(self, flat, name):
         o = self.offsets[name]
@@ -123,23 +140,20 @@ class ResNet18:
 
     # ------------------------------------------------------------------ weights
     def _pack(self, need_bwd):
-        """(tap, c, m) forward and (tap, m, c) data-gradient layouts of every conv weight (once per step)."""
-        dev = self.device
-        for name, cv in self.convs.items():
-            w = self.p[name + ".weight"]
-            f = torch.empty(cv.taps * cv.cin * cv.cout, dtype=torch.float32, device=dev)
-            ops.permute3(w, f, cv.taps, cv.cin, cv.cout, 1, cv.taps, cv.cin * cv.taps)
-            bk = None
-            if need_bwd and name != "conv1":
-                bk = torch.empty_like(f)
-                ops.permute3(w, bk, cv.taps, cv.cout, cv.cin, 1, cv.cin * cv.taps, cv.taps)
-            self._packed[name] = (f, bk)
+        """(tap, c, m) forward and (tap, m, c) data-gradient layouts of every conv weight: one launch each per step."""
+        self._perm_fwd.run(self.flat, self._wf)
+        if need_bwd:
+            self._perm_bwd.run(self.flat, self._wb)
+
+    def _w(self, name, bwd=False):
+        o, n = self._woff[name]
+        return (self._wb if bwd else self._wf)[o:o + n]
 
     def _conv_fwd(self, name, X, B, H, W, training, pro=None):
         cv = self.convs[name]
         Ho, Wo = (H + 2 * cv.pad - cv.k) // cv.stride + 1, (W + 2 * cv.pad - cv.k) // cv.stride + 1
         out = torch.empty((cv.cout, B * Ho * Wo), dtype=torch.float32, device=X.device)
-        r = ops.conv2d_gemm(X, out, self._packed[name][0], cv.cin * cv.cout, cv.cout,
+        r = ops.conv2d_gemm(X, out, self._w(name), cv.cin * cv.cout, cv.cout,
                             epi=L.SAR_EPI_STATS if training else L.SAR_EPI_NONE, B=B, Kc=cv.cin, M=cv.cout, H_src=H,
                             W_src=W, H_out=Ho, W_out=Wo, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro,
                             pro_relu=pro is not None)
@@ -203,17 +217,16 @@ class ResNet18:
     # ------------------------------------------------------------------ backward
     def _conv_wgrad(self, name, X, dout, B, H, W, Ho, Wo, pro=None):
         cv = self.convs[name]
-        tmp = torch.empty(cv.taps * cv.cin * cv.cout, dtype=torch.float32, device=X.device)
-        ops.conv2d_wgrad(X, dout, tmp, B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k, KW=cv.k,
-                         stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None)
-        # (tap, c, m) -> OIHW gradient view
-        ops.permute3(tmp, self.g[name + ".weight"], cv.cout, cv.cin, cv.taps, 1, cv.cout, cv.cin * cv.cout)
+        o, n = self._woff[name]
+        ops.conv2d_wgrad(X, dout, self._gw[o:o + n], B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k,
+                         KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None)
+        # the (tap, c, m) results are re-laid into the OIHW gradient views by ONE launch at the end of backward()
 
     def _conv_dgrad(self, name, dout, B, H, W, Ho, Wo, **epi):
         """gradient w.r.t. the conv's input (H, W) from dout at (Ho, Wo)."""
         cv = self.convs[name]
         dx = torch.empty((cv.cin, B * H * W), dtype=torch.float32, device=dout.device)
-        r = ops.conv2d_gemm(dout, dx, self._packed[name][1], cv.cout * cv.cin, cv.cin, B=B, Kc=cv.cout, M=cv.cin, H_src=Ho,
+        r = ops.conv2d_gemm(dout, dx, self._w(name, True), cv.cout * cv.cin, cv.cin, B=B, Kc=cv.cout, M=cv.cin, H_src=Ho,
                             W_src=Wo, H_out=H, W_out=W, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, transposed=True,
                             **epi)
         return dx, r
@@ -272,11 +285,12 @@ class ResNet18:
         self._bn_bwd("bn1", part, nparts, nparts * 2, 2, 1, B * sv["H1"] * sv["W1"])
         ops.affine2(dz0, c0, (bn0.k1, bn0.k2, bn0.k3), dz0)
         self._conv_wgrad("conv1", sv["x0"], dz0, B, sv["H"], sv["W"], sv["H1"], sv["W1"])
+        self._perm_grad.run(self._gw, self.grad)             # every conv weight gradient: (tap, c, m) -> OIHW
         dx = None
         if need_dx:
             cv = self.convs["conv1"]
             dx = torch.empty((B, 1, sv["H"], sv["W"]), dtype=torch.float32, device=dev)
-            ops.conv2d_stem_dgrad(dz0, self._packed["conv1"][0], dx, B=B, H=sv["H"], W=sv["W"], H_out=sv["H1"], W_out=sv["W1"],
+            ops.conv2d_stem_dgrad(dz0, self._w("conv1"), dx, B=B, H=sv["H"], W=sv["W"], H_out=sv["H1"], W_out=sv["W1"],
                                   M=cv.cout, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad)
         self._saved = None
         return dx

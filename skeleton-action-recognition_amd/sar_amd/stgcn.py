@@ -74,7 +74,7 @@ class STGCN:
         self.tab_fwd = ops.GraphTables(self.A_host, self.device, transpose=False)
         self.tab_bwd = ops.GraphTables(self.A_host, self.device, transpose=True)
         self._side = (torch.cuda.Stream(device=self.device)
-                      if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "0") == "1" else None)
+                      if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1" else None)
         self.motion = bool(motion)   # motion stream (data_gen/gen_motion_data.py:24-27) of the joint / bone data, on the fly
         self.bone_parent = None
         if bone_pairs is not None:
@@ -326,9 +326,10 @@ class STGCN:
         """Weight-gradient kernels feed nothing but the optimizer: they run on a second stream, ordered after
         everything issued so far, so that the MFMA-bound reductions overlap the HBM-bound BatchNorm / ReLU passes of
         the main chain.  `tensors` are the inputs whose memory the caching allocator must not hand out again before
-        the side stream is done with them.  Opt-in (SAR_WGRAD_STREAM=1): measured +2 % clips/s at bs = 64 -- the MFMA
-        kernels fill the register file, so little of the element-wise work can co-reside -- at the price of per-kernel
-        timings that overlap (bench.py's roofline object is measured on one stream)."""
+        the side stream is done with them.  On by default (SAR_WGRAD_STREAM=0 turns it off): measured +3.5 % clips/s at
+        bs = 64 in fp32 -- the MFMA kernels fill the register file, so only part of the element-wise work can co-reside.
+        Per-kernel timings of overlapping kernels are inflated; bench.py therefore also reports the dominant family
+        measured in a short pass with the side stream off (roofline.isolated)."""
         if self._side is None:
             fn()
             return

@@ -1,0 +1,174 @@
+"""Per-kernel repeat test of the CN8 kernels at the NTU layer shapes: same inputs, many launches, bitwise comparison."""
+import sys, os, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/skeleton-action-recognition_amd")
+from sar_amd import ops, ops8, _lib as L
+from graph.ntu_rgb_d import Graph
+dev = torch.device("cuda:0")
+B, V = 12, 25
+REP = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+A = Graph().A.astype(np.float32)
+tab, tabT = ops.GraphTables(A, dev), ops.GraphTables(A, dev, True)
+def rnd(C, n, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return ops8.from_cn(torch.randn((C, n), generator=g, device=dev))
+def pack(W, st, sc, sm, taps, Kc, M):
+    pk = ops.PackedWeights(); pk.add("w", 0, st, sc, sm, taps, Kc, M); pk.finalize(dev); pk.refresh(W.reshape(-1)); return pk.image("w")
+def same_pad(T, k, s):
+    out = -(-T // s); total = max((out - 1) * s + k - T, 0); return out, total // 2
+def check(name, fn):
+    ref = None; bad = 0
+    for r in range(REP):
+        out = fn(); torch.cuda.synchronize()
+        out = [o.clone() for o in out if o is not None]
+        if ref is None: ref = out
+        elif not all(torch.equal(a, b) for a, b in zip(ref, out)): bad += 1
+    print("%-40s %s" % (name, "ok" if bad == 0 else "NONDETERMINISTIC in %d of %d repeats" % (bad, REP - 1)))
+for (cin, f, s, T) in [(3, 64, 1, 300), (64, 64, 1, 300), (64, 128, 2, 300), (128, 128, 1, 150), (128, 256, 2, 150), (256, 256, 1, 75)]:
+    To, pad = same_pad(T, 9, s)
+    n_in, n_out = B * T * V, B * To * V
+    X, G, dU, dG, Y = rnd(cin, n_in, 1), rnd(f, n_in, 2), rnd(f, n_out, 3), rnd(f, n_in, 4), rnd(f, n_out, 5)
+    g = torch.Generator(device=dev).manual_seed(9)
+    Wt = torch.randn((9, f, f), generator=g, device=dev) * 0.05
+    Wg = torch.randn((cin, 3 * f), generator=g, device=dev) * 0.1
+    Wr = torch.randn((cin, f), generator=g, device=dev) * 0.1
+    sc, sh, mean = 1 + 0.2 * torch.randn(f, generator=g, device=dev), 0.3 * torch.randn(f, generator=g, device=dev), 0.1 * torch.randn(f, generator=g, device=dev)
+    k3 = [0.5 * torch.randn(f, generator=g, device=dev) for _ in range(3)]
+    tag = "[%d->%d s%d T%d] " % (cin, f, s, T)
+    pw_tb, pw_gb, pw_rb = pack(Wt, f * f, 1, f, 9, f, f), pack(Wg, f, 1, 3 * f, 3, f, cin), pack(Wr, 0, 1, f, 1, f, cin)
+    pw_tf, pw_gf = pack(Wt, f * f, f, 1, 9, f, f), pack(Wg, f, 3 * f, 1, 3, cin, f)
+    def t_fwd():
+        out = ops8.empty(f, n_out, dev)
+        r = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, G, out, pw_tf, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS)
+        return out, r[0]
+    def g_fwd():
+        out = ops8.empty(f, n_in, dev)
+        r = ops8.conv_gemm(L.SAR_CONV_GRAPH, X, out, pw_gf, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab, epi=L.SAR_EPI_STATS)
+        return out, r[0]
+    def t_dgrad():
+        out = ops8.empty(f, n_in, dev)
+        r = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dU, out, pw_tb, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh), aux_mean=mean)
+        return out, r[0]
+    def g_dgrad():
+        out = ops8.empty(cin, n_in, dev)
+        ops8.conv_gemm(L.SAR_CONV_GRAPH, dG, out, pw_gb, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tabT, epi=L.SAR_EPI_ADD, aux=X)
+        return (out,)
+    def r_dgrad():
+        out = ops8.empty(cin, n_in, dev)
+        ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dU, out, pw_rb, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1, stride=s, pad=0, transposed=True)
+        return (out,)
+    def t_wgrad():
+        flat = torch.zeros(9 * f * f + f, device=dev)
+        ops8.conv_wgrad(L.SAR_CONV_TEMPORAL, G, dU, flat, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad, pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f)
+        return (flat,)
+    def g_wgrad():
+        flat = torch.zeros(cin * 3 * f + 3 * f, device=dev)
+        ops8.conv_wgrad(L.SAR_CONV_GRAPH, X, dG, flat, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab, w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)
+        return (flat,)
+    def r_wgrad():
+        flat = torch.zeros(cin * f + f, device=dev)
+        ops8.conv_wgrad(L.SAR_CONV_TEMPORAL, X, dU, flat, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0, w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f)
+        return (flat,)
+    def ew():
+        p, _ = ops8.bn_add_relu_bwd_reduce(dU, Y, dU, Y, f, mean, mean)
+        du, dr, dz = ops8.empty(f, n_out, dev), ops8.empty(f, n_out, dev), ops8.empty(f, n_out, dev)
+        ops8.bn_add_relu_bwd_apply(dU, Y, dU, Y, k3, k3, du, dr, dz, f)
+        a = ops8.empty(f, n_out, dev); ops8.affine2(dU, Y, k3, a, f)
+        return p, du, dr, dz, a
+    for name, fn in (("temporal fwd", t_fwd), ("graph fwd", g_fwd), ("temporal dgrad+mask", t_dgrad), ("graph dgrad+add", g_dgrad), ("1x1 dgrad", r_dgrad),
+                     ("temporal wgrad", t_wgrad), ("graph wgrad", g_wgrad), ("1x1 wgrad", r_wgrad), ("elementwise bwd", ew)):
+        check(tag + name, fn)
+
+print("---- detail: temporal dgrad + mask, 128->128 s1 T150")
+cin, f, s, T = 128, 128, 1, 150
+To, pad = same_pad(T, 9, s)
+n_in, n_out = B * T * V, B * To * V
+G, dU = rnd(f, n_in, 2), rnd(f, n_out, 3)
+g = torch.Generator(device=dev).manual_seed(9)
+Wt = torch.randn((9, f, f), generator=g, device=dev) * 0.05
+sc, sh, mean = 1 + 0.2 * torch.randn(f, generator=g, device=dev), 0.3 * torch.randn(f, generator=g, device=dev), 0.1 * torch.randn(f, generator=g, device=dev)
+pw = pack(Wt, f * f, 1, f, 9, f, f)
+outs = []
+for epi in (L.SAR_EPI_MASK, L.SAR_EPI_NONE, L.SAR_EPI_ADD, L.SAR_EPI_STATS):
+    res = []
+    for r in range(6):
+        out = ops8.empty(f, n_in, dev)
+        rr = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dU, out, pw, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s, pad=pad, transposed=True, epi=epi,
+                            aux=G if epi in (L.SAR_EPI_MASK, L.SAR_EPI_ADD) else None, aux_affine=(sc, sh) if epi == L.SAR_EPI_MASK else None, aux_mean=mean if epi == L.SAR_EPI_MASK else None)
+        torch.cuda.synchronize()
+        res.append((out.clone(), rr[0].clone() if rr else None))
+    for r in range(1, 6):
+        d = (res[0][0].float() - res[r][0].float()).abs()
+        nd = int((d > 0).sum())
+        pd = 0 if res[0][1] is None else int((res[0][1] != res[r][1]).sum())
+        if nd or pd:
+            idx = (d > 0).nonzero()
+            print("epi %d rep %d: out differs in %d elements (planes %s, cols %s..%s), partials differ in %d" % (
+                epi, r, nd, sorted(set(idx[:, 0].tolist()))[:8] if nd else "-", idx[:, 1].min().item() if nd else "-", idx[:, 1].max().item() if nd else "-", pd))
+    print("epi %d done" % epi)
+
+print("---- sentinel test: are all outputs / partials written?")
+import ctypes as C
+for (f, s, T) in [(128, 1, 150), (128, 2, 300), (256, 1, 75), (64, 1, 300)]:
+    To, pad = same_pad(T, 9, s)
+    n_in, n_out = B * T * V, B * To * V
+    G, dU = rnd(f, n_in, 2), rnd(f, n_out, 3)
+    g = torch.Generator(device=dev).manual_seed(9)
+    Wt = torch.randn((9, f, f), generator=g, device=dev) * 0.05
+    sc, sh, mean = 1 + 0.2 * torch.randn(f, generator=g, device=dev), 0.3 * torch.randn(f, generator=g, device=dev), 0.1 * torch.randn(f, generator=g, device=dev)
+    pw = pack(Wt, f * f, 1, f, 9, f, f)
+    out = ops8.empty(f, n_in, dev)
+    out.fill_(float("nan"))
+    # emulate ops8.conv_gemm but with a sentinel-filled partials tensor
+    d = L.ConvDesc()
+    d.mode, d.transposed, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = L.SAR_CONV_TEMPORAL, 1, B, V, To, T, f, f
+    d.taps, d.stride, d.pad, d.epi = 9, s, pad, L.SAR_EPI_MASK
+    d.src, d.ld_src, d.out, d.ld_out, d.aux, d.ld_aux = dU.data_ptr(), n_out, out.data_ptr(), n_in, G.data_ptr(), n_in
+    d.aux_scale, d.aux_shift, d.aux_mean = sc.data_ptr(), sh.data_ptr(), mean.data_ptr()
+    lib = L.load()
+    nparts = lib.sar_conv_gemm_cn8_nparts(C.byref(d))
+    partials = torch.full((f, nparts, 2), float("nan"), device=dev)
+    d.partials = partials.data_ptr()
+    L.check(lib.sar_conv_gemm_cn8(C.byref(d), pw.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    print("f=%d s=%d T=%d: nparts %d, unwritten out elements %d, unwritten partials %d (rows %s)" % (
+        f, s, T, nparts, int(torch.isnan(out.float()).sum()), int(torch.isnan(partials).sum()),
+        sorted(set(torch.isnan(partials).nonzero()[:, 0].tolist()))[:10]))
+
+print("---- LDS poison test")
+sink = torch.zeros(4, dtype=torch.int32, device=dev)
+def poison(p): L.check(lib.sar_debug_poison_lds(p, sink.data_ptr(), L.stream_ptr()))
+f, s, T = 128, 1, 150
+To, pad = same_pad(T, 9, s)
+n_in, n_out = B * T * V, B * To * V
+G, dU = rnd(f, n_in, 2), rnd(f, n_out, 3)
+g = torch.Generator(device=dev).manual_seed(9)
+Wt = torch.randn((9, f, f), generator=g, device=dev) * 0.05
+sc, sh, mean = 1 + 0.2 * torch.randn(f, generator=g, device=dev), 0.3 * torch.randn(f, generator=g, device=dev), 0.1 * torch.randn(f, generator=g, device=dev)
+pw = pack(Wt, f * f, 1, f, 9, f, f)
+res = {}
+for pat in (0, 0x7fc07fc0, 0x3f803f80, 0):
+    poison(pat)
+    out = ops8.empty(f, n_in, dev)
+    rr = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dU, out, pw, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK,
+                        aux=G, aux_affine=(sc, sh), aux_mean=mean)
+    torch.cuda.synchronize()
+    o, p = out.float(), rr[0]
+    print("pattern %08x: NaN in out %d, NaN in partials %d" % (pat, int(torch.isnan(o).sum()), int(torch.isnan(p).sum())))
+    if pat in res:
+        print("   same as first run with this pattern: out %s partials %s" % (torch.equal(res[pat][0], out), torch.equal(res[pat][1], p)))
+    else:
+        res[pat] = (out.clone(), p.clone())
+d = (res[0][0].float() - res[0x3f803f80][0].float()).abs()
+print("out differs between LDS patterns in %d elements; partials in %d" % (int((d > 0).sum()), int((res[0][1] != res[0x3f803f80][1]).sum())))
+if (d > 0).any():
+    idx = (d > 0).nonzero()
+    print("planes", sorted(set(idx[:, 0].tolist()))[:16], "cols mod 125:", sorted(set((idx[:, 1] % 125).tolist()))[:40], "chan", sorted(set(idx[:, 2].tolist())))
+pd = (res[0][1] != res[0x3f803f80][1]).nonzero()
+if len(pd):
+    print("partials rows", sorted(set(pd[:, 0].tolist()))[:40], "which", sorted(set(pd[:, 2].tolist())))
+if (d > 0).any():
+    i0 = tuple(idx[0].tolist())
+    print("values:", res[0][0].float()[i0].item(), res[0x3f803f80][0].float()[i0].item(), "aux", G.float()[i0].item(),
+          "pre-activation", G.float()[i0].item() * sc[8 * i0[0] + i0[2]].item() + sh[8 * i0[0] + i0[2]].item())
+    print("partials", res[0][1][45].flatten()[:0].shape, (res[0][1][45] - res[0x3f803f80][1][45]).abs().max().item())
