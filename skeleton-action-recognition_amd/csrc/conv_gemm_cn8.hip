@@ -14,6 +14,7 @@
 //  * the epilogue stores the 4 consecutive channels a lane holds in registers 4q .. 4q+3 as ONE 8-byte half unit:
 //    512 contiguous bytes per wave instruction, 4 stores per 32x32 accumulator tile (fp32 CN layout: 16).
 #include "cn8.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -47,8 +48,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // ---- epilogue: mask / add, BatchNorm partial sums from the fp32 accumulators, bf16 half-unit stores.  Every wave is
 // past its last MFMA phase and the closing barrier: the transpose area aliases the operand image.
 template <int MS, int NS, int WN, int BM>
-__device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int wn, int m0, const bool (&colok)[NS],
-                                          const int64_t (&coln)[NS], f32x16 (&acc)[MS][NS], float4* rowp, float* smem) {
+__device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int wn, int m0, const unsigned (&vo)[NS],
+                                          f32x16 (&acc)[MS][NS], float4* rowp, float* smem) {
   const sar_conv_desc& d = k.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,9 +83,7 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_aux ? (char*)d.aux + (int64_t)g_w * d.ld_aux * 16 : (char*)d.out), 0, has_aux ? plane_bytes(d.ld_aux) : 0u,
         0x00020000);
-    unsigned vo[NS];
-#pragma unroll
-    for (int ns = 0; ns < NS; ++ns) vo[ns] = colok[ns] ? (unsigned)(coln[ns] * 16 + 8 * hi) : 0x80000000u;
+    // vo[ns]: byte offset of this lane's half unit inside a plane (0x80000000 = off-tile column: rejected)
     const int so_out = (int)(d.ld_out * 16), so_aux = (int)(d.ld_aux * 16);   // one plane
     float* P = smem + wave * (16 * 65);
 #pragma unroll
@@ -213,8 +212,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
 
   // ---- per-lane column geometry
   bool colok[NS];
-  int64_t coln[NS];
-  int off[JT][NS];
+  unsigned vo[NS];   // epilogue: byte offset of the lane's half unit in a plane of out / aux
+  // LDS unit of tap slot j for column block ns: off0[ns] + j * ostep[ns] (forward: +V per tap; data gradients: -V per tap
+  // slot; off-tile columns: the zero column with step 0).  TR == 2 (generic stride) keeps an explicit table.
+  int off0[NS], ostep[NS];
+  int offt[TR == 2 ? JT : 1][NS];
   unsigned vmask[NS];
   int t_lo;
   if (!TRANSPOSED) t_lo = t0 * d.stride - d.pad;
@@ -238,25 +240,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
     }
     colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
     if (!colok[ns]) fo = par;
-    coln[ns] = ((int64_t)b * d.T_out + (t0 + fo)) * V + v;
+    vo[ns] = colok[ns] ? (unsigned)((((int64_t)b * d.T_out + (t0 + fo)) * V + v) * 16 + 8 * hi) : 0x80000000u;
     vmask[ns] = 0;
+    if (TR == 0) {
+      off0[ns] = fo * d.stride * V + v;
+      ostep[ns] = V;
+    } else if (TR == 1) {
+      off0[ns] = (t0 + fo + d.pad - t_lo) * V + v;                       // tap 0; tap tp reads tp frames earlier
+      ostep[ns] = -V;
+    } else if (PAR) {
+      off0[ns] = (((t0 + fo + d.pad - tp0) >> 1) - t_lo) * V + v;        // exact: the numerator is even
+      ostep[ns] = -V;
+    } else {
+      off0[ns] = 0;
+      ostep[ns] = 0;
 #pragma unroll
-    for (int tp = 0; tp < JT; ++tp) {
-      if (!TRANSPOSED) {
-        off[tp][ns] = (fo * d.stride + tp) * V + v;
-      } else if (PAR) {
-        const int to = (t0 + fo + d.pad - (tp0 + 2 * tp)) >> 1;
-        off[tp][ns] = (to - t_lo) * V + v;
-      } else {
+      for (int tp = 0; tp < JT; ++tp) {
         const int q = t0 + fo + d.pad - tp;
         const int to = floordiv(q, d.stride);
         const bool ok = (q - to * d.stride) == 0;
         vmask[ns] |= (ok ? 1u : 0u) << tp;
-        off[tp][ns] = (to - t_lo) * V + v;
+        offt[tp][ns] = (colok[ns] ? (to - t_lo) * V + v : ZCOL) + hi * SCOLS;
       }
-      if (!colok[ns]) off[tp][ns] = ZCOL;
-      off[tp][ns] += hi * SCOLS;   // this lane's k half
     }
+    if (!colok[ns]) {
+      off0[ns] = ZCOL;
+      ostep[ns] = 0;
+    }
+    off0[ns] += hi * SCOLS;   // this lane's k half
   }
 
   if (tid < BM) {
@@ -272,23 +283,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   // sequence, so the temporal zero padding (negative / past-the-end columns) is the range check's 0
   const int seq_len = d.T_src * V;
   const char* src_b = (const char*)d.src + (int64_t)b * seq_len * 16;
-  int svo[CJ];
-  bool sok[CJ];
+  // unit tid + 256 j of a plane: column t_lo V + tid + 256 j of the sequence (immediate offset 4096 j); sbits: bit j set =
+  // inside the staged width AND inside the sequence (the prologue must keep everything else exactly 0)
+  const int svo0 = (t_lo * V + tid) * 16;
+  unsigned sbits = 0, swidth = 0;
 #pragma unroll
   for (int j = 0; j < CJ; ++j) {
     const int col = tid + 256 * j;
     const int rabs = t_lo * V + col;
-    sok[j] = col < k.RW && (unsigned)rabs < (unsigned)seq_len;
-    svo[j] = col < k.RW ? rabs * 16 : 0x7fffffff;   // lanes beyond the staged width read 0 too
+    swidth |= (col < k.RW ? 1u : 0u) << j;
+    sbits |= ((col < k.RW && (unsigned)rabs < (unsigned)seq_len) ? 1u : 0u) << j;
   }
-  unsigned wvo[WIT];
-#pragma unroll
-  for (int i = 0; i < WIT; ++i) {
-    const int u = tid + 256 * i;
-    const int m = u % BM, h = (u / BM) & 1, tp = u / (2 * BM);
-    const bool ok = u < TC::WUNITS && (m0 + m) < d.M;
-    wvo[i] = ok ? (unsigned)((((int64_t)tp * k.G + h) * d.M + m0 + m) * 16) : 0x80000000u;   // rejected by the range check -> 0
-  }
+  // W unit tid + 256 i = (tap, half, row): 256 = (256 / (2 BM)) whole taps, so the lane's (half, row) is fixed and the tap
+  // advances by 256 / (2 BM) per i: ONE per-lane offset, the rest is a scalar stride
+  static_assert(256 % (2 * BM) == 0, "a W pass must cover whole taps");
+  constexpr int TPI = 256 / (2 * BM);
+  const int wm_ = tid % BM, wh_ = (tid / BM) & 1, wt_ = tid / (2 * BM);
+  const unsigned wvo0 = (m0 + wm_) < d.M ? (unsigned)((((int64_t)wt_ * k.G + wh_) * d.M + m0 + wm_) * 16)
+                                         : 0x80000000u;   // rows beyond M: rejected by the range check -> 0
+  const int wstep = TPI * k.G * d.M * 16;   // bytes per W pass (scalar)
   const unsigned wbytes = (unsigned)((int64_t)TAPS * k.G * d.M * 16);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
   const bool has_pro = d.pro_scale != nullptr;
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   auto issue_loads = [&](int c0) {
     const int wso = (c0 / 8) * d.M * 16;   // scalar: first channel group of the stage
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], wso, 0);
+    for (int i = 0; i < WIT; ++i) {   // taps beyond TAPS (last, partial pass) lie past the image: range check -> 0
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo0, wso + i * wstep, 0);
       wreg[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
 #pragma unroll
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
           (void*)(src_b + (int64_t)(g < k.Gs ? g : 0) * d.ld_src * 16), 0, g < k.Gs ? (unsigned)seq_len * 16u : 0u, 0x00020000);
 #pragma unroll
       for (int j = 0; j < CJ; ++j) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, svo[j], 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((swidth >> j) & 1u) ? svo0 : 0x7fffffff, j * 4096, 0);
         sreg[h][j] = make_uint4(v[0], v[1], v[2], v[3]);
       }
     }
@@ -335,8 +348,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
         for (int j = 0; j < CJ; ++j) {
           float f[8];
           cn8_unpack(sreg[h][j], f);
+          const bool inside = (sbits >> j) & 1u;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) f[q] = sok[j] ? fmaxf(fmaf(f[q], psc[q], psh[q]), relu_lo) : 0.f;   // padding stays exactly 0
+          for (int q = 0; q < 8; ++q) f[q] = inside ? fmaxf(fmaf(f[q], psc[q], psh[q]), relu_lo) : 0.f;   // padding stays exactly 0
           sreg[h][j] = cn8_pack(f);
         }
       }
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
     for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tpw * 2 * BM + ms * 32];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      bq[ns] = Sl[off[j][ns]];
+      bq[ns] = Sl[TR == 2 ? offt[TR == 2 ? j : 0][ns] : off0[ns] + j * ostep[ns]];
       if (TR == 2 && !((vmask[ns] >> j) & 1u)) bq[ns] = make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
     __syncthreads();   // every wave is done with the image (next store / the epilogue's transpose area)
   }
 
-  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, colok, coln, acc, rowp, smem);
+  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
 }
 
 // ---- GraphConvTD (models/gcn.py:199-209) and its data gradient:
@@ -432,14 +446,14 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
   const int ncols = ((t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0) * V;   // live columns of this tile
 
   bool colok[NS];
-  int64_t coln[NS];
+  unsigned vo[NS];
   float gcs[3][NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const int p = (wn * NS + ns) * 32 + l31;
     colok[ns] = p < ncols;
     const int pv = colok[ns] ? p : 0;
-    coln[ns] = ((int64_t)b * d.T_out + t0) * V + pv;
+    vo[ns] = colok[ns] ? (unsigned)((((int64_t)b * d.T_out + t0) * V + pv) * 16 + 8 * hi) : 0x80000000u;
     const int v = pv % V;
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) gcs[tp][ns] = (d.g_colsum && colok[ns]) ? d.g_colsum[tp * V + v] : 0.f;
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
     }
   }
   __syncthreads();   // the epilogue's transpose area aliases the image
-  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, colok, coln, acc, rowp, smem);
+  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
 }
 
 template <int WN>
@@ -665,10 +679,28 @@ int launch_graph_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, 
   return launch_graph_cfg8<1, 2, 1, 4, NZ0, NZ1, NZ2>(d, wp, st, np);
 }
 
+// tile of the temporal / residual GEMMs for M > 64 (experiment switch SAR_CN8_TILE): 0 = 128 x 128, 1 = 128 x 256,
+// 2 = 64 x 256 row blocks (default; the tile of the M <= 64 layers)
+int tile_choice() {
+  static const int v = [] {
+    const char* e = getenv("SAR_CN8_TILE");
+    return e ? atoi(e) : 2;
+  }();
+  return v;
+}
+
 template <int TR, int TAPS>
 int launch_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) {
+  // M > 64: 128 x 256 tiles (wave tile 64 x 128): per output element the weight image -- re-read from L2 by every tile and
+  // stage -- is fetched half as often as with 128 x 128 tiles (measured: SAR_CN8_TN128=1 restores the small tile)
   if constexpr (TR != 3)
-    if (d.M > 64) return launch_cfg8<TR, TAPS, 2, 2, 2, 2>(d, wp, st, np);
+    if (d.M > 64) {
+      const int t = tile_choice();
+      if (t == 1) return launch_cfg8<TR, TAPS, 2, 4, 2, 2>(d, wp, st, np);
+      if (t == 0) return launch_cfg8<TR, TAPS, 2, 2, 2, 2>(d, wp, st, np);
+    }
+  if constexpr (TR != 3)
+    if (d.M > 32 && tile_choice() == 3) return launch_cfg8<TR, TAPS, 2, 1, 1, 4>(d, wp, st, np);   // 64 x 128: 4 workgroups per CU
   if (d.M > 32) return launch_cfg8<TR, TAPS, 2, 2, 1, 4>(d, wp, st, np);
   return launch_cfg8<TR, TAPS, 1, 2, 1, 4>(d, wp, st, np);
 }
@@ -729,6 +761,7 @@ extern "C" int sar_conv_gemm_cn8(const sar_conv_desc* d, const void* packed_w, s
   SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_gemm_cn8: pro_scale/pro_shift mismatch");
   SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 26), "sar_conv_gemm_cn8: sequence row too long");
   SAR_REQUIRE(d->ld_out < (1 << 26) && d->ld_aux < (1 << 26), "sar_conv_gemm_cn8: leading dimension too large (2^26 columns)");
+  SAR_REQUIRE((int64_t)d->B * d->T_out * d->V < (1 << 27), "sar_conv_gemm_cn8: more than 2^27 output columns");
   SAR_REQUIRE((int64_t)d->taps * 2 * ((d->Kc + 15) / 16) * d->M * 16 < (1ll << 31), "sar_conv_gemm_cn8: weight tensor too large");
   if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm_cn8: partials required");
   if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
