@@ -287,6 +287,9 @@ def main():
                          "layout) + bf16 MFMA operands, fp32 accumulation / BatchNorm statistics / master weights; bf16_operands = "
                          "the round-1 intermediate (bf16 MFMA operands, fp32 activations in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated-pass", action="store_true",
+                    help="skip the 3 extra untimed steps that measure the dominant kernel family with the side stream off "
+                         "(profile runs: keeps the launch counts at warmup + steps)")
     ap.add_argument("--cpu-sample", type=int, default=8,
                     help="clips in the CPU-baseline fallback batch (used only when a full --batch step does not fit the budget)")
     args = ap.parse_args()
@@ -333,7 +336,7 @@ def main():
     # chain, which inflates the HIP-event duration of whatever they overlap.  A short untimed pass with that stream off
     # measures the dominant family in isolation (kernel quality); both are reported.
     iso = None
-    if rank == 0 and eng._side is not None:
+    if eng._side is not None and not args.no_isolated_pass:      # every rank: the step contains the collective
         side, eng._side = eng._side, None
         iso_timer = profiler.KernelTimer()
         torch.cuda.synchronize()

@@ -350,6 +350,26 @@ int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_t n, const 
                  float beta1, float beta2, float eps, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense (trainable) adjacency, SURVEY.md 8(f)-4: the contraction of models/gcn.py:207-208 / 236-237 (AdjGraphConv) with
+ * an arbitrary A (K, V, V) in device memory, fp32 CN layout, V <= 32, K <= 8.  y is the 3F-channel output of the 1x1
+ * convolution (channel k*F + m; sar_conv_gemm_f32, TEMPORAL, taps = 1 -- bias included, as in the reference).
+ *   fwd       out[m, (t,w)]      = sum_k sum_v y[k*F + m, (t,v)] * A[k, v, w]        (+ partials[F][nparts][2] = per-row
+ *                                   (sum, sum of squares) per tile when partials != NULL; nparts = sar_graph_dense_nparts)
+ *   bwd_data  dy[k*F + m, (t,v)] = sum_w dout[m, (t,w)] * A[k, v, w]
+ *   dA        dA[k, v, w]        = sum_{m, frames} y[k*F + m, (f,v)] * dout[m, (f,w)]  (slab: sar_graph_dense_dadj_slab_floats
+ *                                   floats of scratch; partial blocks are summed in a fixed order: deterministic)
+ * nframes = B*T frames of V joints (the adjacency acts inside a frame).
+ * ------------------------------------------------------------------------------------------------ */
+int sar_graph_dense_nparts(int64_t nframes);
+int sar_graph_dense_fwd_f32(const float* y, int64_t ld_y, const float* A, float* out, int64_t ld_out, int K, int F, int V,
+                            int64_t nframes, float* partials, sar_stream_t s);
+int sar_graph_dense_bwd_data_f32(const float* dout, int64_t ld_dout, const float* A, float* dy, int64_t ld_dy, int K, int F,
+                                 int V, int64_t nframes, sar_stream_t s);
+int64_t sar_graph_dense_dadj_slab_floats(int K, int F, int V, int nsplit);
+int sar_graph_dense_dadj_f32(const float* y, int64_t ld_y, const float* dout, int64_t ld_dout, int K, int F, int V,
+                           int64_t nframes, int nsplit, float* slab, float* dA, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * bf16 configuration (bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation, fp32
  * BatchNorm statistics, fp32 master weights).
  *

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   // sequence, so the temporal zero padding (negative / past-the-end columns) is the range check's 0
   const int seq_len = d.T_src * V;
   const char* src_b = (const char*)d.src + (int64_t)b * seq_len * 16;
-  // unit tid + 256 j of a plane: column t_lo V + tid + 256 j of the sequence (immediate offset 4096 j); sbits: bit j set =
+  // unit tid + 256 j of a plane: column t_lo V + tid + 256 j of the sequence (byte offset svo0 + 4096 j); sbits: bit j set =
   // inside the staged width AND inside the sequence (the prologue must keep everything else exactly 0)
   const int svo0 = (t_lo * V + tid) * 16;
   unsigned sbits = 0, swidth = 0;
@@ -323,7 +323,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
           (void*)(src_b + (int64_t)(g < k.Gs ? g : 0) * d.ld_src * 16), 0, g < k.Gs ? (unsigned)seq_len * 16u : 0u, 0x00020000);
 #pragma unroll
       for (int j = 0; j < CJ; ++j) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((swidth >> j) & 1u) ? svo0 : 0x7fffffff, j * 4096, 0);
+        // the offset is formed in the vector ALU (32-bit wrap: a negative lane base plus 4096 j is the right non-negative
+        // offset); as a scalar offset the hardware range check would see the un-wrapped sum and reject it
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((swidth >> j) & 1u) ? svo0 + j * 4096 : 0x7fffffff, 0, 0);
         sreg[h][j] = make_uint4(v[0], v[1], v[2], v[3]);
       }
     }

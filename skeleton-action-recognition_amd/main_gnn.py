@@ -61,6 +61,9 @@ def get_parser():
     parser.add_argument('--steps', type=int, default=[10, 50], nargs='+',
                         help='the epoch where optimizer reduce the learning rate, eg: 10 50')
     # additions of this implementation
+    parser.add_argument('--trainable-adjacency', action='store_true',
+                        help="make the stacked adjacency a trainable variable `adjacency_matrix` (models/gcn.py AdjGraphConv); it is "
+                             "trained only while epoch > --freeze-graph-until, as in the reference's train_step")
     parser.add_argument('--synthetic', action='store_true', help='train on synthetic NTU-like clips')
     parser.add_argument('--synthetic-size', type=int, default=40000)
     parser.add_argument('--max-iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
@@ -92,7 +95,8 @@ def main():
 
     run_params = {k: v for k, v in vars(arg).items()
                   if k not in ("train_data_path", "test_data_path", "log_dir", "save_freq", "freeze_graph_until", "gpus", "resume",
-                               "save_scores") and not (k == "mfma" and v == "fp32")}
+                               "save_scores") and not (k == "mfma" and v == "fp32")
+                  and not (k == "trainable_adjacency" and not v)}
     run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
     if arg.notes:
         run_name += "-" + arg.notes
@@ -119,7 +123,8 @@ def main():
             return NpySkeletonData(prefix + ".npy", _label_path(prefix), num_classes=arg.num_classes)
         train_data, test_data = open_data(arg.train_data_path), open_data(arg.test_data_path)
 
-    model = model_mod.Model(num_classes=arg.num_classes, device=dev, stream=arg.stream, mfma=arg.mfma)
+    model = model_mod.Model(num_classes=arg.num_classes, device=dev, stream=arg.stream, mfma=arg.mfma,
+                            trainable_adjacency=arg.trainable_adjacency)
     eng = model.engine
     trainer = Trainer(eng, batch_size=arg.batch_size, base_lr=arg.base_lr, steps=arg.steps, world_size=world)
     log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None
@@ -144,8 +149,10 @@ def main():
             print("Epoch: {}".format(epoch + 1), flush=True)
         t0 = time.time()
         it = -1
-        # `train_adj` (epoch > freeze_graph_until, main_gnn.py:228-232,364) has no effect for models.stgcn: its
-        # adjacency is a non-trainable variable (models/stgcn.py:105-109).
+        # `train_adj` (main_gnn.py:228-232,364-365): variables named *adjacency_matrix* receive gradients only while
+        # epoch > freeze_graph_until (0-based epoch, as in the reference loop).  For the reference's models.stgcn the adjacency
+        # is a non-trainable variable (models/stgcn.py:105-109), so the flag only matters with --trainable-adjacency.
+        eng.train_adjacency = epoch > arg.freeze_graph_until
         # per-iteration scalars stay on the device and are exchanged / read back once per epoch (no host sync per step)
         pending = []
         for it, (x, y) in enumerate(train_data.batches(arg.batch_size, rank, world, dev, shuffle=True, epoch=epoch)):

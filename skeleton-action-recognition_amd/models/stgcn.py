@@ -43,7 +43,8 @@ class _Variable:
 
 
 class Model(torch.nn.Module):
-    def __init__(self, num_classes=60, in_channels=3, device="cuda", seed=0, stream="joint", mfma="fp32"):
+    def __init__(self, num_classes=60, in_channels=3, device="cuda", seed=0, stream="joint", mfma="fp32",
+                 trainable_adjacency=False):
         """stream (not in the reference's constructor, which reads pre-computed files): 'joint', 'bone', 'joint_motion'
         or 'bone_motion' -- the bone (data_gen/gen_bone_data.py) and motion (data_gen/gen_motion_data.py) transforms are
         applied on the fly to JOINT input inside the data_bn prologue, bit-exactly.
@@ -53,12 +54,15 @@ class Model(torch.nn.Module):
         from sar_amd.bone import NTU_BONE_PAIRS
         self.engine = STGCN(num_classes=num_classes, in_channels=in_channels, device=device, seed=seed,
                             bone_pairs=NTU_BONE_PAIRS if stream.startswith("bone") else None,
-                            motion=stream.endswith("motion"), mfma=mfma)
+                            motion=stream.endswith("motion"), mfma=mfma, trainable_adjacency=trainable_adjacency)
         # parameters are views into the engine's flat fp32 buffer (one all-reduce bucket, fused optimizer)
         self._names = list(self.engine.shapes)
         for k in self._names:
             self.register_parameter(k.replace(".", "_"), torch.nn.Parameter(self.engine.p[k]))
-        self.register_buffer("adjacency_matrix", self.engine.A)      # non-trainable, models/stgcn.py:105-109
+        if not trainable_adjacency:
+            self.register_buffer("adjacency_matrix", self.engine.A)      # non-trainable, models/stgcn.py:105-109
+        # trainable_adjacency=True (models/gcn.py:212-238 AdjGraphConv's variable, shared by the blocks): `adjacency_matrix`
+        # is one of the parameters registered above and main_gnn.py's --freeze-graph-until gates its gradient
         self.A = self.adjacency_matrix
 
     @property

@@ -112,6 +112,12 @@ SIGNATURES = {
     "sar_vr_signal_upsampled_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_vr_signal_upsampled_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_conv2d_stem_dgrad_f32": (_i, [_fp, _i64, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
+    # dense (trainable) adjacency
+    "sar_graph_dense_nparts": (_i, [_i64]),
+    "sar_graph_dense_fwd_f32": (_i, [_fp, _i64, _fp, _fp, _i64, _i, _i, _i, _i64, _fp, _fp]),
+    "sar_graph_dense_bwd_data_f32": (_i, [_fp, _i64, _fp, _fp, _i64, _i, _i, _i, _i64, _fp]),
+    "sar_graph_dense_dadj_slab_floats": (_i64, [_i, _i, _i, _i]),
+    "sar_graph_dense_dadj_f32": (_i, [_fp, _i64, _fp, _i64, _i, _i, _i, _i64, _i, _fp, _fp, _fp]),
     # bf16 configuration: CN8 activations
     "sar_conv_gemm_cn8_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_cn8": (_i, [C.POINTER(ConvDesc), _fp, _fp]),

@@ -277,6 +277,32 @@ def transpose(inp, out, batch, R, Cc):
     check(L.load().sar_transpose_f32(ptr(inp), ptr(out), batch, R, Cc, stream_ptr()), "sar_transpose_f32")
 
 
+# ------------------------------------------------------------------------------------------------ dense adjacency
+def graph_dense_fwd(y, A, out, K, F, V, nframes, stats=False):
+    """out[m] = sum_k y[k F + m] . A_k (sar_graph_dense_fwd_f32); returns (partials, nparts) when stats."""
+    lib = L.load()
+    partials, nparts = None, 0
+    if stats:
+        nparts = lib.sar_graph_dense_nparts(nframes)
+        partials = torch.empty((F, nparts, 2), dtype=torch.float32, device=y.device)
+    check(lib.sar_graph_dense_fwd_f32(ptr(_f32(y)), y.stride(0), ptr(_f32(A)), ptr(_f32(out)), out.stride(0), K, F, V, nframes,
+                                      ptr(partials), stream_ptr()), "sar_graph_dense_fwd_f32")
+    return (partials, nparts) if stats else None
+
+
+def graph_dense_bwd_data(dout, A, dy, K, F, V, nframes):
+    check(L.load().sar_graph_dense_bwd_data_f32(ptr(_f32(dout)), dout.stride(0), ptr(_f32(A)), ptr(_f32(dy)), dy.stride(0), K, F, V,
+                                                nframes, stream_ptr()), "sar_graph_dense_bwd_data_f32")
+
+
+def graph_dense_dA(y, dout, dA, K, F, V, nframes, nsplit=64):
+    lib = L.load()
+    nsplit = max(1, min(nsplit, (nframes + 7) // 8))
+    slab = torch.empty(lib.sar_graph_dense_dadj_slab_floats(K, F, V, nsplit), dtype=torch.float32, device=y.device)
+    check(lib.sar_graph_dense_dadj_f32(ptr(_f32(y)), y.stride(0), ptr(_f32(dout)), dout.stride(0), K, F, V, nframes, nsplit,
+                                     ptr(slab), ptr(_f32(dA)), stream_ptr()), "sar_graph_dense_dadj_f32")
+
+
 # ------------------------------------------------------------------------------------------------ ResNet-18 ops
 def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, pad, transposed=False, pro=None,
                  pro_relu=False):

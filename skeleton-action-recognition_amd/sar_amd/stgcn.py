@@ -53,7 +53,7 @@ class _BN:
 
 class STGCN:
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
-                 blocks=None, motion=False, mfma="fp32"):
+                 blocks=None, motion=False, mfma="fp32", trainable_adjacency=False):
         L.load()  # fail loudly if the HIP library is missing
         # mfma="fp32" (default) is the reference's arithmetic.
         # mfma="bf16" is SURVEY.md 8d config 3: activations and activation gradients are stored in HBM as bfloat16 (CN8
@@ -64,6 +64,14 @@ class STGCN:
         assert mfma in ("fp32", "bf16", "bf16_operands")
         self.cn8 = mfma == "bf16"
         self.bf16 = mfma == "bf16_operands"
+        # trainable_adjacency: the stacked adjacency becomes the trainable variable `adjacency_matrix`
+        # (models/gcn.py:212-238 AdjGraphConv) shared by all blocks; the graph convolution then keeps the reference's
+        # order -- 1x1 convolution to 3F channels, dense contraction with A (csrc/graph_dense.hip) -- and the backward pass
+        # produces dA.  `train_adjacency` gates its gradient per step (main_gnn.py:228-232: trained only while
+        # epoch > --freeze-graph-until).  fp32 only.
+        self.dense_A = bool(trainable_adjacency)
+        self.train_adjacency = True
+        assert not (self.dense_A and mfma != "fp32"), "trainable adjacency is built for the fp32 engine"
         self.device = torch.device(device)
         self.num_classes, self.C_in, self.V = num_classes, in_channels, num_node
         self.blocks = list(blocks if blocks is not None else BLOCKS)
@@ -103,6 +111,8 @@ class STGCN:
             cin = f
         self.C_last = cin
         self._add("logits.kernel", (1, 1, cin, num_classes)), self._add("logits.bias", (num_classes,))
+        if self.dense_A:
+            self._add("adjacency_matrix", (KS, num_node, num_node))
         # flat storage: every offset is a multiple of 4 floats so that each weight view is 16-byte aligned
         # (the GEMM kernels stage weight rows as float4); a bias stays glued to its kernel because the
         # weight-gradient slabs are reduced as one contiguous [kernel | bias] range.
@@ -162,6 +172,8 @@ class STGCN:
                 self.packed = pk
         self.p = {k: self._view(self.flat, k) for k in self.shapes}
         self.g = {k: self._view(self.grad, k) for k in self.shapes}
+        if self.dense_A:
+            self.A = self.p["adjacency_matrix"]          # the trainable copy (initialised from the graph in _init_params)
         self.bn = {"data_bn": _BN(nch, dev)}
         for i, (f, s, res) in enumerate(self.blocks):
             self.bn["l%d.bn1" % i], self.bn["l%d.bn2" % i] = _BN(f, dev), _BN(f, dev)
@@ -182,7 +194,9 @@ class STGCN:
         """models/stgcn.py:7-8 VarianceScaling(2, fan_out, truncated_normal); biases 0; BN gamma 1, beta 0."""
         gen = torch.Generator().manual_seed(seed)
         for k, shp in self.shapes.items():
-            if k.endswith(".kernel"):
+            if k == "adjacency_matrix":
+                self.p[k].copy_(torch.from_numpy(self.A_host))
+            elif k.endswith(".kernel"):
                 fan_out = shp[0] * shp[1] * shp[3]
                 std = math.sqrt(2.0 / fan_out) / .87962566103423978
                 w = torch.empty(shp, dtype=torch.float64)
@@ -277,9 +291,16 @@ class STGCN:
         epi = L.SAR_EPI_STATS if training else L.SAR_EPI_NONE
         # sgcn: GraphConvTD (models/gcn.py:199-209)
         g = torch.empty((f, n_in), dtype=torch.float32, device=dev)
-        r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
-                           Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi, bf16=self.bf16,
-                           packed=self._img(pre + "gcn.f"))
+        y3 = None
+        if self.dense_A:   # models/gcn.py:229-237: Conv2D(3F, 1x1) then einsum 'nkctv,kvw->nctw' with the trainable A
+            y3 = torch.empty((KS * f, n_in), dtype=torch.float32, device=dev)
+            ops.conv_gemm(L.SAR_CONV_TEMPORAL, X, y3, self.p[pre + "gcn.kernel"], 0, KS * f, B=B, V=V, T_src=T, T_out=T, Kc=cin,
+                          M=KS * f, taps=1, stride=1, pad=0, bias=self.p[pre + "gcn.bias"])
+            r1 = ops.graph_dense_fwd(y3, self.A, g, KS, f, V, B * T, stats=training)
+        else:
+            r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
+                               Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi, bf16=self.bf16,
+                               packed=self._img(pre + "gcn.f"))
         if training:
             self._bn_forward_stats(pre + "bn1", r1[0], r1[1], n_in, True, True)
         else:
@@ -312,7 +333,7 @@ class STGCN:
         ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r,
                             rbn.scale if rbn else None, rbn.shift if rbn else None, y)
         if training:
-            saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind))
+            saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind, y3=y3))
         if keep is not None:
             keep[pre + "g"], keep[pre + "u"], keep[pre + "y"] = g, u, y
         return y, To
@@ -358,8 +379,15 @@ class STGCN:
                    self.g["logits.kernel"].view(c_last, self.num_classes), self.g["logits.bias"], dfeat)
         dY = torch.empty(sv["y_last_shape"], dtype=torch.float32, device=dev)
         ops.pool_bwd(dfeat, B, sv["T_last"] * V, M, dY)
+        if self.dense_A:
+            self._dA_layers = torch.zeros((len(self.blocks), KS * V * V), dtype=torch.float32, device=dev)
         for i in reversed(range(len(self.blocks))):
             dY = self._block_backward(i, sv["blocks"][i], dY, B)
+        if self.dense_A:       # the adjacency is shared by all blocks: dA = sum over the layers (fixed order); zero while frozen
+            n = KS * V * V
+            ops.check(L.load().sar_slab_reduce_f32(ops.ptr(self._dA_layers), len(self.blocks), n, n,
+                                                   ops.ptr(self.g["adjacency_matrix"]), ops.stream_ptr()), "sar_slab_reduce_f32")
+            self._dA_layers = None
         # data_bn gamma/beta (the input needs no gradient)
         x = sv["x"]
         nch = V * self.C_in
@@ -415,26 +443,14 @@ class STGCN:
                             self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
         dg = dz1
         ops.affine2(dz1, g, (bn1.k1, bn1.k2, bn1.k3), dg)                # BN1 backward apply (in place)
-        # ---- graph conv: weight / bias gradient
         flat_g = self.grad[self.offsets[pre + "gcn.kernel"]:self.offsets[pre + "gcn.bias"] + KS * f]
+        if self.dense_A:
+            return self._graph_backward_dense(i, sb, dg, dY, dr, B, flat_g)
+        # ---- graph conv: weight / bias gradient
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_GRAPH, X, dg, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS, tables=self.tab_fwd,
             w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, bf16=self.bf16), X, dg)
-        # ---- residual conv branch
-        dXres = None
-        if kind == "conv":
-            flat_r = self.grad[self.offsets[pre + "res.kernel"]:self.offsets[pre + "res.bias"] + f]
-            self._off_critical_path(lambda: ops.conv_wgrad(
-                L.SAR_CONV_TEMPORAL, X, dr, flat_r, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
-                w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f), X, dr)
-            rimg = self._img(pre + "res.b")
-            rT = None
-            if rimg is None:
-                rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
-                ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
-            dXres = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
-            ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
-                          stride=s, pad=0, transposed=True, bf16=self.bf16, packed=rimg)
+        dXres = self._residual_backward(i, sb, dr, B)
         # ---- graph conv data gradient (+ skip-path gradient)
         gimg = self._img(pre + "gcn.b")
         gT = None
@@ -446,6 +462,48 @@ class STGCN:
         ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
                       tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux, bf16=self.bf16,
                       packed=gimg)
+        return dX
+
+    def _residual_backward(self, i, sb, dr, B):
+        """weight gradient and data gradient of the strided 1x1 residual convolution (blocks 5 and 8); None otherwise"""
+        if sb["kind"] != "conv":
+            return None
+        V, dev, pre = self.V, dr.device, "l%d." % i
+        X, T, To, cin, f, s = sb["X"], sb["T"], sb["To"], sb["cin"], sb["f"], sb["s"]
+        flat_r = self.grad[self.offsets[pre + "res.kernel"]:self.offsets[pre + "res.bias"] + f]
+        self._off_critical_path(lambda: ops.conv_wgrad(
+            L.SAR_CONV_TEMPORAL, X, dr, flat_r, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
+            w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f), X, dr)
+        rimg = self._img(pre + "res.b")
+        rT = None
+        if rimg is None:
+            rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
+            ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
+        dXres = torch.empty((cin, B * T * V), dtype=torch.float32, device=dev)
+        ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
+                      stride=s, pad=0, transposed=True, bf16=self.bf16, packed=rimg)
+        return dXres
+
+    def _graph_backward_dense(self, i, sb, dg, dY, dr, B, flat_g):
+        """Backward of Conv2D(3F, 1x1) -> einsum with the trainable adjacency (models/gcn.py:229-237): dy3 = dg . A^T per
+        slice, dA from (y3, dg), the 1x1 convolution's weight / bias / data gradients from (X, dy3)."""
+        V, dev, pre = self.V, dg.device, "l%d." % i
+        X, y3, T, cin, f, kind = sb["X"], sb["y3"], sb["T"], sb["cin"], sb["f"], sb["kind"]
+        n_in = B * T * V
+        dy3 = torch.empty_like(y3)
+        ops.graph_dense_bwd_data(dg, self.A, dy3, KS, f, V, B * T)
+        if self.train_adjacency:       # one V x V x K block per layer; summed over the layers at the end of backward()
+            ops.graph_dense_dA(y3, dg, self._dA_layers[i], KS, f, V, B * T)
+        self._off_critical_path(lambda: ops.conv_wgrad(
+            L.SAR_CONV_TEMPORAL, X, dy3, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=KS * f, taps=1, stride=1, pad=0,
+            w_stride_tap=0, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f), X, dy3)
+        dXres = self._residual_backward(i, sb, dr, B)
+        gT = torch.empty((KS * f, cin), dtype=torch.float32, device=dev)
+        ops.transpose(self.p[pre + "gcn.kernel"], gT, 1, cin, KS * f)
+        dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
+        aux = dY if kind == "identity" else dXres
+        ops.conv_gemm(L.SAR_CONV_TEMPORAL, dy3, dX, gT, 0, cin, B=B, V=V, T_src=T, T_out=T, Kc=KS * f, M=cin, taps=1, stride=1,
+                      pad=0, transposed=True, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux)
         return dX
 
     # ------------------------------------------------------------------ training step

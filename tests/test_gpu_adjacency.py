@@ -1,0 +1,144 @@
+"""dense / trainable adjacency (models/gcn.py:212-238 AdjGraphConv semantics, main_gnn.py:228-232
+--freeze-graph-until): the dense contraction kernels (csrc/graph_dense.hip) against torch einsum, the engine with
+trainable_adjacency=True against the oracle with A as a differentiable leaf, and the CLI's freeze schedule."""
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stgcn as O
+from util import to_cn, from_cn, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,F,T,V", [(2, 64, 13, 25), (1, 20, 9, 25), (3, 128, 8, 25), (2, 16, 5, 18)])
+def test_dense_contraction_kernels(dev, B, F, T, V):
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + F)
+    K = 3
+    y = torch.randn(B, K * F, T, V, generator=g)
+    A = torch.randn(K, V, V, generator=g) * 0.3
+    dout = torch.randn(B, F, T, V, generator=g)
+    yd = y.double().view(B, K, F, T, V).requires_grad_(True)
+    Ad = A.double().requires_grad_(True)
+    ref = torch.einsum("nkctv,kvw->nctw", yd, Ad)
+    gy, gA = torch.autograd.grad(ref, (yd, Ad), dout.double())
+    n = B * T * V
+
+    def cn(x):     # generic-V version of util.to_cn
+        Bq, C, Tq, Vq = x.shape
+        return x.permute(1, 0, 2, 3).reshape(C, Bq * Tq * Vq).contiguous()
+    yc, dc, Ac = cn(y).to(dev), cn(dout).to(dev), A.to(dev).contiguous()
+    out = torch.empty((F, n), device=dev)
+    part, nparts = ops.graph_dense_fwd(yc, Ac, out, K, F, V, B * T, stats=True)
+    dy = torch.empty((K * F, n), device=dev)
+    ops.graph_dense_bwd_data(dc, Ac, dy, K, F, V, B * T)
+    dA = torch.empty((K, V, V), device=dev)
+    ops.graph_dense_dA(yc, dc, dA, K, F, V, B * T, nsplit=3)
+    torch.cuda.synchronize()
+    refc = cn(ref.detach())
+    assert rel_err(out.cpu(), refc) < 2e-5
+    p = part.cpu().double().sum(dim=1)
+    assert rel_err(p[:, 0], refc.sum(dim=1)) < 1e-4 and rel_err(p[:, 1], (refc * refc).sum(dim=1)) < 2e-5
+    assert rel_err(dy.cpu(), cn(gy.reshape(B, K * F, T, V))) < 2e-5
+    assert rel_err(dA.cpu(), gA) < 2e-5
+    dA2 = torch.empty_like(dA)                      # the split count does not change the sum beyond rounding; repeats are bitwise
+    ops.graph_dense_dA(yc, dc, dA2, K, F, V, B * T, nsplit=3)
+    torch.cuda.synchronize()
+    assert torch.equal(dA, dA2)
+
+
+def _reference_with_adjacency_leaf(p, x, y, blocks, masks):
+    """oracle/stgcn.py's train step with the adjacency as one more differentiable leaf"""
+    names = O.trainable_names(p) + ["A"]
+    leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
+    q = dict(p)
+    q.update(leaves)
+    logits = O.forward(q, x, True, {}, {}, blocks, masks)
+    loss = O.loss_fn(logits, y, x.shape[0])
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    return logits.detach(), loss.detach(), dict(zip(names, grads))
+
+
+def test_engine_with_trainable_adjacency_matches_the_oracle(dev):
+    """forward, loss and EVERY gradient -- dA included -- with a dense perturbed adjacency, against the float64 oracle
+    (conditioned on the engine's activation pattern like every gradient comparison); with A = the graph's adjacency the
+    dense path reproduces the gather-list path."""
+    from sar_amd.stgcn import STGCN
+    from test_gpu_stgcn_model import _engine_masks
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True)]
+    p = O.randomize_affine(O.init_params(10, seed=2, dtype=torch.float64, blocks=blocks), seed=3)
+    x, y = O.synthetic_batch(3, seed=4, T=20, num_classes=10)
+    # (a) same adjacency: dense path == gather-list path
+    fixed = STGCN(num_classes=10, device=dev, blocks=blocks)
+    fixed.load_params(p)
+    lf, _ = fixed.loss_and_grad(x.to(dev), y.to(dev))
+    dense = STGCN(num_classes=10, device=dev, blocks=blocks, trainable_adjacency=True)
+    assert dense.n_params == fixed.n_params + 3 * 25 * 25
+    dense.load_params(p)
+    ld, _ = dense.loss_and_grad(x.to(dev), y.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(dense.p["adjacency_matrix"].cpu(), p["A"].float())
+    assert rel_err(ld.cpu(), lf.cpu()) < 1e-5
+    for k in fixed.g:
+        if fixed.g[k].abs().max() > 1e-9:
+            assert rel_err(dense.g[k].cpu(), fixed.g[k].cpu()) < 1e-4, k
+    # (b) a dense adjacency (every entry non-zero), gradient w.r.t. A included
+    g = torch.Generator().manual_seed(5)
+    p2 = dict(p)
+    p2["A"] = p["A"] + 0.05 * torch.randn(p["A"].shape, generator=g, dtype=torch.float64)
+    eng = STGCN(num_classes=10, device=dev, blocks=blocks, trainable_adjacency=True)
+    eng.load_params(p2)
+    eng.load_params({"adjacency_matrix": p2["A"]})
+    keep = {}
+    eng.forward(x.to(dev), training=True, keep=keep)
+    masks = _engine_masks(eng, keep, blocks, x.shape[0] * x.shape[4], x.shape[2])
+    logits_ref, loss_ref, grads_ref = _reference_with_adjacency_leaf(p2, x.double(), y, blocks, masks)
+    eng.load_params(p2)
+    logits, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu(), logits_ref) < 1e-4 and rel_err(loss.cpu(), loss_ref.reshape(1)) < 1e-4
+    for k, gref in grads_ref.items():
+        name = "adjacency_matrix" if k == "A" else k
+        if gref.abs().max() > 1e-9:
+            assert rel_err(eng.g[name].cpu(), gref) < 1e-4, k
+    assert eng.g["adjacency_matrix"].abs().max() > 0
+    # frozen: no gradient reaches the adjacency (main_gnn.py:228-232), everything else is unchanged
+    ref_grad = eng.grad.clone()
+    eng.load_params(p2)
+    eng.train_adjacency = False
+    eng.loss_and_grad(x.to(dev), y.to(dev))
+    torch.cuda.synchronize()
+    assert eng.g["adjacency_matrix"].abs().max() == 0
+    o = eng.offsets["adjacency_matrix"]
+    assert torch.equal(eng.grad[:o], ref_grad[:o])
+
+
+def test_cli_freeze_graph_until(dev, tmp_path):
+    """main_gnn.py --trainable-adjacency --freeze-graph-until 0: the adjacency is untouched after epoch 1 (epoch index 0 is not
+    > 0) and trained in epoch 2 -- the reference's `True if epoch > freeze_graph_until else False`."""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "skeleton-action-recognition_amd"))
+    cmd = [sys.executable, os.path.join(ROOT, "skeleton-action-recognition_amd", "main_gnn.py"), "--model", "stgcn", "--synthetic",
+           "--synthetic-size", "16", "--batch-size", "4", "--num-epochs", "2", "--max-iters", "2", "--save-freq", "1",
+           "--trainable-adjacency", "--freeze-graph-until", "0", "--log-dir", str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    ck = sorted(glob.glob(os.path.join(str(tmp_path), "*", "checkpoints", "ckpt-*.pt")))
+    assert len(ck) == 2
+    from graph.ntu_rgb_d import Graph
+    A0 = torch.from_numpy(Graph().A.astype(np.float32))
+    a1, a2 = torch.load(ck[0])["model"]["A"], torch.load(ck[1])["model"]["A"]
+    assert torch.equal(a1, A0)
+    assert not torch.equal(a2, A0) and torch.isfinite(a2).all()

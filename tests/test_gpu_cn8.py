@@ -392,3 +392,74 @@ def test_graph_conv_weight_gradient(dev, B, cin, f, T):
                     tables=tab2, w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)
     torch.cuda.synchronize()
     assert torch.equal(flat, flat2)
+
+
+@pytest.mark.parametrize("cin,f,s,T", [(64, 64, 1, 300), (64, 128, 2, 300), (128, 128, 1, 150), (256, 256, 1, 75)])
+def test_cn8_kernels_repeat_bit_for_bit(dev, cin, f, s, T):
+    """Race / hazard detector at kernel level: every CN8 conv kernel of a block, launched 8 times on the same inputs with an
+    unrelated kernel in between, must reproduce its outputs AND BatchNorm partial sums bit for bit.  (This is the test that
+    exposed the packed-fp32 hazard of conv_gemm_cn8's MASK epilogue: csrc/Makefile.)"""
+    from sar_amd import ops8, _lib as L
+    B = 12
+    To, pad, _ = O.same_pad(T, 9, s)
+    n_in, n_out = B * T * 25, B * To * 25
+    gen = torch.Generator(device=dev).manual_seed(f + T)
+    rnd = lambda C, n: ops8.from_cn(torch.randn((C, n), generator=gen, device=dev))
+    X, G, dU, dG = rnd(cin, n_in), rnd(f, n_in), rnd(f, n_out), rnd(f, n_in)
+    Wt = torch.randn((9, 1, f, f), generator=gen, device=dev) * 0.05
+    Wg = torch.randn((1, 1, cin, 3 * f), generator=gen, device=dev) * 0.1
+    sc, sh, mean = (1 + 0.2 * torch.randn(f, generator=gen, device=dev), 0.3 * torch.randn(f, generator=gen, device=dev),
+                    0.1 * torch.randn(f, generator=gen, device=dev))
+    tab, tabT = _tables(dev), _tables(dev, True)
+    pw_tf, pw_tb = _pack(dev, Wt, f * f, f, 1, 9, f, f), _pack(dev, Wt, f * f, 1, f, 9, f, f)
+    pw_gf, pw_gb = _pack(dev, Wg, f, 3 * f, 1, 3, cin, f), _pack(dev, Wg, f, 1, 3 * f, 3, f, cin)
+    junk = torch.empty(8 << 20, dtype=torch.uint8, device=dev)
+
+    def t_fwd():
+        out = ops8.empty(f, n_out, dev)
+        r = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, G, out, pw_tf, B=B, V=25, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad,
+                           pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS)
+        return out, r[0]
+
+    def t_dgrad():
+        out = ops8.empty(f, n_in, dev)
+        r = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dU, out, pw_tb, B=B, V=25, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s, pad=pad,
+                           transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh), aux_mean=mean)
+        return out, r[0]
+
+    def g_fwd():
+        out = ops8.empty(f, n_in, dev)
+        r = ops8.conv_gemm(L.SAR_CONV_GRAPH, X, out, pw_gf, B=B, V=25, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab,
+                           epi=L.SAR_EPI_STATS)
+        return out, r[0]
+
+    def g_dgrad():
+        out = ops8.empty(cin, n_in, dev)
+        ops8.conv_gemm(L.SAR_CONV_GRAPH, dG, out, pw_gb, B=B, V=25, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tabT,
+                       epi=L.SAR_EPI_ADD, aux=X)
+        return (out,)
+
+    def t_wgrad():
+        flat = torch.zeros(9 * f * f + f, device=dev)
+        ops8.conv_wgrad(L.SAR_CONV_TEMPORAL, G, dU, flat, B=B, V=25, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad,
+                        pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f)
+        return (flat,)
+
+    def g_wgrad():
+        flat = torch.zeros(cin * 3 * f + 3 * f, device=dev)
+        ops8.conv_wgrad(L.SAR_CONV_GRAPH, X, dG, flat, B=B, V=25, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab,
+                        w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f)
+        return (flat,)
+
+    for name, fn in (("temporal fwd", t_fwd), ("temporal dgrad + mask", t_dgrad), ("graph fwd", g_fwd), ("graph dgrad + add", g_dgrad),
+                     ("temporal wgrad", t_wgrad), ("graph wgrad", g_wgrad)):
+        ref = None
+        for rep in range(8):
+            if rep % 2:
+                junk.random_(0, 255)
+            res = [t.clone() for t in fn()]
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = res
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(ref, res)), "%s is not repeatable (rep %d)" % (name, rep)

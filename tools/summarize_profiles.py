@@ -13,10 +13,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# usage: summarize_profiles.py [tag [subdir-of-gpurun_out [bf16]]]
+# usage: summarize_profiles.py [tag [subdir-of-gpurun_out [fp32|bf16|pathB]]]
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 P = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "prof")
-BF16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
+MODE = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+BF16 = MODE == "bf16"
 OUT = os.path.join(ROOT, "profiles")
 os.makedirs(OUT, exist_ok=True)
 
@@ -57,22 +58,26 @@ for k, (calls, avg_ns, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
                  "fetch_kib_raw": None if f is None else round(f, 1), "write_kib": None if w is None else round(w, 1),
                  "hbm_bytes_per_launch": None if hbm is None else int(hbm),
                  "hbm_gbps": None if hbm is None else round(hbm / avg_ns, 1)})
-if BF16:   # conv_gemm_bf16_kernel<TR, TAPS = 9, ...>
-    fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_bf16_kernel<%d, 9" % tr) for tr in (0, 1, 2, 3))]
+if BF16:   # conv_gemm_cn8_kernel<TR, TAPS = 9, ...>  (bf16 CN8 activations)
+    fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_cn8_kernel<%d, 9" % tr) for tr in (0, 1, 2, 3))]
+elif MODE == "pathB":
+    fam = [r for r in rows if r["kernel"].startswith("conv2d_gemm_kernel")]
 else:
     fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_kernel<1, %d, 9" % tr) for tr in (0, 1, 2, 3))]
 calls = sum(r["calls"] for r in fam)
 summary = {
     "command": ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline%s ; "
                 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-                "--no-cpu-baseline%s") % ((" --mfma bf16",) * 2 if BF16 else ("", "")),
+                "--no-cpu-baseline%s") % (({"bf16": " --mfma bf16", "pathB": " --workload spectrogram"}.get(MODE, ""),) * 2),
     "hbm_rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a coalesced stream; calibrated on "
                 "sgd_nesterov / bn_add_relu_fwd / affine2 whose byte counts are known)",
-    "dominant_family": ("conv_gemm_bf16_kernel<9 taps>" if BF16 else "conv_gemm_kernel<TEMPORAL, 9 taps>") +
-                       " (forward + data-gradient instantiations)",
+    "dominant_family": {"bf16": "conv_gemm_cn8_kernel<9 taps>", "pathB": "conv2d_gemm_kernel (3x3 / 1x1)"}.get(
+        MODE, "conv_gemm_kernel<TEMPORAL, 9 taps>") + " (forward + data-gradient instantiations)",
     "dominant_family_launches": calls,
     "dominant_family_avg_us": round(sum(r["avg_us"] * r["calls"] for r in fam) / calls, 2),
     "dominant_family_hbm_bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["calls"] for r in fam) / calls),
+    "total_kernel_ms_per_step": round(sum(r["avg_us"] * r["calls"] for r in rows) / 7e3, 3),
+    "total_hbm_bytes_per_step": int(sum((r["hbm_bytes_per_launch"] or 0) * r["calls"] for r in rows) / 7),
     "kernels": rows,
 }
 json.dump(summary, open(os.path.join(OUT, "%s_kernel_summary.json" % tag), "w"), indent=1)
