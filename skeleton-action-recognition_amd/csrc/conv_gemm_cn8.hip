@@ -21,6 +21,10 @@ namespace {
 
 constexpr int KC16 = 16;   // src channels per main-loop stage = one MFMA k-step = two CN8 planes
 
+#ifndef SAR_ABLATE8
+#define SAR_ABLATE8 0   // diagnostic builds only (tools/ablate8.sh): 1 no MFMA, 2 global loads of stage 0 only, 4 no epilogue, 8 LDS stores of stage 0 only
+#endif
+
 struct ConvK8 {
   sar_conv_desc d;
   const uint4* wp;   // packed weights [taps][G][M] units of 8 bf16 (sar_pack_weights_bf16_batch)
@@ -393,16 +397,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   };
 
   for (int c0 = 0; c0 < d.Kc; c0 += KC16) {
-    store_lds(c0);
+    if (!(SAR_ABLATE8 & 8) || c0 == 0) store_lds(c0);
     __syncthreads();
-    if (c0 + KC16 < d.Kc) issue_loads(c0 + KC16);   // in flight during the MFMA phase
+    if (c0 + KC16 < d.Kc && !(SAR_ABLATE8 & 2)) issue_loads(c0 + KC16);   // in flight during the MFMA phase
     constexpr int JSURE = PAR ? JT - 1 : JT;
+    if (!(SAR_ABLATE8 & 1)) {
 #pragma unroll
-    for (int j = 0; j < JSURE; ++j) taps_mma(j);
-    if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
+      for (int j = 0; j < JSURE; ++j) taps_mma(j);
+      if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
+    }
     __syncthreads();   // every wave is done with the image (next store / the epilogue's transpose area)
   }
-
+  if (SAR_ABLATE8 & 4) {
+    if (acc[0][0][0] == 12345.678f) d.out[0] = 1.f;   // keeps the accumulators alive
+    return;
+  }
   epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
 }
 

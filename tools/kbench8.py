@@ -22,6 +22,7 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
+NOEPI = os.environ.get("KB_NOEPI", "0") == "1"      # forward / data-gradient kernels with the plain store epilogue
 tot = {}
 for (cin, f, s, T, cnt) in [(64, 64, 1, 300, 3), (64, 128, 2, 300, 1), (128, 128, 1, 150, 2), (128, 256, 2, 150, 1), (256, 256, 1, 75, 2)]:
     To = -(-T // s); pad = max((To - 1) * s + 9 - T, 0) // 2
@@ -36,8 +37,8 @@ for (cin, f, s, T, cnt) in [(64, 64, 1, 300, 3), (64, 128, 2, 300, 1), (128, 128
     u, g_, dz, dx = ops8.empty(f, n_out, dev), ops8.empty(f, n_in, dev), ops8.empty(f, n_in, dev), ops8.empty(cin, n_in, dev)
     flat_t, flat_g = torch.zeros(9 * f * f + f, device=dev), torch.zeros(cin * 3 * f + 3 * f, device=dev)
     K = {
-        "t_fwd": lambda: ops8.conv_gemm(L.SAR_CONV_TEMPORAL, G, u, pw_tf, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS),
-        "t_dgrad": lambda: ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dU, dz, pw_tb, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh), aux_mean=mean),
+        "t_fwd": lambda: ops8.conv_gemm(L.SAR_CONV_TEMPORAL, G, u, pw_tf, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_NONE if NOEPI else L.SAR_EPI_STATS),
+        "t_dgrad": lambda: ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dU, dz, pw_tb, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_NONE if NOEPI else L.SAR_EPI_MASK, aux=None if NOEPI else G, aux_affine=None if NOEPI else (sc, sh), aux_mean=None if NOEPI else mean),
         "g_fwd": lambda: ops8.conv_gemm(L.SAR_CONV_GRAPH, X, g_, pw_gf, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab, epi=L.SAR_EPI_STATS),
         "g_dgrad": lambda: ops8.conv_gemm(L.SAR_CONV_GRAPH, dG, dx, pw_gb, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tabT, epi=L.SAR_EPI_ADD, aux=X),
         "t_wgrad": lambda: ops8.conv_wgrad(L.SAR_CONV_TEMPORAL, G, dU, flat_t, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad, pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f),
