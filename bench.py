@@ -27,13 +27,14 @@ FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
 BYTES_PER_CLIP_TRAIN_BF16 = 427.3e6   # block-fused algorithmic HBM traffic per clip and train step, bf16 storage
 
 
-def measured_traffic(bf16=False):
+def measured_traffic(bf16=False, pathB=False):
     """HBM bytes per launch of the dominant kernel family from the committed PMC profile of this same workload
     (profiles/rNN_kernel_summary.json, written by tools/summarize_profiles.py from separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).  None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bf16_kernel_summary.json" if bf16
-                                          else "r[0-9][0-9]_kernel_summary.json")))
+    pat = "r[0-9][0-9]_pathB_kernel_summary.json" if pathB else ("r[0-9][0-9]_bf16_kernel_summary.json" if bf16
+                                                                  else "r[0-9][0-9]_kernel_summary.json")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -217,8 +218,10 @@ def main_spectrogram(args):
                        "global_batch": bs * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches": calls,
-                         "avg_launch_ms": round(ms / max(calls, 1), 4)},
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": measured_traffic(pathB=True)[0] if not args.num_pad_frames else None,
+                         "traffic_unit": "HBM bytes per launch of conv2d_gemm_kernel (PMC, %s)" % measured_traffic(pathB=True)[1],
+                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4)},
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
             "final_loss": round(float(loss.item()), 5),
