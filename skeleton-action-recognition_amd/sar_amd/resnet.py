@@ -80,6 +80,10 @@ class ResNet18:
         self.bn = {name: _BN(c, dev) for name, c in self.bn_names}
         self._init_params(seed)
         self._saved = None
+        # weight-gradient kernels feed only the optimizer: second stream, as in sar_amd/stgcn.py (SAR_WGRAD_STREAM=0: off)
+        import os
+        self._side = (torch.cuda.Stream(device=dev) if dev.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1"
+                      else None)
         # Operand layouts of every conv weight, refreshed by ONE launch per step (and one more for the data-gradient
         # layouts when training): forward (tap, c, m), data gradient (tap, m, c); the weight-gradient kernels write
         # (tap, c, m) tensors into one scratch buffer that ONE launch re-lays into the OIHW gradient views.
@@ -142,8 +146,16 @@ class ResNet18:
     def _pack(self, need_bwd):
         """(tap, c, m) forward and (tap, m, c) data-gradient layouts of every conv weight: one launch each per step."""
         self._perm_fwd.run(self.flat, self._wf)
-        if need_bwd:
-            self._perm_bwd.run(self.flat, self._wb)
+        if need_bwd:            # only the backward pass reads the data-gradient layouts: off the forward's critical path
+            if self._side is None:
+                self._perm_bwd.run(self.flat, self._wb)
+            else:
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)                  # after the optimizer step that produced self.flat
+                with torch.cuda.stream(self._side):
+                    self._perm_bwd.run(self.flat, self._wb)
+                self._wb_ready = torch.cuda.Event()
+                self._wb_ready.record(self._side)
 
     def _w(self, name, bwd=False):
         o, n = self._woff[name]
@@ -218,8 +230,18 @@ class ResNet18:
     def _conv_wgrad(self, name, X, dout, B, H, W, Ho, Wo, pro=None):
         cv = self.convs[name]
         o, n = self._woff[name]
-        ops.conv2d_wgrad(X, dout, self._gw[o:o + n], B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k,
-                         KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None)
+
+        def run():
+            ops.conv2d_wgrad(X, dout, self._gw[o:o + n], B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k,
+                             KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None)
+        if self._side is None:
+            run()
+        else:       # ordered after everything issued so far; X / dout must outlive the side stream's use
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                run()
+            X.record_stream(self._side)
+            dout.record_stream(self._side)
         # the (tap, c, m) results are re-laid into the OIHW gradient views by ONE launch at the end of backward()
 
     def _conv_dgrad(self, name, dout, B, H, W, Ho, Wo, **epi):
@@ -244,6 +266,9 @@ class ResNet18:
         sv = self._saved
         assert sv is not None
         dev, B = dlogits.device, sv["B"]
+        if self._side is not None and getattr(self, "_wb_ready", None) is not None:
+            torch.cuda.current_stream().wait_event(self._wb_ready)      # the data-gradient weight layouts (packed on the side stream)
+            self._wb_ready = None
         dwt = torch.empty_like(sv["wt"])
         dfeat = torch.empty_like(sv["feat"])
         ops.fc_bwd(sv["feat"], sv["wt"], dlogits.contiguous(), dwt, self.g["fc.bias"], dfeat)
@@ -285,6 +310,8 @@ class ResNet18:
         self._bn_bwd("bn1", part, nparts, nparts * 2, 2, 1, B * sv["H1"] * sv["W1"])
         ops.affine2(dz0, c0, (bn0.k1, bn0.k2, bn0.k3), dz0)
         self._conv_wgrad("conv1", sv["x0"], dz0, B, sv["H"], sv["W"], sv["H1"], sv["W1"])
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
         self._perm_grad.run(self._gw, self.grad)             # every conv weight gradient: (tap, c, m) -> OIHW
         dx = None
         if need_dx:
