@@ -354,7 +354,8 @@ int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_t n, const 
  * an arbitrary A (K, V, V) in device memory, fp32 CN layout, V <= 32, K <= 8.  y is the 3F-channel output of the 1x1
  * convolution (channel k*F + m; sar_conv_gemm_f32, TEMPORAL, taps = 1 -- bias included, as in the reference).
  *   fwd       out[m, (t,w)]      = sum_k sum_v y[k*F + m, (t,v)] * A[k, v, w]        (+ partials[F][nparts][2] = per-row
- *                                   (sum, sum of squares) per tile when partials != NULL; nparts = sar_graph_dense_nparts)
+ *                                   (sum, sum of squares) per tile when partials != NULL; nparts = sar_graph_dense_nparts;
+ *                                   + add[m, (t,w)] when add != NULL)
  *   bwd_data  dy[k*F + m, (t,v)] = sum_w dout[m, (t,w)] * A[k, v, w]
  *   dA        dA[k, v, w]        = sum_{m, frames} y[k*F + m, (f,v)] * dout[m, (f,w)]  (slab: sar_graph_dense_dadj_slab_floats
  *                                   floats of scratch; partial blocks are summed in a fixed order: deterministic)
@@ -362,12 +363,37 @@ int sar_adam_f32(float* w, float* m, float* v, const float* g, int64_t n, const 
  * ------------------------------------------------------------------------------------------------ */
 int sar_graph_dense_nparts(int64_t nframes);
 int sar_graph_dense_fwd_f32(const float* y, int64_t ld_y, const float* A, float* out, int64_t ld_out, int K, int F, int V,
-                            int64_t nframes, float* partials, sar_stream_t s);
+                            int64_t nframes, float* partials, const float* add, int64_t ld_add, sar_stream_t s);
 int sar_graph_dense_bwd_data_f32(const float* dout, int64_t ld_dout, const float* A, float* dy, int64_t ld_dy, int K, int F,
                                  int V, int64_t nframes, sar_stream_t s);
 int64_t sar_graph_dense_dadj_slab_floats(int K, int F, int V, int nsplit);
 int sar_graph_dense_dadj_f32(const float* y, int64_t ld_y, const float* dout, int64_t ld_dout, int K, int F, int V,
                            int64_t nframes, int nsplit, float* slab, float* dA, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph isomorphism convolution, SURVEY.md 8(f)-4 (models/gcn.py:112-163 GraphIsoConvTD as used by models/stgin.py:24-25):
+ * fp32 CN layout; the K branch MLPs of a layer are stacked along the channel axis (row k*C + c).
+ *   sar_gin_adjacency_f32   table[k][a][b] = A[k][b][a] (k < Km1), table[Km1] = (1 + eps[0]) I  -- models/gcn.py:150-153
+ *                           A_ = concat(A, diag(1 + epsilon)), transposed for sar_graph_dense_bwd_data_f32 (x . A_k) and
+ *                           sar_graph_dense_fwd_f32 (its gradient);  scale[0:C] = 1 + eps[0] (the prologue of the self slice)
+ *   sar_gin_sum_fwd_f32     s[c, n] = sum_k relu(a[k*C + c, n] * scale[k*C + c] + shift[k*C + c])  -- the last BN + ReLU of
+ *                           every branch and tf.reduce_sum (models/gcn.py:139-142,160); partials[C][nparts][2] = (sum s,
+ *                           sum s^2) per workgroup for the BatchNorm that follows (models/stgin.py:28), nparts = sar_gin_nparts(n)
+ *   sar_gin_bwd_reduce_f32  dz = ds[c] where a*scale+shift > 0 else 0; partials[K*C][nparts][2] = (sum dz, sum dz*(a - mean))
+ *   sar_gin_bwd_apply_f32   da[k*C + c] = k1*dz + k2*a + k3  (k1..k3 from sar_bn_bwd_finalize_f32; da may alias a)
+ *   sar_gin_eps_grad_f32    the self slice's first convolution is W . ((1 + eps) x): given G = dout . x^T (weight gradient
+ *                           taken on the un-scaled x), deps[0] = <G, W> and G *= (1 + eps[0]) in place
+ * ------------------------------------------------------------------------------------------------ */
+int sar_gin_nparts(int64_t n);
+int sar_gin_adjacency_f32(const float* A, int Km1, int V, const float* eps, float* table, float* scale, int C, sar_stream_t s);
+int sar_gin_sum_fwd_f32(const float* a, int64_t ld_a, const float* scale, const float* shift, int K, int C, int64_t n, float* s_out,
+                        int64_t ld_s, float* partials, sar_stream_t s);
+int sar_gin_bwd_reduce_f32(const float* ds, int64_t ld_ds, const float* a, int64_t ld_a, const float* scale, const float* shift,
+                           const float* mean, int K, int C, int64_t n, float* partials, sar_stream_t s);
+int sar_gin_bwd_apply_f32(const float* ds, int64_t ld_ds, const float* a, int64_t ld_a, const float* scale, const float* shift,
+                          const float* k1, const float* k2, const float* k3, int K, int C, int64_t n, float* da, int64_t ld_da,
+                          sar_stream_t s);
+int sar_gin_eps_grad_f32(float* G, const float* W, int64_t n, const float* eps, float* deps, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 configuration (bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation, fp32

@@ -3,6 +3,8 @@
 //   out[m, (t,w)] = sum_k sum_v y[k F + m, (t,v)] A[k, v, w]                   einsum 'nkctv,kvw->nctw', models/gcn.py:207-208,
 //   dy[k F + m, (t,v)] = sum_w dout[m, (t,w)] A[k, v, w]                       236-237 (AdjGraphConv: A is a trainable variable,
 //   dA[k, v, w] = sum_{m, b, t} y[k F + m, (b,t,v)] dout[m, (b,t,w)]           main_gnn.py:228-232 un-freezes it by name)
+// The same two contractions serve the graph isomorphism convolution (models/gcn.py:149-156, 'nctv,kvw->nkctw'): bwd_data
+// with the transposed table of gin.hip produces the K stacked x . A_k, fwd (+ `add`, the skip-path gradient) its gradient.
 //
 // The fixed-adjacency kernels (conv_gemm.hip) fold A into the operand load as <= 4-entry gather lists and never
 // materialise the 3F-channel tensor y; a trained adjacency is dense (625 entries per slice), so this path keeps the
@@ -24,7 +26,8 @@ constexpr int GD_FT = 8;         // frames per tile (FT * V <= TPB for V <= 32)
 template <int MODE>
 __global__ __launch_bounds__(TPB) void graph_dense_kernel(const float* __restrict__ in, int64_t ld_in, const float* __restrict__ A,
                                                           float* __restrict__ out, int64_t ld_out, int K, int F, int V,
-                                                          int64_t nframes, float* __restrict__ partials, int nparts) {
+                                                          int64_t nframes, float* __restrict__ partials, int nparts,
+                                                          const float* __restrict__ add, int64_t ld_add) {
   extern __shared__ float sm[];
   float* As = sm;                       // [K][V][V]
   float* Ys = sm + K * V * V;           // MODE 0: [K][GD_FT * V]; MODE 1: [GD_FT * V]
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(TPB) void graph_dense_kernel(const float* __restric
         const float* ak = As + k * V * V + j;        // column w = j
         for (int v = 0; v < V; ++v) acc = fmaf(yr[v], ak[v * V], acc);
       }
+      if (add) acc += add[(int64_t)m * ld_add + col0 + threadIdx.x];
       out[(int64_t)m * ld_out + col0 + threadIdx.x] = acc;
       s1 = acc;
       s2 = acc * acc;
@@ -140,13 +144,15 @@ static int gd_check(const char* who, const float* in, const float* A, float* out
 extern "C" int sar_graph_dense_nparts(int64_t nframes) { return (int)((nframes + GD_FT - 1) / GD_FT); }
 
 extern "C" int sar_graph_dense_fwd_f32(const float* y, int64_t ld_y, const float* A, float* out, int64_t ld_out, int K, int F,
-                                       int V, int64_t nframes, float* partials, sar_stream_t s) {
+                                       int V, int64_t nframes, float* partials, const float* add, int64_t ld_add,
+                                       sar_stream_t s) {
   if (int rc = gd_check("sar_graph_dense_fwd", y, A, out, K, F, V, nframes)) return rc;
-  SAR_REQUIRE(ld_y >= nframes * V && ld_out >= nframes * V, "sar_graph_dense_fwd: leading dimension smaller than frames * V");
+  SAR_REQUIRE(ld_y >= nframes * V && ld_out >= nframes * V && (!add || ld_add >= nframes * V),
+              "sar_graph_dense_fwd: leading dimension smaller than frames * V");
   const int ntiles = sar_graph_dense_nparts(nframes);
   const size_t lds = (size_t)(K * V * V + K * GD_FT * V) * 4;
   hipLaunchKernelGGL(graph_dense_kernel<0>, dim3(ntiles, F), dim3(TPB), lds, as_stream(s), y, ld_y, A, out, ld_out, K, F, V,
-                     nframes, partials, ntiles);
+                     nframes, partials, ntiles, add, ld_add);
   SAR_LAUNCH_CHECK("sar_graph_dense_fwd_f32");
   return 0;
 }
@@ -158,7 +164,7 @@ extern "C" int sar_graph_dense_bwd_data_f32(const float* dout, int64_t ld_d, con
   const int ntiles = sar_graph_dense_nparts(nframes);
   const size_t lds = (size_t)(K * V * V + GD_FT * V) * 4;
   hipLaunchKernelGGL(graph_dense_kernel<1>, dim3(ntiles, F), dim3(TPB), lds, as_stream(s), dout, ld_d, A, dy, ld_dy, K, F, V,
-                     nframes, (float*)nullptr, 0);
+                     nframes, (float*)nullptr, 0, (const float*)nullptr, (int64_t)0);
   SAR_LAUNCH_CHECK("sar_graph_dense_bwd_data_f32");
   return 0;
 }

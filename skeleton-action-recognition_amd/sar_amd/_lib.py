@@ -113,8 +113,14 @@ SIGNATURES = {
     "sar_vr_signal_upsampled_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_conv2d_stem_dgrad_f32": (_i, [_fp, _i64, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     # dense (trainable) adjacency
+    "sar_gin_nparts": (_i, [_i64]),
+    "sar_gin_adjacency_f32": (_i, [_fp, _i, _i, _fp, _fp, _fp, _i, _fp]),
+    "sar_gin_sum_fwd_f32": (_i, [_fp, _i64, _fp, _fp, _i, _i, _i64, _fp, _i64, _fp, _fp]),
+    "sar_gin_bwd_reduce_f32": (_i, [_fp, _i64, _fp, _i64, _fp, _fp, _fp, _i, _i, _i64, _fp, _fp]),
+    "sar_gin_bwd_apply_f32": (_i, [_fp, _i64, _fp, _i64, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _fp, _i64, _fp]),
+    "sar_gin_eps_grad_f32": (_i, [_fp, _fp, _i64, _fp, _fp, _fp]),
     "sar_graph_dense_nparts": (_i, [_i64]),
-    "sar_graph_dense_fwd_f32": (_i, [_fp, _i64, _fp, _fp, _i64, _i, _i, _i, _i64, _fp, _fp]),
+    "sar_graph_dense_fwd_f32": (_i, [_fp, _i64, _fp, _fp, _i64, _i, _i, _i, _i64, _fp, _fp, _i64, _fp]),
     "sar_graph_dense_bwd_data_f32": (_i, [_fp, _i64, _fp, _fp, _i64, _i, _i, _i, _i64, _fp]),
     "sar_graph_dense_dadj_slab_floats": (_i64, [_i, _i, _i, _i]),
     "sar_graph_dense_dadj_f32": (_i, [_fp, _i64, _fp, _i64, _i, _i, _i, _i64, _i, _fp, _fp, _fp]),

@@ -70,7 +70,7 @@ class PackedWeights:
 
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
-              aux_affine=None, aux_mean=None, bf16=False, packed=None):
+              aux_affine=None, aux_mean=None, bf16=False, packed=None, partials_out=None):
     """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (M % 8 == 0, Kc >= 16: bf16
     MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel).  Returns (partials, nparts) when the
     epilogue reduces, else None."""
@@ -103,7 +103,11 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
         nparts = lib.sar_conv_gemm_nparts(C.byref(d))
         if nparts <= 0:
             check(nparts or -1, "sar_conv_gemm_nparts")
-        partials = torch.empty((M, nparts, 2), dtype=torch.float32, device=src.device)
+        if partials_out is not None:      # caller-owned rows of a stacked partials tensor (sar_amd/stgin.py)
+            assert partials_out.shape == (M, nparts, 2) and partials_out.is_contiguous()
+            partials = partials_out
+        else:
+            partials = torch.empty((M, nparts, 2), dtype=torch.float32, device=src.device)
         d.partials = ptr(partials)
     # algorithmic work: the forward conv's MACs (a data gradient costs the same MACs as its forward conv)
     n_conv = B * (T_src if transposed else T_out) * V
@@ -278,15 +282,16 @@ def transpose(inp, out, batch, R, Cc):
 
 
 # ------------------------------------------------------------------------------------------------ dense adjacency
-def graph_dense_fwd(y, A, out, K, F, V, nframes, stats=False):
-    """out[m] = sum_k y[k F + m] . A_k (sar_graph_dense_fwd_f32); returns (partials, nparts) when stats."""
+def graph_dense_fwd(y, A, out, K, F, V, nframes, stats=False, add=None):
+    """out[m] = sum_k y[k F + m] . A_k (+ add[m]) (sar_graph_dense_fwd_f32); returns (partials, nparts) when stats."""
     lib = L.load()
     partials, nparts = None, 0
     if stats:
         nparts = lib.sar_graph_dense_nparts(nframes)
         partials = torch.empty((F, nparts, 2), dtype=torch.float32, device=y.device)
     check(lib.sar_graph_dense_fwd_f32(ptr(_f32(y)), y.stride(0), ptr(_f32(A)), ptr(_f32(out)), out.stride(0), K, F, V, nframes,
-                                      ptr(partials), stream_ptr()), "sar_graph_dense_fwd_f32")
+                                      ptr(partials), ptr(_f32(add)), add.stride(0) if add is not None else 0, stream_ptr()),
+          "sar_graph_dense_fwd_f32")
     return (partials, nparts) if stats else None
 
 
@@ -301,6 +306,56 @@ def graph_dense_dA(y, dout, dA, K, F, V, nframes, nsplit=64):
     slab = torch.empty(lib.sar_graph_dense_dadj_slab_floats(K, F, V, nsplit), dtype=torch.float32, device=y.device)
     check(lib.sar_graph_dense_dadj_f32(ptr(_f32(y)), y.stride(0), ptr(_f32(dout)), dout.stride(0), K, F, V, nframes, nsplit,
                                      ptr(slab), ptr(_f32(dA)), stream_ptr()), "sar_graph_dense_dadj_f32")
+
+
+# ------------------------------------------------------------------------------------------------ graph isomorphism conv
+def conv_gemm_nparts(B, V, T_src, T_out, Kc, M, taps=1, stride=1, pad=0, transposed=False, epi=L.SAR_EPI_STATS):
+    """partial sums per output row that sar_conv_gemm_f32 (TEMPORAL) writes for this geometry"""
+    d = ConvDesc()
+    d.mode, d.transposed, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = L.SAR_CONV_TEMPORAL, int(transposed), B, V, T_src, T_out, Kc, M
+    d.taps, d.stride, d.pad, d.epi = taps, stride, pad, epi
+    n = L.load().sar_conv_gemm_nparts(C.byref(d))
+    if n <= 0:
+        check(n or -1, "sar_conv_gemm_nparts")
+    return n
+
+
+def gin_adjacency(A, eps, table, scale):
+    Km1, V = (A.shape[0], A.shape[1]) if A is not None else (0, table.shape[1])
+    check(L.load().sar_gin_adjacency_f32(ptr(_f32(A)), Km1, V, ptr(_f32(eps)), ptr(_f32(table)), ptr(_f32(scale)), scale.numel(),
+                                         stream_ptr()), "sar_gin_adjacency_f32")
+
+
+def gin_sum_fwd(a, scale, shift, K, s_out, stats=False):
+    Cc, n = s_out.shape
+    partials, nparts = None, 0
+    if stats:
+        nparts = L.load().sar_gin_nparts(n)
+        partials = torch.empty((Cc, nparts, 2), dtype=torch.float32, device=a.device)
+    check(L.load().sar_gin_sum_fwd_f32(ptr(_f32(a)), a.stride(0), ptr(_f32(scale)), ptr(_f32(shift)), K, Cc, n, ptr(_f32(s_out)),
+                                       s_out.stride(0), ptr(partials), stream_ptr()), "sar_gin_sum_fwd_f32")
+    return (partials, nparts) if stats else None
+
+
+def gin_bwd_reduce(ds, a, scale, shift, mean, K):
+    Cc, n = ds.shape
+    nparts = L.load().sar_gin_nparts(n)
+    partials = torch.empty((K * Cc, nparts, 2), dtype=torch.float32, device=a.device)
+    check(L.load().sar_gin_bwd_reduce_f32(ptr(_f32(ds)), ds.stride(0), ptr(_f32(a)), a.stride(0), ptr(_f32(scale)), ptr(_f32(shift)),
+                                          ptr(_f32(mean)), K, Cc, n, ptr(partials), stream_ptr()), "sar_gin_bwd_reduce_f32")
+    return partials, nparts
+
+
+def gin_bwd_apply(ds, a, scale, shift, k, K, da):
+    Cc, n = ds.shape
+    check(L.load().sar_gin_bwd_apply_f32(ptr(_f32(ds)), ds.stride(0), ptr(_f32(a)), a.stride(0), ptr(_f32(scale)), ptr(_f32(shift)),
+                                         ptr(_f32(k[0])), ptr(_f32(k[1])), ptr(_f32(k[2])), K, Cc, n, ptr(_f32(da)), da.stride(0),
+                                         stream_ptr()), "sar_gin_bwd_apply_f32")
+
+
+def gin_eps_grad(G, W, eps, deps):
+    assert G.is_contiguous() and W.is_contiguous() and G.numel() == W.numel()
+    check(L.load().sar_gin_eps_grad_f32(ptr(G), ptr(W), G.numel(), ptr(eps), ptr(deps), stream_ptr()), "sar_gin_eps_grad_f32")
 
 
 # ------------------------------------------------------------------------------------------------ ResNet-18 ops

@@ -1,0 +1,319 @@
+"""the sibling model models/stgin.py (GraphIsoConvTD, models/gcn.py:112-163) on the HIP engine
+(sar_amd/stgin.py) against its CPU restatement (oracle/stgin.py).
+
+Tolerances as in tests/test_gpu_stgcn_model.py: activations, logits, loss, moving statistics 1e-4 (norm-wise relative to the
+float64 oracle); gradients 1e-4 against the float64 oracle conditioned on the engine's activation pattern, plus the
+unconditioned tie check (wherever the engine's ReLU decision differs from the plain float64 oracle's, that pre-activation is
+within 1e-4 of zero relative to its tensor's maximum).  `epsilon` (one scalar per block) is a fully cancelled sum over a
+whole tensor: its error is judged against the float32 oracle's own distance from the float64 one (both are printed)."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import stgcn as S
+from oracle import stgin as G
+from util import rel_err, from_cn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+K = 3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------ kernels of csrc/gin.hip
+@pytest.mark.parametrize("C,n", [(32, 4 * 25 * 7), (8, 3 * 25 * 5 + 1), (64, 25 * 300)])
+def test_gin_elementwise_kernels(dev, C, n):
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(C + n)
+    a = torch.randn(K * C, n, generator=g)
+    sc, sh = 1 + 0.3 * torch.randn(K * C, generator=g), 0.3 * torch.randn(K * C, generator=g)
+    mean = 0.2 * torch.randn(K * C, generator=g)
+    ds = torch.randn(C, n, generator=g)
+    k1, k2, k3 = (torch.randn(K * C, generator=g) for _ in range(3))
+    ad, scd, shd = a.double(), sc.double()[:, None], sh.double()[:, None]
+    post = torch.relu(ad * scd + shd)
+    s_ref = post.view(K, C, n).sum(0)
+    dz = ds.double().repeat(K, 1) * (post > 0)
+    # forward sum + statistics
+    s = torch.empty(C, n, device=dev)
+    part, nparts = ops.gin_sum_fwd(a.to(dev), sc.to(dev), sh.to(dev), K, s, stats=True)
+    torch.cuda.synchronize()
+    assert rel_err(s.cpu(), s_ref) < 1e-6
+    tot = part.cpu().double().sum(1)
+    assert rel_err(tot[:, 0], s_ref.sum(1)) < 1e-5 and rel_err(tot[:, 1], (s_ref * s_ref).sum(1)) < 1e-5
+    # backward reductions
+    part, nparts = ops.gin_bwd_reduce(ds.to(dev), a.to(dev), sc.to(dev), sh.to(dev), mean.to(dev), K)
+    torch.cuda.synchronize()
+    tot = part.cpu().double().sum(1)
+    assert rel_err(tot[:, 0], dz.sum(1)) < 1e-5
+    assert rel_err(tot[:, 1], (dz * (ad - mean.double()[:, None])).sum(1)) < 1e-5
+    # backward apply, in place over a
+    ag = a.to(dev)
+    ops.gin_bwd_apply(ds.to(dev), ag, sc.to(dev), sh.to(dev), (k1.to(dev), k2.to(dev), k3.to(dev)), K, ag)
+    torch.cuda.synchronize()
+    ref = k1.double()[:, None] * dz + k2.double()[:, None] * ad + k3.double()[:, None]
+    assert rel_err(ag.cpu(), ref) < 1e-6
+
+
+def test_gin_adjacency_table_and_epsilon_gradient(dev):
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(1)
+    A = torch.rand(2, 25, 25, generator=g)
+    eps = torch.tensor(0.37)
+    table = torch.empty(3, 25, 25, device=dev)
+    scale = torch.empty(70, device=dev)
+    ops.gin_adjacency(A.to(dev), eps.to(dev), table, scale)
+    torch.cuda.synchronize()
+    ref = torch.cat([A.transpose(1, 2), (torch.eye(25) * (1 + eps)).unsqueeze(0)])
+    assert torch.equal(table.cpu(), ref) and torch.equal(scale.cpu(), (1 + eps).expand(70))
+    # x . A_k through the dense contraction kernel with that table == einsum 'nctv,kvw->nkctw' (models/gcn.py:154)
+    x = torch.randn(2, 6, 5, 25, generator=g)
+    xc = x.permute(1, 0, 2, 3).reshape(6, -1).contiguous().to(dev)
+    z = torch.empty(3 * 6, xc.shape[1], device=dev)
+    ops.graph_dense_bwd_data(xc, table, z, 3, 6, 25, 2 * 5)
+    torch.cuda.synchronize()
+    A_ = torch.cat([A, (torch.eye(25) * (1 + eps)).unsqueeze(0)]).double()
+    zr = torch.einsum("nctv,kvw->nkctw", x.double(), A_)               # (n, k, c, t, w)
+    assert rel_err(z.cpu().view(3, 6, 2, 5, 25), zr.permute(1, 2, 0, 3, 4)) < 1e-6
+    # d eps = <G, W>, G *= 1 + eps
+    Gm, W = torch.randn(64, 32, generator=g), torch.randn(64, 32, generator=g)
+    Gd, de = Gm.to(dev), torch.empty((), device=dev)
+    ops.gin_eps_grad(Gd, W.to(dev), eps.to(dev), de)
+    torch.cuda.synchronize()
+    assert abs(de.item() - (Gm.double() * W.double()).sum().item()) < 1e-6 * (Gm * W).abs().sum().item()
+    assert torch.equal(Gd.cpu(), Gm * (1 + eps))
+
+
+# ------------------------------------------------------------------------------------------------ the model
+def _params(blocks, classes, seed):
+    p = S.randomize_affine(G.init_params(classes, seed=seed, dtype=torch.float64, blocks=blocks), seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    for i in range(len(blocks)):       # epsilon away from its 0 initial value
+        p["l%d.epsilon" % i] = 0.3 * torch.randn((), generator=g, dtype=torch.float64)
+    return p
+
+
+def _engine_masks(eng, keep, blocks, B, T):
+    """the engine's activation pattern, every ReLU site re-evaluated with the engine's own arithmetic relu(fma(., scale, shift))"""
+    from sar_amd import ops
+    masks = {}
+
+    def pattern(t, bn):
+        out = torch.empty_like(t)
+        ops.bn_add_relu_fwd(t, bn.scale, bn.shift, 0, None, None, None, out)
+        return (out > 0).cpu()
+
+    for i, (f, s, _) in enumerate(blocks):
+        pre, h, To = "l%d." % i, f // 2, -(-T // s)
+        m1 = pattern(keep[pre + "a1"], eng.bn[pre + "mlp.bn1"])
+        m2 = pattern(keep[pre + "a2"], eng.bn[pre + "mlp.bn2"])
+        for k in range(K):
+            masks[pre + "mlp%d.h1" % k] = from_cn(m1[k * h:(k + 1) * h], B, T, 25)
+            masks[pre + "mlp%d.h2" % k] = from_cn(m2[k * h:(k + 1) * h], B, T, 25)
+        masks[pre + "h"] = from_cn(pattern(keep[pre + "g"], eng.bn[pre + "bn1"]), B, T, 25)
+        masks[pre + "y"] = from_cn((keep[pre + "y"] > 0).cpu(), B, To, 25)
+        T = To
+    return masks
+
+
+def _compare(dev, blocks, N, T, classes, seed, x=None, y=None):
+    from sar_amd.stgin import STGIN
+    p = _params(blocks, classes, seed)
+    if x is None:
+        x, y = S.synthetic_batch(N, seed=seed, T=T, num_classes=classes)
+    logits_ref, loss_ref, grads_unc, new_stats, taps = G.loss_and_grads(p, x.double(), y, blocks=blocks)
+    eng = STGIN(num_classes=classes, device=dev, blocks=blocks)
+    assert eng.n_params == sum(v.numel() for k, v in p.items() if S.is_trainable(k))
+    eng.load_params(p)
+    keep = {}
+    xg, yg = x.to(dev), y.to(dev)
+    logits = eng.forward(xg, training=True, keep=keep)
+    torch.cuda.synchronize()
+    B, Tc = x.shape[0] * x.shape[4], x.shape[2]
+    worst = {"x0": rel_err(from_cn(keep["x0"].cpu(), B, Tc, 25), taps["x0"])}
+    for i, (f, s, _) in enumerate(blocks):
+        To = -(-Tc // s)
+        worst["l%d.s" % i] = rel_err(from_cn(keep["l%d.g" % i].cpu(), B, Tc, 25), taps["l%d.s" % i])
+        worst["l%d.u" % i] = rel_err(from_cn(keep["l%d.u" % i].cpu(), B, To, 25), taps["l%d.u" % i])
+        worst["l%d.y" % i] = rel_err(from_cn(keep["l%d.y" % i].cpu(), B, To, 25), taps["l%d.y" % i])
+        Tc = To
+    worst["logits"] = rel_err(logits.cpu(), logits_ref)
+    masks = _engine_masks(eng, keep, blocks, B, x.shape[2])
+    # unconditioned: the activation pattern differs from the float64 oracle's only at rounding-level ties
+    worst_tie, n_flip = 0.0, 0
+    for site, m in masks.items():
+        pre64 = taps[site + "_pre"]
+        diff = m != (pre64 > 0)
+        if diff.any():
+            n_flip += int(diff.sum())
+            worst_tie = max(worst_tie, (pre64[diff].abs().max() / pre64.abs().max()).item())
+    print("activation-pattern differences vs the float64 oracle: %d elements, largest |pre-activation| among them %.2e of its "
+          "tensor's max" % (n_flip, worst_tie))
+    assert worst_tie <= 1e-4
+    _, _, grads_ref, _, _ = G.loss_and_grads(p, x.double(), y, blocks=blocks, masks=masks)
+    _, _, grads32, _, _ = G.loss_and_grads({k: v.float() for k, v in p.items()}, x.float(), y, blocks=blocks, masks=masks)
+    logits2, loss = eng.loss_and_grad(xg, yg)
+    torch.cuda.synchronize()
+    worst["loss"] = rel_err(loss.cpu(), loss_ref.reshape(1))
+    gmax = max(g.abs().max().item() for g in grads_ref.values())
+    for k, gref in grads_ref.items():
+        scale = gref.abs().max().item()
+        if k.endswith("epsilon"):
+            # a scalar = fully cancelled sum over a whole tensor: judged against the float32 oracle's own distance from the
+            # float64 one (x8) with a floor of 1e-4 of the largest gradient entry of the model
+            band = abs(grads32[k].item() - gref.item())
+            err = abs(eng.g[k].item() - gref.item())
+            print("%s: engine %.6e, float64 oracle %.6e (float32 oracle off by %.1e, engine by %.1e)" % (
+                k, eng.g[k].item(), gref.item(), band, err))
+            worst["grad " + k] = 0.0 if err <= max(8 * band, TOL * scale, 1e-6 * gmax) else err / scale
+        elif scale < 1e-9:    # conv biases in front of a BatchNorm: analytically zero gradient
+            wk = grads_ref[k.replace(".bias", ".kernel")].abs().max().item()
+            worst["grad " + k] = eng.g[k].abs().max().item() / max(wk, 1e-30)
+        else:
+            worst["grad " + k] = rel_err(eng.g[k].cpu(), gref)
+    sd = eng.state_dict()
+    for k, v in new_stats.items():      # two training forwards ran on the engine -> the momentum update applied twice
+        m = 0.99
+        batch = (v - m * p[k]) / (1 - m)
+        worst["stat " + k] = rel_err(sd[k], m * v + (1 - m) * batch)
+    report = "\n".join("%-30s %.3e" % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:12])
+    print(report)
+    bad = {k: v for k, v in worst.items() if not (v < TOL)}
+    assert not bad, "parity failures (tol %g):\n%s\nworst:\n%s" % (TOL, bad, report)
+    return eng, p
+
+
+def test_two_blocks_small(dev):
+    _compare(dev, [(64, 1, False), (64, 1, True)], N=2, T=12, classes=10, seed=0)
+
+
+def test_stride2_conv_residual_blocks(dev):
+    _compare(dev, [(64, 1, False), (128, 2, True), (128, 1, True), (256, 2, True)], N=2, T=22, classes=12, seed=1)
+
+
+def test_odd_sizes_single_body(dev):
+    x, y = S.synthetic_batch(3, seed=7, T=17, M=1, num_classes=9)
+    _compare(dev, [(64, 1, False), (64, 1, True), (128, 2, True)], N=3, T=17, classes=9, seed=2, x=x, y=y)
+
+
+def test_full_model_ntu_shape(dev):
+    """all 10 blocks of models/stgin.py:94-103, T = 300, V = 25, M = 2, 60 classes"""
+    eng, _ = _compare(dev, list(G.BLOCKS), N=2, T=300, classes=60, seed=3)
+    assert eng.n_params == 1778172
+
+
+def test_inference_mode_and_state_dict_round_trip(dev):
+    from sar_amd.stgin import STGIN
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True)]
+    p = _params(blocks, 10, 6)
+    x, _ = S.synthetic_batch(3, seed=3, T=16, num_classes=10)
+    ref = torch.softmax(G.forward(p, x.double(), False, blocks=blocks), 1)
+    eng = STGIN(num_classes=10, device=dev, blocks=blocks)
+    eng.load_params(p)
+    probs = eng.predict(x.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(probs.cpu(), ref) < TOL
+    sd = eng.state_dict()
+    assert set(sd) == set(p)
+    other = STGIN(num_classes=10, device=dev, blocks=blocks, seed=5)
+    other.load_params(sd)
+    assert torch.equal(other.predict(x.to(dev)), probs)
+
+
+def test_sgd_training_steps_track_the_oracle(dev):
+    from sar_amd.stgin import STGIN
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True)]
+    p = _params(blocks, 10, 5)
+    eng = STGIN(num_classes=10, device=dev, blocks=blocks)
+    eng.load_params(p)
+    vel = {}
+    for step in range(3):
+        x, y = S.synthetic_batch(4, seed=10 + step, T=20, num_classes=10)
+        stats = {n: (bn.moving_mean.clone(), bn.moving_var.clone()) for n, bn in eng.bn.items()}
+        keep = {}
+        eng.forward(x.to(dev), training=True, keep=keep)
+        masks = _engine_masks(eng, keep, blocks, x.shape[0] * x.shape[4], x.shape[2])
+        for n, (mm, mv) in stats.items():
+            eng.bn[n].moving_mean.copy_(mm)
+            eng.bn[n].moving_var.copy_(mv)
+        _, loss_ref, grads, new, _ = G.loss_and_grads(p, x.double(), y, blocks=blocks, masks=masks)
+        lr = S.lr_schedule(step)
+        S.sgd_nesterov_step(p, grads, vel, lr)
+        p.update(new)
+        _, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+        eng.sgd_step(lr)
+        torch.cuda.synchronize()
+        assert rel_err(loss.cpu(), loss_ref.reshape(1)) < TOL
+    sd = eng.state_dict()
+    for k in S.trainable_names(p):
+        if k.endswith(("tcn.bias", "res.bias", "c1.bias", "c2.bias")):      # a bias in front of a train-mode BatchNorm
+            assert (sd[k] - p[k].float()).abs().max().item() < 1e-5, k
+        elif k.endswith("epsilon"):
+            assert abs(sd[k].item() - p[k].item()) < 1e-4, k
+        else:
+            assert rel_err(sd[k], p[k]) < 2e-4, k
+
+
+def test_train_step_is_bitwise_deterministic(dev):
+    from sar_amd.stgin import STGIN
+    from sar_amd.train import synthetic_clips
+    x, y = synthetic_clips(4, dev, seed=3, num_classes=60)
+    eng = STGIN(num_classes=60, device=dev, seed=0)
+    state = {k: v.clone() for k, v in eng.state_dict().items()}
+    ref = None
+    for _ in range(3):
+        eng.load_params(state)
+        logits, loss = eng.loss_and_grad(x, y)
+        torch.cuda.synchronize()
+        cur = (logits.clone(), loss.clone(), eng.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+    assert torch.isfinite(ref[2]).all()
+
+
+def test_dropin_model_autograd_and_cli(dev, tmp_path):
+    """models.stgin.Model through torch autograd == the engine's fused step; `main_gnn.py --model stgin` trains."""
+    sys.path.insert(0, os.path.join(ROOT, "skeleton-action-recognition_amd"))
+    from models.stgin import Model
+    model = Model(num_classes=60, device=dev, seed=1)
+    names = [v.name for v in model.trainable_variables]
+    assert "l0.epsilon" in names and not any("adjacency" in n for n in names)
+    assert tuple(model.adjacency_matrix.shape) == (2, 25, 25)
+    x, y = S.synthetic_batch(2, seed=1, T=24, num_classes=60)
+    logits = model(x.to(dev), training=True)
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev), reduction="sum") / 2
+    loss.backward()
+    auto = {k: getattr(model, k.replace(".", "_")).grad.clone() for k in model._names}
+    lg, ls = model.engine.loss_and_grad(x.to(dev), y.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(lg, logits.detach()) and rel_err(loss.detach().cpu().reshape(1), ls.cpu()) < 1e-6
+    # torch's softmax / cross-entropy differ from the engine's in the last bits, so the two gradient sets agree to rounding:
+    # 1e-4 of each tensor's scale, floored at 1e-2 of the model's largest gradient entry for the tensors that are (nearly)
+    # cancelled sums -- epsilon, biases in front of a train-mode BatchNorm
+    gmax = max(model.engine.g[k].abs().max().item() for k in model._names)
+    ratio = {k: (auto[k] - model.engine.g[k]).abs().max().item() / max(model.engine.g[k].abs().max().item(), 1e-2 * gmax)
+             for k in model._names}
+    print("autograd vs fused step, worst:", sorted(ratio.items(), key=lambda kv: -kv[1])[:5])
+    assert max(ratio.values()) < 1e-4
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "skeleton-action-recognition_amd"))
+    cmd = [sys.executable, os.path.join(ROOT, "skeleton-action-recognition_amd", "main_gnn.py"), "--model", "stgin", "--synthetic",
+           "--synthetic-size", "16", "--batch-size", "4", "--num-epochs", "1", "--max-iters", "3", "--save-freq", "1",
+           "--log-dir", str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    ck = sorted(glob.glob(os.path.join(str(tmp_path), "*", "checkpoints", "ckpt-*.pt")))
+    assert len(ck) == 1
+    sd = torch.load(ck[0])["model"]
+    assert "l9.mlp2.bn2.moving_var" in sd and all(torch.isfinite(v).all() for v in sd.values())
