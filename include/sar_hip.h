@@ -260,6 +260,20 @@ int64_t sar_stft_logmag_bwd_workspace_floats(int B, int T, int n_fft, int hop);
 int sar_stft_logmag_bwd_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
                             const float* window, int out_cols, const float* dout, float* workspace,
                             float* dz_re, float* dz_im, sar_stream_t s);
+/* Trainable Fourier kernels -- layers/virtual_radar.py:71-76 `train_stft_kernel` (nnAudio STFT(trainable=True): the
+ * conv1d kernels wcos / wsin [n_fft][1][n_fft], window folded in, are Parameters).  Same output as sar_stft_logmag_f32 but
+ * the transform is the matrix product with the CURRENT kernels:
+ *   Z_re[k] = sum_n fr[n] wcos[k][n] + fi[n] wsin[k][n],  Z_im[k] = sum_n fi[n] wcos[k][n] - fr[n] wsin[k][n].
+ * wcosT / wsinT are the [n][k] transposes (sar_transpose_f32).  n_fft <= 1024.
+ * sar_stft_kernels_bwd_f32: dw[2][n_fft][n_fft] = (d wcos, d wsin) and, when dz_re / dz_im != NULL, the cotangent of the
+ * signal for sar_vr_signal_bwd_f32.  workspace: sar_stft_kernels_bwd_workspace_floats floats; the kernel gradient is
+ * reduced over nsplit slabs in a fixed order (no atomics). */
+int sar_stft_kernels_fwd_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop, const float* wcosT,
+                             const float* wsinT, int out_cols, float* out, sar_stream_t s);
+int64_t sar_stft_kernels_bwd_workspace_floats(int B, int T, int n_fft, int hop, int nsplit);
+int sar_stft_kernels_bwd_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop, const float* wcos,
+                             const float* wsin, const float* wcosT, const float* wsinT, int out_cols, const float* dout,
+                             float* workspace, int nsplit, float* dw, float* dz_re, float* dz_im, sar_stream_t s);
 int sar_vr_signal_bwd_nparts(int B, int T);
 int sar_vr_signal_bwd_f32(const float* x, int B, int T, int V, int M, const int32_t* e_src, const int32_t* e_dst,
                           int E, const float* loc, const float* wavelength, const float* dz_re, const float* dz_im,

@@ -138,11 +138,14 @@ def nearest_columns(F_, out_cols):
     return np.minimum(np.floor(j * scale).astype(np.int64), F_ - 1)
 
 
-def spectrogram_torch(x, loc, lam, edges=EDGES, n_fft=256, hop=16, out_cols=0, dtype=None):
+def spectrogram_torch(x, loc, lam, edges=EDGES, n_fft=256, hop=16, out_cols=0, dtype=None, wcos=None, wsin=None):
     """Differentiable restatement of the whole layer (layers/virtual_radar.py:93-133) in torch, for the gradients of
     radar_location / wavelength (autograd of the reference when train_* are set, main_spectrogram.py:133-136).
     x (B,3,T,V,M) tensor; loc (3,) and lam () tensors (requires_grad as wanted); float64 unless dtype is given.
-    out_cols > 0 applies the nearest column select of models/resnet.py:26."""
+    out_cols > 0 applies the nearest column select of models/resnet.py:26.
+    wcos / wsin: (n_fft, n_fft) [k, n] tensors replacing the analytic Fourier kernels -- nnAudio's STFT(trainable=True)
+    holds them as Parameters of shape (n_fft, 1, n_fft) (layers/virtual_radar.py:71-76 train_stft_kernel) and convolves the
+    reflect-padded signal with them; pass leaves with requires_grad to get their gradients."""
     import torch
     dtype = dtype or torch.float64
     x = torch.as_tensor(x).to(dtype)
@@ -168,7 +171,8 @@ def spectrogram_torch(x, loc, lam, edges=EDGES, n_fft=256, hop=16, out_cols=0, d
     w = torch.from_numpy(hann_periodic(n_fft)).to(dtype)
     n = torch.arange(n_fft, dtype=dtype)
     ang = 2 * np.pi * n[:, None] * n[None, :] / n_fft                                          # [k, n]
-    wcos, wsin = w * torch.cos(ang), w * torch.sin(ang)
+    wcos = w * torch.cos(ang) if wcos is None else wcos.to(dtype).reshape(n_fft, n_fft)
+    wsin = w * torch.sin(ang) if wsin is None else wsin.to(dtype).reshape(n_fft, n_fft)
 
     def frames(u):
         up = torch.nn.functional.pad(u[:, None, :], (pad, pad), mode="reflect")[:, 0]

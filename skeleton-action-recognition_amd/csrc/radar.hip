@@ -478,6 +478,178 @@ __global__ __launch_bounds__(64) void upsample_prepare_kernel(const float* __res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Trainable Fourier kernels (layers/virtual_radar.py:71-76 train_stft_kernel -> nnAudio STFT(trainable=True)): the DFT
+// matrices wcos[k][n], wsin[k][n] (window folded in) are Parameters, so the transform is a plain matrix product with
+// whatever they currently hold and the backward pass also produces d wcos / d wsin:
+//   Z_re[k] = sum_n fr[n] wcos[k][n] + fi[n] wsin[k][n]        Z_im[k] = sum_n fi[n] wcos[k][n] - fr[n] wsin[k][n]
+// (fr, fi = the reflect-padded frame of z_re, z_im).  Forward: KF output columns per workgroup, thread k walks n with
+// the TRANSPOSED kernels [n][k] (coalesced).  Backward: per (clip, frame) dZ (kept in HBM for the kernel gradient) and the
+// frame cotangent G; the kernel gradient is a (k x n) outer-product accumulation over all frames, split over workgroups
+// into slabs that are summed in a fixed order.
+constexpr int KF = 4;      // output columns per workgroup in the forward kernel
+constexpr int KWB = 16;    // rows k per workgroup in the kernel-gradient reduction
+
+__device__ __forceinline__ int reflect_index(int i, int T) {
+  if (i < 0) i = -i;
+  if (i >= T) i = 2 * (T - 1) - i;
+  return i;
+}
+
+__device__ __forceinline__ int nearest_src(int j, int F, int ncols, int select) {
+  if (!select) return j;
+  const float scale = (float)F / (float)ncols;
+  return min((int)floorf((float)j * scale), F - 1);
+}
+
+__global__ __launch_bounds__(256) void stft_kernels_fwd_kernel(const float* __restrict__ z_re, const float* __restrict__ z_im,
+                                                               int T, int n_fft, int hop, const float* __restrict__ wcosT,
+                                                               const float* __restrict__ wsinT, int F, int ncols, int select,
+                                                               float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* fr = (float2*)smem;            // [KF][n_fft] (re, im) of the reflect-padded frames
+  const int b = blockIdx.y, j0 = blockIdx.x * KF;
+  const int half = n_fft / 2;
+  for (int q = 0; q < KF; ++q) {
+    const int j = min(j0 + q, ncols - 1);
+    const int f = nearest_src(j, F, ncols, select);
+    for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+      const int i = reflect_index(f * hop + n - half, T);
+      fr[q * n_fft + n] = make_float2(z_re[(int64_t)b * T + i], z_im[(int64_t)b * T + i]);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_fft; k += blockDim.x) {
+    float re[KF], im[KF];
+#pragma unroll
+    for (int q = 0; q < KF; ++q) re[q] = im[q] = 0.f;
+    for (int n = 0; n < n_fft; ++n) {
+      const float c = wcosT[(int64_t)n * n_fft + k], s = wsinT[(int64_t)n * n_fft + k];
+#pragma unroll
+      for (int q = 0; q < KF; ++q) {
+        const float2 v = fr[q * n_fft + n];
+        re[q] = fmaf(v.x, c, fmaf(v.y, s, re[q]));
+        im[q] = fmaf(v.y, c, fmaf(-v.x, s, im[q]));
+      }
+    }
+    const int row = (k + half) % n_fft;
+#pragma unroll
+    for (int q = 0; q < KF; ++q)
+      if (j0 + q < ncols) {
+        const float mag = sqrtf(re[q] * re[q] + im[q] * im[q]);
+        out[((int64_t)b * n_fft + row) * ncols + j0 + q] = (float)log((double)(mag + 1e-6f));
+      }
+  }
+}
+
+// one workgroup per (clip, frame f): dZ[b][f][k] (zero when no output column reads f) and, when G != NULL, the frame
+// cotangent G[b][f][n]
+__global__ __launch_bounds__(256) void stft_kernels_bwd_frames_kernel(const float* __restrict__ z_re, const float* __restrict__ z_im,
+                                                                      int T, int n_fft, int hop, const float* __restrict__ wcos,
+                                                                      const float* __restrict__ wsin, const float* __restrict__ wcosT,
+                                                                      const float* __restrict__ wsinT, int F, int ncols, int select,
+                                                                      const float* __restrict__ dout, float2* __restrict__ dZg,
+                                                                      float2* __restrict__ G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* fr = (float2*)smem;            // [n_fft]
+  float2* dZ = fr + n_fft;               // [n_fft]
+  const int b = blockIdx.y, f = blockIdx.x;
+  int j0 = f, j1 = f + 1;
+  if (select) {
+    j0 = ncols;
+    j1 = 0;
+    for (int j = 0; j < ncols; ++j)
+      if (nearest_src(j, F, ncols, 1) == f) {
+        j0 = min(j0, j);
+        j1 = max(j1, j + 1);
+      }
+  }
+  float2* dZf = dZg + ((int64_t)b * F + f) * n_fft;
+  float2* Gf = G ? G + ((int64_t)b * F + f) * n_fft : nullptr;
+  if (j0 >= j1) {
+    for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+      dZf[n] = make_float2(0.f, 0.f);
+      if (Gf) Gf[n] = make_float2(0.f, 0.f);
+    }
+    return;
+  }
+  const int half = n_fft / 2;
+  for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+    const int i = reflect_index(f * hop + n - half, T);
+    fr[n] = make_float2(z_re[(int64_t)b * T + i], z_im[(int64_t)b * T + i]);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_fft; k += blockDim.x) {
+    float re = 0.f, im = 0.f;
+    for (int n = 0; n < n_fft; ++n) {
+      const float c = wcosT[(int64_t)n * n_fft + k], s = wsinT[(int64_t)n * n_fft + k];
+      const float2 v = fr[n];
+      re = fmaf(v.x, c, fmaf(v.y, s, re));
+      im = fmaf(v.y, c, fmaf(-v.x, s, im));
+    }
+    const float mag = sqrtf(re * re + im * im);
+    const int row = (k + half) % n_fft;
+    float ds = 0.f;
+    for (int j = j0; j < j1; ++j) ds += dout[((int64_t)b * n_fft + row) * ncols + j];
+    const float g = mag > 0.f ? ds / (mag * (mag + 1e-6f)) : 0.f;
+    const float2 d = make_float2(g * re, g * im);
+    dZ[k] = d;
+    dZf[k] = d;
+  }
+  if (!Gf) return;
+  __syncthreads();
+  for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+    float gx = 0.f, gy = 0.f;
+    for (int k = 0; k < n_fft; ++k) {
+      const float c = wcos[(int64_t)k * n_fft + n], s = wsin[(int64_t)k * n_fft + n];
+      const float2 d = dZ[k];
+      gx = fmaf(d.x, c, fmaf(-d.y, s, gx));
+      gy = fmaf(d.x, s, fmaf(d.y, c, gy));
+    }
+    Gf[n] = make_float2(gx, gy);
+  }
+}
+
+// d wcos[k][n] = sum_{b,f} dZre fr[n] + dZim fi[n];  d wsin[k][n] = sum_{b,f} dZre fi[n] - dZim fr[n].
+// Workgroup (k block of KWB rows, split): thread n owns column n of the block; slab[split][2][n_fft][n_fft].
+__global__ __launch_bounds__(1024) void stft_kernels_wgrad_kernel(const float* __restrict__ z_re, const float* __restrict__ z_im,
+                                                                  int B, int T, int n_fft, int hop, int F,
+                                                                  const float2* __restrict__ dZg, int nsplit,
+                                                                  float* __restrict__ slab) {
+  __shared__ float2 dz[KWB];
+  const int k0 = blockIdx.x * KWB, split = blockIdx.y, n = threadIdx.x;
+  const int half = n_fft / 2;
+  const int64_t total = (int64_t)B * F;
+  const int64_t per = (total + nsplit - 1) / nsplit;
+  const int64_t lo = split * per, hi = (lo + per < total) ? lo + per : total;
+  float ac[KWB], as[KWB];
+#pragma unroll
+  for (int q = 0; q < KWB; ++q) ac[q] = as[q] = 0.f;
+  for (int64_t bf = lo; bf < hi; ++bf) {
+    const int b = (int)(bf / F), f = (int)(bf - (int64_t)b * F);
+    __syncthreads();
+    if (n < KWB) dz[n] = (k0 + n < n_fft) ? dZg[bf * n_fft + k0 + n] : make_float2(0.f, 0.f);
+    __syncthreads();
+    const int i = reflect_index(f * hop + n - half, T);
+    const float xr = z_re[(int64_t)b * T + i], xi = z_im[(int64_t)b * T + i];
+#pragma unroll
+    for (int q = 0; q < KWB; ++q) {
+      const float2 d = dz[q];
+      ac[q] = fmaf(d.x, xr, fmaf(d.y, xi, ac[q]));
+      as[q] = fmaf(d.x, xi, fmaf(-d.y, xr, as[q]));
+    }
+  }
+  float* sc = slab + (int64_t)split * 2 * n_fft * n_fft;
+  float* ss = sc + (int64_t)n_fft * n_fft;
+#pragma unroll
+  for (int q = 0; q < KWB; ++q)
+    if (k0 + q < n_fft) {
+      sc[(int64_t)(k0 + q) * n_fft + n] = ac[q];
+      ss[(int64_t)(k0 + q) * n_fft + n] = as[q];
+    }
+}
+
 }  // namespace
 
 extern "C" int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, const int32_t* e_src, const int32_t* e_dst,
@@ -570,6 +742,55 @@ extern "C" int sar_stft_logmag_bwd_f32(const float* z_re, const float* z_im, int
   hipLaunchKernelGGL(stft_logmag_bwd_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s),
                      (const float2*)workspace, B, T, n_fft, hop, F, dz_re, dz_im);
   SAR_LAUNCH_CHECK("sar_stft_logmag_bwd_f32 (gather)");
+  return 0;
+}
+
+extern "C" int sar_stft_kernels_fwd_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
+                                        const float* wcosT, const float* wsinT, int out_cols, float* out, sar_stream_t s) {
+  SAR_REQUIRE(z_re && z_im && wcosT && wsinT && out, "sar_stft_kernels_fwd: null pointer");
+  SAR_REQUIRE(B > 0 && n_fft >= 2 && n_fft <= 1024 && (n_fft % 2) == 0 && hop > 0, "sar_stft_kernels_fwd: bad sizes (n_fft <= 1024)");
+  SAR_REQUIRE(T > n_fft / 2, "sar_stft_kernels_fwd: reflect padding needs T > n_fft/2 (T=%d, n_fft=%d)", T, n_fft);
+  const int F = T / hop + 1;
+  const int ncols = out_cols > 0 ? out_cols : F;
+  hipLaunchKernelGGL(stft_kernels_fwd_kernel, dim3((ncols + KF - 1) / KF, B), dim3(256), sizeof(float2) * KF * n_fft,
+                     as_stream(s), z_re, z_im, T, n_fft, hop, wcosT, wsinT, F, ncols, out_cols > 0 ? 1 : 0, out);
+  SAR_LAUNCH_CHECK("sar_stft_kernels_fwd_f32");
+  return 0;
+}
+
+extern "C" int64_t sar_stft_kernels_bwd_workspace_floats(int B, int T, int n_fft, int hop, int nsplit) {
+  if (B <= 0 || T <= 0 || n_fft <= 0 || hop <= 0 || nsplit <= 0) return -1;
+  return (int64_t)B * (T / hop + 1) * n_fft * 4 + (int64_t)nsplit * 2 * n_fft * n_fft;
+}
+
+extern "C" int sar_stft_kernels_bwd_f32(const float* z_re, const float* z_im, int B, int T, int n_fft, int hop,
+                                        const float* wcos, const float* wsin, const float* wcosT, const float* wsinT,
+                                        int out_cols, const float* dout, float* workspace, int nsplit, float* dw,
+                                        float* dz_re, float* dz_im, sar_stream_t s) {
+  SAR_REQUIRE(z_re && z_im && wcos && wsin && wcosT && wsinT && dout && workspace && dw, "sar_stft_kernels_bwd: null pointer");
+  SAR_REQUIRE((dz_re == nullptr) == (dz_im == nullptr), "sar_stft_kernels_bwd: dz_re / dz_im go together");
+  SAR_REQUIRE(B > 0 && n_fft >= KWB && n_fft <= 1024 && (n_fft % 2) == 0 && hop > 0 && nsplit > 0 && nsplit <= 65535,
+              "sar_stft_kernels_bwd: bad sizes (16 <= n_fft <= 1024)");
+  SAR_REQUIRE(T > n_fft / 2, "sar_stft_kernels_bwd: reflect padding needs T > n_fft/2 (T=%d, n_fft=%d)", T, n_fft);
+  const int F = T / hop + 1;
+  const int ncols = out_cols > 0 ? out_cols : F;
+  float2* dZ = (float2*)workspace;
+  float2* G = dZ + (int64_t)B * F * n_fft;
+  float* slab = (float*)(G + (int64_t)B * F * n_fft);
+  hipLaunchKernelGGL(stft_kernels_bwd_frames_kernel, dim3(F, B), dim3(256), sizeof(float2) * 2 * n_fft, as_stream(s), z_re, z_im,
+                     T, n_fft, hop, wcos, wsin, wcosT, wsinT, F, ncols, out_cols > 0 ? 1 : 0, dout, dZ, dz_re ? G : nullptr);
+  SAR_LAUNCH_CHECK("sar_stft_kernels_bwd_f32 (frames)");
+  hipLaunchKernelGGL(stft_kernels_wgrad_kernel, dim3((n_fft + KWB - 1) / KWB, nsplit), dim3(n_fft), 0, as_stream(s), z_re, z_im, B,
+                     T, n_fft, hop, F, (const float2*)dZ, nsplit, slab);
+  SAR_LAUNCH_CHECK("sar_stft_kernels_bwd_f32 (kernel gradient)");
+  const int64_t nw = (int64_t)2 * n_fft * n_fft;
+  if (int rc = sar_slab_reduce_f32(slab, nsplit, nw, nw, dw, s)) return rc;
+  if (dz_re) {
+    const int64_t n = (int64_t)B * T;
+    hipLaunchKernelGGL(stft_logmag_bwd_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s),
+                       (const float2*)G, B, T, n_fft, hop, F, dz_re, dz_im);
+    SAR_LAUNCH_CHECK("sar_stft_kernels_bwd_f32 (gather)");
+  }
   return 0;
 }
 

@@ -11,8 +11,13 @@ magnitude, roll).  The window is the one nnAudio 0.1.1's STFT builds
 (train_wavelength / train_radar_location, or `requires_grad = True` set later as main_spectrogram.py:133-136 does)
 the forward records an autograd node whose backward runs sar_stft_logmag_bwd_f32 (adjoint of the STFT / log-magnitude
 stage) and sar_vr_signal_bwd_f32 (forward-mode tangents of the geometry w.r.t. the 4 scalars, contracted with the
-signal cotangent).  The skeleton input gets no gradient (it is data).  train_stft_kernel (trainable DFT kernels of
-nnAudio) is not built: requesting it raises NotImplementedError instead of silently freezing.
+signal cotangent).  The skeleton input gets no gradient (it is data).
+
+train_stft_kernel=True (layers/virtual_radar.py:71-76 -> nnAudio STFT(trainable=True)) turns the two conv1d Fourier kernels
+into the Parameters `stft.wcos` / `stft.wsin` of shape (n_fft, 1, n_fft) (window folded in, float32 of the float64
+formula like nnAudio's create_fourier_kernels).  The transform is then the matrix product with whatever the kernels
+currently hold (sar_stft_kernels_fwd_f32) and the backward pass also returns their gradients
+(sar_stft_kernels_bwd_f32: outer-product accumulation over all frames, slab-reduced in a fixed order).
 """
 import numpy as np
 import torch
@@ -60,28 +65,96 @@ class _RadarFunction(torch.autograd.Function):
         dzr, dzi = torch.empty_like(zr), torch.empty_like(zi)
         check(lib.sar_stft_logmag_bwd_f32(ptr(zr), ptr(zi), B, T, mod.n_fft, mod.hop_length, ptr(mod.window), ctx.out_cols,
                                           ptr(dout), ptr(ws), ptr(dzr), ptr(dzi), stream_ptr()), "sar_stft_logmag_bwd_f32")
-        nparts = lib.sar_vr_signal_bwd_nparts(B, T)
-        part = torch.empty((nparts, 4), dtype=torch.float32, device=x.device)
-        if ctx.P:
-            check(lib.sar_vr_signal_upsampled_bwd_f32(ptr(ctx.coef), B, x.shape[2], ctx.P, V, M, ptr(mod._src), ptr(mod._dst),
-                                                      len(mod.src), ptr(mod.radar_location.data),
-                                                      ptr(mod.wavelength.data.reshape(1)), ptr(dzr), ptr(dzi), ptr(part),
-                                                      stream_ptr()), "sar_vr_signal_upsampled_bwd_f32")
-        else:
-            check(lib.sar_vr_signal_bwd_f32(ptr(x), B, T, V, M, ptr(mod._src), ptr(mod._dst), len(mod.src),
-                                            ptr(mod.radar_location.data), ptr(mod.wavelength.data.reshape(1)), ptr(dzr),
-                                            ptr(dzi), ptr(part), stream_ptr()), "sar_vr_signal_bwd_f32")
-        g = part.double().sum(0).float()          # fixed-order reduction of the per-block partial sums
+        g = _signal_backward(mod, x, ctx.coef, ctx.P, dzr, dzi)
         return g[:3].clone(), g[3].reshape(mod.wavelength.shape), None, None, None, None, None
+
+
+class _KernelRadarFunction(torch.autograd.Function):
+    """The layer with nnAudio's trainable Fourier kernels: gradients for wcos / wsin and, when they train too, for
+    radar_location / wavelength."""
+
+    @staticmethod
+    def forward(ctx, loc, wavelength, wcos, wsin, mod, x, out_cols, num_pad_frames, sigma):
+        coef = mod.spline_pieces(x, sigma) if num_pad_frames else None
+        zr, zi = mod.signal(x, num_pad_frames, coef)
+        wT = mod.stft.transposed()
+        ctx.mod, ctx.out_cols, ctx.P, ctx.coef, ctx.wT = mod, out_cols, num_pad_frames, coef, wT
+        ctx.save_for_backward(x, zr, zi)
+        return mod._stft(zr, zi, out_cols, wT)
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        x, zr, zi = ctx.saved_tensors
+        lib = L.load()
+        B, T = zr.shape
+        _, _, _, V, M = x.shape
+        n_fft, hop = mod.n_fft, mod.hop_length
+        dout = dout.contiguous().float()
+        need_radar = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        nsplit = max(1, min(B * (T // hop + 1), 512 // max(1, n_fft // 16)))
+        ws = torch.empty(lib.sar_stft_kernels_bwd_workspace_floats(B, T, n_fft, hop, nsplit), dtype=torch.float32, device=x.device)
+        dw = torch.empty((2, n_fft, 1, n_fft), dtype=torch.float32, device=x.device)
+        dzr = torch.empty_like(zr) if need_radar else None
+        dzi = torch.empty_like(zi) if need_radar else None
+        wcosT, wsinT = ctx.wT
+        check(lib.sar_stft_kernels_bwd_f32(ptr(zr), ptr(zi), B, T, n_fft, hop, ptr(mod.stft.wcos.data), ptr(mod.stft.wsin.data),
+                                           ptr(wcosT), ptr(wsinT), ctx.out_cols, ptr(dout), ptr(ws), nsplit, ptr(dw), ptr(dzr),
+                                           ptr(dzi), stream_ptr()), "sar_stft_kernels_bwd_f32")
+        dloc = dlam = None
+        if need_radar:
+            g = _signal_backward(mod, x, ctx.coef, ctx.P, dzr, dzi)
+            dloc, dlam = g[:3].clone(), g[3].reshape(mod.wavelength.shape)
+        return dloc, dlam, dw[0], dw[1], None, None, None, None, None
+
+
+def _signal_backward(mod, x, coef, P, dzr, dzi):
+    """d loss / d (loc_x, loc_y, loc_z, wavelength) from the signal cotangent (sar_vr_signal*_bwd_f32)"""
+    lib = L.load()
+    B, _, _, V, M = x.shape
+    T = dzr.shape[1]
+    nparts = lib.sar_vr_signal_bwd_nparts(B, T)
+    part = torch.empty((nparts, 4), dtype=torch.float32, device=x.device)
+    if P:
+        check(lib.sar_vr_signal_upsampled_bwd_f32(ptr(coef), B, x.shape[2], P, V, M, ptr(mod._src), ptr(mod._dst), len(mod.src),
+                                                  ptr(mod.radar_location.data), ptr(mod.wavelength.data.reshape(1)), ptr(dzr),
+                                                  ptr(dzi), ptr(part), stream_ptr()), "sar_vr_signal_upsampled_bwd_f32")
+    else:
+        check(lib.sar_vr_signal_bwd_f32(ptr(x), B, T, V, M, ptr(mod._src), ptr(mod._dst), len(mod.src),
+                                        ptr(mod.radar_location.data), ptr(mod.wavelength.data.reshape(1)), ptr(dzr), ptr(dzi),
+                                        ptr(part), stream_ptr()), "sar_vr_signal_bwd_f32")
+    return part.double().sum(0).float()          # fixed-order reduction of the per-block partial sums
+
+
+class _FourierKernels(torch.nn.Module):
+    """nnAudio 0.1.1 STFT(trainable=True)'s parameters: wsin / wcos (n_fft, 1, n_fft), k-th row = window[n] * sin / cos
+    (2 pi k n / n_fft) computed in float64 and stored as float32 (create_fourier_kernels, freq_scale='no', hann)."""
+
+    def __init__(self, n_fft, device):
+        super().__init__()
+        n = np.arange(n_fft, dtype=np.float64)
+        w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
+        ang = 2.0 * np.pi * n[:, None] * n[None, :] / n_fft
+        self.wsin = torch.nn.Parameter(torch.from_numpy((w * np.sin(ang)).astype(np.float32))[:, None, :].contiguous().to(device))
+        self.wcos = torch.nn.Parameter(torch.from_numpy((w * np.cos(ang)).astype(np.float32))[:, None, :].contiguous().to(device))
+        self.n_fft = n_fft
+
+    def transposed(self):
+        """[n][k] copies of the current kernels for the forward kernel's coalesced reads"""
+        N = self.n_fft
+        out = torch.empty((2, N, N), dtype=torch.float32, device=self.wcos.device)
+        for i, w in enumerate((self.wcos, self.wsin)):
+            check(L.load().sar_transpose_f32(ptr(w.data), ptr(out[i]), 1, N, N, stream_ptr()), "sar_transpose_f32")
+        return out[0], out[1]
 
 
 class VirtualRadar(torch.nn.Module):
     def __init__(self, edges=edges, wavelength=1e-3, radar_location=[0., 0., 0.], train_wavelength=False,
                  train_radar_location=False, train_stft_kernel=False, n_fft=256, hop_length=16, device='cuda:0'):
         super().__init__()
-        if train_stft_kernel:
-            raise NotImplementedError("trainable STFT kernels (nnAudio trainable=True) are not built")
         L.load()
+        assert not train_stft_kernel or 16 <= n_fft <= 1024, "trainable STFT kernels are built for 16 <= n_fft <= 1024"
+        self.stft = _FourierKernels(n_fft, device) if train_stft_kernel else None
         # layers/virtual_radar.py:46-52
         self.wavelength = torch.nn.Parameter(torch.as_tensor(wavelength, dtype=torch.float32),
                                              requires_grad=bool(train_wavelength))
@@ -138,16 +211,27 @@ class VirtualRadar(torch.nn.Module):
         num_pad_frames = P > 0: x is the RAW (B,3,T,V,M) clip and the result is what the reference computes from
         utils.Dataset.pad_frames(x) (Gaussian smoothing sigma + cubic interpolation to P*T frames, utils.py:134-140) --
         the up-sampled tensor is never built."""
-        if torch.is_grad_enabled() and (self.radar_location.requires_grad or self.wavelength.requires_grad):
+        radar_grad = self.radar_location.requires_grad or self.wavelength.requires_grad
+        if self.stft is not None:      # nnAudio's trainable kernels: always the matrix product with their current values
+            if torch.is_grad_enabled() and (radar_grad or self.stft.wcos.requires_grad or self.stft.wsin.requires_grad):
+                return _KernelRadarFunction.apply(self.radar_location, self.wavelength, self.stft.wcos, self.stft.wsin, self,
+                                                  x.contiguous(), out_cols, num_pad_frames, sigma)
+            zr, zi = self.signal(x, num_pad_frames, None, sigma)
+            return self._stft(zr, zi, out_cols, self.stft.transposed())
+        if torch.is_grad_enabled() and radar_grad:
             return _RadarFunction.apply(self.radar_location, self.wavelength, self, x.contiguous(), out_cols, num_pad_frames,
                                         sigma)
         zr, zi = self.signal(x, num_pad_frames, None, sigma)
         return self._stft(zr, zi, out_cols)
 
-    def _stft(self, zr, zi, out_cols=0):
+    def _stft(self, zr, zi, out_cols=0, kernels_T=None):
         B, T = zr.shape
         F_ = T // self.hop_length + 1
         out = torch.empty((B, self.n_fft, out_cols if out_cols > 0 else F_), dtype=torch.float32, device=zr.device)
+        if kernels_T is not None:
+            check(L.load().sar_stft_kernels_fwd_f32(ptr(zr), ptr(zi), B, T, self.n_fft, self.hop_length, ptr(kernels_T[0]),
+                                                    ptr(kernels_T[1]), out_cols, ptr(out), stream_ptr()), "sar_stft_kernels_fwd_f32")
+            return out
         check(L.load().sar_stft_logmag_f32(ptr(zr), ptr(zi), B, T, self.n_fft, self.hop_length, ptr(self.window), out_cols,
                                            ptr(out), stream_ptr()), "sar_stft_logmag_f32")
         return out

@@ -103,6 +103,9 @@ SIGNATURES = {
     "sar_vr_signal_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_stft_logmag_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _fp]),
     "sar_stft_logmag_bwd_workspace_floats": (_i64, [_i, _i, _i, _i]),
+    "sar_stft_kernels_fwd_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp]),
+    "sar_stft_kernels_bwd_workspace_floats": (_i64, [_i, _i, _i, _i, _i]),
+    "sar_stft_kernels_bwd_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp]),
     "sar_stft_logmag_bwd_f32": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "sar_vr_signal_bwd_nparts": (_i, [_i, _i]),
     "sar_vr_signal_bwd_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -173,10 +173,86 @@ def test_upsampled_radar_gradient_is_consistent(dev):
     assert (grads[0] - grads[1]).abs().max() <= 1e-4 * grads[1].abs().max()
 
 
-def test_trainable_stft_kernels_are_refused(dev):
+@pytest.mark.parametrize("n_fft,hop", [(64, 8), (256, 16)])
+@pytest.mark.parametrize("variant", ["analytic", "perturbed"])
+def test_trainable_stft_kernels_against_reference_autograd(dev, golden_dir, n_fft, hop, variant):
+    """train_stft_kernel=True (layers/virtual_radar.py:71-76, nnAudio STFT(trainable=True)): output and the gradients of
+    `stft.wsin` / `stft.wcos` / radar_location / wavelength of the HIP path against autograd through the reference's own
+    layer (tests/golden/make_golden_stft_kernels.py).  Truth = the reference run in float64; criterion as for the radar
+    parameters: not further from it than 3x the reference's own float32 run, floor 2e-3 (norm-wise per tensor)."""
     from layers.virtual_radar import VirtualRadar
-    with pytest.raises(NotImplementedError):
-        VirtualRadar(train_stft_kernel=True, device=dev)
+    g = np.load(os.path.join(golden_dir, "stft_kernel_reference_grads.npz"))
+    x = torch.from_numpy(np.load(os.path.join(golden_dir, "radar_reference_grads.npz"))["x"]).to(dev)
+    vr = VirtualRadar(wavelength=0.1, radar_location=[0.5, -1.0, 2.0], train_wavelength=True, train_radar_location=True,
+                      train_stft_kernel=True, n_fft=n_fft, hop_length=hop, device=dev)
+    names = dict(vr.named_parameters())
+    assert set(names) == {"wavelength", "radar_location", "stft.wsin", "stft.wcos"}        # the reference's parameter names
+    assert tuple(names["stft.wsin"].shape) == (n_fft, 1, n_fft)
+    wcos0, wsin0 = R.stft_kernels(n_fft)
+    assert np.array_equal(vr.stft.wcos.detach().cpu().numpy()[:, 0], wcos0) and np.array_equal(
+        vr.stft.wsin.detach().cpu().numpy()[:, 0], wsin0)
+    if variant == "perturbed":
+        rng = np.random.default_rng(100 + n_fft)
+        with torch.no_grad():
+            vr.stft.wsin += torch.from_numpy(0.05 * rng.standard_normal((n_fft, 1, n_fft)).astype(np.float32)).to(dev)
+            vr.stft.wcos += torch.from_numpy(0.05 * rng.standard_normal((n_fft, 1, n_fft)).astype(np.float32)).to(dev)
+    out = vr(x)
+    w = torch.from_numpy(np.random.default_rng(7).standard_normal(tuple(out.shape)).astype(np.float32)).to(dev)
+    (out * w).sum().backward()
+    torch.cuda.synchronize()
+    rows = slice(None) if n_fft == 64 else g["K256"]
+    k32, k64 = "n%d_%s_f32_" % (n_fft, variant), "n%d_%s_f64_" % (n_fft, variant)
+
+    def dist(a, t):
+        return np.abs(np.asarray(a, dtype=np.float64) - t).max() / np.abs(t).max()
+    got = {"out": out.detach().cpu().numpy() if n_fft == 64 else out.detach().cpu().numpy()[:, g["K256"]],
+           "dwsin": vr.stft.wsin.grad.cpu().numpy()[rows, 0], "dwcos": vr.stft.wcos.grad.cpu().numpy()[rows, 0],
+           "dloc": vr.radar_location.grad.cpu().numpy(), "dlam": vr.wavelength.grad.cpu().numpy()}
+    for name, val in got.items():
+        band, err = dist(g[k32 + name], g[k64 + name]), dist(val, g[k64 + name])
+        print("n_fft %d %s %-5s: HIP %.2e from the float64 reference run (reference float32: %.2e)" % (n_fft, variant, name, err, band))
+        assert err <= max(3 * band, 1e-4 if name == "out" else 2e-3), name
+    with torch.no_grad():      # the plain forward uses the CURRENT kernels too
+        assert torch.equal(out.detach(), vr(x))
+
+
+def test_trainable_stft_kernels_properties(dev):
+    """(a) with the analytic kernels the matrix-product path reproduces the closed-form STFT path; (b) the kernel gradient is
+    the same with and without gradients for the radar parameters, with the fused column select it equals the gradient of the
+    explicit column gather, and it repeats bit for bit; (c) one Adam step on the kernels changes the output."""
+    from layers.virtual_radar import VirtualRadar
+    x = torch.from_numpy(np.clip(0.12 * np.random.default_rng(3).standard_normal((3, 3, 300, 25, 2)), -1.1, 0.75).astype(np.float32)).to(dev)
+    plain = VirtualRadar(wavelength=1e-2, radar_location=[0.2, 0.1, -1.0], device=dev)
+    vr = VirtualRadar(wavelength=1e-2, radar_location=[0.2, 0.1, -1.0], train_stft_kernel=True, device=dev)
+    a, b = plain(x), vr(x)
+    ma, mb = torch.exp(a) - 1e-6, torch.exp(b) - 1e-6
+    assert ((ma - mb).abs().max() / ma.max()).item() < 2e-5
+    w = torch.randn(b.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    (b * w).sum().backward()
+    g1 = (vr.stft.wcos.grad.clone(), vr.stft.wsin.grad.clone())
+    vr.zero_grad()
+    (vr(x) * w).sum().backward()
+    assert torch.equal(g1[0], vr.stft.wcos.grad) and torch.equal(g1[1], vr.stft.wsin.grad)
+    both = VirtualRadar(wavelength=1e-2, radar_location=[0.2, 0.1, -1.0], train_stft_kernel=True, train_wavelength=True,
+                        train_radar_location=True, device=dev)
+    (both(x) * w).sum().backward()
+    assert torch.equal(g1[0], both.stft.wcos.grad) and torch.equal(g1[1], both.stft.wsin.grad)
+    assert torch.isfinite(both.radar_location.grad).all() and both.wavelength.grad.abs() > 0
+    # fused column select (models/resnet.py:26): same as gathering the columns of the full spectrogram
+    cols = torch.from_numpy(R.nearest_columns(b.shape[2], 40).astype(np.int64)).to(dev)
+    w40 = torch.randn((3, 256, 40), generator=torch.Generator().manual_seed(2)).to(dev)
+    vr.zero_grad()
+    sel = vr(x, out_cols=40)
+    assert torch.equal(sel, b.detach()[:, :, cols])
+    (sel * w40).sum().backward()
+    gs = vr.stft.wcos.grad.clone()
+    vr.zero_grad()
+    wfull = torch.zeros_like(b).index_add_(2, cols, w40)
+    (vr(x) * wfull).sum().backward()
+    assert (gs - vr.stft.wcos.grad).abs().max() <= 1e-5 * gs.abs().max()
+    opt = torch.optim.Adam(vr.stft.parameters(), lr=1e-3)
+    opt.step()
+    assert not torch.equal(vr(x), b.detach())
 
 
 @pytest.mark.parametrize("lam,loc", [(1e-1, [0.5, -1.0, 2.0]), (1e-2, [0.3, 0.2, -1.5]), (5e-4, [0., 0., 0.])])

@@ -115,6 +115,39 @@ def test_parameter_gradients_match_the_reference_autograd(golden_dir, lam, loc):
     assert g["ntu_dloc_is_nan"].all()     # the reference's own gradient is NaN on clips with an absent body / zero padding
 
 
+@pytest.mark.parametrize("n_fft,hop", [(64, 8), (256, 16)])
+@pytest.mark.parametrize("variant", ["analytic", "perturbed"])
+def test_trainable_stft_kernel_gradients_match_the_reference_autograd(golden_dir, n_fft, hop, variant):
+    """train_stft_kernel=True (layers/virtual_radar.py:71-76): output and d sum(out*w) / d(wsin, wcos, radar_location,
+    wavelength) of the float64 restatement with the Fourier kernels as leaves, against autograd through the reference's
+    own layer run in float64 with nnAudio's trainable kernels (tests/golden/make_golden_stft_kernels.py) -- at the analytic
+    kernels and at a perturbed pair."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "stft_kernel_reference_grads.npz"))
+    x = np.load(os.path.join(golden_dir, "radar_reference_grads.npz"))["x"]
+    wcos32, wsin32 = R.stft_kernels(n_fft)
+    if variant == "perturbed":
+        rng = np.random.default_rng(100 + n_fft)
+        wsin32 = wsin32 + 0.05 * rng.standard_normal((n_fft, 1, n_fft)).astype(np.float32)[:, 0]
+        wcos32 = wcos32 + 0.05 * rng.standard_normal((n_fft, 1, n_fft)).astype(np.float32)[:, 0]
+    wcos = torch.tensor(wcos32.astype(np.float64), requires_grad=True)
+    wsin = torch.tensor(wsin32.astype(np.float64), requires_grad=True)
+    loc = torch.tensor(np.asarray([0.5, -1.0, 2.0], dtype=np.float32).astype(np.float64), requires_grad=True)
+    lam = torch.tensor(float(np.float32(0.1)), dtype=torch.float64, requires_grad=True)
+    out = R.spectrogram_torch(x, loc, lam, n_fft=n_fft, hop=hop, wcos=wcos, wsin=wsin)
+    w = torch.from_numpy(np.random.default_rng(7).standard_normal(tuple(out.shape)).astype(np.float32)).double()
+    (out * w).sum().backward()
+    key = "n%d_%s_f64_" % (n_fft, variant)
+    rows = slice(None) if n_fft == 64 else g["K256"]
+    ref_out = g[key + "out"]
+    got_out = out.detach().numpy() if n_fft == 64 else out.detach().numpy()[:, g["K256"]]
+    assert np.abs(got_out - ref_out).max() <= 1e-6 * np.abs(ref_out).max()
+    for name, got in (("dwsin", wsin.grad.numpy()[rows]), ("dwcos", wcos.grad.numpy()[rows]), ("dloc", loc.grad.numpy()),
+                      ("dlam", lam.grad.numpy())):
+        ref = g[key + name]
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), name
+
+
 def test_pad_frames_restatement_equals_the_reference(golden_dir):
     """utils.py:134-140 (Gaussian smoothing + cubic up-sampling x250): the oracle's scipy calls against the reference's
     own Dataset.pad_frames output at ~1 000 of the 75 000 frames (tests/golden/make_golden_upsample.py)."""
