@@ -307,9 +307,16 @@ int sar_vr_signal_upsampled_bwd_f32(const double* coef, int B, int T, int P, int
  *   resolution, src = gradient at its output resolution).  Supported: 3x3 and 1x1, stride 1|2; the 7x7/2 stem
  *   (1 input channel, models/resnet18.py:159-164) forward.  W is the repacked weight: element (tap=kh*KW+kw, c, m)
  *   at tap*w_stride_tap + c*w_stride_c + m.  pro / epi / aux / partials as in sar_conv_gemm_f32.
+ *   The data gradient of a 3x3 / stride 2 / pad 1 layer whose input is exactly twice its output (every stride-2 layer of
+ *   resnet18) runs as four parity-class launches (output pixels (y&1, x&1) use 1, 2, 2, 4 of the 9 taps): 9 tap products per
+ *   4 pixels instead of 36.  flags & SAR_C2D_AUX_EVEN_PIXELS (that geometry, epi = ADD): aux is a COMPACT tensor
+ *   [M][B*H_src*W_src] added to the output pixels (2i, 2j) only -- the data gradient of the block's parallel 1x1 / stride 2
+ *   down-sampling convolution (models/resnet18.py:92-100), which is non-zero exactly there and is computed at the small
+ *   resolution by an ordinary stride-1 call.
  * sar_conv2d_wgrad_f32: dW[tap][c][m] = sum_n dout[m,n] * OP_tap(pro(src))[c,n] as per-split slabs laid out
  *   (tap, c, m) with m contiguous: slab[split][taps*Kc*M]; reduce with sar_slab_reduce_f32.
  * ------------------------------------------------------------------------------------------------ */
+#define SAR_C2D_AUX_EVEN_PIXELS 1
 typedef struct sar_conv2d_desc {
   int32_t transposed;
   int32_t B, Kc, M;
@@ -317,7 +324,7 @@ typedef struct sar_conv2d_desc {
   int32_t KH, KW, stride, pad;
   int32_t pro_relu, epi;
   int32_t nsplit;          /* wgrad only */
-  int32_t reserved;
+  int32_t flags;           /* SAR_C2D_* bits, 0 = none */
   const float* src; int64_t ld_src;
   float* out; int64_t ld_out;                        /* gemm: output activations; wgrad: unused */
   const float* dout; int64_t ld_dout;                /* wgrad only */

@@ -12,6 +12,9 @@ from . import profiler
 from ._lib import ConvDesc, WgradDesc, check, ptr, stream_ptr
 
 
+_PROFILE_SHAPES = __import__("os").environ.get("SAR_PROFILE_SHAPES", "0") == "1"
+
+
 def _f32(t):
     assert t is None or (t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()), "need contiguous cuda float32"
     return t
@@ -359,6 +362,13 @@ def gin_eps_grad(G, W, eps, deps):
 
 
 # ------------------------------------------------------------------------------------------------ ResNet-18 ops
+def _shape_tag(geo):
+    """SAR_PROFILE_SHAPES=1 (diagnostic, tools/pathb_layers.py): one profiler bucket per layer geometry"""
+    if not _PROFILE_SHAPES:
+        return ""
+    return " Kc%d M%d %dx%d->%dx%d s%d" % (geo["Kc"], geo["M"], geo["H_src"], geo["W_src"], geo["H_out"], geo["W_out"], geo["stride"])
+
+
 def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, pad, transposed=False, pro=None,
                  pro_relu=False):
     d = L.Conv2dDesc()
@@ -372,10 +382,12 @@ def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, p
 
 
 def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, aux=None, aux_affine=None, aux_mean=None,
-                **geo):
-    """sar_conv2d_gemm_f32.  Returns (partials, nparts) when the epilogue reduces."""
+                aux_even_pixels=False, **geo):
+    """sar_conv2d_gemm_f32.  Returns (partials, nparts) when the epilogue reduces.  aux_even_pixels: SAR_C2D_AUX_EVEN_PIXELS
+    (aux is the compact data gradient of the parallel 1x1 / stride 2 convolution, added at the even pixels only)."""
     lib = L.load()
     d = _conv2d_desc(src, **geo)
+    d.flags = L.SAR_C2D_AUX_EVEN_PIXELS if aux_even_pixels else 0
     d.out, d.ld_out = ptr(_f32(out)), out.stride(0)
     d.W, d.w_stride_tap, d.w_stride_c, d.epi = ptr(_f32(W)), w_stride_tap, w_stride_c, epi
     if aux is not None:
@@ -393,7 +405,7 @@ def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, au
         d.partials = ptr(partials)
     n_conv = geo["B"] * (geo["H_src"] * geo["W_src"] if geo.get("transposed") else geo["H_out"] * geo["W_out"])
     flops = 2.0 * geo["M"] * geo["Kc"] * geo["KH"] * geo["KW"] * n_conv
-    with profiler.region("conv2d_%dx%d%s" % (geo["KH"], geo["KW"], "_dgrad" if geo.get("transposed") else ""), flops):
+    with profiler.region("conv2d_%dx%d%s" % (geo["KH"], geo["KW"], "_dgrad" if geo.get("transposed") else "") + _shape_tag(geo), flops):
         check(lib.sar_conv2d_gemm_f32(C.byref(d), stream_ptr()), "sar_conv2d_gemm_f32")
     return (partials, nparts) if partials is not None else None
 
@@ -411,7 +423,7 @@ def conv2d_wgrad(src, dout, dW_tcm, **geo):
     slab = torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
     d.slab = ptr(slab)
     flops = 2.0 * geo["M"] * geo["Kc"] * taps * geo["B"] * geo["H_out"] * geo["W_out"]
-    with profiler.region("conv2d_wgrad_%dx%d" % (geo["KH"], geo["KW"]), flops):
+    with profiler.region("conv2d_wgrad_%dx%d" % (geo["KH"], geo["KW"]) + _shape_tag(geo), flops):
         check(lib.sar_conv2d_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv2d_wgrad_f32")
     check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")
 

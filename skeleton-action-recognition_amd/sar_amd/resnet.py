@@ -297,11 +297,20 @@ class ResNet18:
             self._bn_bwd(pre + "bn1", pm[0], pm[1], pm[1] * 2, 2, 1, n_out)
             ops.affine2(dz1, c1, (b1.k1, b1.k2, b1.k3), dz1)            # dc1 in place
             self._conv_wgrad(pre + "conv1", X, dz1, B, H, W, Ho, Wo)
-            aux = dY
+            aux, even = dY, False
             if ds:
                 self._conv_wgrad(pre + "downsample.0", X, ddsc, B, H, W, Ho, Wo)
-                aux, _ = self._conv_dgrad(pre + "downsample.0", ddsc, B, H, W, Ho, Wo)
-            dY, _ = self._conv_dgrad(pre + "conv1", dz1, B, H, W, Ho, Wo, epi=L.SAR_EPI_ADD, aux=aux)
+                cd = self.convs[pre + "downsample.0"]
+                if cd.k == 1 and cd.stride == 2 and cd.pad == 0 and stride == 2 and H == 2 * Ho and W == 2 * Wo:
+                    # the 1x1 / stride 2 data gradient is non-zero at the even pixels only: computed at the small resolution
+                    # (a plain stride-1 product) and added there by the parity-class launches of conv1's data gradient
+                    aux = torch.empty((cd.cin, B * Ho * Wo), dtype=torch.float32, device=dev)
+                    ops.conv2d_gemm(ddsc, aux, self._w(pre + "downsample.0", True), cd.cout * cd.cin, cd.cin, B=B, Kc=cd.cout,
+                                    M=cd.cin, H_src=Ho, W_src=Wo, H_out=Ho, W_out=Wo, KH=1, KW=1, stride=1, pad=0, transposed=True)
+                    even = True
+                else:
+                    aux, _ = self._conv_dgrad(pre + "downsample.0", ddsc, B, H, W, Ho, Wo)
+            dY, _ = self._conv_dgrad(pre + "conv1", dz1, B, H, W, Ho, Wo, epi=L.SAR_EPI_ADD, aux=aux, aux_even_pixels=even)
         # stem: maxpool + relu + bn backward, then the 7x7 weight gradient (the image needs no gradient)
         bn0 = self.bn["bn1"]
         c0 = sv["c0"]

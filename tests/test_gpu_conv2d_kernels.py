@@ -73,6 +73,51 @@ def test_conv2d_forward_dgrad_wgrad(cin, cout, k, s, H):
         assert rel_err(uncn(dx.cpu() - add, B, H, H), gh) < TOL
 
 
+@pytest.mark.parametrize("cin,cout,H", [(64, 128, 64), (256, 512, 16), (16, 32, 12), (8, 16, 15)])
+def test_stride2_data_gradient_parity_classes(cin, cout, H):
+    """3x3 / stride 2 / pad 1 data gradient: the parity-class launches (H even; H = 15 takes the masked kernel) with (a) the
+    ReLU-mask epilogue + BatchNorm partial sums spread over the four launches, (b) SAR_C2D_AUX_EVEN_PIXELS: the compact data
+    gradient of the parallel 1x1 / stride 2 convolution (models/resnet18.py:92-100) added at the even pixels."""
+    from sar_amd import ops, _lib as L
+    dev = torch.device("cuda:0")
+    B, k, s, pad = 3, 3, 2, 1
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(B, cin, H, H, generator=g).double().requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).double()
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    Ho = y.shape[2]
+    dy = torch.randn(y.shape, generator=g)
+    gx, = torch.autograd.grad(y, x, dy.double())
+    wb = torch.empty(9 * cin * cout, device=dev)
+    ops.permute3(w.float().to(dev).contiguous(), wb, 9, cout, cin, 1, cin * 9, 9)
+    dyd = cn(dy).to(dev)
+    geo = dict(B=B, Kc=cout, M=cin, H_src=Ho, W_src=Ho, H_out=H, W_out=H, KH=3, KW=3, stride=2, pad=1, transposed=True)
+    # (a) MASK: dz = dx where relu'(aux * sc + sh); partials = (sum dz, sum dz (aux - mean))
+    aux = torch.randn(cin, B * H * H, generator=g)
+    sc, sh, mu = 1 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
+    dx = torch.empty((cin, B * H * H), device=dev)
+    r = ops.conv2d_gemm(dyd, dx, wb, cout * cin, cin, epi=L.SAR_EPI_MASK, aux=aux.to(dev), aux_affine=(sc.to(dev), sh.to(dev)),
+                        aux_mean=mu.to(dev), **geo)
+    torch.cuda.synchronize()
+    mask = (aux.double() * sc.double()[:, None] + sh.double()[:, None]) > 0
+    ref = cn(gx) * mask
+    assert rel_err(dx.cpu(), ref) < TOL
+    part = r[0].cpu().double().sum(1)
+    assert rel_err(part[:, 0], ref.sum(1)) < 1e-4 and rel_err(part[:, 1], (ref * (aux.double() - mu.double()[:, None])).sum(1)) < 1e-4
+    # (b) compact aux at the even pixels
+    if H % 2 == 0:
+        small = torch.randn(cin, B * Ho * Ho, generator=g)
+        dx2 = torch.empty((cin, B * H * H), device=dev)
+        ops.conv2d_gemm(dyd, dx2, wb, cout * cin, cin, epi=L.SAR_EPI_ADD, aux=small.to(dev), aux_even_pixels=True, **geo)
+        torch.cuda.synchronize()
+        full = torch.zeros(B, cin, H, H, dtype=torch.float64)
+        full[:, :, ::2, ::2] = uncn(small.double(), B, Ho, Ho)
+        assert rel_err(uncn(dx2.cpu(), B, H, H), gx + full) < TOL
+    else:
+        with pytest.raises(L.SarError):
+            ops.conv2d_gemm(dyd, dx, wb, cout * cin, cin, epi=L.SAR_EPI_ADD, aux=aux.to(dev), aux_even_pixels=True, **geo)
+
+
 def test_stem_tail_maxpool_forward_backward():
     from sar_amd import ops
     dev = torch.device("cuda:0")
