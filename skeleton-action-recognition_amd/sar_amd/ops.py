@@ -223,9 +223,12 @@ def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y):
                                            u.shape[0], u.shape[1], u.stride(0), stream_ptr()), "sar_bn_add_relu_fwd_f32")
 
 
+_REDUCE_CHUNK = int(__import__("os").environ.get("SAR_BWD_REDUCE_CHUNK", "8192"))      # row elements per workgroup of the BN-backward reductions
+
+
 def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None):
     Cc, n = u.shape
-    nparts = max(1, min(256, (n + 8191) // 8192))
+    nparts = max(1, min(4096, (n + _REDUCE_CHUNK - 1) // _REDUCE_CHUNK))
     partials = torch.empty((Cc, nparts, 4), dtype=torch.float32, device=u.device)
     check(L.load().sar_bn_add_relu_bwd_reduce_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(mu), ptr(mr), ptr(partials), nparts, Cc, n,
                                                   u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_reduce_f32")

@@ -123,9 +123,12 @@ def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, channels):
                                            channels, u.shape[1], u.shape[1], stream_ptr()), "sar_bn_add_relu_fwd_cn8")
 
 
+_REDUCE_CHUNK = int(__import__("os").environ.get("SAR_BWD_REDUCE_CHUNK8", "8192"))     # units per workgroup of the BN-backward reduction
+
+
 def bn_add_relu_bwd_reduce(dy, y, u, r, channels, mu=None, mr=None):
     n = u.shape[1]
-    nparts = max(1, min(256, (n + 8191) // 8192))
+    nparts = max(1, min(4096, (n + _REDUCE_CHUNK - 1) // _REDUCE_CHUNK))
     partials = torch.empty((channels, nparts, 4), dtype=torch.float32, device=u.device)
     check(L.load().sar_bn_add_relu_bwd_reduce_cn8(ptr(_cn8(dy)), ptr(_cn8(y)), ptr(_cn8(u)), ptr(_cn8(r)), ptr(mu), ptr(mr),
                                                   ptr(partials), nparts, channels, n, n, stream_ptr()),
