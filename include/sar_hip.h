@@ -396,7 +396,13 @@ int sar_graph_dense_dadj_f32(const float* y, int64_t ld_y, const float* dout, in
  * fp32 CN layout; the K branch MLPs of a layer are stacked along the channel axis (row k*C + c).
  *   sar_gin_adjacency_f32   table[k][a][b] = A[k][b][a] (k < Km1), table[Km1] = (1 + eps[0]) I  -- models/gcn.py:150-153
  *                           A_ = concat(A, diag(1 + epsilon)), transposed for sar_graph_dense_bwd_data_f32 (x . A_k) and
- *                           sar_graph_dense_fwd_f32 (its gradient);  scale[0:C] = 1 + eps[0] (the prologue of the self slice)
+ *                           sar_graph_dense_fwd_f32 (its gradient);  scale[0:C] = 1 + eps[0] (the prologue of the self slice);
+ *                           slice_scale[0:Km1+1] = (1, .., 1, 1 + eps[0]) when != NULL; table may be NULL
+ *   sar_graph_gather_*_f32  the same contractions for a FIXED sparse adjacency given as gather lists (idx / wt [K][V][4],
+ *                           sar_amd/graph_tables.py -- what the ST-GCN kernels fold into their operand loads):
+ *                           expand: out[k*F + m, (t,v)] = sum_j wt[k][v][j] * in[m, (t, idx[k][v][j])]
+ *                           sum:    out[m, (t,w)] = sum_k scale[k] * sum_j wt[k][w][j] * in[k*F + m, (t, idx[k][w][j])] (+ add)
+ *                           n = frames * V columns; HBM-bound (every tensor moved once)
  *   sar_gin_sum_fwd_f32     s[c, n] = sum_k relu(a[k*C + c, n] * scale[k*C + c] + shift[k*C + c])  -- the last BN + ReLU of
  *                           every branch and tf.reduce_sum (models/gcn.py:139-142,160); partials[C][nparts][2] = (sum s,
  *                           sum s^2) per workgroup for the BatchNorm that follows (models/stgin.py:28), nparts = sar_gin_nparts(n)
@@ -406,7 +412,8 @@ int sar_graph_dense_dadj_f32(const float* y, int64_t ld_y, const float* dout, in
  *                           taken on the un-scaled x), deps[0] = <G, W> and G *= (1 + eps[0]) in place
  * ------------------------------------------------------------------------------------------------ */
 int sar_gin_nparts(int64_t n);
-int sar_gin_adjacency_f32(const float* A, int Km1, int V, const float* eps, float* table, float* scale, int C, sar_stream_t s);
+int sar_gin_adjacency_f32(const float* A, int Km1, int V, const float* eps, float* table, float* scale, int C, float* slice_scale,
+                          sar_stream_t s);
 int sar_gin_sum_fwd_f32(const float* a, int64_t ld_a, const float* scale, const float* shift, int K, int C, int64_t n, float* s_out,
                         int64_t ld_s, float* partials, sar_stream_t s);
 int sar_gin_bwd_reduce_f32(const float* ds, int64_t ld_ds, const float* a, int64_t ld_a, const float* scale, const float* shift,
@@ -415,6 +422,10 @@ int sar_gin_bwd_apply_f32(const float* ds, int64_t ld_ds, const float* a, int64_
                           const float* k1, const float* k2, const float* k3, int K, int C, int64_t n, float* da, int64_t ld_da,
                           sar_stream_t s);
 int sar_gin_eps_grad_f32(float* G, const float* W, int64_t n, const float* eps, float* deps, sar_stream_t s);
+int sar_graph_gather_sum_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const float* scale, int K, int F,
+                             int V, int64_t n, float* out, int64_t ld_out, const float* add, int64_t ld_add, sar_stream_t s);
+int sar_graph_gather_expand_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, int K, int F, int V, int64_t n,
+                                float* out, int64_t ld_out, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 configuration (bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation, fp32

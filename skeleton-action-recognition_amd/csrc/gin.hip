@@ -129,13 +129,15 @@ __global__ __launch_bounds__(TPB) void gin_bwd_kernel(const float* __restrict__ 
 
 // table[k][a][b] = A[k][b][a] (k < K-1), table[K-1] = (1 + eps) I;  scale[c] = 1 + eps
 __global__ void gin_adjacency_kernel(const float* __restrict__ A, int Km1, int V, const float* __restrict__ eps, float* table,
-                                     float* scale, int C) {
+                                     float* scale, int C, float* slice_scale) {
   const float e = 1.f + eps[0];
+  if (slice_scale && blockIdx.x == 0 && (int)threadIdx.x <= Km1) slice_scale[threadIdx.x] = (int)threadIdx.x < Km1 ? 1.f : e;
   const int VV = V * V, total = (Km1 + 1) * VV;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int k = i / VV, rem = i - k * VV, r = rem / V, col = rem - r * V;
-    table[i] = (k < Km1) ? A[k * VV + col * V + r] : (r == col ? e : 0.f);
-  }
+  if (table)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const int k = i / VV, rem = i - k * VV, r = rem / V, col = rem - r * V;
+      table[i] = (k < Km1) ? A[k * VV + col * V + r] : (r == col ? e : 0.f);
+    }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) scale[i] = e;
 }
 
@@ -157,6 +159,51 @@ __global__ __launch_bounds__(1024) void gin_eps_grad_kernel(float* G, const floa
     double t = 0.0;
     for (int w = 0; w < 16; ++w) t += red[w];
     deps[0] = (float)t;
+  }
+}
+
+// Frame-local weighted gathers for a FIXED sparse adjacency (<= 4 entries per joint: sar_amd/graph_tables.py), the form the
+// ST-GCN kernels fold into their operand loads, as stand-alone HBM-bound passes for the graph isomorphism convolution:
+//   MODE 0 (sum):    out[m, (t,w)] = sum_k scale[k] sum_j wt[k][w][j] in[k F + m, (t, idx[k][w][j])]  (+ add[m, (t,w)])
+//   MODE 1 (expand): out[k F + m, (t,v)] = sum_j wt[k][v][j] in[m, (t, idx[k][v][j])]
+// One thread per (row m, column); the K V 4 table entries sit in LDS; neighbours of a joint lie in the same frame (<= 128 B
+// away), so the gathers are cache hits and the pass moves each tensor once.
+constexpr int GG_KMAX = 8, GG_VMAX = 32, GG_NZ = 4;
+template <int MODE>
+__global__ __launch_bounds__(TPB) void graph_gather_kernel(const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ wt, const float* __restrict__ scale, int K,
+                                                           int F, int V, int64_t n, float* __restrict__ out, int64_t ld_out,
+                                                           const float* __restrict__ add, int64_t ld_add) {
+  __shared__ int sidx[GG_KMAX * GG_VMAX * GG_NZ];
+  __shared__ float swt[GG_KMAX * GG_VMAX * GG_NZ];
+  for (int i = threadIdx.x; i < K * V * GG_NZ; i += TPB) {
+    sidx[i] = idx[i];
+    swt[i] = wt[i] * (scale ? scale[i / (V * GG_NZ)] : 1.f);
+  }
+  __syncthreads();
+  const int m = blockIdx.y;
+  for (int64_t col = (int64_t)blockIdx.x * TPB + threadIdx.x; col < n; col += (int64_t)gridDim.x * TPB) {
+    const int w = (int)(col % V);
+    const int64_t fb = col - w;
+    if (MODE == 0) {
+      float acc = add ? add[(int64_t)m * ld_add + col] : 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float* row = in + (int64_t)(k * F + m) * ld_in + fb;
+        const int e = (k * V + w) * GG_NZ;
+#pragma unroll
+        for (int j = 0; j < GG_NZ; ++j) acc = fmaf(swt[e + j], row[sidx[e + j]], acc);
+      }
+      out[(int64_t)m * ld_out + col] = acc;
+    } else {
+      const float* row = in + (int64_t)m * ld_in + fb;
+      for (int k = 0; k < K; ++k) {
+        const int e = (k * V + w) * GG_NZ;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < GG_NZ; ++j) acc = fmaf(swt[e + j], row[sidx[e + j]], acc);
+        out[(int64_t)(k * F + m) * ld_out + col] = acc;
+      }
+    }
   }
 }
 
@@ -214,10 +261,10 @@ extern "C" int sar_gin_bwd_apply_f32(const float* ds, int64_t ld_ds, const float
 }
 
 extern "C" int sar_gin_adjacency_f32(const float* A, int Km1, int V, const float* eps, float* table, float* scale, int C,
-                                     sar_stream_t st_) {
-  SAR_REQUIRE((A || Km1 == 0) && Km1 >= 0 && Km1 < 8 && V > 0 && V <= 32 && eps && table && (scale || C == 0) && C >= 0,
+                                     float* slice_scale, sar_stream_t st_) {
+  SAR_REQUIRE((A || Km1 == 0 || !table) && Km1 >= 0 && Km1 < 8 && V > 0 && V <= 32 && eps && (scale || C == 0) && C >= 0,
               "sar_gin_adjacency: bad arguments");
-  hipLaunchKernelGGL(gin_adjacency_kernel, dim3(8), dim3(256), 0, as_stream(st_), A, Km1, V, eps, table, scale, C);
+  hipLaunchKernelGGL(gin_adjacency_kernel, dim3(8), dim3(256), 0, as_stream(st_), A, Km1, V, eps, table, scale, C, slice_scale);
   SAR_LAUNCH_CHECK("sar_gin_adjacency_f32");
   return 0;
 }
@@ -226,5 +273,33 @@ extern "C" int sar_gin_eps_grad_f32(float* G, const float* W, int64_t n, const f
   SAR_REQUIRE(G && W && n > 0 && eps && deps, "sar_gin_eps_grad: bad arguments");
   hipLaunchKernelGGL(gin_eps_grad_kernel, dim3(1), dim3(1024), 0, as_stream(st_), G, W, n, eps, deps);
   SAR_LAUNCH_CHECK("sar_gin_eps_grad_f32");
+  return 0;
+}
+
+static int gg_check(const char* who, const float* in, const int32_t* idx, const float* wt, float* out, int K, int F, int V, int64_t n,
+                    int64_t ld_in, int64_t ld_out) {
+  SAR_REQUIRE(in && idx && wt && out && K > 0 && K <= GG_KMAX && F > 0 && F <= 65535 && V > 0 && V <= GG_VMAX && n > 0 && n % V == 0 &&
+                  ld_in >= n && ld_out >= n,
+              "%s: bad arguments (K <= %d, V <= %d, whole frames)", who, GG_KMAX, GG_VMAX);
+  return 0;
+}
+
+extern "C" int sar_graph_gather_sum_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const float* scale, int K,
+                                        int F, int V, int64_t n, float* out, int64_t ld_out, const float* add, int64_t ld_add,
+                                        sar_stream_t st_) {
+  if (int rc = gg_check("sar_graph_gather_sum", in, idx, wt, out, K, F, V, n, ld_in, ld_out)) return rc;
+  SAR_REQUIRE(!add || ld_add >= n, "sar_graph_gather_sum: bad add");
+  hipLaunchKernelGGL(graph_gather_kernel<0>, dim3(row_blocks(n, 1), F), dim3(TPB), 0, as_stream(st_), in, ld_in, idx, wt, scale, K, F, V,
+                     n, out, ld_out, add, ld_add);
+  SAR_LAUNCH_CHECK("sar_graph_gather_sum_f32");
+  return 0;
+}
+
+extern "C" int sar_graph_gather_expand_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, int K, int F, int V,
+                                           int64_t n, float* out, int64_t ld_out, sar_stream_t st_) {
+  if (int rc = gg_check("sar_graph_gather_expand", in, idx, wt, out, K, F, V, n, ld_in, ld_out)) return rc;
+  hipLaunchKernelGGL(graph_gather_kernel<1>, dim3(row_blocks(n, 1), F), dim3(TPB), 0, as_stream(st_), in, ld_in, idx, wt,
+                     (const float*)nullptr, K, F, V, n, out, ld_out, (const float*)nullptr, (int64_t)0);
+  SAR_LAUNCH_CHECK("sar_graph_gather_expand_f32");
   return 0;
 }

@@ -326,10 +326,27 @@ def conv_gemm_nparts(B, V, T_src, T_out, Kc, M, taps=1, stride=1, pad=0, transpo
     return n
 
 
-def gin_adjacency(A, eps, table, scale):
-    Km1, V = (A.shape[0], A.shape[1]) if A is not None else (0, table.shape[1])
+def gin_adjacency(A, eps, table, scale, slice_scale=None, Km1=None, V=None):
+    """table [Km1+1][V][V] (or None), scale[C] = 1 + eps, slice_scale[Km1+1] = (1, .., 1, 1 + eps) (or None)"""
+    if A is not None:
+        Km1, V = A.shape[0], A.shape[1]
     check(L.load().sar_gin_adjacency_f32(ptr(_f32(A)), Km1, V, ptr(_f32(eps)), ptr(_f32(table)), ptr(_f32(scale)), scale.numel(),
-                                         stream_ptr()), "sar_gin_adjacency_f32")
+                                         ptr(_f32(slice_scale)), stream_ptr()), "sar_gin_adjacency_f32")
+
+
+def graph_gather_sum(inp, tables, scale, K, F, V, out, add=None, k0=0):
+    """out[m] = sum_k scale[k] (in[k F + m] gathered with slice k0 + k of `tables`) (+ add[m])"""
+    n = out.shape[1]
+    check(L.load().sar_graph_gather_sum_f32(ptr(_f32(inp)), inp.stride(0), ptr(tables.idx[k0:]), ptr(tables.wt[k0:]), ptr(_f32(scale)),
+                                            K, F, V, n, ptr(_f32(out)), out.stride(0), ptr(_f32(add)),
+                                            add.stride(0) if add is not None else 0, stream_ptr()), "sar_graph_gather_sum_f32")
+
+
+def graph_gather_expand(inp, tables, K, F, V, out, k0=0):
+    """out[k F + m] = in[m] gathered with slice k0 + k of `tables`"""
+    n = inp.shape[1]
+    check(L.load().sar_graph_gather_expand_f32(ptr(_f32(inp)), inp.stride(0), ptr(tables.idx[k0:]), ptr(tables.wt[k0:]), K, F, V, n,
+                                               ptr(_f32(out)), out.stride(0), stream_ptr()), "sar_graph_gather_expand_f32")
 
 
 def gin_sum_fwd(a, scale, shift, K, s_out, stats=False):

@@ -3,9 +3,10 @@ convolution -- models/stgin.py:11-140, GraphIsoConvTD models/gcn.py:112-163 -- o
 gradient buffers and train step as sar_amd/stgcn.py (main_gnn.py:219-239 is model-agnostic: `--model stgin`).
 
 Per block (models/stgin.py:58-66):
-    x' = einsum('nctv,kvw->nkctw', x, concat(A[:2], diag(1 + epsilon)))           sar_graph_dense_bwd_data_f32 with the table of
-                                                                                  sar_gin_adjacency_f32 (slices 0, 1); the self
-                                                                                  slice reads x with the prologue scale 1 + eps
+    x' = einsum('nctv,kvw->nkctw', x, concat(A[:2], diag(1 + epsilon)))           <= 4-entry gathers (sar_graph_gather_expand_f32)
+                                                                                  for the fixed sparse A; identity slices and the
+                                                                                  self slice read x itself (prologue scale 1 + eps);
+                                                                                  dense A: sar_graph_dense_bwd_data_f32
     per slice k:  Conv2D(h,1x1) -> BN -> ReLU -> Conv2D(h,1x1) -> BN -> ReLU      sar_conv_gemm_f32 (taps = 1, BN statistics in
                                                                                   the epilogue, BN + ReLU folded into the next
                                                                                   convolution's operand load), h = filters / 2
@@ -40,6 +41,17 @@ class STGIN(STGCN):
         assert A.shape == (KS - 1, num_node, num_node)
         self.A_host = A.astype(np.float32)
         self.A = torch.from_numpy(self.A_host).to(self.device).contiguous()    # 'adjacency_matrix', non-trainable
+        # The adjacency is fixed, so the contractions x . A_k run as <= 4-entry gathers (sar_graph_gather_*_f32) when every
+        # column / row of [A_0, .., diag(1)] has <= 4 non-zeros (the NTU graph); a slice that IS the identity (slice 0 of the
+        # 'spatial' strategy) is not materialised at all.  Denser adjacencies take the dense kernels (csrc/graph_dense.hip).
+        a_ext = np.concatenate([self.A_host, np.eye(num_node, dtype=np.float32)[None]])
+        try:
+            self.tab_f = ops.GraphTables(a_ext, self.device, transpose=False)
+            self.tab_b = ops.GraphTables(a_ext, self.device, transpose=True)
+            self.identity_slice = [bool(np.array_equal(self.A_host[k], np.eye(num_node, dtype=np.float32))) for k in range(KS - 1)]
+        except ValueError:
+            self.tab_f = self.tab_b = None
+            self.identity_slice = [False] * (KS - 1)
         self._side = (torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SAR_WGRAD_PRIO", "0")))
                       if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1" else None)
         self.motion = bool(motion)
@@ -163,12 +175,23 @@ class STGIN(STGCN):
         epi = L.SAR_EPI_STATS if training else L.SAR_EPI_NONE
         new = lambda rows, n: torch.empty((rows, n), dtype=torch.float32, device=dev)
         # ---- sgcn: GraphIsoConvTD (models/gcn.py:149-163)
-        table = torch.empty((K, V, V), dtype=torch.float32, device=dev)      # [A_0^T, A_1^T, (1 + eps) I]
         escale = torch.empty(cin, dtype=torch.float32, device=dev)           # 1 + eps per input channel
-        ops.gin_adjacency(self.A, self.p[pre + "epsilon"], table, escale)
-        z = new((K - 1) * cin, n_in)                                          # z[k cin + c] = x[c] . A_k
-        ops.graph_dense_bwd_data(X, table, z, K - 1, cin, V, B * T)
-        src = [z[k * cin:(k + 1) * cin] for k in range(K - 1)] + [X]
+        sscale = torch.empty(K, dtype=torch.float32, device=dev)             # per slice: (1, .., 1, 1 + eps)
+        if self.tab_f is not None:                                            # gather lists; identity slices read x itself
+            table = None
+            ops.gin_adjacency(None, self.p[pre + "epsilon"], None, escale, sscale, Km1=K - 1, V=V)
+            live = [k for k in range(K - 1) if not self.identity_slice[k]]
+            z = new(max(1, len(live)) * cin, n_in)                            # z_k = x . A_k for the slices that need it
+            src = [X] * K
+            for i, k in enumerate(live):
+                src[k] = z[i * cin:(i + 1) * cin]
+                ops.graph_gather_expand(X, self.tab_f, 1, cin, V, src[k], k0=k)
+        else:
+            table = torch.empty((K, V, V), dtype=torch.float32, device=dev)  # [A_0^T, A_1^T, (1 + eps) I]
+            ops.gin_adjacency(self.A, self.p[pre + "epsilon"], table, escale, sscale)
+            z = new((K - 1) * cin, n_in)                                      # z[k cin + c] = x[c] . A_k
+            ops.graph_dense_bwd_data(X, table, z, K - 1, cin, V, B * T)
+            src = [z[k * cin:(k + 1) * cin] for k in range(K - 1)] + [X]
         a1, a2 = new(K * h, n_in), new(K * h, n_in)
         geo = dict(B=B, V=V, T_src=T, T_out=T, taps=1, stride=1, pad=0)
         part1 = part2 = None
@@ -227,8 +250,8 @@ class STGIN(STGCN):
         ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, {"none": 0, "identity": 1, "conv": 2}[kind], X if kind == "identity" else r,
                             rbn.scale if rbn else None, rbn.shift if rbn else None, y)
         if training:
-            saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind, z=z, a1=a1,
-                                        a2=a2, table=table))
+            saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind, src=src, a1=a1,
+                                        a2=a2, table=table, sscale=sscale))
         if keep is not None:
             keep[pre + "g"], keep[pre + "u"], keep[pre + "y"], keep[pre + "a1"], keep[pre + "a2"] = g, u, y, a1, a2
         return y, To
@@ -237,7 +260,7 @@ class STGIN(STGCN):
     def _block_backward(self, i, sb, dY, B):
         V, dev = self.V, dY.device
         pre, K = "l%d." % i, KS
-        X, g, u, r, y, z, a1, a2 = sb["X"], sb["g"], sb["u"], sb["r"], sb["y"], sb["z"], sb["a1"], sb["a2"]
+        X, g, u, r, y, src, a1, a2 = sb["X"], sb["g"], sb["u"], sb["r"], sb["y"], sb["src"], sb["a1"], sb["a2"]
         T, To, pad, cin, f, s, kind = sb["T"], sb["To"], sb["pad"], sb["cin"], sb["f"], sb["s"], sb["kind"]
         h = f // 2
         n_in, n_out = B * T * V, B * To * V
@@ -301,7 +324,6 @@ class STGIN(STGCN):
         # ---- first 1x1 convolution of every branch; the self slice also yields d epsilon
         dzz = new(K * cin, n_in)
         w1T = torch.empty((K, h, cin), dtype=torch.float32, device=dev)
-        src = [z[k * cin:(k + 1) * cin] for k in range(K - 1)] + [X]
         for k in range(K):
             kn, bi = pre + "mlp%d.c1.kernel" % k, pre + "mlp%d.c1.bias" % k
             flat = self.grad[self.offsets[kn]:self.offsets[bi] + h]
@@ -311,12 +333,16 @@ class STGIN(STGCN):
                                wsize=cin * h, bsize=h, **geo)
                 if k == K - 1:     # taken on the un-scaled x: d eps = <G, W>, dW = (1 + eps) G
                     ops.gin_eps_grad(self.g[kn], self.p[kn], self.p[pre + "epsilon"], self.g[pre + "epsilon"])
-            self._off_critical_path(wgrad, z, X, da1)
+            self._off_critical_path(wgrad, src[k], da1)
             ops.transpose(self.p[kn], w1T[k], 1, cin, h)
             ops.conv_gemm(L.SAR_CONV_TEMPORAL, rows(da1, k), dzz[k * cin:(k + 1) * cin], w1T[k], 0, cin, Kc=h, M=cin,
                           transposed=True, **geo)
         dXres = self._residual_backward(i, sb, dr, B)
         # ---- dX = sum_k dz_k . A_k^T + (1 + eps) dz_self (+ the skip-path gradient)
         dX = new(cin, n_in)
-        ops.graph_dense_fwd(dzz, sb["table"], dX, K, cin, V, B * T, add=dY if kind == "identity" else dXres)
+        aux = dY if kind == "identity" else dXres
+        if sb["table"] is None:
+            ops.graph_gather_sum(dzz, self.tab_b, sb["sscale"], K, cin, V, dX, add=aux)
+        else:
+            ops.graph_dense_fwd(dzz, sb["table"], dX, K, cin, V, B * T, add=aux)
         return dX

@@ -72,8 +72,10 @@ def test_gin_adjacency_table_and_epsilon_gradient(dev):
     eps = torch.tensor(0.37)
     table = torch.empty(3, 25, 25, device=dev)
     scale = torch.empty(70, device=dev)
-    ops.gin_adjacency(A.to(dev), eps.to(dev), table, scale)
+    sscale = torch.empty(3, device=dev)
+    ops.gin_adjacency(A.to(dev), eps.to(dev), table, scale, sscale)
     torch.cuda.synchronize()
+    assert torch.equal(sscale.cpu(), torch.stack([torch.tensor(1.0), torch.tensor(1.0), 1 + eps]))
     ref = torch.cat([A.transpose(1, 2), (torch.eye(25) * (1 + eps)).unsqueeze(0)])
     assert torch.equal(table.cpu(), ref) and torch.equal(scale.cpu(), (1 + eps).expand(70))
     # x . A_k through the dense contraction kernel with that table == einsum 'nctv,kvw->nkctw' (models/gcn.py:154)
@@ -126,13 +128,16 @@ def _engine_masks(eng, keep, blocks, B, T):
     return masks
 
 
-def _compare(dev, blocks, N, T, classes, seed, x=None, y=None):
+def _compare(dev, blocks, N, T, classes, seed, x=None, y=None, A=None):
     from sar_amd.stgin import STGIN
     p = _params(blocks, classes, seed)
+    if A is not None:
+        p["A"] = A.double()
     if x is None:
         x, y = S.synthetic_batch(N, seed=seed, T=T, num_classes=classes)
     logits_ref, loss_ref, grads_unc, new_stats, taps = G.loss_and_grads(p, x.double(), y, blocks=blocks)
-    eng = STGIN(num_classes=classes, device=dev, blocks=blocks)
+    eng = STGIN(num_classes=classes, device=dev, blocks=blocks, A=None if A is None else A.numpy())
+    assert (eng.tab_f is None) == (A is not None)          # the NTU graph takes the gather kernels, a dense A the dense ones
     assert eng.n_params == sum(v.numel() for k, v in p.items() if S.is_trainable(k))
     eng.load_params(p)
     keep = {}
@@ -199,6 +204,46 @@ def test_two_blocks_small(dev):
 
 def test_stride2_conv_residual_blocks(dev):
     _compare(dev, [(64, 1, False), (128, 2, True), (128, 1, True), (256, 2, True)], N=2, T=22, classes=12, seed=1)
+
+
+def test_dense_adjacency_takes_the_dense_kernels(dev):
+    """an adjacency with more than 4 non-zeros per column (here: every entry) cannot be a gather list: csrc/graph_dense.hip"""
+    g = torch.Generator().manual_seed(11)
+    A = (0.2 * torch.rand(2, 25, 25, generator=g)).float()
+    _compare(dev, [(64, 1, False), (64, 1, True), (128, 2, True)], N=2, T=14, classes=7, seed=8, A=A)
+
+
+@pytest.mark.parametrize("F,frames", [(64, 40), (3, 17), (20, 301)])
+def test_graph_gather_kernels(dev, F, frames):
+    """sar_graph_gather_{expand,sum}_f32 with the gather lists of [A_0, A_1, I] against the einsums of models/gcn.py:154 and
+    their transposes"""
+    import numpy as np
+    from sar_amd import ops
+    from oracle.graph import spatial_adjacency
+    V, K = 25, 3
+    A_ext = np.concatenate([spatial_adjacency().astype(np.float32)[:2], np.eye(V, dtype=np.float32)[None]])
+    tf_, tb_ = ops.GraphTables(A_ext, dev, transpose=False), ops.GraphTables(A_ext, dev, transpose=True)
+    g = torch.Generator().manual_seed(F + frames)
+    n = frames * V
+    x = torch.randn(F, n, generator=g)
+    At = torch.from_numpy(A_ext).double()
+    z = torch.empty(K * F, n, device=dev)
+    ops.graph_gather_expand(x.to(dev), tf_, K, F, V, z)
+    ref = torch.einsum("ctv,kvw->kctw", x.double().view(F, frames, V), At).reshape(K * F, n)
+    torch.cuda.synchronize()
+    assert rel_err(z.cpu(), ref) < 1e-6
+    z1 = torch.empty(F, n, device=dev)                      # one slice through the k0 offset
+    ops.graph_gather_expand(x.to(dev), tf_, 1, F, V, z1, k0=1)
+    torch.cuda.synchronize()
+    assert torch.equal(z1.cpu(), z.cpu()[F:2 * F])
+    dz = torch.randn(K * F, n, generator=g)
+    add = torch.randn(F, n, generator=g)
+    sc = torch.tensor([1.0, 1.0, 1.3])
+    out = torch.empty(F, n, device=dev)
+    ops.graph_gather_sum(dz.to(dev), tb_, sc.to(dev), K, F, V, out, add=add.to(dev))
+    torch.cuda.synchronize()
+    ref = torch.einsum("kctw,kvw->ctv", dz.double().view(K, F, frames, V) * sc.double().view(K, 1, 1, 1), At).reshape(F, n) + add.double()
+    assert rel_err(out.cpu(), ref) < 1e-6
 
 
 def test_odd_sizes_single_body(dev):
