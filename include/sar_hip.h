@@ -402,7 +402,8 @@ int sar_graph_dense_dadj_f32(const float* y, int64_t ld_y, const float* dout, in
  *                           sar_amd/graph_tables.py -- what the ST-GCN kernels fold into their operand loads):
  *                           expand: out[k*F + m, (t,v)] = sum_j wt[k][v][j] * in[m, (t, idx[k][v][j])]
  *                           sum:    out[m, (t,w)] = sum_k scale[k] * sum_j wt[k][w][j] * in[k*F + m, (t, idx[k][w][j])] (+ add)
- *                           n = frames * V columns; HBM-bound (every tensor moved once)
+ *                           n = frames * V columns; HBM-bound (every tensor moved once).  nz_host: HOST array [K], entries per
+ *                           joint used by slice k (1 for an identity slice; NULL = 4): idx / wt beyond it are not read
  *   sar_gin_sum_fwd_f32     s[c, n] = sum_k relu(a[k*C + c, n] * scale[k*C + c] + shift[k*C + c])  -- the last BN + ReLU of
  *                           every branch and tf.reduce_sum (models/gcn.py:139-142,160); partials[C][nparts][2] = (sum s,
  *                           sum s^2) per workgroup for the BatchNorm that follows (models/stgin.py:28), nparts = sar_gin_nparts(n)
@@ -422,10 +423,11 @@ int sar_gin_bwd_apply_f32(const float* ds, int64_t ld_ds, const float* a, int64_
                           const float* k1, const float* k2, const float* k3, int K, int C, int64_t n, float* da, int64_t ld_da,
                           sar_stream_t s);
 int sar_gin_eps_grad_f32(float* G, const float* W, int64_t n, const float* eps, float* deps, sar_stream_t s);
-int sar_graph_gather_sum_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const float* scale, int K, int F,
-                             int V, int64_t n, float* out, int64_t ld_out, const float* add, int64_t ld_add, sar_stream_t s);
-int sar_graph_gather_expand_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, int K, int F, int V, int64_t n,
-                                float* out, int64_t ld_out, sar_stream_t s);
+int sar_graph_gather_sum_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const int32_t* nz_host,
+                             const float* scale, int K, int F, int V, int64_t n, float* out, int64_t ld_out, const float* add,
+                             int64_t ld_add, sar_stream_t s);
+int sar_graph_gather_expand_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const int32_t* nz_host, int K,
+                                int F, int V, int64_t n, float* out, int64_t ld_out, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 configuration (bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation, fp32

@@ -169,11 +169,12 @@ __global__ __launch_bounds__(1024) void gin_eps_grad_kernel(float* G, const floa
 // One thread per (row m, column); the K V 4 table entries sit in LDS; neighbours of a joint lie in the same frame (<= 128 B
 // away), so the gathers are cache hits and the pass moves each tensor once.
 constexpr int GG_KMAX = 8, GG_VMAX = 32, GG_NZ = 4;
+struct GGnz { int nz[GG_KMAX]; };      // entries per joint actually used by slice k (1 for an identity slice): uniform loop bounds
 template <int MODE>
 __global__ __launch_bounds__(TPB) void graph_gather_kernel(const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx,
                                                            const float* __restrict__ wt, const float* __restrict__ scale, int K,
                                                            int F, int V, int64_t n, float* __restrict__ out, int64_t ld_out,
-                                                           const float* __restrict__ add, int64_t ld_add) {
+                                                           const float* __restrict__ add, int64_t ld_add, const GGnz nzs) {
   __shared__ int sidx[GG_KMAX * GG_VMAX * GG_NZ];
   __shared__ float swt[GG_KMAX * GG_VMAX * GG_NZ];
   for (int i = threadIdx.x; i < K * V * GG_NZ; i += TPB) {
@@ -190,17 +191,17 @@ __global__ __launch_bounds__(TPB) void graph_gather_kernel(const float* __restri
       for (int k = 0; k < K; ++k) {
         const float* row = in + (int64_t)(k * F + m) * ld_in + fb;
         const int e = (k * V + w) * GG_NZ;
-#pragma unroll
-        for (int j = 0; j < GG_NZ; ++j) acc = fmaf(swt[e + j], row[sidx[e + j]], acc);
+        const int nz = nzs.nz[k];
+        for (int j = 0; j < nz; ++j) acc = fmaf(swt[e + j], row[sidx[e + j]], acc);
       }
       out[(int64_t)m * ld_out + col] = acc;
     } else {
       const float* row = in + (int64_t)m * ld_in + fb;
       for (int k = 0; k < K; ++k) {
         const int e = (k * V + w) * GG_NZ;
+        const int nz = nzs.nz[k];
         float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < GG_NZ; ++j) acc = fmaf(swt[e + j], row[sidx[e + j]], acc);
+        for (int j = 0; j < nz; ++j) acc = fmaf(swt[e + j], row[sidx[e + j]], acc);
         out[(int64_t)(k * F + m) * ld_out + col] = acc;
       }
     }
@@ -276,6 +277,12 @@ extern "C" int sar_gin_eps_grad_f32(float* G, const float* W, int64_t n, const f
   return 0;
 }
 
+static GGnz gg_nz(const int32_t* nz, int K) {
+  GGnz r;
+  for (int k = 0; k < GG_KMAX; ++k) r.nz[k] = (nz && k < K && nz[k] >= 1 && nz[k] <= GG_NZ) ? nz[k] : GG_NZ;
+  return r;
+}
+
 static int gg_check(const char* who, const float* in, const int32_t* idx, const float* wt, float* out, int K, int F, int V, int64_t n,
                     int64_t ld_in, int64_t ld_out) {
   SAR_REQUIRE(in && idx && wt && out && K > 0 && K <= GG_KMAX && F > 0 && F <= 65535 && V > 0 && V <= GG_VMAX && n > 0 && n % V == 0 &&
@@ -284,22 +291,22 @@ static int gg_check(const char* who, const float* in, const int32_t* idx, const 
   return 0;
 }
 
-extern "C" int sar_graph_gather_sum_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const float* scale, int K,
-                                        int F, int V, int64_t n, float* out, int64_t ld_out, const float* add, int64_t ld_add,
-                                        sar_stream_t st_) {
+extern "C" int sar_graph_gather_sum_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const int32_t* nz,
+                                        const float* scale, int K, int F, int V, int64_t n, float* out, int64_t ld_out,
+                                        const float* add, int64_t ld_add, sar_stream_t st_) {
   if (int rc = gg_check("sar_graph_gather_sum", in, idx, wt, out, K, F, V, n, ld_in, ld_out)) return rc;
   SAR_REQUIRE(!add || ld_add >= n, "sar_graph_gather_sum: bad add");
   hipLaunchKernelGGL(graph_gather_kernel<0>, dim3(row_blocks(n, 1), F), dim3(TPB), 0, as_stream(st_), in, ld_in, idx, wt, scale, K, F, V,
-                     n, out, ld_out, add, ld_add);
+                     n, out, ld_out, add, ld_add, gg_nz(nz, K));
   SAR_LAUNCH_CHECK("sar_graph_gather_sum_f32");
   return 0;
 }
 
-extern "C" int sar_graph_gather_expand_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, int K, int F, int V,
-                                           int64_t n, float* out, int64_t ld_out, sar_stream_t st_) {
+extern "C" int sar_graph_gather_expand_f32(const float* in, int64_t ld_in, const int32_t* idx, const float* wt, const int32_t* nz, int K,
+                                           int F, int V, int64_t n, float* out, int64_t ld_out, sar_stream_t st_) {
   if (int rc = gg_check("sar_graph_gather_expand", in, idx, wt, out, K, F, V, n, ld_in, ld_out)) return rc;
   hipLaunchKernelGGL(graph_gather_kernel<1>, dim3(row_blocks(n, 1), F), dim3(TPB), 0, as_stream(st_), in, ld_in, idx, wt,
-                     (const float*)nullptr, K, F, V, n, out, ld_out, (const float*)nullptr, (int64_t)0);
+                     (const float*)nullptr, K, F, V, n, out, ld_out, (const float*)nullptr, (int64_t)0, gg_nz(nz, K));
   SAR_LAUNCH_CHECK("sar_graph_gather_expand_f32");
   return 0;
 }

@@ -119,8 +119,8 @@ SIGNATURES = {
     # dense (trainable) adjacency
     "sar_gin_nparts": (_i, [_i64]),
     "sar_gin_adjacency_f32": (_i, [_fp, _i, _i, _fp, _fp, _fp, _i, _fp, _fp]),
-    "sar_graph_gather_sum_f32": (_i, [_fp, _i64, _fp, _fp, _fp, _i, _i, _i, _i64, _fp, _i64, _fp, _i64, _fp]),
-    "sar_graph_gather_expand_f32": (_i, [_fp, _i64, _fp, _fp, _i, _i, _i, _i64, _fp, _i64, _fp]),
+    "sar_graph_gather_sum_f32": (_i, [_fp, _i64, _fp, _fp, _fp, _fp, _i, _i, _i, _i64, _fp, _i64, _fp, _i64, _fp]),
+    "sar_graph_gather_expand_f32": (_i, [_fp, _i64, _fp, _fp, _fp, _i, _i, _i, _i64, _fp, _i64, _fp]),
     "sar_gin_sum_fwd_f32": (_i, [_fp, _i64, _fp, _fp, _i, _i, _i64, _fp, _i64, _fp, _fp]),
     "sar_gin_bwd_reduce_f32": (_i, [_fp, _i64, _fp, _i64, _fp, _fp, _fp, _i, _i, _i64, _fp, _fp]),
     "sar_gin_bwd_apply_f32": (_i, [_fp, _i64, _fp, _i64, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _fp, _i64, _fp]),

@@ -337,7 +337,9 @@ def gin_adjacency(A, eps, table, scale, slice_scale=None, Km1=None, V=None):
 def graph_gather_sum(inp, tables, scale, K, F, V, out, add=None, k0=0):
     """out[m] = sum_k scale[k] (in[k F + m] gathered with slice k0 + k of `tables`) (+ add[m])"""
     n = out.shape[1]
-    check(L.load().sar_graph_gather_sum_f32(ptr(_f32(inp)), inp.stride(0), ptr(tables.idx[k0:]), ptr(tables.wt[k0:]), ptr(_f32(scale)),
+    nz = (C.c_int32 * K)(*tables.nz[k0:k0 + K])
+    check(L.load().sar_graph_gather_sum_f32(ptr(_f32(inp)), inp.stride(0), ptr(tables.idx[k0:]), ptr(tables.wt[k0:]),
+                                            C.cast(nz, C.c_void_p), ptr(_f32(scale)),
                                             K, F, V, n, ptr(_f32(out)), out.stride(0), ptr(_f32(add)),
                                             add.stride(0) if add is not None else 0, stream_ptr()), "sar_graph_gather_sum_f32")
 
@@ -345,8 +347,10 @@ def graph_gather_sum(inp, tables, scale, K, F, V, out, add=None, k0=0):
 def graph_gather_expand(inp, tables, K, F, V, out, k0=0):
     """out[k F + m] = in[m] gathered with slice k0 + k of `tables`"""
     n = inp.shape[1]
-    check(L.load().sar_graph_gather_expand_f32(ptr(_f32(inp)), inp.stride(0), ptr(tables.idx[k0:]), ptr(tables.wt[k0:]), K, F, V, n,
-                                               ptr(_f32(out)), out.stride(0), stream_ptr()), "sar_graph_gather_expand_f32")
+    nz = (C.c_int32 * K)(*tables.nz[k0:k0 + K])
+    check(L.load().sar_graph_gather_expand_f32(ptr(_f32(inp)), inp.stride(0), ptr(tables.idx[k0:]), ptr(tables.wt[k0:]),
+                                               C.cast(nz, C.c_void_p), K, F, V, n, ptr(_f32(out)), out.stride(0), stream_ptr()),
+          "sar_graph_gather_expand_f32")
 
 
 def gin_sum_fwd(a, scale, shift, K, s_out, stats=False):
