@@ -16,6 +16,7 @@ from sar_amd import _lib as L, ops  # noqa: E402
 from sar_amd.stgcn import BLOCKS, same_pad, ntu_adjacency  # noqa: E402
 
 PEAK = 157.3
+NOPRO = os.environ.get("KB_NOPRO", "0") == "1"      # diagnostic: temporal forward / weight gradient without the folded BN + ReLU prologue
 
 
 def timeit(fn, reps):
@@ -70,7 +71,7 @@ def main():
                     tables=tf_, epi=L.SAR_EPI_STATS, bf16=a.bf16)),
                 "tconv_fwd": (2.0 * f * f * 9 * n_out, lambda: ops.conv_gemm(
                     L.SAR_CONV_TEMPORAL, G, out_out, Wt, f * f, f, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s,
-                    pad=pad, bias=bt, pro=(sc, sh), pro_relu=True, epi=L.SAR_EPI_STATS, bf16=a.bf16)),
+                    pad=pad, bias=bt, pro=None if NOPRO else (sc, sh), pro_relu=not NOPRO, epi=L.SAR_EPI_STATS, bf16=a.bf16)),
                 "tconv_dgrad": (2.0 * f * f * 9 * n_out, lambda: ops.conv_gemm(
                     L.SAR_CONV_TEMPORAL, U, out_in, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s,
                     pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=G, aux_affine=(sc, sh), bf16=a.bf16)),
@@ -79,7 +80,7 @@ def main():
                     epi=L.SAR_EPI_ADD, aux=X, bf16=a.bf16)),
                 "tconv_wgrad": (2.0 * f * f * 9 * n_out, lambda: ops.conv_wgrad(
                     L.SAR_CONV_TEMPORAL, G, U, flat_t, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad,
-                    pro=(sc, sh), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f, bf16=a.bf16)),
+                    pro=None if NOPRO else (sc, sh), pro_relu=not NOPRO, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f, bf16=a.bf16)),
                 "gcn_wgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_wgrad(
                     L.SAR_CONV_GRAPH, X, G, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tf_,
                     w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f, bf16=a.bf16)),
