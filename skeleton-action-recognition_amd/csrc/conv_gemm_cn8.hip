@@ -690,8 +690,9 @@ int launch_graph_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, 
   return launch_graph_cfg8<1, 2, 1, 4, NZ0, NZ1, NZ2>(d, wp, st, np);
 }
 
-// tile of the temporal / residual GEMMs for M > 64 (experiment switch SAR_CN8_TILE): 0 = 128 x 128, 1 = 128 x 256,
-// 2 = 64 x 256 row blocks (default; the tile of the M <= 64 layers)
+// tile of the temporal / residual GEMMs for M > 64 (experiment switch SAR_CN8_TILE): 0 = 128 x 128 (7 % slower step),
+// 1 = 128 x 256 (256 VGPRs + scratch: 7x slower, kept only as the measured counter-example), 2 = 64 x 256 row blocks
+// (default; the tile of the M <= 64 layers), 3 = 64 x 128 (12 % slower)
 int tile_choice() {
   static const int v = [] {
     const char* e = getenv("SAR_CN8_TILE");

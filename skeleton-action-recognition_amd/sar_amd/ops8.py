@@ -83,6 +83,9 @@ def conv_gemm(mode, src, out, packed, *, B, V, T_src, T_out, Kc, M, taps, stride
     return (partials, nparts) if partials is not None else None
 
 
+_WGRAD_SLOTS = int(__import__("os").environ.get("SAR_WGRAD8_SLOTS", "512"))
+
+
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
                tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None):
     """sar_conv_wgrad_cn8 + sar_slab_reduce_f32: dW (and dbias right behind it) -> dW_out[0 : wsize + bsize] (flat fp32)."""
@@ -94,8 +97,8 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     ntiles = B * ((T_out + ft - 1) // ft)
     cb = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
     blocks = ((M + 63) // 64) * ((Kc + cb - 1) // cb)
-    if nsplit is None:           # two resident workgroups per CU
-        nsplit = max(1, min(ntiles, (512 + blocks - 1) // blocks))
+    if nsplit is None:           # two resident workgroups per CU (SAR_WGRAD8_SLOTS: sweep knob, tools)
+        nsplit = max(1, min(ntiles, (_WGRAD_SLOTS + blocks - 1) // blocks))
     d.nsplit = nsplit
     _cn8(src), _cn8(dout)
     d.src, d.ld_src, d.dout, d.ld_dout = ptr(src), src.shape[1], ptr(dout), dout.shape[1]
