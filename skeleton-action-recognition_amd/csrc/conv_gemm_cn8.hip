@@ -624,14 +624,17 @@ int tile_geometry8(const sar_conv_desc& d, int NSv, bool parity, ConvK8& k) {
     if (k.FT > d.T_out) k.FT = d.T_out;
   }
   if (k.FT < 1) return -1;
-  k.TPS = (d.T_out + k.FT - 1) / k.FT;
-  if (d.mode == SAR_CONV_GRAPH) k.NF = k.FT;
-  else if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
-  else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
-  k.RW = k.NF * d.V;
-  k.nparts = d.B * k.TPS * WN;
   const int rwmax = (d.mode == SAR_CONV_GRAPH) ? tile_n : (NSv * WN == 4 ? 448 : 704);
+  for (;; k.FT -= parity ? 2 : 1) {      // as many frames as the staged window allows
+    if (d.mode == SAR_CONV_GRAPH) k.NF = k.FT;
+    else if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
+    else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
+    k.RW = k.NF * d.V;
+    if (k.RW <= rwmax || k.FT <= (parity ? 2 : 1)) break;
+  }
   if (k.RW > rwmax) return -2;
+  k.TPS = (d.T_out + k.FT - 1) / k.FT;
+  k.nparts = d.B * k.TPS * WN;
   return 0;
 }
 
@@ -692,7 +695,9 @@ int launch_graph_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, 
 
 // tile of the temporal / residual GEMMs for M > 64 (experiment switch SAR_CN8_TILE): 0 = 128 x 128 (7 % slower step),
 // 1 = 128 x 256 (256 VGPRs + scratch: 7x slower, kept only as the measured counter-example), 2 = 64 x 256 row blocks
-// (default; the tile of the M <= 64 layers), 3 = 64 x 128 (12 % slower)
+// (default; the tile of the M <= 64 layers), 3 = 64 x 128 (12 % slower), 4 = 64 x 512 for the stride-1 9-tap launches (wave
+// tile 64 x 128, 0.75 LDS operand reads per MFMA, 254 VGPRs: 8-15 % faster per kernel in isolation -- 3.85 -> 3.54 ms per
+// step for forward + data gradient -- but 2 waves per SIMD co-reside worse with the weight-gradient stream: step 1-3 % slower)
 int tile_choice() {
   static const int v = [] {
     const char* e = getenv("SAR_CN8_TILE");
@@ -713,6 +718,9 @@ int launch_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* n
     }
   if constexpr (TR != 3)
     if (d.M > 32 && tile_choice() == 3) return launch_cfg8<TR, TAPS, 2, 1, 1, 4>(d, wp, st, np);   // 64 x 128: 4 workgroups per CU
+  if constexpr (TR == 0 || TR == 1)
+    if (d.M > 32 && tile_choice() == 4 && d.stride == 1 && TAPS == 9)   // 64 x 512: wave tile 64 x 128 (0.75 LDS reads per MFMA)
+      return launch_cfg8<TR, TAPS, 2, 4, 1, 4>(d, wp, st, np);
   if (d.M > 32) return launch_cfg8<TR, TAPS, 2, 2, 1, 4>(d, wp, st, np);
   return launch_cfg8<TR, TAPS, 1, 2, 1, 4>(d, wp, st, np);
 }
