@@ -206,3 +206,29 @@ def test_image_gradient_of_the_stem(dev):
     torch.nn.functional.cross_entropy(lo, y).backward()
     assert dx.shape == x.shape
     assert rel_err(dx.cpu(), xr.grad) < 1e-4
+
+
+def test_spectrogram_train_step_is_bitwise_deterministic(dev):
+    """VirtualRadar -> resnet18 train step at the bench shape (256 x 256 images, full width): logits, loss and the whole
+    gradient buffer repeat bit for bit -- the weight-gradient stream, the concurrent parity-class launches of the stride-2 data
+    gradients (library-owned streams) and the slab reductions have a fixed order; a mismatch would be a race."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "skeleton-action-recognition_amd"))
+    from models.resnet import Model
+    from sar_amd.train import synthetic_clips
+    model = Model(num_classes=60, device=dev)
+    eng = model.base_model.engine
+    x, y = synthetic_clips(8, dev, seed=5)
+    with torch.no_grad():
+        img = model.spectrogram(x)
+    state = {k: v.clone() for k, v in eng.state_dict().items()}
+    ref = None
+    for _ in range(3):
+        eng.load_params(state)
+        logits, loss = eng.loss_and_grad(img, y)
+        torch.cuda.synchronize()
+        cur = (logits.clone(), loss.clone(), eng.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+    assert torch.isfinite(ref[2]).all() and ref[2].abs().max() > 0
