@@ -127,6 +127,9 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     return (partials, nparts) if partials is not None else None
 
 
+_WGRAD1_SLOTS = int(__import__("os").environ.get("SAR_WGRAD1_SLOTS", "1024"))      # workgroups in flight of the 1-tap weight gradients
+
+
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
                tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, bf16=False):
     """dW (and dbias, stored right behind it) -> dW_out[0 : wsize+bsize] (flat float32 view).  bf16=True routes the
@@ -153,7 +156,7 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
         wgs = ((M + bf - 1) // bf) * ((Kc + ct - 1) // ct)
         # workgroups in flight: two rounds of the 512 resident slots for the temporal kernels, one for the graph kernel
         # (tools/nsplit_sweep.py)
-        target = 512 if (mode == L.SAR_CONV_GRAPH and ft == 2) else 1024
+        target = 512 if (mode == L.SAR_CONV_GRAPH and ft == 2) else (_WGRAD1_SLOTS if taps == 1 else 1024)
         nsplit = max(1, min(ntiles, (target + wgs - 1) // wgs))
     d.nsplit = nsplit
     _f32(src), _f32(dout)
