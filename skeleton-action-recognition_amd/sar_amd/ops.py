@@ -128,6 +128,8 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
 
 
 _WGRAD1_SLOTS = int(__import__("os").environ.get("SAR_WGRAD1_SLOTS", "1024"))      # workgroups in flight of the 1-tap weight gradients
+_WGRAD9_SLOTS = int(__import__("os").environ.get("SAR_WGRAD9_SLOTS", "1024"))      # ... of the 9-tap temporal ones (sweep knobs)
+_WGRADG_SLOTS = int(__import__("os").environ.get("SAR_WGRADG_SLOTS", "512"))       # ... of the graph ones
 
 
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
@@ -156,7 +158,7 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
         wgs = ((M + bf - 1) // bf) * ((Kc + ct - 1) // ct)
         # workgroups in flight: two rounds of the 512 resident slots for the temporal kernels, one for the graph kernel
         # (tools/nsplit_sweep.py)
-        target = 512 if (mode == L.SAR_CONV_GRAPH and ft == 2) else (_WGRAD1_SLOTS if taps == 1 else 1024)
+        target = _WGRADG_SLOTS if (mode == L.SAR_CONV_GRAPH and ft == 2) else (_WGRAD1_SLOTS if taps == 1 else _WGRAD9_SLOTS)
         nsplit = max(1, min(ntiles, (target + wgs - 1) // wgs))
     d.nsplit = nsplit
     _f32(src), _f32(dout)
