@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   const unsigned wbytes = (unsigned)((int64_t)TAPS * k.G * d.M * 16);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
   const bool has_pro = d.pro_scale != nullptr;
-  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  const bool pro_relu = d.pro_relu != 0;
+  const int ncj = (k.RW + 255) >> 8;   // live 256-column chunks of the staged window (wave-uniform, <= CJ)
   uint4 wreg[WIT];
   uint4 sreg[2][CJ];
 
@@ -326,12 +327,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(src_b + (int64_t)(g < k.Gs ? g : 0) * d.ld_src * 16), 0, g < k.Gs ? (unsigned)seq_len * 16u : 0u, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < CJ; ++j) {
-        // the offset is formed in the vector ALU (32-bit wrap: a negative lane base plus 4096 j is the right non-negative
-        // offset); as a scalar offset the hardware range check would see the un-wrapped sum and reject it
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((swidth >> j) & 1u) ? svo0 + j * 4096 : 0x7fffffff, 0, 0);
-        sreg[h][j] = make_uint4(v[0], v[1], v[2], v[3]);
-      }
+      for (int j = 0; j < CJ; ++j)
+        if (j < ncj) {   // wave-uniform: chunks beyond the staged width are never loaded, transformed, stored or read
+          // the offset is formed in the vector ALU (32-bit wrap: a negative lane base plus 4096 j is the right non-negative
+          // offset); as a scalar offset the hardware range check would see the un-wrapped sum and reject it
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((swidth >> j) & 1u) ? svo0 + j * 4096 : 0x7fffffff, 0, 0);
+          sreg[h][j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
     }
   };
 
@@ -343,26 +345,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
     for (int h = 0; h < 2; ++h) {
       if (has_pro) {   // uniform: BatchNorm + ReLU of the producer folded into the operand (models/stgcn.py:27-28)
         float psc[8], psh[8];
+        cn8_params8(d.pro_scale, c0 + 8 * h, d.Kc, psc);
+        cn8_params8(d.pro_shift, c0 + 8 * h, d.Kc, psh);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int c = c0 + 8 * h + q;
-          const bool rok = c < d.Kc;
-          psc[q] = rok ? d.pro_scale[c] : 0.f;
-          psh[q] = rok ? d.pro_shift[c] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < CJ; ++j) {
-          float f[8];
-          cn8_unpack(sreg[h][j], f);
-          const bool inside = (sbits >> j) & 1u;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) f[q] = inside ? fmaxf(fmaf(f[q], psc[q], psh[q]), relu_lo) : 0.f;   // padding stays exactly 0
-          sreg[h][j] = cn8_pack(f);
-        }
+        for (int j = 0; j < CJ; ++j)
+          if (j < ncj)   // padding / columns outside the sequence stay exactly 0 (keep mask)
+            sreg[h][j] = cn8_bn_relu_unit(sreg[h][j], psc, psh, pro_relu, ((sbits >> j) & 1u) ? 0xffffffffu : 0u);
       }
 #pragma unroll
       for (int j = 0; j < CJ; ++j)
-        if ((j + 1) * 256 <= TC::RWMAX || tid + 256 * j < TC::RWMAX) Sl[h * SCOLS + tid + 256 * j] = sreg[h][j];
+        if (j < ncj && ((j + 1) * 256 <= TC::RWMAX || tid + 256 * j < TC::RWMAX)) Sl[h * SCOLS + tid + 256 * j] = sreg[h][j];
     }
   };
 
@@ -408,8 +400,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
     }
     __syncthreads();   // every wave is done with the image (next store / the epilogue's transpose area)
   }
-  if (SAR_ABLATE8 & 4) {
-    if (acc[0][0][0] == 12345.678f) d.out[0] = 1.f;   // keeps the accumulators alive
+  if (SAR_ABLATE8 & 4) {   // every accumulator stays live (an un-used one would take its MFMAs with it)
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[ms][ns][r]));
     return;
   }
   epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, vo, acc, rowp, smem);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
   const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
   const int seq_src = d.T_src * WV, seq_out = d.T_out * WV;
   const bool has_pro = d.pro_scale != nullptr;
-  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  const bool pro_relu = d.pro_relu != 0;
   const bool do_bias = d.bsize > 0 && bz == 0;
 
   // ---- stager geometry.  Wave w stages src image planes w, w+4 and dout planes w, w+4; lane -> units lane + 64 j.
@@ -199,21 +199,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
       if (has_pro) {   // uniform: BatchNorm + ReLU of the producer folded into the operand (models/stgcn.py:27-28)
         const int cb = c0 + 8 * (C::SPLIT ? (ip & 3) : ip);
         float psc[8], psh[8];
+        cn8_params8(d.pro_scale, cb, d.Kc, psc);
+        cn8_params8(d.pro_shift, cb, d.Kc, psh);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const bool rok = cb + e < d.Kc;
-          psc[e] = rok ? d.pro_scale[cb + e] : 0.f;
-          psh[e] = rok ? d.pro_shift[cb + e] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < SJ; ++j) {
-          float f[8];
-          cn8_unpack(sreg[q][j], f);
-          const bool inside = (sin[q] >> j) & 1u;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = inside ? fmaxf(fmaf(f[e], psc[e], psh[e]), relu_lo) : 0.f;
-          sreg[q][j] = cn8_pack(f);
-        }
+        for (int j = 0; j < SJ; ++j)   // padding / columns outside the sequence stay exactly 0 (keep mask)
+          sreg[q][j] = cn8_bn_relu_unit(sreg[q][j], psc, psh, pro_relu, ((sin[q] >> j) & 1u) ? 0xffffffffu : 0u);
       }
 #pragma unroll
       for (int j = 0; j < SJ; ++j)

@@ -103,7 +103,8 @@ extern "C" int64_t sar_tfrecord_index(const void* file, int64_t nbytes, int veri
     memcpy(&len, p + pos, 8);
     memcpy(&lcrc, p + pos + 8, 4);
     if (verify && mask(crc_any(p + pos, 8)) != lcrc) return -(3 + n * 4);  // corrupt length CRC
-    if (len > (uint64_t)(nbytes - pos - 16)) return -(4 + n * 4);          // truncated record
+    // header + footer alone need 16 bytes: with 12..15 left the subtraction below would go negative (and huge as uint64)
+    if (nbytes - pos < 16 || len > (uint64_t)(nbytes - pos - 16)) return -(4 + n * 4);   // truncated record
     if (verify >= 2) {
       uint32_t dcrc;
       memcpy(&dcrc, p + pos + 12 + len, 4);

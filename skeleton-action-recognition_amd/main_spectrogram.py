@@ -136,7 +136,14 @@ def main():
                 scalar('{}_acc'.format(phase), ok / n, epoch * 100000 + it)
             run_loss, run_ok = sum(h[0] for h in host), sum(h[1] for h in host)
             n_it, n_seen = len(host), sum(sizes)
-            if run_loss != run_loss:
+            bad = run_loss != run_loss
+            if world > 1 and phase == 'train':
+                # every rank must raise together: a rank that kept going would block in its next all-reduce until the
+                # collective timed out (the val phase reads the same clips on every rank, so it needs no exchange)
+                flag = torch.tensor([1.0 if bad else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                bad = flag.item() > 0
+            if bad:
                 raise FloatingPointError("NaN loss in phase %s of epoch %d (labels outside [0, --num-classes)?)" % (phase, epoch + 1))
             if rank == 0:
                 scalar('{}_epoch_cross_entropy_loss'.format(phase), run_loss / max(n_it, 1), epoch)

@@ -183,8 +183,8 @@ class STGIN(STGCN):
             live = [k for k in range(K - 1) if not self.identity_slice[k]]
             z = new(max(1, len(live)) * cin, n_in)                            # z_k = x . A_k for the slices that need it
             src = [X] * K
-            for i, k in enumerate(live):
-                src[k] = z[i * cin:(i + 1) * cin]
+            for j, k in enumerate(live):
+                src[k] = z[j * cin:(j + 1) * cin]
                 ops.graph_gather_expand(X, self.tab_f, 1, cin, V, src[k], k0=k)
         else:
             table = torch.empty((K, V, V), dtype=torch.float32, device=dev)  # [A_0^T, A_1^T, (1 + eps) I]

@@ -193,6 +193,8 @@ def index_records(buf, verify=True):
     if n >= 0:
         off, ln = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
         n = lib.sar_tfrecord_index(a, len(keep), level, off.ctypes.data, ln.ctypes.data, n)
+    if n == -1:
+        raise IOError("sar_tfrecord_index: bad arguments")
     if n < 0:
         code, rec = 2 + (-n - 2) % 4, (-n - 2) // 4
         raise IOError("%s (record %d)" % (_ERRORS.get(code, "bad arguments"), rec))

@@ -121,6 +121,36 @@ def test_shards_roundtrip_interleave_and_corruption(tmp_path):
     assert T.masked_crc(h[:8]) == struct.unpack("<I", h[8:])[0]
 
 
+def test_truncated_shards_are_rejected_at_every_cut(tmp_path):
+    """a shard that ends inside a record -- in particular with 12..15 bytes of it (a whole header but not
+    header + footer) -- must raise 'truncated', at every verification level, never index past the end of the file."""
+    from sar_amd import _lib
+    lib = _lib.load()
+    recs = [bytes(range(40)), b"", bytes(7)]
+    path = str(tmp_path / "t.tfrecord")
+    T.write_records(path, recs)
+    whole = open(path, "rb").read()
+    assert [bytes(r) for r in T.read_records(path)] == recs
+    starts = [0, 16 + 40, 16 + 40 + 16]                       # first byte of each record
+    for rec_i, st in enumerate(starts):
+        for extra in list(range(1, 16)) + [16 + len(recs[rec_i]) - 1]:
+            if extra >= 16 + len(recs[rec_i]):
+                continue
+            cut = np.frombuffer(whole[:st + extra], dtype=np.uint8).copy()
+            for level in (0, 1, 2):
+                rc = lib.sar_tfrecord_index(cut.ctypes.data, len(cut), level, None, None, 0)
+                assert rc < -1, (rec_i, extra, level, rc)
+                code, rec = 2 + (-rc - 2) % 4, (-rc - 2) // 4
+                assert rec == rec_i and code == (2 if extra < 12 else 4), (rec_i, extra, level, rc)
+            with pytest.raises(IOError, match="truncated"):
+                T.index_records(cut)
+    # bad arguments are reported as such, not decoded as a record error
+    assert lib.sar_tfrecord_index(None, 10, 0, None, None, 0) == -1
+    with pytest.raises(IOError, match="truncated"):
+        open(path, "wb").write(whole[:-2])
+        list(T.read_records(path))
+
+
 def test_crc32c_instruction_path_equals_table_path():
     """sar_crc32c (SSE4.2 crc32 instruction when present) against sar_crc32c_sw (slice-by-8 tables) on every length /
     alignment class, and against the bit-serial definition."""
