@@ -27,18 +27,27 @@ FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
 BYTES_PER_CLIP_TRAIN_BF16 = 427.3e6   # block-fused algorithmic HBM traffic per clip and train step, bf16 storage
 
 
-def measured_traffic(bf16=False, pathB=False):
-    """HBM bytes per launch of the dominant kernel family from the committed PMC profile of this same workload
-    (profiles/rNN_kernel_summary.json, written by tools/summarize_profiles.py from separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).  None if absent."""
+FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<"),
+                 "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",)}
+
+
+def measured_traffic(mode="fp32"):
+    """(bytes per launch, 'file @ commit') of the dominant kernel family from the newest COMMITTED PMC profile of this same
+    workload (profiles/rNN_*kernel_summary.json, written by tools/summarize_profiles.py from separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).  It is a figure of the profiled
+    build, not of this run: the file and the commit it was taken at are named next to it, and a summary whose kernels
+    are not this mode's kernel family is refused (None)."""
     import glob
-    pat = "r[0-9][0-9]_pathB_kernel_summary.json" if pathB else ("r[0-9][0-9]_bf16_kernel_summary.json" if bf16
-                                                                  else "r[0-9][0-9]_kernel_summary.json")
+    pat = {"pathB": "r[0-9][0-9]_pathB_kernel_summary.json", "bf16": "r[0-9][0-9]_bf16_kernel_summary.json",
+           "bf16_operands": "r[0-9][0-9]_bf16_operands_kernel_summary.json"}.get(mode, "r[0-9][0-9]_kernel_summary.json")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    return d.get("dominant_family_hbm_bytes_per_launch"), os.path.basename(files[-1])
+    names = [r.get("kernel", "") for r in d.get("kernels", [])]
+    if not any(n.startswith(FAMILY_PREFIX[mode]) for n in names):
+        return None, None
+    return d.get("dominant_family_hbm_bytes_per_launch"), "%s @ %s" % (os.path.basename(files[-1]), d.get("commit", "commit not recorded"))
 
 
 def physical_cores():
@@ -146,94 +155,6 @@ def cpu_baseline_spectrogram(sample_clips, budget_s=25.0):
                       "%d threads" % (n, sample_clips, cores)}
 
 
-def main_spectrogram(args):
-    """Path B: VirtualRadar (signal + STFT/log-magnitude/column select) -> resnet18 fwd+bwd -> Adam; bs = --batch per GPU
-    (configs[3] uses 32).  Not the headline metric: selected with --workload spectrogram."""
-    import torch
-    import torch.distributed as dist
-    from sar_amd import profiler
-    from sar_amd.train import SpectrogramTrainer, synthetic_clips
-    from models.resnet import Model
-    rank, world, dev = rank_setup(args)
-    bs = 32 if args.batch == 64 else args.batch
-    model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=args.num_pad_frames)
-    trainer = SpectrogramTrainer(model, 1e-3, world_size=world)      # the product step of main_spectrogram.py
-    batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
-
-    def step(i):
-        return trainer.step(*batches[i % 4], 1e-3)[1]
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    graphs = None
-    if os.environ.get("SAR_BENCH_GRAPH", "0") == "1" and world == 1:
-        # one captured hipGraph per resident batch: at bs = 32 the ~250 launches of a step are short enough for the
-        # host launch path to show (experiment switch; the kernels read lr / step counters from device memory)
-        graphs = []
-        sync()
-        for i in range(4):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step(i)
-            graphs.append(g)
-    timer = profiler.KernelTimer()
-    if graphs is None:
-        profiler.install(timer)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if graphs is None:
-            loss = step(i)
-        else:
-            graphs[i % 4].replay()
-    sync()
-    dt = time.perf_counter() - t0
-    profiler.install(None)
-    if graphs is not None:
-        loss = step(0)
-    dt = max_over_ranks(dt, dev)
-    if rank == 0:
-        summ = timer.summary()
-        fam = [k for k in summ if k.startswith("conv2d_3x3")]
-        ms = sum(summ[k]["ms"] for k in fam)
-        fl = sum(summ[k]["flops"] for k in fam)
-        calls = sum(summ[k]["calls"] for k in fam)
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        value = bs * world * args.steps / dt
-        out = {
-            "metric": "spectrogram clips/sec training (VirtualRadar + resnet18, bs=%d/GPU)" % bs,
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VirtualRadar -> (B,1,256,256) log-spectrogram -> resnet18 fp32 training step (fwd+bwd+Adam), "
-                                   "synthetic NTU clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
-                                   % (" up-sampled x%d on the GPU" % args.num_pad_frames if args.num_pad_frames else "",
-                                      args.classes, bs),
-                       "global_batch": bs * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": measured_traffic(pathB=True)[0] if not args.num_pad_frames else None,
-                         "traffic_unit": "HBM bytes per launch of conv2d_gemm_kernel (PMC, %s)" % measured_traffic(pathB=True)[1],
-                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4)},
-            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())},
-            "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
-            "final_loss": round(float(loss.item()), 5),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_spectrogram(4)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through torch.distributed.run
     and relay their output.  Called BEFORE this process imports torch or touches the GPU (a process that has initialised
@@ -264,14 +185,299 @@ def rank_setup(args):
     return rank, world, dev
 
 
-def max_over_ranks(dt, dev):
+def gather_over_ranks(value, dev):
+    """every rank's `value` (a float) as a list, on every rank"""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return dt
-    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return t.item()
+        return [value]
+    on_cpu = dist.get_backend() == "gloo"
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_cpu else dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+class Leg:
+    """The timing protocol shared by every workload: W untimed steps (and, for the sustained legs, untimed load until
+    `warm_seconds` have passed -- the bf16 step draws the most power and the clocks settle after the first second), then
+    EXACTLY K timed steps bracketed by barrier + torch.cuda.synchronize() on both sides; the job's time is the MAX over
+    ranks; every rank's own time and the mean time of the gradient collective are reported next to it."""
+
+    def __init__(self, world, dev):
+        self.world, self.dev = world, dev
+
+    def sync(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup, warm_seconds=0.0, trainer=None):
+        import torch
+        import torch.distributed as dist
+        for i in range(warmup):
+            step(i)
+        warm_done = 0.0
+        if warm_seconds > 0:
+            # the same number of untimed steps on every rank (the step contains the collective): timed on 10 steps, MAX-agreed
+            self.sync()
+            t0 = time.perf_counter()
+            for i in range(10):
+                step(i)
+            self.sync()
+            per = (time.perf_counter() - t0) / 10
+            n = max(0, int(warm_seconds / max(per, 1e-4)) - 10)
+            n = int(max(gather_over_ranks(float(n), self.dev)))
+            for i in range(n):
+                step(i)
+            self.sync()
+            warm_done = time.perf_counter() - t0
+        if trainer is not None:
+            trainer.comm_events = []
+        self.sync()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(steps):
+            last = step(i)
+        self.sync()
+        dt = time.perf_counter() - t0
+        per_rank = gather_over_ranks(dt, self.dev)
+        comm_ms = None
+        if trainer is not None:
+            ev, trainer.comm_events = trainer.comm_events, None
+            comm_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1) if ev else 0.0
+            comm_ms = max(gather_over_ranks(comm_ms, self.dev))
+        return {"dt": max(per_rank), "per_rank_ms": [round(t / max(steps, 1) * 1e3, 3) for t in per_rank],
+                "allreduce_ms": None if comm_ms is None else round(comm_ms, 4), "warm_s": round(warm_done, 2), "last": last}
+
+
+def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolated_pass, first_run=False, instrument_steps=0):
+    """ST-GCN train step (main_gnn.py:219-239) in one arithmetic mode; returns the result dict of rank 0 (None elsewhere).
+    instrument_steps = 0: the per-kernel HIP events are recorded inside the timed region (the headline leg, as in every
+    round); > 0: the timed region runs bare and that many extra steps are instrumented afterwards (long secondary legs:
+    two event records per launch are not free on a 7-15 ms step)."""
+    import torch
+    import torch.distributed as dist
+    from sar_amd import profiler
+    from sar_amd.stgcn import STGCN
+    from sar_amd.train import Trainer, synthetic_clips
+    eng = STGCN(num_classes=args.classes, device=dev, seed=0, mfma=mfma)  # identical init on every rank
+    trainer = Trainer(eng, batch_size=args.batch, world_size=world)
+    nb = 4     # a few distinct batches resident in HBM, cycled (per-rank seeds: each rank trains on its own shard)
+    batches = [synthetic_clips(args.batch, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(nb)]
+    leg = Leg(world, dev)
+
+    def step(i):
+        return trainer.step(*batches[i % nb])[1]
+
+    first = None
+    if first_run:     # the rate of a cool GPU (what a short run sees): 10 warm-up steps (allocator, lazy initialisation) + 20
+        r = leg.run(step, 20, 10)   # timed steps, before the sustained leg
+        first = args.batch * world * 20 / r["dt"]
+    timer = profiler.KernelTimer()
+    for i in range(warmup):
+        step(i)
+    warm_s = leg.run(step, 0, 0, warm_seconds)["warm_s"] if warm_seconds > 0 else 0.0   # untimed load only
+    if instrument_steps == 0:
+        profiler.install(timer)
+    res = leg.run(step, steps, 0, 0.0, trainer)
+    profiler.install(None)
+    ksteps = steps
+    if instrument_steps > 0:
+        profiler.install(timer)
+        leg.run(step, instrument_steps, 0)
+        profiler.install(None)
+        ksteps = instrument_steps
+    res["warm_s"] = warm_s
+    dt = res["dt"]
+    loss_val = float(res["last"].item())
+    assert loss_val == loss_val, "loss is NaN"
+    # The timed region is the production schedule: weight-gradient kernels run on a second stream and overlap the main
+    # chain, which inflates the HIP-event duration of whatever they overlap.  A short untimed pass with that stream off
+    # measures the dominant family in isolation (kernel quality); both are reported.
+    iso = None
+    if eng._side is not None and isolated_pass:      # every rank: the step contains the collective
+        side, eng._side = eng._side, None
+        iso_timer = profiler.KernelTimer()
+        torch.cuda.synchronize()
+        profiler.install(iso_timer)
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        profiler.install(None)
+        eng._side = side
+        iso = iso_timer.summary()
+    out = None
+    if rank == 0:
+        clips = args.batch * world * steps
+        value = clips / dt
+        summ = timer.summary()
+        fam = [k for k in summ if k.startswith("gemm_temporal9")]
+        ms = sum(summ[k]["ms"] for k in fam)
+        fl = sum(summ[k]["flops"] for k in fam)
+        calls = sum(summ[k]["calls"] for k in fam)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(mfma)
+        kern_ms = {k: round(v["ms"] / ksteps, 3) for k, v in sorted(summ.items())}
+        kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
+        bf16 = mfma != "fp32"
+        desc = {"fp32": "fp32",
+                "bf16": "bf16 (bf16 CN8 activations in HBM, bf16 MFMA operands; fp32 accumulation, BatchNorm statistics, master "
+                        "weights, optimizer)",
+                "bf16_operands": "bf16-MFMA-operand (fp32 activations in HBM)"}[mfma]
+        overl = eng._side is not None
+        in_step = ("IN-STEP figure: HIP events over the timed region%s" %
+                   (", weight-gradient kernels running concurrently on a second stream (inflates the bracketed time; "
+                    "roofline.isolated = the same kernels alone)" if overl else ", single stream"))
+        out = {
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "steps": steps, "warmup": warmup, "warm_s": res["warm_s"],
+            "ms_per_step": round(dt / steps * 1e3, 3), "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"],
+            "dtype": "bf16" if bf16 else "f32",
+            "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
+                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (desc, args.classes, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches); " + in_step,
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch, PMC passes of the PROFILED build (%s), not of this run" % traffic_src
+                                         if traffic else None,
+                         "algorithmic_bytes_per_launch": int(sum(summ[k]["bytes"] for k in fam) / max(calls, 1)),
+                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
+                         "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
+            "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),
+        }
+        if first is not None:
+            out["first_run_value"] = round(first, 2)
+        if iso is not None:
+            ims = sum(iso[k]["ms"] for k in fam if k in iso)
+            ifl = sum(iso[k]["flops"] for k in fam if k in iso)
+            iby = sum(iso[k]["bytes"] for k in fam if k in iso)
+            icalls = sum(iso[k]["calls"] for k in fam if k in iso)
+            out["roofline"]["isolated"] = {
+                "what": "same kernel family, 3 untimed steps with the weight-gradient side stream off (no overlapping kernels)",
+                "tflops": round(ifl / (ims * 1e-3) / 1e12, 2) if ims > 0 else None,
+                "gbps": round(iby / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
+                "avg_launch_ms": round(ims / max(icalls, 1), 4),
+                "frac_of_fp32_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if (ims > 0 and not bf16) else None}
+            out["kernel_ms_per_step_isolated"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(iso.items())}
+            out["wgrad_side_stream"] = True
+        if bf16:   # the bf16 kernels are bound by moving activations, not by the matrix pipe (2.5 PFLOP/s dense bf16)
+            by = sum(summ[k]["bytes"] for k in fam)
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            step_bytes = BYTES_PER_CLIP_TRAIN_BF16 if mfma == "bf16" else 2 * BYTES_PER_CLIP_TRAIN_BF16
+            isolated = out["roofline"].get("isolated")
+            out["roofline"] = {"bound": "hbm", "kernel": "9-tap temporal conv GEMMs on CN8 activations (fwd + data-grad launches); " + in_step,
+                               "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                               "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch, PMC passes of the PROFILED build (%s), not of this run" % traffic_src
+                                               if traffic else None,
+                               "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
+                               "avg_launch_ms": round(ms / max(calls, 1), 4),
+                               "mfma_tflops": round(achieved, 1),
+                               # whole step in SURVEY.md 8(d)'s convention: clips/s/GPU x algorithmic bytes per clip / 8 TB/s
+                               "step_frac_of_hbm_roof": round(value / world * step_bytes / 8.0e12, 4),
+                               "step_algorithmic_bytes_per_clip": step_bytes}
+            if isolated:
+                out["roofline"]["isolated"] = isolated
+    del trainer, eng, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrument_steps=0):
+    """Path B: VirtualRadar (signal + STFT/log-magnitude/column select) -> resnet18 fwd+bwd -> Adam; bs = --batch per GPU
+    (configs[3] uses 32)."""
+    import torch
+    import torch.distributed as dist
+    from sar_amd import profiler
+    from sar_amd.train import SpectrogramTrainer, synthetic_clips
+    from models.resnet import Model
+    bs = 32 if args.batch == 64 else args.batch
+    model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=args.num_pad_frames)
+    trainer = SpectrogramTrainer(model, 1e-3, world_size=world)      # the product step of main_spectrogram.py
+    batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
+    leg = Leg(world, dev)
+
+    def step(i):
+        return trainer.step(*batches[i % 4], 1e-3)[1]
+
+    for i in range(warmup):
+        step(i)
+    warm_s = leg.run(step, 0, 0, warm_seconds)["warm_s"] if warm_seconds > 0 else 0.0
+    graphs = None
+    if os.environ.get("SAR_BENCH_GRAPH", "0") == "1" and world == 1:
+        # one captured hipGraph per resident batch: at bs = 32 the ~250 launches of a step are short enough for the
+        # host launch path to show (experiment switch; the kernels read lr / step counters from device memory)
+        graphs = []
+        leg.sync()
+        for i in range(4):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(i)
+            graphs.append(g)
+    timer = profiler.KernelTimer()
+    ksteps = steps
+    if graphs is None:
+        if instrument_steps == 0:
+            profiler.install(timer)
+        res = leg.run(step, steps, 0, 0.0, trainer)
+        profiler.install(None)
+        if instrument_steps > 0:
+            profiler.install(timer)
+            leg.run(step, instrument_steps, 0)
+            profiler.install(None)
+            ksteps = instrument_steps
+    else:
+        res = leg.run(lambda i: graphs[i % 4].replay(), steps, 0, 0.0, None)
+        res["last"] = step(0)
+    dt, loss = res["dt"], res["last"]
+    out = None
+    if rank == 0:
+        summ = timer.summary()
+        fam = [k for k in summ if k.startswith("conv2d_3x3")]
+        ms = sum(summ[k]["ms"] for k in fam)
+        fl = sum(summ[k]["flops"] for k in fam)
+        calls = sum(summ[k]["calls"] for k in fam)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        value = bs * world * steps / dt
+        traffic, traffic_src = measured_traffic("pathB") if not args.num_pad_frames else (None, None)
+        out = {
+            "metric": "spectrogram clips/sec training (VirtualRadar + resnet18, bs=%d/GPU)" % bs,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "steps": steps, "warmup": warmup, "warm_s": warm_s,
+            "ms_per_step": round(dt / steps * 1e3, 3), "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VirtualRadar -> (B,1,256,256) log-spectrogram -> resnet18 fp32 training step (fwd+bwd+Adam), "
+                                   "synthetic NTU clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
+                                   % (" up-sampled x%d on the GPU" % args.num_pad_frames if args.num_pad_frames else "",
+                                      args.classes, bs),
+                       "global_batch": bs * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches); IN-STEP "
+                                                    "figure: HIP events over the timed region, weight-gradient kernels on a second stream",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch of conv2d_gemm_kernel, PMC passes of the PROFILED build (%s), not of "
+                                         "this run" % traffic_src if traffic else None,
+                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
+                         "step_frac_of_fp32_roof": round(value / world * 13.6e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
+            "kernel_ms_per_step": {k: round(v["ms"] / ksteps, 3) for k, v in sorted(summ.items())},
+            "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
+            "final_loss": round(float(loss.item()), 5),
+        }
+    del trainer, model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def slim(leg):
+    """a secondary leg without the per-kernel tables (the headline line stays readable)"""
+    return {k: v for k, v in leg.items() if k not in ("kernel_ms_per_step", "kernel_tflops", "kernel_ms_per_step_isolated")}
 
 
 def main():
@@ -293,131 +499,46 @@ def main():
     ap.add_argument("--no-isolated-pass", action="store_true",
                     help="skip the 3 extra untimed steps that measure the dominant kernel family with the side stream off "
                          "(profile runs: keeps the launch counts at warmup + steps)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline line only (profile runs); by default the fp32 headline is followed, in the same process, by "
+                         "~2 s each of configs[2] (--mfma bf16, after >= 3 s of untimed load) and configs[3] (Path B), reported "
+                         "under 'secondary'")
+    ap.add_argument("--warm-seconds", type=float, default=0.0,
+                    help="untimed load before the timed steps of the selected workload (the bf16 step's clocks settle after the "
+                         "first second of load; the secondary bf16 leg always uses 3 s)")
     ap.add_argument("--cpu-sample", type=int, default=8,
                     help="clips in the CPU-baseline fallback batch (used only when a full --batch step does not fit the budget)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
-    import torch
     import torch.distributed as dist
-    from sar_amd import profiler
-    from sar_amd.stgcn import STGCN
-    from sar_amd.train import Trainer, synthetic_clips
-
-    if args.workload == "spectrogram":
-        return main_spectrogram(args)
     rank, world, dev = rank_setup(args)
-
-    eng = STGCN(num_classes=args.classes, device=dev, seed=0, mfma=args.mfma)  # identical init on every rank
-    trainer = Trainer(eng, batch_size=args.batch, world_size=world)
-    # a few distinct batches resident in HBM, cycled (per-rank seeds: each rank trains on its own shard)
-    nb = 4
-    batches = [synthetic_clips(args.batch, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(nb)]
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        trainer.step(*batches[i % nb])
-    timer = profiler.KernelTimer()
-    profiler.install(timer)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        _, loss = trainer.step(*batches[i % nb])
-    sync()
-    dt = time.perf_counter() - t0
-    profiler.install(None)
-    dt = max_over_ranks(dt, dev)
-    loss_val = float(loss.item())
-    assert loss_val == loss_val, "loss is NaN"
-    # The timed region is the production schedule: weight-gradient kernels run on a second stream and overlap the main
-    # chain, which inflates the HIP-event duration of whatever they overlap.  A short untimed pass with that stream off
-    # measures the dominant family in isolation (kernel quality); both are reported.
-    iso = None
-    if eng._side is not None and not args.no_isolated_pass:      # every rank: the step contains the collective
-        side, eng._side = eng._side, None
-        iso_timer = profiler.KernelTimer()
-        torch.cuda.synchronize()
-        profiler.install(iso_timer)
-        for i in range(3):
-            trainer.step(*batches[i % nb])
-        torch.cuda.synchronize()
-        profiler.install(None)
-        eng._side = side
-        iso = iso_timer.summary()
-
-    if rank == 0:
-        clips = args.batch * world * args.steps
-        value = clips / dt
-        summ = timer.summary()
-        fam = [k for k in summ if k.startswith("gemm_temporal9")]
-        ms = sum(summ[k]["ms"] for k in fam)
-        fl = sum(summ[k]["flops"] for k in fam)
-        calls = sum(summ[k]["calls"] for k in fam)
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(args.mfma != "fp32")
-        kern_ms = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items())}
-        kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
-        bf16 = args.mfma != "fp32"
-        desc = {"fp32": "fp32",
-                "bf16": "bf16 (bf16 CN8 activations in HBM, bf16 MFMA operands; fp32 accumulation, BatchNorm statistics, master "
-                        "weights, optimizer)",
-                "bf16_operands": "bf16-MFMA-operand (fp32 activations in HBM)"}[args.mfma]
-        out = {
-            "metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)",
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
-                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (desc, args.classes, args.batch),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
-                         "algorithmic_bytes_per_launch": int(sum(summ[k]["bytes"] for k in fam) / max(calls, 1)),
-                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
-                         "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
-            "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),
-        }
-        if iso is not None:
-            ims = sum(iso[k]["ms"] for k in fam if k in iso)
-            ifl = sum(iso[k]["flops"] for k in fam if k in iso)
-            iby = sum(iso[k]["bytes"] for k in fam if k in iso)
-            icalls = sum(iso[k]["calls"] for k in fam if k in iso)
-            out["roofline"]["isolated"] = {
-                "what": "same kernel family, 3 untimed steps with the weight-gradient side stream off (no overlapping kernels)",
-                "tflops": round(ifl / (ims * 1e-3) / 1e12, 2) if ims > 0 else None,
-                "gbps": round(iby / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
-                "avg_launch_ms": round(ims / max(icalls, 1), 4),
-                "frac_of_fp32_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if (ims > 0 and not bf16) else None}
-            out["kernel_ms_per_step_isolated"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(iso.items())}
-            out["wgrad_side_stream"] = True
-        if bf16:   # the bf16 kernels are bound by moving activations, not by the matrix pipe (2.5 PFLOP/s dense bf16)
-            by = sum(summ[k]["bytes"] for k in fam)
-            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            step_bytes = BYTES_PER_CLIP_TRAIN_BF16 if args.mfma == "bf16" else 2 * BYTES_PER_CLIP_TRAIN_BF16
-            isolated = out["roofline"].get("isolated")
-            out["roofline"] = {"bound": "hbm", "kernel": "9-tap temporal conv GEMMs (fwd + data-grad launches)",
-                               "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                               "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
-                               "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
-                               "avg_launch_ms": round(ms / max(calls, 1), 4),
-                               "mfma_tflops": round(achieved, 1),
-                               # whole step in SURVEY.md 8(d)'s convention: clips/s/GPU x algorithmic bytes per clip / 8 TB/s
-                               "step_frac_of_hbm_roof": round(value / world * step_bytes / 8.0e12, 4),
-                               "step_algorithmic_bytes_per_clip": step_bytes}
-            if isolated:
-                out["roofline"]["isolated"] = isolated
-        if world == 1 and not args.no_cpu_baseline:
+    if args.workload == "spectrogram":
+        out = spectrogram_leg(args, args.steps, args.warmup, args.warm_seconds, rank, world, dev)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_spectrogram(4)
+    else:
+        head = stgcn_leg(args, args.mfma, args.steps, args.warmup, args.warm_seconds, rank, world, dev, not args.no_isolated_pass)
+        out = None
+        if rank == 0:
+            out = {"metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)", "value": head["value"], "unit": "clips/s",
+                   "n_gpus": world, "rccl_ranks": head["rccl_ranks"], "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": head["dtype"], "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
+            out.update({k: v for k, v in head.items() if k not in out})
+        if args.mfma == "fp32" and not args.no_secondary:
+            # configs[2] and configs[3] in the same process, driver-timed with the headline.  bf16: the
+            # SUSTAINED rate (>= 3 s of untimed load first) is `value`; the cold-GPU rate of a short run is first_run_value.
+            sec = {}
+            b = stgcn_leg(args, "bf16", 120, 3, 3.0, rank, world, dev, False, first_run=True, instrument_steps=5)
+            p = spectrogram_leg(args, 250, 5, 1.0, rank, world, dev, instrument_steps=5)
+            if rank == 0:
+                sec["bf16"], sec["pathB"] = slim(b), slim(p)
+                out["secondary"] = sec
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample)
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -33,12 +33,23 @@ extern "C" {
 typedef void* sar_stream_t;
 
 int sar_version(void);
-/* diagnostic: fills 64 KiB of LDS on every CU with `pattern` (tests: a kernel whose result depends on LDS it never
- * wrote becomes visible); sink: 4 device bytes */
-int sar_debug_poison_lds(unsigned pattern, void* sink, sar_stream_t s);
-/* diagnostic: workgroups/CU the runtime predicts for the temporal GEMM at a dynamic-LDS size */
-int sar_debug_occupancy(int which, int lds_bytes);
-const char* sar_last_error_string(void);
+const char* sar_last_error_string(void);   /* thread-local */
+/* (the diagnostic entry points sar_debug_* are declared in include/sar_hip_debug.h and exist only in a `make DEBUG=1`
+ * build of the library: they are not part of the product ABI) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Caller-owned launch context.  The library keeps NO global mutable state: everything is asynchronous on the stream the
+ * caller passes and re-entrant from several host threads on distinct streams.  A few operators are faster when they fan
+ * out over several streams -- today the 3x3 / stride-2 data gradient of sar_conv2d_gemm_f32, whose four parity-class
+ * launches are individually too small to fill the chip.  The streams and events that takes are owned by a sar_context
+ * the CALLER creates (one per host thread and device) and hands in through sar_conv2d_desc.ctx; with ctx == NULL the same
+ * launches run one after the other on the caller's stream.  A context is created for the CURRENT device
+ * (hipGetDevice); used while another device is current it is ignored (caller's stream only).  Whatever happens inside
+ * the call -- including a failing launch -- the side streams are joined back into the caller's stream before it returns.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct sar_context sar_context;
+int sar_context_create(sar_context** out);   /* 3 non-blocking side streams + 4 events; 0 or a hipError_t */
+int sar_context_destroy(sar_context* ctx);   /* waits for nothing: synchronise the caller's stream first */
 
 /* ------------------------------------------------------------------------------------------------
  * Fused conv-GEMM on the CN layout (fp32 MFMA, v_mfma_f32_32x32x2_f32).
@@ -333,6 +344,7 @@ typedef struct sar_conv2d_desc {
   const float* aux; int64_t ld_aux; const float* aux_scale; const float* aux_shift; const float* aux_mean;
   float* partials;         /* gemm: [M][nparts][2] */
   float* slab;             /* wgrad: [nsplit][KH*KW*Kc*M] */
+  sar_context* ctx;        /* optional side streams for launches that fan out (see sar_context); NULL = caller's stream only */
 } sar_conv2d_desc;
 
 int sar_conv2d_nparts(const sar_conv2d_desc* d);

@@ -184,6 +184,36 @@ def data_bn(x, p, training, new_stats=None):
     return h
 
 
+class _RoundBF16(torch.autograd.Function):
+    """Where the bf16 configuration stores a tensor as bfloat16: the VALUE is rounded in the forward
+    pass and the GRADIENT flowing back through the same tensor in the backward pass (the engine stores both the activation
+    and its gradient as bfloat16); the rounding itself is treated as the identity (straight-through), which is exactly
+    what a network that computes with the rounded values does."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return x.to(torch.bfloat16).to(x.dtype) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
+
+
+def _q(x, site, quant):
+    """quant: None (the reference arithmetic) or a set of storage sites to emulate in bfloat16: 'x0' data_bn output, 'g'
+    graph-conv output, 'h' the BN + ReLU operand staged for the temporal conv, 'u' temporal-conv output, 'r' residual-conv
+    output, 'y' block output, 'w' the conv weights as MFMA operands (forward value only); '<site>:fwd' rounds the value
+    but not the gradient."""
+    if not quant:
+        return x
+    if site in quant:
+        return _RoundBF16.apply(x, True, site != "w")
+    if site + ":fwd" in quant:
+        return _RoundBF16.apply(x, True, False)
+    return x
+
+
 def _relu(z, masks, site):
     """ReLU, or multiplication by a prescribed activation pattern (see oracle/resnet.py:_relu)."""
     if masks is None:
@@ -191,8 +221,8 @@ def _relu(z, masks, site):
     return z * masks[site].to(z.dtype)
 
 
-def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None, masks=None):
-    """models/stgcn.py:58-64 for block i.  x (B,Cin,T,V)."""
+def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None, masks=None, quant=None):
+    """models/stgcn.py:58-64 for block i.  x (B,Cin,T,V).  quant: see _q (bf16-storage emulation, tests only)."""
     f, s, res = (blocks or BLOCKS)[i]
     pre = "l%d." % i
     kind = block_residual_kind(x.shape[1], f, s, res)
@@ -201,20 +231,20 @@ def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None, masks
     elif kind == "identity":
         r = x
     else:
-        r = F.conv2d(x, hwio_to_oihw(p[pre + "res.kernel"]), p[pre + "res.bias"], stride=(s, 1))
+        r = _q(F.conv2d(x, hwio_to_oihw(_q(p[pre + "res.kernel"], "w", quant)), p[pre + "res.bias"], stride=(s, 1)), "r", quant)
         r = batch_norm(r, p[pre + "res_bn.gamma"], p[pre + "res_bn.beta"], p[pre + "res_bn.moving_mean"],
                        p[pre + "res_bn.moving_var"], training, (0, 2, 3), True, new_stats, pre + "res_bn")
-    g = graph_conv_td(x, p[pre + "gcn.kernel"], p[pre + "gcn.bias"], A)
+    g = _q(graph_conv_td(x, _q(p[pre + "gcn.kernel"], "w", quant), p[pre + "gcn.bias"], A), "g", quant)
     h = batch_norm(g, p[pre + "bn1.gamma"], p[pre + "bn1.beta"], p[pre + "bn1.moving_mean"],
                    p[pre + "bn1.moving_var"], training, (0, 2, 3), True, new_stats, pre + "bn1")
     h_pre = h
-    h = _relu(h, masks, pre + "h")
-    u = temporal_conv(h, p[pre + "tcn.kernel"], p[pre + "tcn.bias"], s)
+    h = _q(_relu(h, masks, pre + "h"), "h", quant)
+    u = _q(temporal_conv(h, _q(p[pre + "tcn.kernel"], "w", quant), p[pre + "tcn.bias"], s), "u", quant)
     z = batch_norm(u, p[pre + "bn2.gamma"], p[pre + "bn2.beta"], p[pre + "bn2.moving_mean"],
                    p[pre + "bn2.moving_var"], training, (0, 2, 3), True, new_stats, pre + "bn2")
     if r is not None:
         z = z + r
-    y = _relu(z, masks, pre + "y")
+    y = _q(_relu(z, masks, pre + "y"), "y", quant)
     if taps is not None:
         taps[pre + "g"] = g
         taps[pre + "u"] = u
@@ -224,15 +254,15 @@ def st_block(x, p, i, A, training, new_stats=None, taps=None, blocks=None, masks
     return y
 
 
-def forward(p, x, training, new_stats=None, taps=None, blocks=None, masks=None):
+def forward(p, x, training, new_stats=None, taps=None, blocks=None, masks=None, quant=None):
     """models/stgcn.py:135-160.  x (N,C,T,V,M) -> logits (N, classes)."""
     N, C, T, V, M = x.shape
-    h = data_bn(x, p, training, new_stats)
+    h = _q(data_bn(x, p, training, new_stats), "x0", quant)
     if taps is not None:
         taps["x0"] = h
     A = p["A"]
     for i in range(len(blocks or BLOCKS)):
-        h = st_block(h, p, i, A, training, new_stats, taps, blocks, masks)
+        h = st_block(h, p, i, A, training, new_stats, taps, blocks, masks, quant)
     pooled = h.mean(dim=(2, 3))                    # GlobalAveragePooling2D, stgcn.py:154
     feat = pooled.reshape(N, M, -1).mean(dim=1)    # stgcn.py:155-156
     if taps is not None:
@@ -247,14 +277,14 @@ def loss_fn(logits, labels, global_batch_size):
     return ce * (1.0 / global_batch_size)
 
 
-def loss_and_grads(p, x, labels, global_batch_size=None, blocks=None, masks=None):
+def loss_and_grads(p, x, labels, global_batch_size=None, blocks=None, masks=None, quant=None):
     """One train_step's differentiable part (main_gnn.py:221-233)."""
     names = trainable_names(p)
     leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
     q = dict(p)
     q.update(leaves)
     new_stats, taps = {}, {}
-    logits = forward(q, x, True, new_stats, taps, blocks, masks)
+    logits = forward(q, x, True, new_stats, taps, blocks, masks, quant)
     gbs = global_batch_size or x.shape[0]
     loss = loss_fn(logits, labels, gbs)
     used = names

@@ -710,6 +710,8 @@ int dispatch(const sar_conv_desc& d, hipStream_t st, bool query_only, int* npart
 
 }  // namespace
 
+#ifdef SAR_DEBUG
+#include "../../include/sar_hip_debug.h"
 // Diagnostic: resident workgroups per CU the runtime predicts for the 9-tap temporal forward kernel
 // (128x128 tile) at a given dynamic-LDS size.  which=1 selects the 64x256 tile.
 extern "C" int sar_debug_occupancy(int which, int lds_bytes) {
@@ -728,6 +730,7 @@ extern "C" int sar_debug_occupancy(int which, int lds_bytes) {
             at.maxDynamicSharedSizeBytes, at.localSizeBytes, at.constSizeBytes, at.maxThreadsPerBlock, n);
   return e == hipSuccess ? n : -(int)e;
 }
+#endif
 
 extern "C" int sar_conv_gemm_nparts(const sar_conv_desc* d) {
   if (!d || d->V <= 0 || d->T_out <= 0 || d->B <= 0 || d->M <= 0) return SAR_E_ARG;

@@ -31,6 +31,7 @@ struct ConvK8 {
   int G;             // channel groups of 8 in the packed weights (even)
   int Gs, Go;        // CN8 planes of src / out (= aux)
   int FT, TPS, NF, RW, nparts, ntiles, ny;
+  int stagger, stagger_shift;   // experiment (SAR_CN8_STAGGER): first-round workgroups start (id >> shift) % 3 * stagger x 1024 cycles late
 };
 
 template <int TAPS, int MS, int NS, int WM, int WN>
@@ -51,9 +52,35 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- epilogue: mask / add, BatchNorm partial sums from the fp32 accumulators, bf16 half-unit stores.  Every wave is
 // past its last MFMA phase and the closing barrier: the transpose area aliases the operand image.
-template <int MS, int NS, int WN, int BM>
+// PRE: the caller has already (a) loaded the aux half units into axr[((ms * 2 + rb) * 2 + q2) * NS + ns] (issued before
+// its last MFMA phase, so their HBM latency is hidden) and (b) staged the MASK parameters (scale, shift, mean) in rowp.
+struct Epi8Desc {
+  __amdgpu_buffer_rsrc_t ro, ra;
+  int so_out, so_aux, g_w, rows_w;
+};
+
+template <int MS>
+__device__ __forceinline__ Epi8Desc epi8_desc(const ConvK8& k, int wm, int m0, bool has_aux) {
+  const sar_conv_desc& d = k.d;
+  Epi8Desc e;
+  e.rows_w = m0 + wm * MS * 32;          // first output row of this wave (multiple of 32)
+  e.g_w = e.rows_w >> 3;                 // its first CN8 plane
+  auto plane_bytes = [&](int64_t ld) {   // bytes from plane g_w to the end of the tensor (clamped to 2 GiB)
+    const int64_t n = (int64_t)(k.Go - e.g_w) * ld * 16;
+    return (unsigned)(n <= 0 ? 0 : (n > 0x7fffffffll ? 0x7fffffffll : n));
+  };
+  e.ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)d.out + (int64_t)e.g_w * d.ld_out * 16), 0, plane_bytes(d.ld_out),
+                                           0x00020000);
+  e.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(has_aux ? (char*)d.aux + (int64_t)e.g_w * d.ld_aux * 16 : (char*)d.out), 0,
+                                           has_aux ? plane_bytes(d.ld_aux) : 0u, 0x00020000);
+  e.so_out = (int)(d.ld_out * 16), e.so_aux = (int)(d.ld_aux * 16);   // one plane
+  return e;
+}
+
+template <int MS, int NS, int WN, int BM, bool PRE = false>
 __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int wn, int m0, const unsigned (&vo)[NS],
-                                          f32x16 (&acc)[MS][NS], float4* rowp, float* smem) {
+                                          f32x16 (&acc)[MS][NS], float4* rowp, float* smem,
+                                          const u32x2* axr = nullptr) {
   const sar_conv_desc& d = k.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,7 +90,7 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
     constexpr int EPI = decltype(EPI_)::value;
     constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
     constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
-    if (EPI == SAR_EPI_MASK) {
+    if (EPI == SAR_EPI_MASK && !PRE) {
       if (tid < BM) {
         const int row = m0 + tid;
         float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -76,19 +103,11 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
       }
       __syncthreads();
     }
-    const int rows_w = m0 + wm * MS * 32;          // first output row of this wave (multiple of 32)
-    const int g_w = rows_w >> 3;                   // its first CN8 plane
-    auto plane_bytes = [&](int64_t ld) {           // bytes from plane g_w to the end of the tensor (clamped to 2 GiB)
-      const int64_t n = (int64_t)(k.Go - g_w) * ld * 16;
-      return (unsigned)(n <= 0 ? 0 : (n > 0x7fffffffll ? 0x7fffffffll : n));
-    };
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((char*)d.out + (int64_t)g_w * d.ld_out * 16), 0, plane_bytes(d.ld_out), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(has_aux ? (char*)d.aux + (int64_t)g_w * d.ld_aux * 16 : (char*)d.out), 0, has_aux ? plane_bytes(d.ld_aux) : 0u,
-        0x00020000);
+    const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, has_aux);
+    const int rows_w = e8.rows_w, g_w = e8.g_w;
+    const __amdgpu_buffer_rsrc_t ro = e8.ro, ra = e8.ra;
     // vo[ns]: byte offset of this lane's half unit inside a plane (0x80000000 = off-tile column: rejected)
-    const int so_out = (int)(d.ld_out * 16), so_aux = (int)(d.ld_aux * 16);   // one plane
+    const int so_out = e8.so_out, so_aux = e8.so_aux;
     float* P = smem + wave * (16 * 65);
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
@@ -101,7 +120,9 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
           for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
-              const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(ra, vo[ns], (4 * ms + 2 * rb + q2) * so_aux, 0);
+              u32x2 a;
+              if constexpr (PRE) a = axr[((ms * 2 + rb) * 2 + q2) * NS + ns];
+              else a = __builtin_amdgcn_raw_buffer_load_b64(ra, vo[ns], (4 * ms + 2 * rb + q2) * so_aux, 0);
               float f[4];
               cn8_unpack4(make_uint2(a[0], a[1]), f);
 #pragma unroll
@@ -209,6 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   const int ny = k.ny;
   const int w = xcd_work(k.ntiles * ny);
   if (w < 0) return;
+  if (k.stagger && blockIdx.x < 768) {   // de-phase the co-resident workgroups (they would otherwise run their phases in lockstep)
+    const int ph = (blockIdx.x >> k.stagger_shift) % 3;
+    for (int i = 0; i < ph * k.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   const int tile = w / ny;
   const int b = tile / k.TPS;
   const int t0 = (tile - b * k.TPS) * k.FT;
@@ -388,18 +413,58 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
                                                               *reinterpret_cast<bf16x8*>(&bq[ns]), acc[ms][ns], 0, 0, 0);
   };
 
-  for (int c0 = 0; c0 < d.Kc; c0 += KC16) {
-    if (!(SAR_ABLATE8 & 8) || c0 == 0) store_lds(c0);
-    __syncthreads();
-    if (c0 + KC16 < d.Kc && !(SAR_ABLATE8 & 2)) issue_loads(c0 + KC16);   // in flight during the MFMA phase
+  auto mma_phase = [&]() {
     constexpr int JSURE = PAR ? JT - 1 : JT;
     if (!(SAR_ABLATE8 & 1)) {
 #pragma unroll
       for (int j = 0; j < JSURE; ++j) taps_mma(j);
       if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
     }
-    __syncthreads();   // every wave is done with the image (next store / the epilogue's transpose area)
+  };
+  // aux half units of the whole wave tile (ReLU-mask source / residual gradient): MS x 2 x 2 x NS loads of 8 bytes issued
+  // BEFORE the last MFMA phase.  Loaded inside the epilogue they were four dependent HBM round trips per workgroup (one per
+  // 32-row half block): 12 us of a 25 us workgroup on the 64-channel data gradient.
+  const bool epi_mask = d.epi == SAR_EPI_MASK;
+  const bool has_aux = epi_mask || d.epi == SAR_EPI_ADD;
+  u32x2 axr[MS * 4 * NS];
+  auto issue_aux = [&]() {
+    const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            axr[((ms * 2 + rb) * 2 + q2) * NS + ns] =
+                __builtin_amdgcn_raw_buffer_load_b64(e8.ra, vo[ns], (4 * ms + 2 * rb + q2) * e8.so_aux, 0);
+  };
+
+  int c0 = 0;
+  for (; c0 + KC16 < d.Kc; c0 += KC16) {
+    if (!(SAR_ABLATE8 & 8) || c0 == 0) store_lds(c0);
+    __syncthreads();
+    if (!(SAR_ABLATE8 & 2)) issue_loads(c0 + KC16);   // in flight during the MFMA phase
+    mma_phase();
+    __syncthreads();   // every wave is done with the image (next store)
   }
+  // last stage (peeled: the aux registers take the place of the staging registers)
+  if (!(SAR_ABLATE8 & 8) || c0 == 0) store_lds(c0);
+  __syncthreads();
+  if (has_aux) issue_aux();   // uniform
+  if (epi_mask && tid < BM) {   // MASK parameters replace the bias rows (every wave is past its accumulator initialisation)
+    const int row = m0 + tid;
+    float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < d.M) {
+      ap.x = d.aux_scale[row];
+      ap.y = d.aux_shift[row];
+      if (d.aux_mean) ap.z = d.aux_mean[row];
+    }
+    rowp[tid] = ap;
+  }
+  mma_phase();
+  __syncthreads();   // the epilogue's transpose area aliases the image; rowp is complete
   if (SAR_ABLATE8 & 4) {   // every accumulator stays live (an un-used one would take its MFMAs with it)
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
@@ -409,7 +474,262 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[ms][ns][r]));
     return;
   }
-  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+  if (has_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
+  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Double-buffered 9-tap kernel: stride-1 forward (TR 0), stride-1 data gradient (TR 1), parity-split stride-2 data
+// gradient (TR 3) on 64 x 256 tiles.  Same arithmetic, operand images and epilogue as conv_gemm_cn8_kernel; what differs is
+// the schedule (the recipe of the fp32 kernel, conv_gemm.hip):
+//   * two LDS images and ONE barrier per stage: the loads of stage s+1 are issued before the MFMA phase of stage s,
+//     land in registers during it, and are transformed / written into the OTHER image right after it -- while the other
+//     waves of the workgroup (and the second workgroup of the CU) are still multiplying;
+//   * the staged window is at most 512 columns (18-19 frames), so two images fit twice per CU (2 x 35 KB per workgroup);
+//   * the epilogue's aux half units (ReLU-mask source / residual gradient) are loaded BEFORE the last MFMA phase and its
+//     per-row parameters staged at kernel start: the epilogue opens with its operands in registers instead of a
+//     dependent HBM round trip per 32-row block.
+template <int TR, int MS, int NS, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k) {
+  constexpr int TAPS = 9;
+  constexpr int PAR = (TR == 3);
+  constexpr int JT = PAR ? (TAPS + 1) / 2 : TAPS;
+  constexpr int BM = 32 * MS * WM;
+  constexpr int RWMAX = 512, SCOLS = RWMAX + 8, ZCOL = RWMAX, CJ = RWMAX / 256;
+  constexpr int WUNITS = TAPS * 2 * BM, SUNITS = 2 * SCOLS, BUF = WUNITS + SUNITS;
+  constexpr int WIT = (WUNITS + 255) / 256;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(TR == 0 || TR == 1 || TR == 3, "forward, stride-1 and parity-split data gradients");
+  static_assert(BUF >= 4 * 16 * 65 / 4, "the epilogue's transpose area aliases image 0");
+  __shared__ uint4 smem_u[2 * BUF + 2 * BM];   // image 0 | image 1 | bias rows | MASK parameter rows
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + 2 * BUF);
+  float4* rowpa = rowp + BM;
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int V = d.V;
+  const int ny = k.ny;
+  const int w = xcd_work(k.ntiles * ny);
+  if (w < 0) return;
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+
+  // ---- per-lane column geometry (conv_gemm_cn8_kernel)
+  bool colok[NS];
+  unsigned vo[NS];
+  int off0[NS], ostep[NS];
+  int t_lo;
+  if (TR == 0) t_lo = t0 * d.stride - d.pad;
+  else t_lo = floordiv(t0 + d.pad - (TAPS - 1), d.stride);
+  constexpr int HALFC = 16 * NS * WN;
+  const int par = PAR ? (wn * NS * 32 >= HALFC ? 1 : 0) : 0;
+  const int tp0 = PAR ? ((par + d.pad) & 1) : 0;
+  const int ntap_w = PAR ? (TAPS - tp0 + 1) / 2 : TAPS;
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    int fo, v;
+    if (PAR) {
+      const int pp = p - par * HALFC;
+      const int fh = pp / V;
+      v = pp - fh * V;
+      fo = 2 * fh + par;
+    } else {
+      fo = p / V;
+      v = p - fo * V;
+    }
+    colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
+    if (!colok[ns]) fo = par;
+    vo[ns] = colok[ns] ? (unsigned)((((int64_t)b * d.T_out + (t0 + fo)) * V + v) * 16 + 8 * hi) : 0x80000000u;
+    if (TR == 0) {
+      off0[ns] = fo * d.stride * V + v;
+      ostep[ns] = V;
+    } else if (TR == 1) {
+      off0[ns] = (t0 + fo + d.pad - t_lo) * V + v;
+      ostep[ns] = -V;
+    } else {
+      off0[ns] = (((t0 + fo + d.pad - tp0) >> 1) - t_lo) * V + v;
+      ostep[ns] = -V;
+    }
+    if (!colok[ns]) {
+      off0[ns] = ZCOL;
+      ostep[ns] = 0;
+    }
+    off0[ns] += hi * SCOLS;
+  }
+
+  const bool epi_mask = d.epi == SAR_EPI_MASK;
+  const bool has_aux = epi_mask || d.epi == SAR_EPI_ADD;
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f), ap = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < d.M) {
+      if (d.bias) bp.x = d.bias[row];
+      if (epi_mask) {
+        ap.x = d.aux_scale[row];
+        ap.y = d.aux_shift[row];
+        if (d.aux_mean) ap.z = d.aux_mean[row];
+      }
+    }
+    rowp[tid] = bp;
+    rowpa[tid] = ap;
+  }
+  if (tid < 4) smem_u[(tid >> 1) * BUF + WUNITS + (tid & 1) * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);   // zero column, both images
+  f32x16 acc[MS][NS];
+
+  // ---- staging (conv_gemm_cn8_kernel)
+  const int seq_len = d.T_src * V;
+  const char* src_b = (const char*)d.src + (int64_t)b * seq_len * 16;
+  const int svo0 = (t_lo * V + tid) * 16;
+  unsigned sbits = 0, swidth = 0;
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int col = tid + 256 * j;
+    const int rabs = t_lo * V + col;
+    swidth |= (col < k.RW ? 1u : 0u) << j;
+    sbits |= ((col < k.RW && (unsigned)rabs < (unsigned)seq_len) ? 1u : 0u) << j;
+  }
+  static_assert(256 % (2 * BM) == 0, "a W pass must cover whole taps");
+  constexpr int TPI = 256 / (2 * BM);
+  const int wm_ = tid % BM, wh_ = (tid / BM) & 1, wt_ = tid / (2 * BM);
+  const unsigned wvo0 = (m0 + wm_) < d.M ? (unsigned)((((int64_t)wt_ * k.G + wh_) * d.M + m0 + wm_) * 16) : 0x80000000u;
+  const int wstep = TPI * k.G * d.M * 16;
+  const unsigned wbytes = (unsigned)((int64_t)TAPS * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const bool has_pro = d.pro_scale != nullptr;
+  const bool pro_relu = d.pro_relu != 0;
+  const int ncj = (k.RW + 255) >> 8;
+  uint4 wreg[WIT];
+  uint4 sreg[2][CJ];
+
+  auto issue_loads = [&](int c0) {
+    const int wso = (c0 / 8) * d.M * 16;
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo0, wso + i * wstep, 0);
+      wreg[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int g = c0 / 8 + h;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(src_b + (int64_t)(g < k.Gs ? g : 0) * d.ld_src * 16), 0, g < k.Gs ? (unsigned)seq_len * 16u : 0u, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < CJ; ++j)
+        if (j < ncj) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((swidth >> j) & 1u) ? svo0 + j * 4096 : 0x7fffffff, 0, 0);
+          sreg[h][j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    }
+  };
+
+  auto store_lds = [&](int c0, uint4* img) {
+    uint4* Wl = img;
+    uint4* Sl = img + WUNITS;
+#pragma unroll
+    for (int i = 0; i < WIT; ++i)
+      if ((i + 1) * 256 <= WUNITS || tid + 256 * i < WUNITS) Wl[tid + 256 * i] = wreg[i];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (has_pro) {
+        float psc[8], psh[8];
+        cn8_params8(d.pro_scale, c0 + 8 * h, d.Kc, psc);
+        cn8_params8(d.pro_shift, c0 + 8 * h, d.Kc, psh);
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+          if (j < ncj) sreg[h][j] = cn8_bn_relu_unit(sreg[h][j], psc, psh, pro_relu, ((sbits >> j) & 1u) ? 0xffffffffu : 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < CJ; ++j)
+        if (j < ncj) Sl[h * SCOLS + tid + 256 * j] = sreg[h][j];
+    }
+  };
+
+  // aux half units of the whole wave tile (MS x 2 x 2 x NS loads of 8 bytes), issued before the last MFMA phase
+  u32x2 axr[MS * 4 * NS];
+  auto issue_aux = [&]() {
+    const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            axr[((ms * 2 + rb) * 2 + q2) * NS + ns] =
+                __builtin_amdgcn_raw_buffer_load_b64(e8.ra, vo[ns], (4 * ms + 2 * rb + q2) * e8.so_aux, 0);
+  };
+
+  auto mma_phase = [&](auto IT) {
+    constexpr int it = decltype(IT)::value;
+    const uint4* Wl = smem_u + it * BUF;
+    const uint4* Sl = Wl + WUNITS;
+    const uint4* Wa = Wl + (tp0 * 2 + hi) * BM + wm * MS * 32 + l31;
+    auto taps_mma = [&](int j) {
+      const int tpw = PAR ? 2 * j : j;
+      uint4 a[MS], bq[NS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tpw * 2 * BM + ms * 32];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) bq[ns] = Sl[off0[ns] + j * ostep[ns]];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[ms]),
+                                                                *reinterpret_cast<bf16x8*>(&bq[ns]), acc[ms][ns], 0, 0, 0);
+    };
+    constexpr int JSURE = PAR ? JT - 1 : JT;
+#pragma unroll
+    for (int j = 0; j < JSURE; ++j) taps_mma(j);
+    if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
+  };
+
+  issue_loads(0);
+  __syncthreads();   // rowp / rowpa / zero columns
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = colok[ns] ? bp.x : 0.f;
+    }
+  store_lds(0, smem_u);
+  __syncthreads();
+
+  // stage s multiplies image s & 1; every stage but the last also fills the other image for stage s + 1
+  const int nst = (d.Kc + KC16 - 1) / KC16;
+  auto stage = [&](int s, auto IT) {
+    constexpr int it = decltype(IT)::value;
+    issue_loads((s + 1) * KC16);
+    mma_phase(IT);
+    store_lds((s + 1) * KC16, smem_u + (it ^ 1) * BUF);
+    __syncthreads();
+  };
+  int s = 0;
+  for (; s + 2 < nst; s += 2) {
+    stage(s, std::integral_constant<int, 0>());
+    stage(s + 1, std::integral_constant<int, 1>());
+  }
+  if (s + 1 < nst) {
+    stage(s, std::integral_constant<int, 0>());
+    ++s;
+  }
+  // last stage (image s & 1): the aux loads take the place of the next stage's loads
+  if (has_aux) issue_aux();   // uniform
+  if (s & 1) mma_phase(std::integral_constant<int, 1>());
+  else mma_phase(std::integral_constant<int, 0>());
+  __syncthreads();   // the epilogue's transpose area aliases image 0
+  if (has_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowpa, smem, axr);
+  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowpa, smem);
 }
 
 // ---- GraphConvTD (models/gcn.py:199-209) and its data gradient:
@@ -584,12 +904,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
     }
   const uint4* Wa = Wl + hi * BM + wm * MS * 32 + l31;
   const uint4* Za = Zl + hi * TN + wn * NS * 32 + l31;
-  for (int c0 = 0; c0 < d.Kc; c0 += KC16) {
-    store_raw();
-    __syncthreads();   // raw image complete; every wave is past the MFMA phase of the previous stage
-    build_units();
-    __syncthreads();
-    if (c0 + KC16 < d.Kc) issue_loads(c0 + KC16);
+  auto mma_phase = [&]() {
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {
       uint4 a[MS], bq[NS];
@@ -604,13 +919,46 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
           acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[ms]),
                                                                 *reinterpret_cast<bf16x8*>(&bq[ns]), acc[ms][ns], 0, 0, 0);
     }
+  };
+  // the ADD epilogue's aux half units (skip-path / residual gradient of the data gradient) are loaded while the last stage
+  // is built and multiplied, not inside the epilogue (conv_gemm_cn8_kernel)
+  const bool pre_aux = d.epi == SAR_EPI_ADD;
+  u32x2 axr[MS * 4 * NS];
+  auto issue_aux = [&]() {
+    const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            axr[((ms * 2 + rb) * 2 + q2) * NS + ns] =
+                __builtin_amdgcn_raw_buffer_load_b64(e8.ra, vo[ns], (4 * ms + 2 * rb + q2) * e8.so_aux, 0);
+  };
+  int c0 = 0;
+  for (; c0 + KC16 < d.Kc; c0 += KC16) {
+    store_raw();
+    __syncthreads();   // raw image complete; every wave is past the MFMA phase of the previous stage
+    build_units();
+    __syncthreads();
+    issue_loads(c0 + KC16);
+    mma_phase();
   }
+  store_raw();         // last stage (peeled: the aux registers take the place of the staging registers)
+  __syncthreads();
+  if (pre_aux) issue_aux();   // uniform
+  build_units();
+  __syncthreads();
+  mma_phase();
   __syncthreads();   // the epilogue's transpose area aliases the image
-  epilogue8<MS, NS, WN, BM>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+  if (pre_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
+  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
 }
 
 template <int WN>
-int tile_geometry8(const sar_conv_desc& d, int NSv, bool parity, ConvK8& k) {
+int tile_geometry8(const sar_conv_desc& d, int NSv, bool parity, ConvK8& k, int rwmax_db = 0) {
   const int tile_n = 32 * NSv * WN;
   if (parity) {
     k.FT = 2 * ((tile_n / 2) / d.V);
@@ -621,7 +969,7 @@ int tile_geometry8(const sar_conv_desc& d, int NSv, bool parity, ConvK8& k) {
     if (k.FT > d.T_out) k.FT = d.T_out;
   }
   if (k.FT < 1) return -1;
-  const int rwmax = (d.mode == SAR_CONV_GRAPH) ? tile_n : (NSv * WN == 4 ? 448 : 704);
+  const int rwmax = rwmax_db ? rwmax_db : (d.mode == SAR_CONV_GRAPH) ? tile_n : (NSv * WN == 4 ? 448 : 704);
   for (;; k.FT -= parity ? 2 : 1) {      // as many frames as the staged window allows
     if (d.mode == SAR_CONV_GRAPH) k.NF = k.FT;
     else if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
@@ -636,6 +984,9 @@ int tile_geometry8(const sar_conv_desc& d, int NSv, bool parity, ConvK8& k) {
 }
 
 void fill_common(const sar_conv_desc& d, const uint4* wp, ConvK8& k) {
+  static const int stg = [] { const char* e = getenv("SAR_CN8_STAGGER"); return e ? atoi(e) : 0; }();
+  static const int stg_sh = [] { const char* e = getenv("SAR_CN8_STAGGER_SHIFT"); return e ? atoi(e) : 8; }();
+  k.stagger = stg, k.stagger_shift = stg_sh;
   k.d = d;
   k.wp = wp;
   k.G = 2 * ((d.Kc + 15) / 16);
@@ -660,6 +1011,37 @@ int launch_cfg8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np
   k.ny = (d.M + BM - 1) / BM;
   const int nwork = k.ntiles * k.ny;
   hipLaunchKernelGGL((conv_gemm_cn8_kernel<TR, TAPS, MS, NS, WM, WN>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
+  return 0;
+}
+
+// the double-buffered kernel (9 taps; stride-1 forward, stride-1 / parity-split data gradients) is an EXPERIMENT switch
+// (SAR_CN8_DB=1): with two 35 KB images only two workgroups fit a CU, and measured against three single-image workgroups
+// it is 5-10 % slower per kernel (forward 1.81 vs 1.73 ms per step, data gradient 2.10 vs 1.89; profiles/r03 notes)
+bool db_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("SAR_CN8_DB");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
+template <int TR, int MS, int NS, int WM, int WN>
+int launch_db8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* nparts_only) {
+  ConvK8 k;
+  fill_common(d, wp, k);
+  if (int g = tile_geometry8<WN>(d, NS, TR == 3, k, 512)) {
+    sar_set_error("sar_conv_gemm_cn8: unsupported tile geometry (V=%d, stride=%d)", d.V, d.stride);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
+  }
+  if (nparts_only) {
+    *nparts_only = k.nparts;
+    return 0;
+  }
+  constexpr int BM = 32 * MS * WM;
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + BM - 1) / BM;
+  const int nwork = k.ntiles * k.ny;
+  hipLaunchKernelGGL((conv_gemm_cn8_db_kernel<TR, MS, NS, WM, WN>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
   return 0;
 }
 
@@ -707,6 +1089,9 @@ template <int TR, int TAPS>
 int launch_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) {
   // M > 64: 128 x 256 tiles (wave tile 64 x 128): per output element the weight image -- re-read from L2 by every tile and
   // stage -- is fetched half as often as with 128 x 128 tiles (measured: SAR_CN8_TN128=1 restores the small tile)
+  if constexpr (TAPS == 9 && (TR == 0 || TR == 1 || TR == 3))
+    if (d.M > 32 && (TR != 0 || d.stride == 1) && tile_choice() == 2 && db_enabled() && d.V * 19 <= 512)
+      return launch_db8<TR, 2, 2, 1, 4>(d, wp, st, np);
   if constexpr (TR != 3)
     if (d.M > 64) {
       const int t = tile_choice();

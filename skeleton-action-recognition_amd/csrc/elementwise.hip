@@ -6,6 +6,7 @@
 // every reduction is deterministic).  Reference call sites are cited in include/sar_hip.h.
 #include <stdarg.h>
 #include "sar_common.h"
+#include <stdlib.h>
 #include "cn8.h"
 
 // ------------------------------------------------------------------------------------ error state
@@ -18,6 +19,56 @@ void sar_set_error(const char* fmt, ...) {
 }
 extern "C" const char* sar_last_error_string(void) { return g_err; }
 extern "C" int sar_version(void) { return 100; }
+extern "C" int sar_context_create(sar_context** out) {
+  SAR_REQUIRE(out != nullptr, "sar_context_create: null output pointer");
+  *out = nullptr;
+  sar_context* c = new sar_context();
+  c->nstreams = 0;
+  hipError_t e = hipGetDevice(&c->device);
+  const char* env = getenv("SAR_C2D_PARITY_STREAMS");      // experiment switch: 0 = contexts without side streams
+  const bool want = !(env && env[0] == '0');
+  if (e == hipSuccess && want) {
+    e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    int made = 0;
+    for (; e == hipSuccess && made < 3; ++made) {
+      e = hipStreamCreateWithFlags(&c->s[made], hipStreamNonBlocking);
+      if (e == hipSuccess) {
+        e = hipEventCreateWithFlags(&c->join[made], hipEventDisableTiming);
+        if (e != hipSuccess) hipStreamDestroy(c->s[made]);
+      }
+      if (e != hipSuccess) break;
+    }
+    if (e == hipSuccess) c->nstreams = 3;
+    else {
+      for (int i = 0; i < made; ++i) {
+        hipStreamDestroy(c->s[i]);
+        hipEventDestroy(c->join[i]);
+      }
+      hipEventDestroy(c->fork);
+    }
+  }
+  if (e != hipSuccess) {
+    sar_set_error("sar_context_create: %s", hipGetErrorString(e));
+    delete c;
+    return (int)e;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int sar_context_destroy(sar_context* c) {
+  if (!c) return 0;
+  if (c->nstreams == 3) {
+    for (int i = 0; i < 3; ++i) {
+      hipStreamDestroy(c->s[i]);
+      hipEventDestroy(c->join[i]);
+    }
+    hipEventDestroy(c->fork);
+  }
+  delete c;
+  return 0;
+}
+
 extern "C" int sar_struct_size(int which) { return which == 0 ? (int)sizeof(sar_conv_desc) : which == 1 ? (int)sizeof(sar_wgrad_desc) : which == 2 ? (int)sizeof(sar_conv2d_desc) : -1; }
 
 namespace {

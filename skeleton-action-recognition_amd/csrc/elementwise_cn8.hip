@@ -219,6 +219,7 @@ __global__ __launch_bounds__(TPB) void cn8_to_cn_kernel(const uint4* __restrict_
   }
 }
 
+#ifdef SAR_DEBUG
 // diagnostic: leave a known pattern in the LDS of every CU (a kernel that reads LDS it never wrote then shows it)
 __global__ __launch_bounds__(TPB) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
   extern __shared__ unsigned dyn[];
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(TPB) void poison_lds_kernel(unsigned pattern, unsig
   __syncthreads();
   if (dyn[(threadIdx.x * 61) & 16383] != pattern) sink[0] = 1;   // keeps the stores alive
 }
+#endif
 
 inline bool al16(std::initializer_list<const void*> ptrs) {
   for (const void* p : ptrs)
@@ -306,12 +308,15 @@ extern "C" int sar_pool_bwd_cn8(const float* dfeat, int64_t ld, int C, int B, in
   return 0;
 }
 
+#ifdef SAR_DEBUG
+#include "../../include/sar_hip_debug.h"
 extern "C" int sar_debug_poison_lds(unsigned pattern, void* sink, sar_stream_t s) {
   SAR_REQUIRE(sink, "sar_debug_poison_lds: sink required");
   hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(TPB), 65536, as_stream(s), pattern, (unsigned*)sink);
   SAR_LAUNCH_CHECK("sar_debug_poison_lds");
   return 0;
 }
+#endif
 
 extern "C" int sar_cn_to_cn8(const float* x, int64_t ld_x, void* out, int64_t ld_out, int C, int64_t n, sar_stream_t s) {
   SAR_REQUIRE(x && out && C > 0 && n > 0 && ld_x >= n && ld_out >= n && al16({out}), "sar_cn_to_cn8: bad arguments");

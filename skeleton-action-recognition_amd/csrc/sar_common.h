@@ -7,6 +7,14 @@
 
 void sar_set_error(const char* fmt, ...);
 
+// the caller-owned launch context of include/sar_hip.h: side streams + fork / join events on ONE device
+struct sar_context {
+  int device;
+  int nstreams;            // 3, or 0 when SAR_C2D_PARITY_STREAMS=0 disabled the fan-out at creation
+  hipStream_t s[3];
+  hipEvent_t fork, join[3];
+};
+
 #define SAR_REQUIRE(cond, ...)                  \
   do {                                          \
     if (!(cond)) {                              \

@@ -64,6 +64,9 @@ def get_parser():
     parser.add_argument('--trainable-adjacency', action='store_true',
                         help="make the stacked adjacency a trainable variable `adjacency_matrix` (models/gcn.py AdjGraphConv); it is "
                              "trained only while epoch > --freeze-graph-until, as in the reference's train_step")
+    parser.add_argument('--verify-crc', default='full', choices=['full', 'length', 'off'],
+                        help="TFRecord shards: 'full' checks the masked CRC-32C of every length field and payload (what tf.data's "
+                             "reader does), 'length' the length fields only, 'off' the framing only")
     parser.add_argument('--synthetic', action='store_true', help='train on synthetic NTU-like clips')
     parser.add_argument('--synthetic-size', type=int, default=40000)
     parser.add_argument('--max-iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
@@ -95,7 +98,7 @@ def main():
 
     run_params = {k: v for k, v in vars(arg).items()
                   if k not in ("train_data_path", "test_data_path", "log_dir", "save_freq", "freeze_graph_until", "gpus", "resume",
-                               "save_scores") and not (k == "mfma" and v == "fp32")
+                               "save_scores", "verify_crc") and not (k == "mfma" and v == "fp32")
                   and not (k == "trainable_adjacency" and not v)}
     run_name = str(run_params).replace(" ", "").replace("'", "").replace(",", "-")[1:-1]
     if arg.notes:
@@ -119,7 +122,7 @@ def main():
             # or the <prefix>.npy + label pkl pair of data_gen/gen_joint_data.py
             if os.path.isdir(prefix) and any(f.endswith("tfrecord") for f in os.listdir(prefix)):
                 from sar_amd.tfrecord import TFRecordSkeletonData
-                return TFRecordSkeletonData(prefix, num_classes=arg.num_classes)
+                return TFRecordSkeletonData(prefix, verify_crc=arg.verify_crc, num_classes=arg.num_classes)
             return NpySkeletonData(prefix + ".npy", _label_path(prefix), num_classes=arg.num_classes)
         train_data, test_data = open_data(arg.train_data_path), open_data(arg.test_data_path)
 
@@ -133,6 +136,10 @@ def main():
         if log:
             log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
 
+    # test hook (tests/test_gpu_multirank.py): SAR_TRACE_DIR=<dir> makes every rank record the first coordinate of the clips
+    # it trains on (a test data set stores the clip id there) and a digest of its final parameters.  Not set in production:
+    # reading the ids back synchronises the host with the GPU every step.
+    trace_dir, trace = os.environ.get("SAR_TRACE_DIR"), {"ids": [], "logged": False}
     train_iter = test_iter = 0
     start_epoch = 0
     if arg.resume:
@@ -157,6 +164,8 @@ def main():
         pending = []
         for it, (x, y) in enumerate(train_data.batches(arg.batch_size, rank, world, dev, shuffle=True, epoch=epoch)):
             logits, loss = trainer.step(x, y)
+            if trace_dir:
+                trace["ids"].append([epoch, x[:, 0, 0, 0, 0].tolist()])
             pending.append(torch.stack([loss.reshape(()) * 1.0, topk_correct(logits, y, 1).float() / global_batch_size,
                                         topk_correct(logits, y, 5).float() / global_batch_size]))
             if arg.max_iters and it + 1 >= arg.max_iters:
@@ -208,6 +217,12 @@ def main():
             log.flush()
         if world > 1:
             dist.barrier()
+    if trace_dir:
+        import hashlib
+        trace["digest"] = hashlib.sha256(eng.flat.cpu().numpy().tobytes()).hexdigest()
+        trace["iterations"], trace["has_log"] = trainer.iteration, log is not None
+        with open(os.path.join(trace_dir, "rank%d.json" % rank), "w") as f:
+            json.dump(trace, f)
     if world > 1:
         dist.destroy_process_group()
 

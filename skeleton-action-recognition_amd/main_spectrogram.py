@@ -98,6 +98,8 @@ def main():
         if log:
             log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
 
+    # test hook (tests/test_gpu_multirank.py), see main_gnn.py: clip ids seen by this rank + a digest of its final parameters
+    trace_dir, trace = os.environ.get("SAR_TRACE_DIR"), {"ids": []}
     for epoch in range(arg.num_epochs):
         if rank == 0:
             print('Epoch {}/{}'.format(epoch + 1, arg.num_epochs), flush=True)
@@ -121,6 +123,8 @@ def main():
                                                             drop_remainder=phase == 'train')):
                 if phase == 'train':
                     logits, loss = trainer.step(x, y, lr)
+                    if trace_dir:
+                        trace["ids"].append([epoch, x[:, 0, 0, 0, 0].tolist()])
                 else:
                     with torch.no_grad():
                         img = model.spectrogram(x)
@@ -154,6 +158,12 @@ def main():
                                                                model.virtual_radar.wavelength.item()), flush=True)
         if log:
             log.flush()
+    if trace_dir:
+        import hashlib
+        trace["digest"] = hashlib.sha256(eng.flat.cpu().numpy().tobytes()).hexdigest()
+        trace["has_log"] = log is not None
+        with open(os.path.join(trace_dir, "rank%d.json" % rank), "w") as f:
+            json.dump(trace, f)
     if world > 1:
         dist.destroy_process_group()
 

@@ -55,7 +55,7 @@ class Conv2dDesc(C.Structure):
         ("W", _fp), ("w_stride_tap", C.c_int64), ("w_stride_c", C.c_int64),
         ("pro_scale", _fp), ("pro_shift", _fp),
         ("aux", _fp), ("ld_aux", C.c_int64), ("aux_scale", _fp), ("aux_shift", _fp), ("aux_mean", _fp),
-        ("partials", _fp), ("slab", _fp),
+        ("partials", _fp), ("slab", _fp), ("ctx", _fp),
     ]
 
 
@@ -64,8 +64,8 @@ _i, _i64, _f, _d = C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     "sar_version": (_i, []),
     "sar_last_error_string": (C.c_char_p, []),
-    "sar_debug_occupancy": (_i, [_i, _i]),
-    "sar_debug_poison_lds": (C.c_int, [C.c_uint32, _fp, _fp]),
+    "sar_context_create": (_i, [C.POINTER(C.c_void_p)]),
+    "sar_context_destroy": (_i, [_fp]),
     "sar_struct_size": (_i, [_i]),
     "sar_conv_gemm_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),
@@ -178,6 +178,25 @@ def load():
         raise SarError("descriptor layout mismatch between include/sar_hip.h and sar_amd/_lib.py")
     _lib = lib
     return lib
+
+
+class Context:
+    """A caller-owned sar_context (include/sar_hip.h): side streams + events on the CURRENT device for the launches that
+    fan out (the parity classes of the 3x3 / stride-2 data gradient).  One per engine -- i.e. per host thread and device;
+    the library itself holds no streams."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(load().sar_context_create(C.byref(h)), "sar_context_create")
+        self.handle = h
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and _lib is not None:
+            try:
+                _lib.sar_context_destroy(h)
+            except Exception:
+                pass
 
 
 def check(rc, what=""):

@@ -411,11 +411,13 @@ def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, p
 
 
 def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, aux=None, aux_affine=None, aux_mean=None,
-                aux_even_pixels=False, **geo):
+                aux_even_pixels=False, ctx=None, **geo):
     """sar_conv2d_gemm_f32.  Returns (partials, nparts) when the epilogue reduces.  aux_even_pixels: SAR_C2D_AUX_EVEN_PIXELS
-    (aux is the compact data gradient of the parallel 1x1 / stride 2 convolution, added at the even pixels only)."""
+    (aux is the compact data gradient of the parallel 1x1 / stride 2 convolution, added at the even pixels only).
+    ctx: an L.Context whose side streams the call may fan out over (None: the current stream only)."""
     lib = L.load()
     d = _conv2d_desc(src, **geo)
+    d.ctx = ctx.handle if ctx is not None else None
     d.flags = L.SAR_C2D_AUX_EVEN_PIXELS if aux_even_pixels else 0
     d.out, d.ld_out = ptr(_f32(out)), out.stride(0)
     d.W, d.w_stride_tap, d.w_stride_c, d.epi = ptr(_f32(W)), w_stride_tap, w_stride_c, epi

@@ -84,6 +84,9 @@ class ResNet18:
         import os
         self._side = (torch.cuda.Stream(device=dev) if dev.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1"
                       else None)
+        # side streams of the launches that fan out (stride-2 data gradients): owned by this engine, not by the library
+        with torch.cuda.device(dev):
+            self._ctx = L.Context() if dev.type == "cuda" else None
         # Operand layouts of every conv weight, refreshed by ONE launch per step (and one more for the data-gradient
         # layouts when training): forward (tap, c, m), data gradient (tap, m, c); the weight-gradient kernels write
         # (tap, c, m) tensors into one scratch buffer that ONE launch re-lays into the OIHW gradient views.
@@ -102,6 +105,26 @@ class ResNet18:
             pk.finalize(dev)
         self._perm_fwd, self._perm_bwd, self._perm_grad = pf, pb, pg
         self._wf, self._wb, self._gw = z(off), z(off), z(off)
+        # Gradient buckets for the data-parallel exchange (main_spectrogram.py:118-119), in the order backward() completes
+        # them: [layer4 + fc], [layer3], [layer2], [conv1 + bn1 + layer1].  Each is a contiguous slice of the flat gradient
+        # buffer (parameters are laid out in declaration order) with its own (tap, c, m) -> OIHW re-layout launch, so that a
+        # bucket can be all-reduced while the earlier layers are still in backward.
+        names = list(self.shapes)
+        stage_of = lambda k: (4 if k.startswith(("layer4.", "fc.")) else 3 if k.startswith("layer3.") else
+                              2 if k.startswith("layer2.") else 1)
+        self._buckets = []
+        for st in (4, 3, 2, 1):
+            ks = [k for k in names if stage_of(k) == st]
+            lo = min(self.offsets[k] for k in ks)
+            hi = max(self.offsets[k] + (int(np.prod(self.shapes[k])) + 3) // 4 * 4 for k in ks)
+            perm = ops.PermuteBatch()
+            for name, cv in self.convs.items():
+                if stage_of(name + ".weight") == st:
+                    o, _ = self._woff[name]
+                    perm.add(o, self.offsets[name + ".weight"], cv.cout, cv.cin, cv.taps, 1, cv.cout, cv.cin * cv.cout)
+            perm.finalize(dev)
+            self._buckets.append(dict(stage=st, lo=lo, hi=hi, perm=perm))
+        assert sorted((b["lo"], b["hi"]) for b in self._buckets)[0][0] == 0 and max(b["hi"] for b in self._buckets) == total
 
     def _view(self, flat, name):
         o = self.offsets[name]
@@ -250,7 +273,7 @@ class ResNet18:
         dx = torch.empty((cv.cin, B * H * W), dtype=torch.float32, device=dout.device)
         r = ops.conv2d_gemm(dout, dx, self._w(name, True), cv.cout * cv.cin, cv.cin, B=B, Kc=cv.cout, M=cv.cin, H_src=Ho,
                             W_src=Wo, H_out=H, W_out=W, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, transposed=True,
-                            **epi)
+                            ctx=self._ctx, **epi)
         return dx, r
 
     def _bn_bwd(self, name, part, nparts, chan_stride, part_stride, off2, count):
@@ -260,9 +283,29 @@ class ResNet18:
                             b.k1, b.k2, b.k3)
         return b
 
-    def backward(self, dlogits, need_dx=False):
+    def _bucket_done(self, bi, cb):
+        """Every gradient of bucket bi has been ISSUED: its weight gradients on the side stream (re-laid to OIHW right behind
+        them, on that stream), its BatchNorm / fc gradients on the main stream.  cb(bi, flat slice, events) may start the
+        slice's all-reduce as soon as the events have completed -- the main stream goes on with the earlier layers."""
+        bk = self._buckets[bi]
+        events = []
+        if self._side is not None:
+            with torch.cuda.stream(self._side):
+                bk["perm"].run(self._gw, self.grad)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            events.append(ev)
+        else:
+            bk["perm"].run(self._gw, self.grad)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        events.append(ev)
+        cb(bi, self.grad[bk["lo"]:bk["hi"]], events)
+
+    def backward(self, dlogits, need_dx=False, bucket_cb=None):
         """Gradients of every parameter into self.g; need_dx additionally returns d loss / d image (B,1,H,W) -- only
-        wanted when the image depends on trainable VirtualRadar parameters."""
+        wanted when the image depends on trainable VirtualRadar parameters.  bucket_cb: see _bucket_done (data-parallel
+        training: the gradient exchange overlaps the rest of backward)."""
         sv = self._saved
         assert sv is not None
         dev, B = dlogits.device, sv["B"]
@@ -275,7 +318,8 @@ class ResNet18:
         ops.transpose(dwt, self.g["fc.weight"], 1, self.c_last, self.num_classes)
         dY = torch.empty((self.c_last, B * sv["Hl"] * sv["Wl"]), dtype=torch.float32, device=dev)
         ops.pool_bwd(dfeat, B, sv["Hl"] * sv["Wl"], 1, dY)
-        for (pre, inpl, planes, stride, ds), sb in zip(reversed(self.blocks), reversed(sv["blocks"])):
+        nblk = len(self.blocks)
+        for bidx, ((pre, inpl, planes, stride, ds), sb) in enumerate(zip(reversed(self.blocks), reversed(sv["blocks"]))):
             X, c1, c2, dsc, y = sb["X"], sb["c1"], sb["c2"], sb["dsc"], sb["y"]
             H, W, Ho, Wo = sb["H"], sb["W"], sb["Ho"], sb["Wo"]
             n_out = B * Ho * Wo
@@ -311,6 +355,8 @@ class ResNet18:
                 else:
                     aux, _ = self._conv_dgrad(pre + "downsample.0", ddsc, B, H, W, Ho, Wo)
             dY, _ = self._conv_dgrad(pre + "conv1", dz1, B, H, W, Ho, Wo, epi=L.SAR_EPI_ADD, aux=aux, aux_even_pixels=even)
+            if bucket_cb is not None and pre.endswith(".0.") and pre[5] in "432":   # first block of layer 4 / 3 / 2: that stage is done
+                self._bucket_done({"4": 0, "3": 1, "2": 2}[pre[5]], bucket_cb)
         # stem: maxpool + relu + bn backward, then the 7x7 weight gradient (the image needs no gradient)
         bn0 = self.bn["bn1"]
         c0 = sv["c0"]
@@ -319,9 +365,14 @@ class ResNet18:
         self._bn_bwd("bn1", part, nparts, nparts * 2, 2, 1, B * sv["H1"] * sv["W1"])
         ops.affine2(dz0, c0, (bn0.k1, bn0.k2, bn0.k3), dz0)
         self._conv_wgrad("conv1", sv["x0"], dz0, B, sv["H"], sv["W"], sv["H1"], sv["W1"])
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-        self._perm_grad.run(self._gw, self.grad)             # every conv weight gradient: (tap, c, m) -> OIHW
+        if bucket_cb is not None:
+            self._bucket_done(3, bucket_cb)                      # conv1 + bn1 + layer1
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+            self._perm_grad.run(self._gw, self.grad)             # every conv weight gradient: (tap, c, m) -> OIHW
         dx = None
         if need_dx:
             cv = self.convs["conv1"]
@@ -332,14 +383,17 @@ class ResNet18:
         return dx
 
     # ------------------------------------------------------------------ training step
-    def loss_and_grad(self, x, labels, need_dx=False):
+    def loss_and_grad(self, x, labels, need_dx=False, grad_scale=1.0, bucket_cb=None):
         """main_spectrogram.py:152-157: CrossEntropyLoss() (mean) and backward.  With need_dx also returns
-        d loss / d image as a third value."""
+        d loss / d image as a third value.  grad_scale (1 / world under data parallelism) scales every gradient -- the mean
+        over ranks is then a plain SUM all-reduce -- but not the returned loss; bucket_cb: backward()."""
         logits = self.forward(x, training=True)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlogits = torch.empty_like(logits)
-        ops.softmax_ce(logits, labels, 1.0 / x.shape[0], loss, dlogits)
-        dx = self.backward(dlogits, need_dx)
+        ops.softmax_ce(logits, labels, grad_scale / x.shape[0], loss, dlogits)
+        if grad_scale != 1.0:
+            loss.mul_(1.0 / grad_scale)
+        dx = self.backward(dlogits, need_dx, bucket_cb)
         return (logits, loss, dx) if need_dx else (logits, loss)
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):

@@ -246,10 +246,15 @@ class TFRecordSkeletonData:
     Parsing runs in a background thread into pinned buffers (sar_amd/data.py:prefetch_to_device)."""
 
     def __init__(self, directory, verify_crc=True, num_classes=None):
+        """verify_crc: True / "full" = framing + length CRCs + data CRCs (what tf.data's reader does), "length" = framing +
+        length CRCs only (a flipped payload byte goes unnoticed; the CRC pass over 180 KB per clip is skipped), False /
+        "off" = framing only (main_gnn.py --verify-crc)."""
         self.files = sorted(os.path.join(directory, f) for f in os.listdir(directory) if f.endswith("tfrecord"))
         if not self.files:
             raise FileNotFoundError("no *.tfrecord shard in %s" % directory)
-        self.verify = verify_crc
+        level = {True: 2, "full": 2, "length": 1, False: 0, "off": 0, None: 0}[verify_crc]
+        self.verify_level = level
+        self.verify = level == 2           # host_batches(): the single-threaded reference path
         self.num_classes = num_classes
         self._counts = None
 
@@ -325,7 +330,80 @@ class TFRecordSkeletonData:
 
         return shuffled(batches()) if shuffle else batches()
 
-    def batches(self, batch_size, rank, world, device, shuffle, epoch=0, drop_remainder=True, shuffle_size=1000):
-        from .data import prefetch_to_device
-        return prefetch_to_device(self.host_batches(batch_size, rank, world, shuffle, epoch, drop_remainder, shuffle_size),
-                                  device)
+    def plan(self, batch_size, rank=0, world=1, shuffle=False, epoch=0, drop_remainder=True, shuffle_size=1000,
+             shuffle_bytes=2 << 30):
+        """The batches host_batches() would yield, as index work for parallel parsing: a list of jobs, each a list of
+        (shard buffer, payload offset, payload length).  Framing (+ length CRCs unless verification is off) of every shard
+        this rank reads is checked here, in native code; the data CRC of a record is checked by the thread that parses it."""
+        files, stride, phase, mine, fewest = self._plan(rank, world)
+        n_batches = fewest // batch_size if drop_remainder else -(-mine // batch_size)
+        bufs, offs, lens = [], [], []
+        lib = _native()
+        for f in files:
+            if os.path.getsize(f) == 0:
+                bufs.append(None), offs.append([]), lens.append([])
+                continue
+            buf = np.memmap(f, dtype=np.uint8, mode="r")
+            a, keep = _addr(buf)
+            n = lib.sar_tfrecord_index(a, len(keep), 0, None, None, 0)
+            if n >= 0:
+                off, ln = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+                n = lib.sar_tfrecord_index(a, len(keep), min(self.verify_level, 1), off.ctypes.data, ln.ctypes.data, n)
+            if n == -1:
+                raise IOError("%s: sar_tfrecord_index: bad arguments" % f)
+            if n < 0:
+                code, rec = 2 + (-n - 2) % 4, (-n - 2) // 4
+                raise IOError("%s: %s (record %d)" % (f, _ERRORS.get(code, "bad arguments"), rec))
+            bufs.append(buf), offs.append(off.tolist()), lens.append(ln.tolist())
+        recs = []
+        for j in range(max([len(o) for o in offs] + [0])):          # cyclic interleave of the shards (main_gnn.py:167-171)
+            for i in range(len(files)):
+                if j < len(offs[i]):
+                    recs.append((bufs[i], offs[i][j], lens[i][j]))
+        recs = recs[phase::stride]
+        jobs = [recs[b * batch_size:(b + 1) * batch_size] for b in range(n_batches)]
+        jobs = [j for j in jobs if j]
+        if shuffle and jobs:       # the bounded shuffle buffer of host_batches(), run over batch indices (same draws)
+            rng = np.random.default_rng(4321 + epoch)
+            x0, _ = parse_example(self._payload(jobs[0][0]))
+            cap = max(1, min(shuffle_size, shuffle_bytes // max(x0.nbytes * batch_size, 1)))
+            order, buf = [], []
+            for b in range(len(jobs)):
+                buf.append(b)
+                if len(buf) > cap:
+                    order.append(buf.pop(int(rng.integers(len(buf)))))
+            while buf:
+                order.append(buf.pop(int(rng.integers(len(buf)))))
+            jobs = [jobs[b] for b in order]
+        return jobs
+
+    @staticmethod
+    def _payload(rec):
+        buf, off, ln = rec
+        return memoryview(buf)[off:off + ln]
+
+    def batches(self, batch_size, rank, world, device, shuffle, epoch=0, drop_remainder=True, shuffle_size=1000, workers=None):
+        """device batches, parsed by `workers` host threads straight into pinned memory (sar_amd/data.py:parallel_batches)"""
+        from .data import LOADER_THREADS, parallel_batches
+        jobs = self.plan(batch_size, rank, world, shuffle, epoch, drop_remainder, shuffle_size)
+        if not jobs:
+            return iter(())
+        lib = _native()
+        x0, _ = parse_example(self._payload(jobs[0][0]))
+        clip = x0.shape
+
+        def build(job, x, y):
+            for k, rec in enumerate(job):
+                buf, off, ln = rec
+                if self.verify_level == 2:      # masked CRC-32C of the payload against the record's footer (native, no GIL)
+                    a, keep = _addr(buf[off:off + ln + 4])
+                    if lib.sar_masked_crc32c(a, ln) != int.from_bytes(bytes(keep[ln:ln + 4]), "little"):
+                        raise IOError("corrupt data CRC (payload at offset %d)" % off)
+                xk, yk = parse_example(memoryview(buf)[off:off + ln])
+                if self.num_classes is not None and not 0 <= yk < self.num_classes:
+                    raise ValueError("label %d outside [0, %d)" % (yk, self.num_classes))
+                np.copyto(x[k], xk)
+                y[k] = yk
+
+        return parallel_batches(jobs, build, lambda job: (len(job),) + tuple(clip), device,
+                                workers=LOADER_THREADS if workers is None else workers)

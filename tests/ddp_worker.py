@@ -33,6 +33,10 @@ def make_trainer(workload, dev, world):
         from sar_amd.stgcn import STGCN
         eng = STGCN(num_classes=10, device=dev, seed=5, blocks=BLOCKS)
         return eng, Trainer(eng, batch_size=4, world_size=world)
+    if workload == "stgcn_bf16":  # BASELINE configs[2]: the bf16-storage engine (CN8 activations) under the same train step
+        from sar_amd.stgcn import STGCN
+        eng = STGCN(num_classes=10, device=dev, seed=5, blocks=BLOCKS, mfma="bf16")
+        return eng, Trainer(eng, batch_size=4, world_size=world)
     if workload == "stgin":       # the sibling model through the same model-agnostic train step (main_gnn.py --model stgin)
         from sar_amd.stgin import STGIN
         eng = STGIN(num_classes=10, device=dev, seed=5, blocks=BLOCKS)
@@ -46,7 +50,7 @@ def make_trainer(workload, dev, world):
 
 
 def run_shard(workload, trainer, eng, x, y, dev):
-    if workload in ("stgcn", "stgin"):
+    if workload in ("stgcn", "stgin", "stgcn_bf16"):
         _, loss = trainer.step(x.to(dev), y.to(dev))
         extra = {}
     else:

@@ -34,7 +34,7 @@ def _launch(workload, out):
     return [torch.load(os.path.join(out, "rank%d.pt" % k)) for k in range(2)]
 
 
-@pytest.mark.parametrize("workload", ["stgcn", "stgin", "spectrogram"])
+@pytest.mark.parametrize("workload", ["stgcn", "stgcn_bf16", "stgin", "spectrogram"])
 def test_two_rank_product_step_equals_single_process_combination(workload, tmp_path):
     import ddp_worker as W
     from sar_amd.train import shard_indices
@@ -53,7 +53,7 @@ def test_two_rank_product_step_equals_single_process_combination(workload, tmp_p
         eng, trainer = W.make_trainer(workload, dev, 2)
         eng_before = eng.flat.cpu().clone()
         # capture the un-reduced local gradient: run the engine half of the step only
-        if workload in ("stgcn", "stgin"):
+        if workload in ("stgcn", "stgin", "stgcn_bf16"):
             eng.loss_and_grad(x[shards[r]].to(dev), y[shards[r]].to(dev), n)
             singles.append(dict(grad=eng.grad.cpu().clone()))
         else:
@@ -64,7 +64,7 @@ def test_two_rank_product_step_equals_single_process_combination(workload, tmp_p
             singles.append(dict(grad=eng.grad.cpu().clone(),
                                 radar_grad=torch.cat([p.grad.reshape(-1) for p in trainer.radar_params]).cpu()))
         torch.cuda.synchronize()
-    if workload in ("stgcn", "stgin"):
+    if workload in ("stgcn", "stgin", "stgcn_bf16"):
         total = singles[0]["grad"] + singles[1]["grad"]            # SUM of per-replica gradients (loss / global batch)
         assert torch.equal(ranks[0]["grad"], total)
         # the fused Nesterov step on the summed gradient from the common initial weights
@@ -96,3 +96,81 @@ def test_bench_starts_its_own_ranks(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+
+
+def _write_npy_dataset(d, n, T, classes, split):
+    """<d>/<split>_data_joint.npy + <d>/<split>_label.pkl (data_gen/gen_joint_data.py:138-151); clip i carries its id in
+    its first coordinate so that a rank's trace says which clips it trained on."""
+    import pickle
+
+    import numpy as np
+    rng = np.random.default_rng(5)
+    x = (0.12 * rng.standard_normal((n, 3, T, 25, 2))).astype(np.float32).clip(-1.1, 0.75)
+    x[:, 0, 0, 0, 0] = np.arange(n, dtype=np.float32) / 1024.0
+    np.save(os.path.join(d, "%s_data_joint.npy" % split), x)
+    with open(os.path.join(d, "%s_label.pkl" % split), "wb") as f:
+        pickle.dump((["c%d" % i for i in range(n)], rng.integers(0, classes, n).tolist()), f)
+
+
+def _run_cli(script, extra, tmp_path, world=2):
+    trace = tmp_path / "trace"
+    trace.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SAR_DIST_BACKEND="gloo", SAR_TRACE_DIR=str(trace))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    pkg = os.path.join(ROOT, "skeleton-action-recognition_amd")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(pkg, script)] + extra + ["--log-dir", str(tmp_path / "logs")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=pkg)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return [json.load(open(trace / ("rank%d.json" % k))) for k in range(world)], r.stdout
+
+
+def _check_cli_traces(traces, n_clips, bs, epochs):
+    """disjoint shards covering each epoch's global batches, the same number of steps on every rank, identical parameters
+    after training, log files on rank 0 only (main_gnn.py:257-258,290-301; main_spectrogram.py:118-121)"""
+    assert traces[0]["digest"] == traces[1]["digest"]
+    assert traces[0]["has_log"] and not traces[1]["has_log"]
+    per_epoch = n_clips // (bs * 2)
+    for ep in range(epochs):
+        seen = []
+        for t in traces:
+            batches = [ids for e, ids in t["ids"] if e == ep]
+            assert len(batches) == per_epoch and all(len(b) == bs for b in batches)
+            seen.append(sorted(round(v * 1024) for b in batches for v in b))
+        assert not set(seen[0]) & set(seen[1])                                   # disjoint shards
+        assert len(set(seen[0]) | set(seen[1])) == per_epoch * bs * 2            # no clip twice in an epoch
+        assert set(seen[0]) | set(seen[1]) <= set(range(n_clips))
+    e0 = [sorted(round(v * 1024) for e, b in traces[0]["ids"] if e == 0 for v in b)]
+    e1 = [sorted(round(v * 1024) for e, b in traces[0]["ids"] if e == 1 for v in b)]
+    assert e0 != e1 or per_epoch * bs * 2 == n_clips                            # the shuffle depends on the epoch
+
+
+@pytest.mark.parametrize("mfma", ["fp32", "bf16"])
+def test_main_gnn_cli_under_two_ranks(mfma, tmp_path):
+    """the REAL main_gnn.py as two ranks (gloo, both on cuda:0): rank > 0 branches -- sharded batches(),
+    rank-0-only logging / evaluation / checkpoint, the per-epoch barrier -- for the fp32 and the bf16 engine."""
+    d = tmp_path / "data"
+    d.mkdir()
+    _write_npy_dataset(str(d), 64, 32, 10, "train")
+    _write_npy_dataset(str(d), 16, 32, 10, "val")
+    traces, out = _run_cli("main_gnn.py", ["--model", "stgcn", "--mfma", mfma, "--num-classes", "10", "--batch-size", "8", "--num-epochs", "2",
+                                           "--save-freq", "2", "--train-data-path", str(d / "train_data_joint"),
+                                           "--test-data-path", str(d / "val_data_joint")], tmp_path)
+    _check_cli_traces(traces, 64, 8, 2)
+    assert traces[0]["iterations"] == traces[1]["iterations"] == 2 * (64 // 16)
+    assert out.count("Saving checkpoint") == 1 and out.count("test: top1") == 2          # rank 0 only
+    runs = os.listdir(tmp_path / "logs")
+    assert len(runs) == 1 and os.path.exists(tmp_path / "logs" / runs[0] / "checkpoints" / "ckpt-2.pt")
+
+
+def test_main_spectrogram_cli_under_two_ranks(tmp_path):
+    d = tmp_path / "data"
+    d.mkdir()
+    _write_npy_dataset(str(d), 32, 300, 10, "train")
+    _write_npy_dataset(str(d), 8, 300, 10, "val")
+    traces, out = _run_cli("main_spectrogram.py", ["--num-classes", "10", "--batch-size", "4", "--num-epochs", "2", "--num-filters", "8",
+                                                   "--num-pad-frames", "0", "--base-lr", "1e-3", "--data-path", str(d / "{}_data_joint.npy"),
+                                                   "--label-path", str(d / "{}_label.pkl")], tmp_path)
+    _check_cli_traces(traces, 32, 4, 2)
+    assert out.count("train Loss") == 2 and out.count("val Loss") == 2                       # rank 0 prints

@@ -137,7 +137,13 @@ for (f, s, T) in [(128, 1, 150), (128, 2, 300), (256, 1, 75), (64, 1, 300)]:
 
 print("---- LDS poison test")
 sink = torch.zeros(4, dtype=torch.int32, device=dev)
-def poison(p): L.check(lib.sar_debug_poison_lds(p, sink.data_ptr(), L.stream_ptr()))
+def poison(p):
+    # only a `make DEBUG=1` build exports the diagnostic entry points (include/sar_hip_debug.h)
+    import ctypes
+    fn = getattr(ctypes.CDLL(L.LIB_PATH), "sar_debug_poison_lds", None)
+    if fn is not None:
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.check(fn(p, sink.data_ptr(), L.stream_ptr()))
 f, s, T = 128, 1, 150
 To, pad = same_pad(T, 9, s)
 n_in, n_out = B * T * V, B * To * V
