@@ -479,18 +479,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Double-buffered 9-tap kernel: stride-1 forward (TR 0), stride-1 data gradient (TR 1), parity-split stride-2 data
-// gradient (TR 3) on 64 x 256 tiles.  Same arithmetic, operand images and epilogue as conv_gemm_cn8_kernel; what differs is
-// the schedule (the recipe of the fp32 kernel, conv_gemm.hip):
-//   * two LDS images and ONE barrier per stage: the loads of stage s+1 are issued before the MFMA phase of stage s,
-//     land in registers during it, and are transformed / written into the OTHER image right after it -- while the other
-//     waves of the workgroup (and the second workgroup of the CU) are still multiplying;
-//   * the staged window is at most 512 columns (18-19 frames), so two images fit twice per CU (2 x 35 KB per workgroup);
-//   * the epilogue's aux half units (ReLU-mask source / residual gradient) are loaded BEFORE the last MFMA phase and its
-//     per-row parameters staged at kernel start: the epilogue opens with its operands in registers instead of a
-//     dependent HBM round trip per 32-row block.
+// Deep-prefetch 9-tap kernel (experiment switch SAR_CN8_DB=1): stride-1 forward (TR 0), stride-1 data gradient (TR 1),
+// parity-split stride-2 data gradient (TR 3) on 64 x 256 tiles.  Same arithmetic, operand image and epilogue as
+// conv_gemm_cn8_kernel; the src units of stage s+2 are loaded (into a second register set) while stage s is multiplied, so
+// that an HBM round trip has TWO MFMA phases to land (the weights of stage s+1, which come from L2, stay one stage ahead).
+// The staged window is capped at 512 columns (18-19 frames): the image is 35 KB.
+// (The first variant tried here kept two LDS images with one barrier per stage: only two workgroups fit a CU and it was
+// 5-10 % slower than three single-image workgroups -- forward 1.81 vs 1.73 ms per step, data gradient 2.10 vs 1.89.)
 template <int TR, int MS, int NS, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k) {
+__global__ __launch_bounds__(256, 3) void conv_gemm_cn8_db_kernel(const ConvK8 k) {
   constexpr int TAPS = 9;
   constexpr int PAR = (TR == 3);
   constexpr int JT = PAR ? (TAPS + 1) / 2 : TAPS;
@@ -500,11 +497,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
   constexpr int WIT = (WUNITS + 255) / 256;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TR == 0 || TR == 1 || TR == 3, "forward, stride-1 and parity-split data gradients");
-  static_assert(BUF >= 4 * 16 * 65 / 4, "the epilogue's transpose area aliases image 0");
-  __shared__ uint4 smem_u[2 * BUF + 2 * BM];   // image 0 | image 1 | bias rows | MASK parameter rows
+  static_assert(BUF >= 4 * 16 * 65 / 4, "the epilogue's transpose area aliases the image");
+  __shared__ uint4 smem_u[BUF + BM];   // image | per-row parameters
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + WUNITS;
   float* smem = reinterpret_cast<float*>(smem_u);
-  float4* rowp = reinterpret_cast<float4*>(smem_u + 2 * BUF);
-  float4* rowpa = rowp + BM;
+  float4* rowp = reinterpret_cast<float4*>(smem_u + BUF);
   const sar_conv_desc& d = k.d;
 
   const int tid = threadIdx.x;
@@ -568,19 +566,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
   const bool has_aux = epi_mask || d.epi == SAR_EPI_ADD;
   if (tid < BM) {
     const int row = m0 + tid;
-    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f), ap = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < d.M) {
-      if (d.bias) bp.x = d.bias[row];
-      if (epi_mask) {
-        ap.x = d.aux_scale[row];
-        ap.y = d.aux_shift[row];
-        if (d.aux_mean) ap.z = d.aux_mean[row];
-      }
-    }
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) bp.x = d.bias[row];
     rowp[tid] = bp;
-    rowpa[tid] = ap;
   }
-  if (tid < 4) smem_u[(tid >> 1) * BUF + WUNITS + (tid & 1) * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);   // zero column, both images
+  if (tid < 2) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
   f32x16 acc[MS][NS];
 
   // ---- staging (conv_gemm_cn8_kernel)
@@ -606,15 +596,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
   const bool pro_relu = d.pro_relu != 0;
   const int ncj = (k.RW + 255) >> 8;
   uint4 wreg[WIT];
-  uint4 sreg[2][CJ];
+  uint4 sregA[2][CJ], sregB[2][CJ];
 
-  auto issue_loads = [&](int c0) {
+  auto issue_w = [&](int c0) {
     const int wso = (c0 / 8) * d.M * 16;
 #pragma unroll
     for (int i = 0; i < WIT; ++i) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo0, wso + i * wstep, 0);
       wreg[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
+  };
+  auto issue_s = [&](int c0, uint4 (&sreg)[2][CJ]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int g = c0 / 8 + h;
@@ -628,10 +620,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
         }
     }
   };
-
-  auto store_lds = [&](int c0, uint4* img) {
-    uint4* Wl = img;
-    uint4* Sl = img + WUNITS;
+  auto store_lds = [&](int c0, uint4 (&sreg)[2][CJ]) {
 #pragma unroll
     for (int i = 0; i < WIT; ++i)
       if ((i + 1) * 256 <= WUNITS || tid + 256 * i < WUNITS) Wl[tid + 256 * i] = wreg[i];
@@ -651,7 +640,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
     }
   };
 
-  // aux half units of the whole wave tile (MS x 2 x 2 x NS loads of 8 bytes), issued before the last MFMA phase
   u32x2 axr[MS * 4 * NS];
   auto issue_aux = [&]() {
     const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
@@ -667,11 +655,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
                 __builtin_amdgcn_raw_buffer_load_b64(e8.ra, vo[ns], (4 * ms + 2 * rb + q2) * e8.so_aux, 0);
   };
 
-  auto mma_phase = [&](auto IT) {
-    constexpr int it = decltype(IT)::value;
-    const uint4* Wl = smem_u + it * BUF;
-    const uint4* Sl = Wl + WUNITS;
-    const uint4* Wa = Wl + (tp0 * 2 + hi) * BM + wm * MS * 32 + l31;
+  const uint4* Wa = Wl + (tp0 * 2 + hi) * BM + wm * MS * 32 + l31;
+  auto mma_phase = [&]() {
     auto taps_mma = [&](int j) {
       const int tpw = PAR ? 2 * j : j;
       uint4 a[MS], bq[NS];
@@ -692,8 +677,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
     if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
   };
 
-  issue_loads(0);
-  __syncthreads();   // rowp / rowpa / zero columns
+  issue_w(0);
+  issue_s(0, sregA);
+  if (KC16 < d.Kc) issue_s(KC16, sregB);
+  __syncthreads();   // rowp / zero column
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -702,34 +689,50 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_db_kernel(const ConvK8 k
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = colok[ns] ? bp.x : 0.f;
     }
-  store_lds(0, smem_u);
-  __syncthreads();
 
-  // stage s multiplies image s & 1; every stage but the last also fills the other image for stage s + 1
+  // stage s consumes register set s & 1 and refills it with the src units of stage s + 2
   const int nst = (d.Kc + KC16 - 1) / KC16;
-  auto stage = [&](int s, auto IT) {
-    constexpr int it = decltype(IT)::value;
-    issue_loads((s + 1) * KC16);
-    mma_phase(IT);
-    store_lds((s + 1) * KC16, smem_u + (it ^ 1) * BUF);
+  auto stage = [&](int s, uint4 (&sreg)[2][CJ]) {
+    store_lds(s * KC16, sreg);
+    __syncthreads();
+    issue_w((s + 1) * KC16);
+    if (s + 2 < nst) issue_s((s + 2) * KC16, sreg);   // uniform
+    mma_phase();
+    __syncthreads();
+  };
+  auto last_stage = [&](int s, uint4 (&sreg)[2][CJ]) {
+    store_lds(s * KC16, sreg);
+    __syncthreads();
+    if (epi_mask && tid < BM) {   // MASK parameters replace the bias rows
+      const int row = m0 + tid;
+      float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < d.M) {
+        ap.x = d.aux_scale[row];
+        ap.y = d.aux_shift[row];
+        if (d.aux_mean) ap.z = d.aux_mean[row];
+      }
+      rowp[tid] = ap;
+    }
+    mma_phase();
     __syncthreads();
   };
   int s = 0;
   for (; s + 2 < nst; s += 2) {
-    stage(s, std::integral_constant<int, 0>());
-    stage(s + 1, std::integral_constant<int, 1>());
+    stage(s, sregA);
+    stage(s + 1, sregB);
   }
   if (s + 1 < nst) {
-    stage(s, std::integral_constant<int, 0>());
+    stage(s, sregA);
     ++s;
   }
-  // last stage (image s & 1): the aux loads take the place of the next stage's loads
-  if (has_aux) issue_aux();   // uniform
-  if (s & 1) mma_phase(std::integral_constant<int, 1>());
-  else mma_phase(std::integral_constant<int, 0>());
-  __syncthreads();   // the epilogue's transpose area aliases image 0
-  if (has_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowpa, smem, axr);
-  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowpa, smem);
+  if (s & 1) last_stage(s, sregB);
+  else last_stage(s, sregA);
+  if (has_aux) {   // every aux half unit in ONE round trip (the second register set leaves no room to prefetch them earlier)
+    issue_aux();
+    epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
+  } else {
+    epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+  }
 }
 
 // ---- GraphConvTD (models/gcn.py:199-209) and its data gradient:
@@ -1014,9 +1017,7 @@ int launch_cfg8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np
   return 0;
 }
 
-// the double-buffered kernel (9 taps; stride-1 forward, stride-1 / parity-split data gradients) is an EXPERIMENT switch
-// (SAR_CN8_DB=1): with two 35 KB images only two workgroups fit a CU, and measured against three single-image workgroups
-// it is 5-10 % slower per kernel (forward 1.81 vs 1.73 ms per step, data gradient 2.10 vs 1.89; profiles/r03 notes)
+// the deep-prefetch kernel (9 taps; stride-1 forward, stride-1 / parity-split data gradients): experiment switch SAR_CN8_DB=1
 bool db_enabled() {
   static const bool v = [] {
     const char* e = getenv("SAR_CN8_DB");

@@ -115,6 +115,55 @@ __device__ __forceinline__ void temporal_tile_fixed(f32x16 (&acc)[TPW], float& b
   }
 }
 
+// 9 taps on two wave groups WITHOUT a phantom tap slot: each group owns four whole taps (0-3 / 5-8) and HALF of the middle
+// tap 4 -- its reduction over the tile's two frame pairs is split, group g takes frame pair g.  Every wave runs the same
+// code: its "first" frame pair (pair g) with 5 MFMAs per step, the other one with 4 -- 225 MFMAs per tile instead of the
+// 250 of the 2 x 5 slot scheme (one slot of which multiplied the zero padding).  The caller adds the two partial
+// accumulators of tap 4 through LDS after the tile loop.  D1 / S1: this wave's first frame pair, D2 / S2: the second;
+// Sf*: first of the four whole taps, Ssh1: tap 4.
+template <int VC, bool BIAS>
+__device__ __forceinline__ void temporal_tile_shared(f32x16 (&acc)[5], float& bsum, const float* D1, const float* D2,
+                                                     const float* Sf1, const float* Sf2, const float* Ssh1) {
+  constexpr int NSTEP = 2 * VC;
+  auto fetch = [&](int st, float& dv, float (&sv)[5]) {
+    const int half = st / VC, v = st % VC;
+    dv = (half ? D2 : D1)[v];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sv[i] = (half ? Sf2 : Sf1)[i * VC + v];
+    if (!half) sv[4] = Ssh1[v];
+  };
+  auto mma = [&](int st, float dv, const float (&sv)[5], bool have_next) {
+    const int nm = (st / VC) ? 4 : 5;
+    if (BIAS) bsum += dv;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i < nm) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i], dv, acc[i], 0, 0, 0);
+    // issue order: MFMA, then the next step's reads spread behind the MFMAs (temporal_tile_fixed)
+    int done = 0;
+    const int rd = have_next ? 1 + (((st + 1) / VC) ? 4 : 5) : 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i < nm) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        const int n = (rd - done + (nm - i) - 1) / (nm - i);
+        if (n == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (n == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        done += n;
+      }
+  };
+  float d0, s0[5], d1, s1[5];
+  fetch(0, d0, s0);
+#pragma unroll
+  for (int st = 0; st < NSTEP; st += 2) {
+    if (st + 1 < NSTEP) fetch(st + 1, d1, s1);
+    mma(st, d0, s0, st + 1 < NSTEP);
+    if (st + 1 < NSTEP) {
+      if (st + 2 < NSTEP) fetch(st + 2, d0, s0);
+      mma(st + 1, d1, s1, st + 2 < NSTEP);
+    }
+  }
+}
+
 // Graph reduction: per joint v one packed LDS table row {gather joints[E], weights[E], colsum[3]} read with a
 // wave-uniform address.  Three-stage register pipeline: table row of joint v+2, gathered x values of joint
 // v+1 and the MFMAs of joint v are in flight together.
@@ -186,6 +235,11 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
   // NW waves per workgroup: 4, or 6 for the 9-tap kernel (2 m-blocks x 3 tap groups of 3: no phantom tap slot)
   constexpr int NW = WF * WC * WT, NHW = 2 * NW, NTH = 64 * NW;
   static_assert(NW == 4 || NW == 6, "4 or 6 waves per workgroup");
+#ifndef SAR_WGRAD_SHARED_TAP
+#define SAR_WGRAD_SHARED_TAP 1   // 0: the 2 x 5 tap-slot scheme with one phantom slot (A/B builds)
+#endif
+  // 9 taps on 2 wave groups at fixed geometry: no phantom tap slot (temporal_tile_shared)
+  constexpr bool SHARED_TAP = SAR_WGRAD_SHARED_TAP && MODE == SAR_CONV_TEMPORAL && TAPS == 9 && WT == 2 && TPW == 5 && WC == 1 && VC != 0;
   static_assert(WT * TPW >= TAPS, "taps must be covered");
   constexpr int BF = 32 * WF, CT = 32 * WC;
   constexpr int NZMAX = 4;
@@ -389,7 +443,12 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
       // every wave runs TPW taps: taps beyond TAPS (last wave class when WT*TPW > TAPS) read the padded
       // tail of the S rows and land in accumulators that are never stored -- those SIMDs would otherwise
       // idle at the tile barrier, and one code path keeps the accumulators in AGPRs.
-      if constexpr (VC != 0) {
+      if constexpr (SHARED_TAP) {
+        // wave group wt: whole taps 5 wt .. 5 wt + 3 and frame pair wt of tap 4 (temporal_tile_shared)
+        const int fa = wt * 2 * VC, fb = (1 - wt) * 2 * VC;
+        temporal_tile_shared<VC, true>(acc, bsum[0], Dbase + fa, Dbase + fb, Sbase + fa * STRIDEC + wt * 5 * VC,
+                                       Sbase + fb * STRIDEC + wt * 5 * VC, Sbase + fa * STRIDEC + 4 * VC);
+      } else if constexpr (VC != 0) {
         // (one code path for every wave: a do_bias / no-bias pair of unrolled loops makes the register allocator
         // keep two copies of the accumulators)
         temporal_tile_fixed<TPW, VC, STRIDEC, 2, true>(acc, bsum[0], Dbase, Sbase + wt * TPW * VC);
@@ -401,13 +460,26 @@ __global__ __launch_bounds__(64 * WF * WC * WT, (WF * WC * WT == 6) ? 3 : 2) voi
     }
   }
 
+  if constexpr (SHARED_TAP) {   // tap 4: group 1's half of the reduction is added to group 0's (through LDS, fixed order)
+    __syncthreads();             // every wave is done with the last tile's operands
+    float* X = smem + wf * (16 * 64);
+    if (wt == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[r * 64 + lane] = acc[4][r];
+    }
+    __syncthreads();
+    if (wt == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[4][r] += X[r * 64 + lane];
+    }
+  }
   // ---- write this split's slab
   float* slab = d.slab + (int64_t)wg.split * (d.wsize + d.bsize);
   const int f = f0 + wf * 32 + l31;
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int tp = wt * TPW + i;
-    if (tp < TAPS) {
+    const int tp = SHARED_TAP ? (wt ? 5 + i : i) : wt * TPW + i;
+    if (tp < TAPS && !(SHARED_TAP && wt == 1 && i == 4)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = c0 + wc * 32 + mfma_row(r, hi);

@@ -338,23 +338,9 @@ class TFRecordSkeletonData:
         files, stride, phase, mine, fewest = self._plan(rank, world)
         n_batches = fewest // batch_size if drop_remainder else -(-mine // batch_size)
         bufs, offs, lens = [], [], []
-        lib = _native()
         for f in files:
-            if os.path.getsize(f) == 0:
-                bufs.append(None), offs.append([]), lens.append([])
-                continue
-            buf = np.memmap(f, dtype=np.uint8, mode="r")
-            a, keep = _addr(buf)
-            n = lib.sar_tfrecord_index(a, len(keep), 0, None, None, 0)
-            if n >= 0:
-                off, ln = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
-                n = lib.sar_tfrecord_index(a, len(keep), min(self.verify_level, 1), off.ctypes.data, ln.ctypes.data, n)
-            if n == -1:
-                raise IOError("%s: sar_tfrecord_index: bad arguments" % f)
-            if n < 0:
-                code, rec = 2 + (-n - 2) % 4, (-n - 2) // 4
-                raise IOError("%s: %s (record %d)" % (f, _ERRORS.get(code, "bad arguments"), rec))
-            bufs.append(buf), offs.append(off.tolist()), lens.append(ln.tolist())
+            b, o, ln = self._index(f)
+            bufs.append(b), offs.append(o), lens.append(ln)
         recs = []
         for j in range(max([len(o) for o in offs] + [0])):          # cyclic interleave of the shards (main_gnn.py:167-171)
             for i in range(len(files)):
@@ -376,6 +362,30 @@ class TFRecordSkeletonData:
                 order.append(buf.pop(int(rng.integers(len(buf)))))
             jobs = [jobs[b] for b in order]
         return jobs
+
+    def _index(self, f):
+        """(memory map, payload offsets, payload lengths) of one shard, verified once (framing, + length CRCs unless
+        verification is off) and kept: every epoch re-plans from the same index"""
+        cache = self.__dict__.setdefault("_index_cache", {})
+        if f in cache:
+            return cache[f]
+        if os.path.getsize(f) == 0:
+            cache[f] = (None, [], [])
+            return cache[f]
+        lib = _native()
+        buf = np.memmap(f, dtype=np.uint8, mode="r")
+        a, keep = _addr(buf)
+        n = lib.sar_tfrecord_index(a, len(keep), 0, None, None, 0)
+        if n >= 0:
+            off, ln = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+            n = lib.sar_tfrecord_index(a, len(keep), min(self.verify_level, 1), off.ctypes.data, ln.ctypes.data, n)
+        if n == -1:
+            raise IOError("%s: sar_tfrecord_index: bad arguments" % f)
+        if n < 0:
+            code, rec = 2 + (-n - 2) % 4, (-n - 2) // 4
+            raise IOError("%s: %s (record %d)" % (f, _ERRORS.get(code, "bad arguments"), rec))
+        cache[f] = (buf, off.tolist(), ln.tolist())
+        return cache[f]
 
     @staticmethod
     def _payload(rec):

@@ -129,7 +129,7 @@ def test_tfrecord_input_pipeline_keeps_up_with_the_gpu(tmp_path):
     configuration, the fastest consumer."""
     import re
     from sar_amd import tfrecord as T
-    n = 1024
+    n = 2048                 # 32 steps per epoch: the loader's per-epoch start (first batch) is a few per cent of it, as in a real epoch
     rng = np.random.default_rng(0)
     data = np.clip(0.12 * rng.standard_normal((n, 3, 300, 25, 2)), -1.1, 0.75).astype(np.float32)
     labels = rng.integers(0, 60, n)
