@@ -83,6 +83,11 @@ int sar_context_destroy(sar_context* ctx);   /* waits for nothing: synchronise t
 enum { SAR_CONV_GRAPH = 0, SAR_CONV_TEMPORAL = 1 };
 enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3 };
 
+/* g_flags: the caller asserts that EVERY gather weight g_wt is exactly representable in bfloat16 (the NTU adjacency of
+ * graph/ntu_rgb_d.py holds 0.25 / 0.5 / 1).  The bf16 (CN8) kernels then apply a dense adjacency slice on the matrix cores
+ * (z_k = x . A_k as a 16 x 16 x 32 MFMA per frame, exact products, fp32 accumulation) instead of in the vector ALU; without
+ * the flag they keep the fp32 gather.  Ignored by the fp32 kernels. */
+#define SAR_GRAPH_WT_BF16_EXACT 1
 typedef struct sar_conv_desc {
   int32_t mode;        /* SAR_CONV_* */
   int32_t transposed;  /* TEMPORAL only */
@@ -93,6 +98,8 @@ typedef struct sar_conv_desc {
   int32_t pro_relu;
   int32_t epi;
   int32_t nz[3];       /* GRAPH: gather-list length per adjacency slice (<=4) */
+  int32_t g_flags;     /* GRAPH: SAR_GRAPH_* bits, 0 = none */
+  int32_t reserved0;   /* 0 */
   const float* src; int64_t ld_src;
   float* out; int64_t ld_out;
   const float* W;          /* element (tap, c, m) at tap*w_stride_tap + c*w_stride_c + m (m contiguous) */
@@ -146,6 +153,7 @@ typedef struct sar_wgrad_desc {
   int32_t pro_relu;
   int32_t nz[3];
   int32_t nsplit;           /* number of slabs (grid.x) */
+  int32_t g_flags;          /* GRAPH: SAR_GRAPH_* bits, 0 = none */
   const float* src; int64_t ld_src;
   const float* dout; int64_t ld_dout;
   const float* pro_scale; const float* pro_shift;

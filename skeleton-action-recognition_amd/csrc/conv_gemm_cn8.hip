@@ -49,6 +49,11 @@ struct TileCfg8 {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+constexpr int pad_stride8(int n) { return n + ((4 - n % 16) + 16) % 16; }   // smallest plane stride >= n that is 4 (mod 16)
 
 // ---- epilogue: mask / add, BatchNorm partial sums from the fp32 accumulators, bf16 half-unit stores.  Every wave is
 // past its last MFMA phase and the closing barrier: the transpose area aliases the operand image.
@@ -741,11 +746,20 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_cn8_db_kernel(const ConvK8 k
 // Stage = 16 src channels: (1) the tile's raw units -> LDS (straight copy), (2) every thread builds the three z_k
 // units of its (channel half, column): NZ gather entries, each ONE ds_read_b128 of 8 channels, weighted in fp32 and
 // rounded once (an entry list {(v, 1.0)} is a plain copy), (3) 3 slices x MS x NS MFMAs.
+// MATRIX-CORE GATHER (SAR_GRAPH_WT_BF16_EXACT, V <= 32, one dense slice): step (2) of the slice with 4-entry lists costs
+// ~70 vector instructions per unit (unpack, 32 fma, pack) -- a third of the kernel's time, measured by replacing it with a
+// copy -- while the matrix pipe is idle (12 MFMAs per stage).  With gather weights that are exact in bfloat16 the slice is
+// instead ONE small matrix product per frame: Z_f[16 channels x V] = X_f[16 x 32 joints] . A_k[32 x 32]
+// (two v_mfma_f32_16x16x32_bf16; products exact, fp32 accumulation, rounded once like the vector path).  The A operand --
+// 8 consecutive joints of one channel -- is the TRANSPOSE of the unit image and comes from ds_read_b64_tr_b16; A_k lives
+// in 8 registers per lane for the whole kernel; a result register quad is 4 consecutive channels of one joint = half a
+// unit of the z image (one 8-byte LDS store).  Frames are dealt round-robin to the four waves.
 template <int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
 __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) {
   constexpr int BM = 32 * MS * WM, TN = 32 * NS * WN;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
-  constexpr int XS = TN + 1;                 // raw plane stride (units)
+  constexpr int DENSE = ((NZ0 > 1) + (NZ1 > 1) + (NZ2 > 1) == 1) ? (NZ0 > 1 ? 0 : NZ1 > 1 ? 1 : 2) : -1;   // the slice the matrix cores may gather
+  constexpr int XS = pad_stride8(TN + 8);    // raw plane stride (units): 4 (mod 16) for the transposed reads, 8 columns of slack behind the tile
   constexpr int CPT = TN / 128;              // columns per thread in the unit builder (thread = (half, column))
   constexpr int WUNITS = 3 * 2 * BM;         // [slice][h][m]
   constexpr int ZUNITS = 3 * 2 * TN;         // [slice][h][col]
@@ -775,6 +789,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
   const int t0 = (tile - b * k.TPS) * k.FT;
   const int m0 = (w - tile * ny) * BM;
   const int ncols = ((t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0) * V;   // live columns of this tile
+  const bool mg = DENSE >= 0 && (d.g_flags & SAR_GRAPH_WT_BF16_EXACT) && V <= 32;   // uniform: dense slice on the matrix cores
 
   bool colok[NS];
   unsigned vo[NS];
@@ -813,10 +828,44 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
     for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < NZ[tp]) {
+        if (j < NZ[tp] && !(mg && tp == DENSE)) {
           go[q][tp][j] = fo * V + d.g_idx[(tp * V + v) * 4 + j];
           gwt[q][tp][j] = live ? d.g_wt[(tp * V + v) * 4 + j] : 0.f;
         }
+  }
+  // matrix-core gather: this lane's B fragments (A_k[v = 8 G + j][w = (lane & 15) + 16 nb], j = 0..7) and LDS addresses
+  const int gG = lane >> 4, gi = lane & 15;
+  bf16x8 bfr[2];
+  unsigned tr_addr = 0;
+  int zst_unit = 0;
+  if (mg) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int wv = gi + 16 * nb;
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      if (wv < V) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < NZ[DENSE >= 0 ? DENSE : 0]) {
+            const int vi = d.g_idx[((DENSE >= 0 ? DENSE : 0) * V + wv) * 4 + e];
+            const float wt = d.g_wt[((DENSE >= 0 ? DENSE : 0) * V + wv) * 4 + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += (vi == 8 * gG + j) ? wt : 0.f;
+          }
+      }
+      const uint4 pk = cn8_pack(a);
+      bfr[nb] = *reinterpret_cast<const bf16x8*>(&pk);
+    }
+    // transposed read: lane 4 q + p of a 16-lane group supplies joint 8 G + q, channels 4 p .. 4 p + 3 (plane p >> 1)
+    const int q = gi >> 2, p = gi & 3;
+    tr_addr = (unsigned)(uintptr_t)XR + (unsigned)((((p >> 1) * XS + 8 * gG + q) * 16) + 8 * (p & 1));
+    // result quad = channels 4 G .. 4 G + 3 of joint gi (+ 16): half (G & 1) of the unit in plane G >> 1 of the dense z slice
+    zst_unit = ((DENSE >= 0 ? DENSE : 0) * 2 + (gG >> 1)) * TN + gi;
+    // the dense z slice beyond the last whole frame and the slack columns of the raw image are read but never written
+    for (int i = tid; i < 2 * TN; i += 256) Zl[(DENSE >= 0 ? DENSE : 0) * 2 * TN + i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * (XS - TN); i += 256) XR[(i / (XS - TN)) * XS + TN + i % (XS - TN)] = make_uint4(0u, 0u, 0u, 0u);
   }
 
   f32x16 acc[MS][NS];
@@ -869,10 +918,44 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
     for (int i = 0; i < WIT; ++i)
       if ((i + 1) * 256 <= WUNITS || tid + 256 * i < WUNITS) Wl[tid + 256 * i] = wreg[i];
     const uint4* Xh = XR + uh * XS;
+    if (mg) {   // uniform: the dense slice as one 16 x V x 32 matrix product per frame, frames dealt to the waves
+      // three frames per pass, software-pipelined by hand: all transposed reads, then all MFMAs, then the stores (one frame at
+      // a time is a dependent read -> MFMA -> convert -> store chain per frame: as slow as the vector gather it replaces)
+      for (int f0 = wave; f0 < k.FT; f0 += 12) {
+        bf16x8 afr[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int f = (f0 + 4 * i < k.FT) ? f0 + 4 * i : f0;   // a frame beyond the tile repeats frame f0 (its result is dropped)
+          const unsigned ra = tr_addr + (unsigned)(f * V * 16);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)ra);
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(ra + 64));
+          const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          afr[i] = *reinterpret_cast<const bf16x8*>(&av);
+        }
+        f32x4 z[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            z[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[nb], zero, 0, 0, 0);
+          }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int f = f0 + 4 * i;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            if (f < k.FT && gi + 16 * nb < V)
+              reinterpret_cast<uint2*>(Zl + zst_unit + f * V + 16 * nb)[gG & 1] =
+                  make_uint2(cn8_pack2(z[i][nb][0], z[i][nb][1]), cn8_pack2(z[i][nb][2], z[i][nb][3]));
+        }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
 #pragma unroll
       for (int tp = 0; tp < 3; ++tp) {
+        if (mg && tp == DENSE) continue;
         uint4 zu;
         if (NZ[tp] == 1 && gwt[q][tp][0] == 1.0f) {
           zu = Xh[go[q][tp][0]];                       // a {(v, 1.0)} list: bf16(1.0 * x) = x

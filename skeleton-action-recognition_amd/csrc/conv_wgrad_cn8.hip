@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
   constexpr int FT = 5, NLIVE = FT * WV, NPOS = 128, KSTEPS = NPOS / 16;
   constexpr int PS = pad_stride(NPOS);   // 132
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  constexpr int DENSE = ((NZ0 > 1) + (NZ1 > 1) + (NZ2 > 1) == 1) ? (NZ0 > 1 ? 0 : NZ1 > 1 ? 1 : 2) : -1;   // slice the matrix cores may gather
   constexpr int NZI = ID0 ? 2 : 3;       // built z images
   constexpr int XJ = (NLIVE + 63) / 64;
   __shared__ uint4 lds[(2 + NZI) * 8 * PS];
@@ -344,6 +345,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
   // unit builder: thread -> (plane quartet ph, column pos); gather offsets / weights of its joint
   const int ph = tid >> 7, pos = tid & 127;
   const bool blive = pos < NLIVE;
+  // matrix-core gather of the dense slice (conv_gemm_cn8.hip, conv_graph_cn8_kernel): gather weights exact in bfloat16
+  const bool mg = DENSE >= 0 && (d.g_flags & SAR_GRAPH_WT_BF16_EXACT);   // uniform
   int go[3][4];
   float gwt[3][4];
   {
@@ -353,10 +356,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < NZ[t]) {
+        if (j < NZ[t] && !(mg && t == DENSE)) {
           go[t][j] = fo * WV + d.g_idx[(t * WV + v) * 4 + j];
           gwt[t][j] = d.g_wt[(t * WV + v) * 4 + j];
         }
+  }
+  // B fragments A_k[v = 8 G + j][w = (lane & 15) + 16 nb] and the lane's LDS addresses: wave w gathers channel group w
+  // (planes 2 w, 2 w + 1) of every frame
+  const int gG = lane >> 4, gi = lane & 15;
+  bf16x8 bfr[2];
+  unsigned tr_addr = 0;
+  int zst_unit = 0;
+  if (mg) {
+    constexpr int DS = DENSE >= 0 ? DENSE : 0;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int wv = gi + 16 * nb;
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      if (wv < WV) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < NZ[DS]) {
+            const int vi = d.g_idx[(DS * WV + wv) * 4 + e];
+            const float wt = d.g_wt[(DS * WV + wv) * 4 + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += (vi == 8 * gG + j) ? wt : 0.f;
+          }
+      }
+      const uint4 pk = cn8_pack(a);
+      bfr[nb] = *reinterpret_cast<const bf16x8*>(&pk);
+    }
+    const int q = gi >> 2, p = gi & 3;
+    tr_addr = (unsigned)(uintptr_t)Ximg + (unsigned)((((2 * wave + (p >> 1)) * PS + 8 * gG + q) * 16) + 8 * (p & 1));
+    zst_unit = ((DS - (ID0 ? 1 : 0)) * 8 + 2 * wave + (gG >> 1)) * PS + gi;
   }
   // colsum(A_k)[w] of the dout units this lane stages (bias gradient)
   float cs[XJ][3];
@@ -415,12 +449,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
     }
   };
   auto build_z = [&]() {
+    if (mg) {   // uniform: Z_f[16 channels x V] = X_f[16 x 32 joints] . A_k[32 x 32], two MFMAs per frame and channel group;
+      // all transposed reads first, then the MFMAs, then the stores (conv_graph_cn8_kernel)
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      bf16x8 afr[FT];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        const unsigned ra = tr_addr + (unsigned)(f * WV * 16);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)ra);
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(ra + 64));
+        const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        afr[f] = *reinterpret_cast<const bf16x8*>(&av);
+      }
+      f32x4 z[FT][2];
+#pragma unroll
+      for (int f = 0; f < FT; ++f)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          z[f][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[f], bfr[nb], zero, 0, 0, 0);
+        }
+#pragma unroll
+      for (int f = 0; f < FT; ++f)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          if (gi + 16 * nb < WV)
+            reinterpret_cast<uint2*>(Zimg + zst_unit + f * WV + 16 * nb)[gG & 1] =
+                make_uint2(cn8_pack2(z[f][nb][0], z[f][nb][1]), cn8_pack2(z[f][nb][2], z[f][nb][3]));
+    }
     if (!blive) return;
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl) {
       const uint4* Xp = Ximg + (4 * ph + pl) * PS;
 #pragma unroll
       for (int t = ID0 ? 1 : 0; t < 3; ++t) {
+        if (mg && t == DENSE) continue;
         uint4 zu;
         if (NZ[t] == 1 && gwt[t][0] == 1.0f) {
           zu = Xp[go[t][0]];

@@ -151,6 +151,7 @@ def main():
         train_iter = trainer.iteration
         if rank == 0:
             print("Resumed from {} (epoch {}, iteration {})".format(arg.resume, start_epoch, trainer.iteration), flush=True)
+    next_iter = None      # the loader of the NEXT epoch is created (its threads start parsing) before the current epoch is evaluated
     for epoch in range(start_epoch, arg.num_epochs):
         if rank == 0:
             print("Epoch: {}".format(epoch + 1), flush=True)
@@ -162,7 +163,10 @@ def main():
         eng.train_adjacency = epoch > arg.freeze_graph_until
         # per-iteration scalars stay on the device and are exchanged / read back once per epoch (no host sync per step)
         pending = []
-        for it, (x, y) in enumerate(train_data.batches(arg.batch_size, rank, world, dev, shuffle=True, epoch=epoch)):
+        if next_iter is None:
+            next_iter = train_data.batches(arg.batch_size, rank, world, dev, shuffle=True, epoch=epoch)
+        train_iter_obj, next_iter = next_iter, None
+        for it, (x, y) in enumerate(train_iter_obj):
             logits, loss = trainer.step(x, y)
             if trace_dir:
                 trace["ids"].append([epoch, x[:, 0, 0, 0, 0].tolist()])
@@ -183,6 +187,8 @@ def main():
             torch.cuda.synchronize()
             print("  train: %d iters, %.1f clips/s" % (it + 1, (it + 1) * global_batch_size / (time.time() - t0)),
                   flush=True)
+        if epoch + 1 < arg.num_epochs and not arg.max_iters:
+            next_iter = train_data.batches(arg.batch_size, rank, world, dev, shuffle=True, epoch=epoch + 1)
         # ---- test (main_gnn.py:381-408), un-distributed like the reference: rank 0 evaluates
         if rank == 0:
             c1 = c5 = n = 0

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("SAR_HIP_LIB") or os.path.join(_HERE, "libsar_hip.so")
 
 SAR_CONV_GRAPH, SAR_CONV_TEMPORAL = 0, 1
 SAR_EPI_NONE, SAR_EPI_STATS, SAR_EPI_MASK, SAR_EPI_ADD = 0, 1, 2, 3
+SAR_GRAPH_WT_BF16_EXACT = 1
 SAR_C2D_AUX_EVEN_PIXELS = 1
 
 _fp = C.c_void_p  # every device pointer crosses the ABI as void*
@@ -21,7 +22,7 @@ class ConvDesc(C.Structure):
         ("mode", C.c_int32), ("transposed", C.c_int32), ("B", C.c_int32), ("V", C.c_int32),
         ("T_src", C.c_int32), ("T_out", C.c_int32), ("Kc", C.c_int32), ("M", C.c_int32),
         ("taps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("pro_relu", C.c_int32),
-        ("epi", C.c_int32), ("nz", C.c_int32 * 3),
+        ("epi", C.c_int32), ("nz", C.c_int32 * 3), ("g_flags", C.c_int32), ("reserved0", C.c_int32),
         ("src", _fp), ("ld_src", C.c_int64), ("out", _fp), ("ld_out", C.c_int64),
         ("W", _fp), ("w_stride_tap", C.c_int64), ("w_stride_c", C.c_int64), ("bias", _fp),
         ("pro_scale", _fp), ("pro_shift", _fp),
@@ -35,7 +36,7 @@ class WgradDesc(C.Structure):
     _fields_ = [
         ("mode", C.c_int32), ("B", C.c_int32), ("V", C.c_int32), ("T_src", C.c_int32), ("T_out", C.c_int32),
         ("Kc", C.c_int32), ("M", C.c_int32), ("taps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-        ("pro_relu", C.c_int32), ("nz", C.c_int32 * 3), ("nsplit", C.c_int32),
+        ("pro_relu", C.c_int32), ("nz", C.c_int32 * 3), ("nsplit", C.c_int32), ("g_flags", C.c_int32),
         ("src", _fp), ("ld_src", C.c_int64), ("dout", _fp), ("ld_dout", C.c_int64),
         ("pro_scale", _fp), ("pro_shift", _fp),
         ("g_idx", _fp), ("g_wt", _fp), ("g_colsum", _fp),

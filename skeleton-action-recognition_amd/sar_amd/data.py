@@ -87,90 +87,101 @@ def prefetch_to_device(host_batches, device, depth=3):
         free.put({"x": None, "y": None, "event": None})
 
 
-def parallel_batches(jobs, build, shape_of, device, workers=4, depth=3):
-    """Yields (x, y) device tensors for `jobs` IN ORDER while `workers` host threads build the next ones concurrently.
+class parallel_batches:
+    """Iterator over (x, y) device tensors for `jobs` IN ORDER while `workers` host threads build the next ones.
 
     build(job, x_view, y_view) fills one batch straight into PINNED memory (x_view float32 of shape_of(job), y_view int64
     of its first dimension) -- no intermediate np.stack, one pass over the clip bytes -- and runs without the GIL where it
     matters (CRC in libsar_hip.so, numpy block copies).  tf.data's `num_parallel_calls` / the reference's
     DataLoader(num_workers=10) (main_spectrogram.py:94-101): one parser thread delivers ~4 300 clips/s with CRC
-    verification, about ONE MI355X's bf16 training rate; N threads keep a margin.  A slot is recycled only after the event
-    recorded behind its H2D copy has completed.  With a CPU `device` the yielded tensors ARE the slot (no copy): they are
-    valid until the next batch is requested."""
-    device = torch.device(device)
-    cuda = device.type == "cuda"
-    jobs = list(jobs)
-    nslots = workers + depth
-    free = queue.Queue()
-    for _ in range(nslots):
-        free.put({"x": None, "y": None, "event": None})
-    done, cond, stop = {}, threading.Condition(), threading.Event()
-    next_job = [0]
-    lock = threading.Lock()
+    verification, about ONE MI355X's bf16 training rate; N threads keep a margin.  The workers START AT CONSTRUCTION (the
+    next epoch's loader can be created while the current epoch is being evaluated: its first batches are then ready when
+    training resumes).  A slot is recycled only after the event recorded behind its H2D copy has completed.  With a CPU
+    `device` the yielded tensors ARE the slot (no copy): they are valid until the next batch is requested."""
 
-    def pinned(slot, key, n, dtype):
+    def __init__(self, jobs, build, shape_of, device, workers=4, depth=3):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.jobs, self.build, self.shape_of = list(jobs), build, shape_of
+        self.free = queue.Queue()
+        for _ in range(max(1, workers) + depth):
+            self.free.put({"x": None, "y": None, "event": None})
+        self.done, self.cond, self.stop = {}, threading.Condition(), threading.Event()
+        self.next_job, self.lock = [0], threading.Lock()
+        self.threads = [threading.Thread(target=self._worker, name="sar-loader-%d" % i, daemon=True) for i in range(max(1, workers))]
+        for t in self.threads:
+            t.start()
+
+    def _pinned(self, slot, key, n, dtype):
         t = slot[key]
         if t is None or t.numel() < n:
-            t = torch.empty(n, dtype=dtype, pin_memory=cuda)
+            t = torch.empty(n, dtype=dtype, pin_memory=self.cuda)
             slot[key] = t
         return t
 
-    def worker():
+    def _worker(self):
         try:
-            while not stop.is_set():
+            while not self.stop.is_set():
                 # job number AND pinned slot are taken under one lock, i.e. slots are handed out in job order: the job the
                 # consumer is waiting for always owns a slot before any later job does (no deadlock with all slots holding
                 # finished later batches)
-                with lock:
-                    if stop.is_set():
+                with self.lock:
+                    if self.stop.is_set():
                         return
-                    j = next_job[0]
-                    if j >= len(jobs):
+                    j = self.next_job[0]
+                    if j >= len(self.jobs):
                         return
-                    next_job[0] = j + 1
-                    slot = free.get()
-                if stop.is_set():
+                    self.next_job[0] = j + 1
+                    slot = self.free.get()
+                if self.stop.is_set():
                     return
                 if slot["event"] is not None:
                     slot["event"].synchronize()
-                shp = tuple(shape_of(jobs[j]))
+                shp = tuple(self.shape_of(self.jobs[j]))
                 n = int(np.prod(shp))
-                hx = pinned(slot, "x", n, torch.float32)[:n].view(shp)
-                hy = pinned(slot, "y", shp[0], torch.int64)[:shp[0]]
-                build(jobs[j], hx.numpy(), hy.numpy())
-                with cond:
-                    done[j] = (slot, hx, hy)
-                    cond.notify_all()
+                hx = self._pinned(slot, "x", n, torch.float32)[:n].view(shp)
+                hy = self._pinned(slot, "y", shp[0], torch.int64)[:shp[0]]
+                self.build(self.jobs[j], hx.numpy(), hy.numpy())
+                with self.cond:
+                    self.done[j] = (slot, hx, hy)
+                    self.cond.notify_all()
         except BaseException as e:
-            with cond:
-                done["error"] = e
-                cond.notify_all()
+            with self.cond:
+                self.done["error"] = e
+                self.cond.notify_all()
 
-    threads = [threading.Thread(target=worker, name="sar-loader-%d" % i, daemon=True) for i in range(max(1, workers))]
-    for t in threads:
-        t.start()
-    try:
-        for j in range(len(jobs)):
-            with cond:
-                while j not in done and "error" not in done:
-                    cond.wait()
-                if "error" in done:
-                    raise done["error"]
-                slot, hx, hy = done.pop(j)
-            if cuda:
-                x = hx.to(device, non_blocking=True)
-                y = hy.to(device, non_blocking=True)
-                slot["event"] = torch.cuda.Event()
-                slot["event"].record()
-                free.put(slot)
-                yield x, y
-            else:                  # a CPU consumer gets the slot itself: valid until it asks for the next batch
-                yield hx, hy
-                free.put(slot)
-    finally:
-        stop.set()
-        for _ in threads:
-            free.put({"x": None, "y": None, "event": None})
+    def close(self):
+        self.stop.set()
+        for _ in self.threads:
+            self.free.put({"x": None, "y": None, "event": None})
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __iter__(self):
+        try:
+            for j in range(len(self.jobs)):
+                with self.cond:
+                    while j not in self.done and "error" not in self.done:
+                        self.cond.wait()
+                    if "error" in self.done:
+                        raise self.done["error"]
+                    slot, hx, hy = self.done.pop(j)
+                if self.cuda:
+                    x = hx.to(self.device, non_blocking=True)
+                    y = hy.to(self.device, non_blocking=True)
+                    slot["event"] = torch.cuda.Event()
+                    slot["event"].record()
+                    self.free.put(slot)
+                    yield x, y
+                else:                  # a CPU consumer gets the slot itself: valid until it asks for the next batch
+                    yield hx, hy
+                    self.free.put(slot)
+        finally:
+            self.close()
 
 
 LOADER_THREADS = int(__import__("os").environ.get("SAR_LOADER_THREADS", "4"))

@@ -34,6 +34,10 @@ class GraphTables:
         # slice 0 is the identity (the 'spatial' strategy's self-links, graph/tools.py:22-30): gather list {(v, 1.0)}
         import numpy as np
         self.slice0_identity = bool(nz[0] == 1 and np.array_equal(idx[0, :, 0], np.arange(self.V)) and np.all(wt[0, :, 0] == 1.0))
+        # every gather weight exactly representable in bfloat16 (NTU: 0.25 / 0.5 / 1): the CN8 kernels may then apply a dense
+        # slice on the matrix cores (SAR_GRAPH_WT_BF16_EXACT, include/sar_hip.h)
+        w32 = torch.from_numpy(np.ascontiguousarray(wt, dtype=np.float32))
+        self.g_flags = L.SAR_GRAPH_WT_BF16_EXACT if bool(torch.equal(w32.to(torch.bfloat16).to(torch.float32), w32)) else 0
 
 
 class PackedWeights:

@@ -5,11 +5,15 @@ A CN8 activation is a torch.bfloat16 tensor of shape (G, ld, 8): G = ceil(C/8) p
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
 from . import profiler
 from ._lib import ConvDesc, WgradDesc, check, ptr, stream_ptr
+
+_MFMA_GATHER = os.environ.get("SAR_CN8_MFMA_GATHER", "1") == "1"   # A/B switch: 0 keeps the vector-ALU gather of the dense adjacency slice
 
 
 def empty(channels, n, device):
@@ -61,6 +65,7 @@ def conv_gemm(mode, src, out, packed, *, B, V, T_src, T_out, Kc, M, taps, stride
         d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
     if tables is not None:
         d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
+        d.g_flags = getattr(tables, "g_flags", 0) if _MFMA_GATHER else 0
         for i in range(3):
             d.nz[i] = tables.nz[i]
     if aux is not None:
@@ -107,6 +112,7 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     ident = 0
     if tables is not None:
         d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
+        d.g_flags = getattr(tables, "g_flags", 0) if _MFMA_GATHER else 0
         for i in range(3):
             d.nz[i] = tables.nz[i]
         ident = int(getattr(tables, "slice0_identity", False))

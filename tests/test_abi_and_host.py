@@ -35,9 +35,9 @@ def test_library_exports_every_declared_symbol():
 def test_descriptor_struct_layout_matches_header():
     """ctypes mirrors of sar_conv_desc / sar_wgrad_desc: field order and natural alignment."""
     from sar_amd import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4 + 19 * 8
-    assert ctypes.sizeof(_lib.WgradDesc) == 15 * 4 + 4 + 14 * 8
-    assert _lib.ConvDesc.src.offset == 64 and _lib.WgradDesc.src.offset == 64
+    assert ctypes.sizeof(_lib.ConvDesc) == 18 * 4 + 19 * 8
+    assert ctypes.sizeof(_lib.WgradDesc) == 16 * 4 + 14 * 8
+    assert _lib.ConvDesc.src.offset == 72 and _lib.WgradDesc.src.offset == 64
     lib = _lib.load()                                   # the library reports the sizes it was compiled with
     assert lib.sar_struct_size(0) == ctypes.sizeof(_lib.ConvDesc)
     assert lib.sar_struct_size(1) == ctypes.sizeof(_lib.WgradDesc)

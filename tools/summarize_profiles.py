@@ -58,17 +58,26 @@ for k, (calls, avg_ns, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
                  "fetch_kib_raw": None if f is None else round(f, 1), "write_kib": None if w is None else round(w, 1),
                  "hbm_bytes_per_launch": None if hbm is None else int(hbm),
                  "hbm_gbps": None if hbm is None else round(hbm / avg_ns, 1)})
-if BF16:   # conv_gemm_cn8_kernel<TR, TAPS = 9, ...>  (bf16 CN8 activations)
-    fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_cn8_kernel<%d, 9" % tr) for tr in (0, 1, 2, 3))]
+if BF16:   # conv_gemm_cn8_kernel<TR, TAPS = 9, ...> / the deep-prefetch variant (bf16 CN8 activations)
+    fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_cn8_kernel<%d, 9" % tr) for tr in (0, 1, 2, 3))
+           or r["kernel"].startswith("conv_gemm_cn8_db_kernel<")]
 elif MODE == "pathB":
     fam = [r for r in rows if r["kernel"].startswith("conv2d_gemm_kernel")]
 else:
     fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_kernel<1, %d, 9" % tr) for tr in (0, 1, 2, 3))]
 calls = sum(r["calls"] for r in fam)
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "skeleton-action-recognition_amd", "bench.py"], text=True).strip():
+        commit += "+uncommitted"
+except Exception:
+    commit = "unknown"
 summary = {
-    "command": ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline%s ; "
+    "commit": commit,          # the tree the profiled build was made from (bench.py quotes it next to roofline.traffic)
+    "command": ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary%s ; "
                 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-                "--no-cpu-baseline%s") % (({"bf16": " --mfma bf16", "pathB": " --workload spectrogram"}.get(MODE, ""),) * 2),
+                "--no-cpu-baseline --no-isolated-pass --no-secondary%s") % (({"bf16": " --mfma bf16", "pathB": " --workload spectrogram"}.get(MODE, ""),) * 2),
     "hbm_rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a coalesced stream; calibrated on "
                 "sgd_nesterov / bn_add_relu_fwd / affine2 whose byte counts are known)",
     "dominant_family": {"bf16": "conv_gemm_cn8_kernel<9 taps>", "pathB": "conv2d_gemm_kernel (3x3 / 1x1)"}.get(
