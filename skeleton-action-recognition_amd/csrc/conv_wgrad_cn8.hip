@@ -26,6 +26,7 @@
 //    ends and missing planes are the range check's zeros.  The loads of tile i+1 are in flight during the MFMA phase
 //    of tile i (72 KB per workgroup): the kernel is bound by HBM, not by staging latency.
 #include "cn8.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -75,13 +76,16 @@ __device__ __forceinline__ bool xcd_split(int nsplit, int gy, int gz, int& split
 }
 
 // ------------------------------------------------------------------------------------------------ temporal / residual
-template <int TAPS, int STRIDE>
+// WIDE (9 taps, stride 1): a workgroup owns 64 src x 64 out channels and every wave ALL nine taps of its 32 x 32 block (nine
+// accumulators) instead of 32 src channels with the taps split 5 + 4 over the wave pairs: dout is re-read by half as many
+// workgroups and no wave idles for a missing tap
+template <int TAPS, int STRIDE, bool WIDE = false>
 struct TCfg {
   static constexpr int FT = 7;                                   // output frames per tile
   static constexpr int NPOS = 176;                               // columns per tile padded to 11 k-steps of 16
   static constexpr int KSTEPS = NPOS / 16;
   static constexpr bool SPLIT = (STRIDE == 2 && TAPS == 9);      // parity images E / O
-  static constexpr bool TSPLIT = (TAPS == 9);                    // taps split over the two wave pairs (32 src channels per workgroup)
+  static constexpr bool TSPLIT = (TAPS == 9) && !WIDE;           // taps split over the two wave pairs (32 src channels per workgroup)
   static constexpr int NIMG = SPLIT ? 2 : 1;
   static constexpr int CBLK = TSPLIT ? 32 : 64;                  // src channels per workgroup
   static constexpr int NSP = NIMG * CBLK / 8;                    // staged src image planes (8 or 4)
@@ -96,9 +100,10 @@ struct TCfg {
   static constexpr int LDS_UNITS = NSP * PS_S + 8 * PS_D;
 };
 
-template <int TAPS, int STRIDE>
+template <int TAPS, int STRIDE, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
-  using C = TCfg<TAPS, STRIDE>;
+  using C = TCfg<TAPS, STRIDE, WIDE>;
+  static_assert(!WIDE || (TAPS == 9 && STRIDE == 1), "the wide block is built for 9 taps at stride 1");
   constexpr int FT = C::FT, PS_S = C::PS_S, PS_D = C::PS_D, SJ = C::SJ, DJ = C::DJ, SU = C::SU, NACC = C::NACC;
   __shared__ uint4 lds[C::LDS_UNITS];
   __shared__ float bred[4][16];
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
   // stride 2: out frame t, tap tp reads src frame 2 t + tp - pad = parity image (tp - pad) & 1 at image frame
   // t + floor((tp - pad) / 2); the images start at image frame t0 - 2.  pad 3 (even T): E <- taps 1,3,5,7 at shifts 1..4,
   // O <- taps 0,2,..,8 at shifts 0..4; pad 4 (odd T): E <- taps 0,2,..,8 at shifts 0..4, O <- taps 1,3,5,7 at shifts 0..3.
-  int nt = 1, sh0 = 0, tap0 = 0;
+  int nt = C::TSPLIT ? 1 : TAPS, sh0 = 0, tap0 = 0;
   constexpr int tstep = C::SPLIT ? 2 : 1;
   if (C::TSPLIT && !C::SPLIT) {
     nt = tg == 0 ? 5 : 4;
@@ -250,8 +255,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
       const bf16x8 bv = tr_frag(b_base + ks * 256);
       const unsigned a_ks = a_base + ks * 256;
       if constexpr (!C::TSPLIT) {
-        // one tap.  stride 1: the image as staged; stride 2 (pad 0): the E image as staged
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(a_ks), bv, acc[0], 0, 0, 0);
+        // every tap of the kernel (1, or 9 in the wide block): tap t reads the image shifted by t frames.  One tap, stride 2
+        // (pad 0): the E image as staged
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(a_ks + t * WV * 16), bv, acc[t], 0, 0, 0);
       } else {
         // this wave's tap group: accumulator s = tap tap0 + s * tstep, window shift (sh0 + s) frames
 #pragma unroll
@@ -559,10 +567,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
   }
 }
 
-template <int TAPS, int STRIDE>
+template <int TAPS, int STRIDE, bool WIDE = false>
 void launch_t(const WgradK8& k, hipStream_t st) {
   const int nwork = k.d.nsplit * k.gy * k.gz;
-  hipLaunchKernelGGL((wgrad_cn8_kernel<TAPS, STRIDE>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
+  hipLaunchKernelGGL((wgrad_cn8_kernel<TAPS, STRIDE, WIDE>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k);
 }
 
 template <int NZ0, int NZ1, int NZ2>
@@ -620,7 +628,11 @@ extern "C" int sar_conv_wgrad_cn8(const sar_wgrad_desc* d, int slice0_identity, 
                     d->taps, d->stride, d->pad);
       return SAR_E_UNSUP;
     }
-    if (d->taps == 9 && d->stride == 1) {
+    static const bool wide = [] { const char* e = getenv("SAR_CN8_WGRAD_WIDE"); return e && e[0] == '1'; }();   // experiment switch
+    if (d->taps == 9 && d->stride == 1 && wide) {
+      k.gz = (d->Kc + 63) / 64;
+      launch_t<9, 1, true>(k, as_stream(s));
+    } else if (d->taps == 9 && d->stride == 1) {
       k.gz = (d->Kc + 31) / 32;
       launch_t<9, 1>(k, as_stream(s));
     } else if (d->taps == 9) {
