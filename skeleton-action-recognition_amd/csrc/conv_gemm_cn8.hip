@@ -421,9 +421,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   auto mma_phase = [&]() {
     constexpr int JSURE = PAR ? JT - 1 : JT;
     if (!(SAR_ABLATE8 & 1)) {
+#ifdef SAR_CN8_SETPRIO
+      __builtin_amdgcn_s_setprio(1);   // experiment: the multiplying wave wins issue arbitration against co-resident staging waves
+#endif
 #pragma unroll
       for (int j = 0; j < JSURE; ++j) taps_mma(j);
       if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
+#ifdef SAR_CN8_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   };
   // aux half units of the whole wave tile (ReLU-mask source / residual gradient): MS x 2 x 2 x NS loads of 8 bytes issued

@@ -96,6 +96,13 @@ def test_bench_starts_its_own_ranks(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+    # self-diagnosing scaling runs (VERDICT r02 #3c): every rank's own step time, the time of the gradient collective, and the
+    # bf16 / Path B configurations measured by the same ranks in the same process
+    assert len(out["per_rank_ms"]) == 2 and all(t > 0 for t in out["per_rank_ms"]) and out["allreduce_ms"] is not None
+    assert abs(max(out["per_rank_ms"]) - out["ms_per_step"]) < 1e-6
+    sec = out["secondary"]
+    assert sec["bf16"]["n_gpus"] == 2 and sec["bf16"]["dtype"] == "bf16" and sec["bf16"]["value"] > 0 and sec["bf16"]["warm_s"] >= 2.5
+    assert sec["pathB"]["n_gpus"] == 2 and sec["pathB"]["value"] > 0 and len(sec["pathB"]["per_rank_ms"]) == 2
 
 
 def _write_npy_dataset(d, n, T, classes, split):

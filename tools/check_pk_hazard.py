@@ -10,12 +10,13 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "skeleton-action-recognition_amd", "csrc")
-files = sys.argv[1:] or sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and not f.startswith("conv2d_"))
+# every translation unit of the library by default: the conv2d_* shims compile conv2d.hip part by part
+files = sys.argv[1:] or sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f != "conv2d.hip")
 pat = re.compile(r"\s*v_pk_(fma|mul|add)_f32 (v\[\d+:\d+\]), ([^,]+), ([^,\s]+)(?:, ([^,\s]+))?(.*)")
 for f in files:
     extra = ["-fno-slp-vectorize"] if f == "conv_gemm_cn8.hip" else (["-ffp-contract=off"] if f == "radar.hip" else [])
     with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
-        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *extra,
+        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + CSRC, *extra,
                         os.path.join(CSRC, f), "-o", tmp.name], check=True, stderr=subprocess.DEVNULL)
         total = hazard = 0
         for line in open(tmp.name):
