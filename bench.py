@@ -383,9 +383,8 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
                                "step_algorithmic_bytes_per_clip": step_bytes}
             if isolated:
                 out["roofline"]["isolated"] = isolated
-    del trainer, eng, batches
-    torch.cuda.empty_cache()
-    return out
+    del trainer, eng, batches    # (the cached device blocks stay with torch's allocator: the next leg reuses them instead of paying
+    return out                   #  hipMalloc for every tensor of its first steps)
 
 
 def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrument_steps=0):
@@ -471,7 +470,6 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
             "final_loss": round(float(loss.item()), 5),
         }
     del trainer, model, batches
-    torch.cuda.empty_cache()
     return out
 
 
