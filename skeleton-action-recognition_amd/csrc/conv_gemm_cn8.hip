@@ -25,6 +25,31 @@ constexpr int KC16 = 16;   // src channels per main-loop stage = one MFMA k-step
 #define SAR_ABLATE8 0   // diagnostic builds only (tools/ablate8.sh): 1 no MFMA, 2 global loads of stage 0 only, 4 no epilogue, 8 LDS stores of stage 0 only
 #endif
 
+// In-kernel phase stamps of conv_gemm_cn8_kernel (diagnostic build -DSAR_CN8_STAMPS, tools/stamps8.sh): wave 0 of every
+// workgroup adds the shader-clock cycles it spent in [0] store_lds, [1] the wait at the barrier behind it, [2] load issue +
+// MFMA phase, [3] the wait at the closing barrier, [4] the prologue, [5] the epilogue; [6] = workgroups, [7] = their
+// lifetimes in 100 MHz ticks (s_memrealtime), [8] = the same in shader-clock cycles, [9] = the graph kernel's loads + MFMA phase.
+#ifdef SAR_CN8_STAMPS
+constexpr int STAMP_WG = 8192;
+__device__ unsigned g_stamps8[STAMP_WG][10];   // one row per workgroup (plain stores: same-address atomics would stall the L2 channel)
+#define STAMP8_(i)                                               \
+  do {                                                           \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    st_acc[i] += t_ - st_last;                                   \
+    st_last = t_;                                                \
+  } while (0)
+#if SAR_CN8_STAMPS == 2   // the graph kernel's prologue in pieces ([0] geometry + colsum, [1] gather tables, [2] B fragments + zero fill, [3] loads + barrier + bias)
+#define STAMP8(i)
+#define STAMP8P(i) STAMP8_(i)
+#else
+#define STAMP8(i) STAMP8_(i)
+#define STAMP8P(i)
+#endif
+#else
+#define STAMP8(i)
+#define STAMP8P(i)
+#endif
+
 struct ConvK8 {
   sar_conv_desc d;
   const uint4* wp;   // packed weights [taps][G][M] units of 8 bf16 (sar_pack_weights_bf16_batch)
@@ -210,7 +235,7 @@ __device__ __forceinline__ int xcd_work(int nwork) {
 // TR: 0 forward; 1 data gradient, stride 1; 2 data gradient, generic stride (tap validity mask); 3 data gradient,
 // stride 2, parity-split column map (see conv_gemm.hip)
 template <int TR, int TAPS, int MS, int NS, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
+__global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel(const ConvK8 k) {
   using TC = TileCfg8<TAPS, MS, NS, WM, WN>;
   constexpr int TRANSPOSED = TR != 0;
   constexpr int PAR = (TR == 3);
@@ -235,6 +260,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   const int ny = k.ny;
   const int w = xcd_work(k.ntiles * ny);
   if (w < 0) return;
+#ifdef SAR_CN8_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0;
+#endif
   if (k.stagger && blockIdx.x < 768) {   // de-phase the co-resident workgroups (they would otherwise run their phases in lockstep)
     const int ph = (blockIdx.x >> k.stagger_shift) % 3;
     for (int i = 0; i < ph * k.stagger; ++i) __builtin_amdgcn_s_sleep(16);
@@ -400,16 +430,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
     }
 
   const uint4* Wa = Wl + (tp0 * 2 + hi) * BM + wm * MS * 32 + l31;
-  auto taps_mma = [&](int j) {
+  // Operand fragments of tap slot j.  The tap loop is software-pipelined BY HAND over two fragment sets: the four
+  // ds_read_b128 of slot j + 1 are issued before the four MFMAs of slot j.  (Left to the compiler, every slot re-used ONE
+  // fragment set -- read, wait for the LDS round trip, multiply, read ... : ~270 cycles per slot for 128 cycles of matrix
+  // work, which is what a wave's MFMA phase cost whenever its co-resident waves were not multiplying themselves.)
+  // The B addresses are formed per use (off0 + j * ostep): kept loop-invariant they were 18 VGPRs.
+  auto frag_load = [&](int j, const int (&ost)[NS], uint4 (&a)[MS], uint4 (&bq)[NS]) {
     const int tpw = PAR ? 2 * j : j;
-    uint4 a[MS], bq[NS];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tpw * 2 * BM + ms * 32];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      bq[ns] = Sl[TR == 2 ? offt[TR == 2 ? j : 0][ns] : off0[ns] + j * ostep[ns]];
+      bq[ns] = Sl[TR == 2 ? offt[TR == 2 ? j : 0][ns] : off0[ns] + j * ost[ns]];
       if (TR == 2 && !((vmask[ns] >> j) & 1u)) bq[ns] = make_uint4(0u, 0u, 0u, 0u);
     }
+  };
+  auto frag_mma = [&](uint4 (&a)[MS], uint4 (&bq)[NS]) {
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -424,9 +460,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
 #ifdef SAR_CN8_SETPRIO
       __builtin_amdgcn_s_setprio(1);   // experiment: the multiplying wave wins issue arbitration against co-resident staging waves
 #endif
+      int ost[NS];
 #pragma unroll
-      for (int j = 0; j < JSURE; ++j) taps_mma(j);
-      if (PAR && ntap_w == JT) taps_mma(JT - 1);   // wave-uniform
+      for (int ns = 0; ns < NS; ++ns) {
+        ost[ns] = ostep[ns];
+        asm volatile("" : "+v"(ost[ns]));   // not loop-invariant any more: the addresses are re-formed, not kept
+      }
+      uint4 fa[2][MS], fb[2][NS];
+      frag_load(0, ost, fa[0], fb[0]);
+#pragma unroll
+      for (int j = 0; j < JSURE; ++j) {
+        if (j + 1 < JSURE) frag_load(j + 1, ost, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+        else if (PAR && ntap_w == JT) frag_load(JT - 1, ost, fa[(j + 1) & 1], fb[(j + 1) & 1]);   // wave-uniform
+        __builtin_amdgcn_sched_barrier(0);   // the reads of the next slot stay AHEAD of this slot's MFMAs
+        frag_mma(fa[j & 1], fb[j & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (PAR && ntap_w == JT) frag_mma(fa[JSURE & 1], fb[JSURE & 1]);
 #ifdef SAR_CN8_SETPRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
@@ -453,16 +503,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   };
 
   int c0 = 0;
+  STAMP8(4);
   for (; c0 + KC16 < d.Kc; c0 += KC16) {
     if (!(SAR_ABLATE8 & 8) || c0 == 0) store_lds(c0);
+    STAMP8(0);
     __syncthreads();
+    STAMP8(1);
     if (!(SAR_ABLATE8 & 2)) issue_loads(c0 + KC16);   // in flight during the MFMA phase
     mma_phase();
+    STAMP8(2);
     __syncthreads();   // every wave is done with the image (next store)
+    STAMP8(3);
   }
   // last stage (peeled: the aux registers take the place of the staging registers)
   if (!(SAR_ABLATE8 & 8) || c0 == 0) store_lds(c0);
+  STAMP8(0);
   __syncthreads();
+  STAMP8(1);
   if (has_aux) issue_aux();   // uniform
   if (epi_mask && tid < BM) {   // MASK parameters replace the bias rows (every wave is past its accumulator initialisation)
     const int row = m0 + tid;
@@ -475,7 +532,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
     rowp[tid] = ap;
   }
   mma_phase();
+  STAMP8(2);
   __syncthreads();   // the epilogue's transpose area aliases the image; rowp is complete
+  STAMP8(3);
   if (SAR_ABLATE8 & 4) {   // every accumulator stays live (an un-used one would take its MFMAs with it)
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
@@ -487,6 +546,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_cn8_kernel(const ConvK8 k) {
   }
   if (has_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
   else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+#ifdef SAR_CN8_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have left
+  STAMP8(5);
+  if (tid == 0 && blockIdx.x < STAMP_WG) {
+    unsigned* row = g_stamps8[blockIdx.x];
+    for (int i = 0; i < 6; ++i) row[i] = (unsigned)st_acc[i];
+    row[6] = 1u;
+    row[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    row[8] = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -761,7 +831,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_cn8_db_kernel(const ConvK8 k
 // in 8 registers per lane for the whole kernel; a result register quad is 4 consecutive channels of one joint = half a
 // unit of the z image (one 8-byte LDS store).  Frames are dealt round-robin to the four waves.
 template <int MS, int NS, int WM, int WN, int NZ0, int NZ1, int NZ2>
-__global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) {
+__global__ __launch_bounds__(256, (NZ0 + NZ1 + NZ2 > 6) ? 2 : 3) void conv_graph_cn8_kernel(const ConvK8 k) {
   constexpr int BM = 32 * MS * WM, TN = 32 * NS * WN;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
   constexpr int DENSE = ((NZ0 > 1) + (NZ1 > 1) + (NZ2 > 1) == 1) ? (NZ0 > 1 ? 0 : NZ1 > 1 ? 1 : 2) : -1;   // the slice the matrix cores may gather
@@ -790,6 +860,11 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
   const int ny = k.ny;
   const int w = xcd_work(k.ntiles * ny);
   if (w < 0) return;
+#ifdef SAR_CN8_STAMPS   // graph kernel: [0] store_raw, [1] barrier, [2] build_units, [3] barrier, [4] prologue, [5] epilogue; loads + MFMA in g_stamps8g
+  unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0;
+#endif
   const int tile = w / ny;
   const int b = tile / k.TPS;
   const int t0 = (tile - b * k.TPS) * k.FT;
@@ -797,83 +872,9 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
   const int ncols = ((t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0) * V;   // live columns of this tile
   const bool mg = DENSE >= 0 && (d.g_flags & SAR_GRAPH_WT_BF16_EXACT) && V <= 32;   // uniform: dense slice on the matrix cores
 
-  bool colok[NS];
-  unsigned vo[NS];
-  float gcs[3][NS];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns) {
-    const int p = (wn * NS + ns) * 32 + l31;
-    colok[ns] = p < ncols;
-    const int pv = colok[ns] ? p : 0;
-    vo[ns] = colok[ns] ? (unsigned)((((int64_t)b * d.T_out + t0) * V + pv) * 16 + 8 * hi) : 0x80000000u;
-    const int v = pv % V;
-#pragma unroll
-    for (int tp = 0; tp < 3; ++tp) gcs[tp][ns] = (d.g_colsum && colok[ns]) ? d.g_colsum[tp * V + v] : 0.f;
-  }
-  if (tid < BM) {
-    const int row = m0 + tid;
-    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.bias && row < d.M) {
-      bp.x = d.bias[row];
-      bp.y = d.bias[d.M + row];
-      bp.z = d.bias[2 * d.M + row];
-    }
-    rowp[tid] = bp;
-  }
-  // unit builder geometry: this thread's channel half and columns, gather offsets (units inside a raw plane) and weights
-  const int uh = tid >> 7;   // 0 / 1 (wave-uniform)
-  int go[CPT][3][4];
-  float gwt[CPT][3][4];
-#pragma unroll
-  for (int q = 0; q < CPT; ++q) {
-    const int col = (tid & 127) + 128 * q;
-    const bool live = col < ncols;
-    const int cc = live ? col : 0;
-    const int fo = cc / V, v = cc - fo * V;
-#pragma unroll
-    for (int tp = 0; tp < 3; ++tp)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < NZ[tp] && !(mg && tp == DENSE)) {
-          go[q][tp][j] = fo * V + d.g_idx[(tp * V + v) * 4 + j];
-          gwt[q][tp][j] = live ? d.g_wt[(tp * V + v) * 4 + j] : 0.f;
-        }
-  }
-  // matrix-core gather: this lane's B fragments (A_k[v = 8 G + j][w = (lane & 15) + 16 nb], j = 0..7) and LDS addresses
-  const int gG = lane >> 4, gi = lane & 15;
-  bf16x8 bfr[2];
-  unsigned tr_addr = 0;
-  int zst_unit = 0;
-  if (mg) {
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int wv = gi + 16 * nb;
-      float a[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = 0.f;
-      if (wv < V) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < NZ[DENSE >= 0 ? DENSE : 0]) {
-            const int vi = d.g_idx[((DENSE >= 0 ? DENSE : 0) * V + wv) * 4 + e];
-            const float wt = d.g_wt[((DENSE >= 0 ? DENSE : 0) * V + wv) * 4 + e];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += (vi == 8 * gG + j) ? wt : 0.f;
-          }
-      }
-      const uint4 pk = cn8_pack(a);
-      bfr[nb] = *reinterpret_cast<const bf16x8*>(&pk);
-    }
-    // transposed read: lane 4 q + p of a 16-lane group supplies joint 8 G + q, channels 4 p .. 4 p + 3 (plane p >> 1)
-    const int q = gi >> 2, p = gi & 3;
-    tr_addr = (unsigned)(uintptr_t)XR + (unsigned)((((p >> 1) * XS + 8 * gG + q) * 16) + 8 * (p & 1));
-    // result quad = channels 4 G .. 4 G + 3 of joint gi (+ 16): half (G & 1) of the unit in plane G >> 1 of the dense z slice
-    zst_unit = ((DENSE >= 0 ? DENSE : 0) * 2 + (gG >> 1)) * TN + gi;
-    // the dense z slice beyond the last whole frame and the slack columns of the raw image are read but never written
-    for (int i = tid; i < 2 * TN; i += 256) Zl[(DENSE >= 0 ? DENSE : 0) * 2 * TN + i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = tid; i < 2 * (XS - TN); i += 256) XR[(i / (XS - TN)) * XS + TN + i % (XS - TN)] = make_uint4(0u, 0u, 0u, 0u);
-  }
-
+  // ---- prologue.  Everything that comes from global memory -- the first stage's operands, the gather tables, the column
+  // sums, the bias -- is ISSUED first and consumed afterwards: one memory round trip, not one per table (as a sequence of
+  // load -> use blocks the prologue was 8 700 cycles, a quarter of a 64-channel workgroup's life)
   f32x16 acc[MS][NS];
   const int seq_left = (d.T_src - t0) * V;   // columns from the tile start to the end of the sequence
   const char* src_b = (const char*)d.src + ((int64_t)b * d.T_src + t0) * V * 16;
@@ -898,7 +899,6 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
   uint4 wreg[WIT];
   uint4 xreg[XJ];
-
   auto issue_loads = [&](int c0) {
     const int wso = (c0 / 8) * d.M * 16;
 #pragma unroll
@@ -915,6 +915,95 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
       xreg[j] = make_uint4(v[0], v[1], v[2], v[3]);
     }
   };
+  issue_loads(0);
+  // table loads (clamped indices, no branches), all in flight together
+  bool colok[NS];
+  unsigned vo[NS];
+  float gcs[3][NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    colok[ns] = p < ncols;
+    const int pv = colok[ns] ? p : 0;
+    vo[ns] = colok[ns] ? (unsigned)((((int64_t)b * d.T_out + t0) * V + pv) * 16 + 8 * hi) : 0x80000000u;
+    const int v = pv % V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) gcs[tp][ns] = d.g_colsum ? d.g_colsum[tp * V + v] : 0.f;   // masked by colok at the use
+  }
+  float4 bias_row = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < BM && d.bias && m0 + tid < d.M) {
+    bias_row.x = d.bias[m0 + tid];
+    bias_row.y = d.bias[d.M + m0 + tid];
+    bias_row.z = d.bias[2 * d.M + m0 + tid];
+  }
+  // unit builder geometry: this thread's channel half and columns, gather offsets (units inside a raw plane) and weights
+  const int uh = tid >> 7;   // 0 / 1 (wave-uniform)
+  int go[CPT][3][4];
+  float gwt[CPT][3][4];
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const int col = (tid & 127) + 128 * q;
+    const bool live = col < ncols;
+    const int cc = live ? col : 0;
+    const int fo = cc / V, v = cc - fo * V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < NZ[tp] && !(mg && tp == DENSE)) {
+          go[q][tp][j] = fo * V + d.g_idx[(tp * V + v) * 4 + j];
+          gwt[q][tp][j] = live ? d.g_wt[(tp * V + v) * 4 + j] : 0.f;
+        }
+  }
+  // matrix-core gather: the table entries of this lane's B fragments (A_k[v = 8 G + j][w = (lane & 15) + 16 nb], j = 0..7)
+  const int gG = lane >> 4, gi = lane & 15;
+  constexpr int DS = DENSE >= 0 ? DENSE : 0;
+  int bvi[2][4];
+  float bwt[2][4];
+  if (mg) {   // uniform
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int wv = gi + 16 * nb, wvc = wv < V ? wv : 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < NZ[DS]) {
+          bvi[nb][e] = d.g_idx[(DS * V + wvc) * 4 + e];
+          bwt[nb][e] = wv < V ? d.g_wt[(DS * V + wvc) * 4 + e] : 0.f;
+        }
+    }
+  }
+  STAMP8P(0);
+  // ---- consumers
+  if (tid < BM) rowp[tid] = bias_row;
+  bf16x8 bfr[2];
+  unsigned tr_addr = 0;
+  int zst_unit = 0;
+  if (mg) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < NZ[DS]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += (bvi[nb][e] == 8 * gG + j) ? bwt[nb][e] : 0.f;
+        }
+      const uint4 pk = cn8_pack(a);
+      bfr[nb] = *reinterpret_cast<const bf16x8*>(&pk);
+    }
+    // transposed read: lane 4 q + p of a 16-lane group supplies joint 8 G + q, channels 4 p .. 4 p + 3 (plane p >> 1)
+    const int q = gi >> 2, p = gi & 3;
+    tr_addr = (unsigned)(uintptr_t)XR + (unsigned)((((p >> 1) * XS + 8 * gG + q) * 16) + 8 * (p & 1));
+    // result quad = channels 4 G .. 4 G + 3 of joint gi (+ 16): half (G & 1) of the unit in plane G >> 1 of the dense z slice
+    zst_unit = (DS * 2 + (gG >> 1)) * TN + gi;
+    // the dense z slice beyond the last whole frame and the slack columns of the raw image are read but never written
+    for (int i = tid; i < 2 * TN; i += 256) Zl[DS * 2 * TN + i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * (XS - TN); i += 256) XR[(i / (XS - TN)) * XS + TN + i % (XS - TN)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  STAMP8P(1);
+  STAMP8P(2);
   auto store_raw = [&]() {
 #pragma unroll
     for (int j = 0; j < XJ; ++j) XR[xdst[j]] = xreg[j];
@@ -984,7 +1073,6 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
     }
   };
 
-  issue_loads(0);
   __syncthreads();   // rowp
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
@@ -992,10 +1080,14 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
     for (int r = 0; r < 16; ++r) {
       const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
+      for (int ns = 0; ns < NS; ++ns)
+        acc[ms][ns][r] = colok[ns] ? fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns])) : 0.f;
     }
+  STAMP8P(3);
   const uint4* Wa = Wl + hi * BM + wm * MS * 32 + l31;
   const uint4* Za = Zl + hi * TN + wn * NS * 32 + l31;
+  // (the reads of slice tp + 1 ahead of the MFMAs of slice tp -- the hand pipelining of conv_gemm_cn8_kernel -- needs 16 more
+  // VGPRs: 172-184, i.e. two waves per SIMD, or 44-148 bytes of scratch at three; measured neutral, not kept)
   auto mma_phase = [&]() {
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {
@@ -1030,23 +1122,47 @@ __global__ __launch_bounds__(256, 2) void conv_graph_cn8_kernel(const ConvK8 k) 
                 __builtin_amdgcn_raw_buffer_load_b64(e8.ra, vo[ns], (4 * ms + 2 * rb + q2) * e8.so_aux, 0);
   };
   int c0 = 0;
+  STAMP8(4);
   for (; c0 + KC16 < d.Kc; c0 += KC16) {
     store_raw();
+    STAMP8(0);
     __syncthreads();   // raw image complete; every wave is past the MFMA phase of the previous stage
+    STAMP8(1);
     build_units();
+    STAMP8(2);
     __syncthreads();
+    STAMP8(3);
     issue_loads(c0 + KC16);
     mma_phase();
+    STAMP8(6);
   }
   store_raw();         // last stage (peeled: the aux registers take the place of the staging registers)
+  STAMP8(0);
   __syncthreads();
+  STAMP8(1);
   if (pre_aux) issue_aux();   // uniform
   build_units();
+  STAMP8(2);
   __syncthreads();
+  STAMP8(3);
   mma_phase();
+  STAMP8(6);
   __syncthreads();   // the epilogue's transpose area aliases the image
+  STAMP8(3);
   if (pre_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
   else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+#ifdef SAR_CN8_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  STAMP8(5);
+  if (tid == 0 && blockIdx.x < STAMP_WG) {
+    unsigned* row = g_stamps8[blockIdx.x];
+    for (int i = 0; i < 6; ++i) row[i] = (unsigned)st_acc[i];
+    row[6] = 1u;
+    row[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    row[8] = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0);
+    row[9] = (unsigned)st_acc[6];
+  }
+#endif
 }
 
 template <int WN>
@@ -1227,6 +1343,23 @@ int check8(const sar_conv_desc* d) {
 }
 
 }  // namespace
+
+#ifdef SAR_CN8_STAMPS
+extern "C" int sar_debug_cn8_stamps(unsigned long long* out10, int reset) {
+  static unsigned host[STAMP_WG][10];
+  if (out10) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps8), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 10; ++i) out10[i] = 0;
+    for (int w = 0; w < STAMP_WG; ++w)
+      for (int i = 0; i < 10; ++i) out10[i] += host[w][i];
+  }
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps8)) != hipSuccess || hipMemset(p, 0, sizeof(host)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int sar_conv_gemm_cn8_nparts(const sar_conv_desc* d) {
   if (int rc = check8(d)) return rc;

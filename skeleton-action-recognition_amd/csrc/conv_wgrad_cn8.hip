@@ -250,23 +250,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
     store_lds();
     __syncthreads();
     if (tile + 1 < tile_hi) issue_loads(tile + 1);   // in flight during the MFMA phase
-#pragma unroll 1
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      const bf16x8 bv = tr_frag(b_base + ks * 256);
+    // k-steps, software-pipelined BY HAND over two fragment sets: the transposed reads of k-step ks + 1 are issued before
+    // the MFMAs of k-step ks.  (As one un-pipelined loop body the compiler emitted read, wait, multiply three times per
+    // k-step: three exposed LDS round trips for 160 cycles of matrix work.)
+    constexpr int NFR = C::TSPLIT ? 5 : TAPS;
+    bf16x8 fb[2], fa[2][NFR];
+    auto frag_load = [&](int ks, bf16x8& bv, bf16x8 (&av)[NFR]) {
+      bv = tr_frag(b_base + ks * 256);
       const unsigned a_ks = a_base + ks * 256;
       if constexpr (!C::TSPLIT) {
         // every tap of the kernel (1, or 9 in the wide block): tap t reads the image shifted by t frames.  One tap, stride 2
         // (pad 0): the E image as staged
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(a_ks + t * WV * 16), bv, acc[t], 0, 0, 0);
+        for (int t = 0; t < TAPS; ++t) av[t] = tr_frag(a_ks + t * WV * 16);
       } else {
         // this wave's tap group: accumulator s = tap tap0 + s * tstep, window shift (sh0 + s) frames
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(a_ks + s * WV * 16), bv, acc[s], 0, 0, 0);
-        if (nt == 5) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(a_ks + 4 * WV * 16), bv, acc[4], 0, 0, 0);   // wave-uniform
+        for (int s = 0; s < 5; ++s) av[s] = tr_frag(a_ks + s * WV * 16);   // the 4-tap group reads (and ignores) a fifth window: inside the LDS image, and no branch
       }
+    };
+    auto frag_mma = [&](const bf16x8& bv, const bf16x8 (&av)[NFR]) {
+      if constexpr (!C::TSPLIT) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t], bv, acc[t], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], bv, acc[s], 0, 0, 0);
+        if (nt == 5) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[4], bv, acc[4], 0, 0, 0);   // wave-uniform
+      }
+    };
+    frag_load(0, fb[0], fa[0]);
+    int ks = 0;
+#pragma unroll 1
+    for (; ks + 2 < C::KSTEPS; ks += 2) {   // whole pairs with a successor: no branch between the reads and the MFMAs
+      frag_load(ks + 1, fb[1], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);   // the reads of the next k-step stay AHEAD of this k-step's MFMAs
+      frag_mma(fb[0], fa[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_load(ks + 2, fb[0], fa[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(fb[1], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (C::KSTEPS % 2 == 0) {
+      frag_load(ks + 1, fb[1], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(fb[0], fa[0]);
+      frag_mma(fb[1], fa[1]);
+    } else {
+      frag_mma(fb[0], fa[0]);
     }
     __syncthreads();
   }
@@ -527,14 +559,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
     if (tile + 1 < tile_hi) issue_loads(tile + 1);
     build_z();
     __syncthreads();
-#pragma unroll 1
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const bf16x8 bv = tr_frag(b_base + ks * 256);
+    // k-steps, software-pipelined by hand over two fragment sets (see wgrad_cn8_kernel): the eight transposed reads of
+    // k-step ks + 1 are issued before the three MFMAs of k-step ks
+    bf16x8 fb[2], fa[2][3];
+    auto frag_load = [&](int ks, bf16x8& bv, bf16x8 (&av)[3]) {
+      bv = tr_frag(b_base + ks * 256);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const unsigned a = (ID0 && t == 0) ? x_base + ks * 256 : z_base + ((t - (ID0 ? 1 : 0)) * 8 * PS) * 16 + ks * 256;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(a), bv, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < 3; ++t)
+        av[t] = tr_frag((ID0 && t == 0) ? x_base + ks * 256 : z_base + ((t - (ID0 ? 1 : 0)) * 8 * PS) * 16 + ks * 256);
+    };
+    auto frag_mma = [&](const bf16x8& bv, const bf16x8 (&av)[3]) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t], bv, acc[t], 0, 0, 0);
+    };
+    frag_load(0, fb[0], fa[0]);
+    int ks = 0;
+#pragma unroll 1
+    for (; ks + 2 < KSTEPS; ks += 2) {
+      frag_load(ks + 1, fb[1], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(fb[0], fa[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_load(ks + 2, fb[0], fa[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(fb[1], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (KSTEPS % 2 == 0) {
+      frag_load(ks + 1, fb[1], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(fb[0], fa[0]);
+      frag_mma(fb[1], fa[1]);
+    } else {
+      frag_mma(fb[0], fa[0]);
     }
     __syncthreads();
   }

@@ -3,9 +3,10 @@ classifier (reference models/resnet18.py:131-254: stem Conv7x7/2 + BN + ReLU + M
 BasicBlocks :26-72, AdaptiveAvgPool, Linear) and its train step (main_spectrogram.py:105-111,152-158: mean
 CrossEntropyLoss, Adam).
 
-Parameters keep the reference's state_dict names and torch layouts (conv OIHW, fc (classes, 512)) as views of one
-flat fp32 buffer; per step the conv weights are re-packed once into the (tap, c, m) / (tap, m, c) layouts the GEMM
-kernels read.  Activations are CN matrices [C][B*H*W]; per BasicBlock the tensors crossing a BatchNorm barrier
+Parameters keep the reference's state_dict names and torch shapes (conv OIHW, fc (classes, 512)) as views of one flat
+fp32 buffer; a conv weight is STORED in the forward GEMM's operand order (tap, c, m) -- its OIHW tensor is a strided
+view -- so the forward reads the master weights and the weight-gradient kernels write the gradient buffer in place;
+only the (tap, m, c) layout of the data-gradient GEMMs is re-packed, once per step on the side stream.  Activations are CN matrices [C][B*H*W]; per BasicBlock the tensors crossing a BatchNorm barrier
 (c1, c2, downsample out, block out) are materialised once; BN+ReLU is folded into the consumer conv's operand load,
 BN statistics into the producer's epilogue, the block tail reuses the ST-GCN BN+add+ReLU kernels.
 """
@@ -87,28 +88,24 @@ class ResNet18:
         # side streams of the launches that fan out (stride-2 data gradients): owned by this engine, not by the library
         with torch.cuda.device(dev):
             self._ctx = L.Context() if dev.type == "cuda" else None
-        # Operand layouts of every conv weight, refreshed by ONE launch per step (and one more for the data-gradient
-        # layouts when training): forward (tap, c, m), data gradient (tap, m, c); the weight-gradient kernels write
-        # (tap, c, m) tensors into one scratch buffer that ONE launch re-lays into the OIHW gradient views.
+        # The data-gradient GEMMs read (tap, m, c): ONE re-layout launch per training step, on the side stream (the forward
+        # reads the stored (tap, c, m) weights in place and the weight-gradient kernels write self.grad in place).
         self._woff, off = {}, 0
-        pf, pb, pg = ops.PermuteBatch(), ops.PermuteBatch(), ops.PermuteBatch()
+        pb = ops.PermuteBatch()
         for name, cv in self.convs.items():
             n = cv.taps * cv.cin * cv.cout
             src = self.offsets[name + ".weight"]
             self._woff[name] = (off, n)
-            pf.add(src, off, cv.taps, cv.cin, cv.cout, 1, cv.taps, cv.cin * cv.taps)
             if name != "conv1":
-                pb.add(src, off, cv.taps, cv.cout, cv.cin, 1, cv.cin * cv.taps, cv.taps)
-            pg.add(off, src, cv.cout, cv.cin, cv.taps, 1, cv.cout, cv.cin * cv.cout)      # (tap, c, m) -> OIHW
+                pb.add(src, off, cv.taps, cv.cout, cv.cin, cv.cin * cv.cout, 1, cv.cout)
             off += (n + 3) // 4 * 4
-        for pk in (pf, pb, pg):
-            pk.finalize(dev)
-        self._perm_fwd, self._perm_bwd, self._perm_grad = pf, pb, pg
-        self._wf, self._wb, self._gw = z(off), z(off), z(off)
+        pb.finalize(dev)
+        self._perm_bwd = pb
+        self._wb = z(off)
         # Gradient buckets for the data-parallel exchange (main_spectrogram.py:118-119), in the order backward() completes
         # them: [layer4 + fc], [layer3], [layer2], [conv1 + bn1 + layer1].  Each is a contiguous slice of the flat gradient
-        # buffer (parameters are laid out in declaration order) with its own (tap, c, m) -> OIHW re-layout launch, so that a
-        # bucket can be all-reduced while the earlier layers are still in backward.
+        # buffer (parameters are laid out in declaration order), so that a bucket can be all-reduced while the earlier layers are
+        # still in backward.
         names = list(self.shapes)
         stage_of = lambda k: (4 if k.startswith(("layer4.", "fc.")) else 3 if k.startswith("layer3.") else
                               2 if k.startswith("layer2.") else 1)
@@ -117,18 +114,19 @@ class ResNet18:
             ks = [k for k in names if stage_of(k) == st]
             lo = min(self.offsets[k] for k in ks)
             hi = max(self.offsets[k] + (int(np.prod(self.shapes[k])) + 3) // 4 * 4 for k in ks)
-            perm = ops.PermuteBatch()
-            for name, cv in self.convs.items():
-                if stage_of(name + ".weight") == st:
-                    o, _ = self._woff[name]
-                    perm.add(o, self.offsets[name + ".weight"], cv.cout, cv.cin, cv.taps, 1, cv.cout, cv.cin * cv.cout)
-            perm.finalize(dev)
-            self._buckets.append(dict(stage=st, lo=lo, hi=hi, perm=perm))
+            self._buckets.append(dict(stage=st, lo=lo, hi=hi))
         assert sorted((b["lo"], b["hi"]) for b in self._buckets)[0][0] == 0 and max(b["hi"] for b in self._buckets) == total
 
     def _view(self, flat, name):
+        """The named tensor in torch's shape.  Conv weights are STORED in the forward GEMM's operand order (kh, kw, c, m)
+        -- Adam is element-wise, so the optimizer does not care, the forward kernels read the master weights in place and
+        the weight-gradient kernels write the gradient buffer in place: the OIHW tensor is a strided view of it."""
         o = self.offsets[name]
-        return flat[o:o + int(np.prod(self.shapes[name]))].view(self.shapes[name])
+        shp = self.shapes[name]
+        t = flat[o:o + int(np.prod(shp))]
+        if len(shp) == 4:
+            return t.view(shp[2], shp[3], shp[1], shp[0]).permute(3, 2, 0, 1)
+        return t.view(shp)
 
     def _init_params(self, seed):
         """models/resnet18.py:187-194: kaiming_normal_(fan_out, relu) for convs, BN weight 1 / bias 0;
@@ -167,8 +165,7 @@ class ResNet18:
 
     # ------------------------------------------------------------------ weights
     def _pack(self, need_bwd):
-        """(tap, c, m) forward and (tap, m, c) data-gradient layouts of every conv weight: one launch each per step."""
-        self._perm_fwd.run(self.flat, self._wf)
+        """(tap, m, c) data-gradient layout of every conv weight: one launch per training step."""
         if need_bwd:            # only the backward pass reads the data-gradient layouts: off the forward's critical path
             if self._side is None:
                 self._perm_bwd.run(self.flat, self._wb)
@@ -181,8 +178,11 @@ class ResNet18:
                 self._wb_ready.record(self._side)
 
     def _w(self, name, bwd=False):
-        o, n = self._woff[name]
-        return (self._wb if bwd else self._wf)[o:o + n]
+        if bwd:
+            o, n = self._woff[name]
+            return self._wb[o:o + n]
+        o, n = self.offsets[name + ".weight"], self._woff[name][1]
+        return self.flat[o:o + n]                      # the stored weights ARE the forward operand
 
     def _conv_fwd(self, name, X, B, H, W, training, pro=None):
         cv = self.convs[name]
@@ -252,10 +252,10 @@ class ResNet18:
     # ------------------------------------------------------------------ backward
     def _conv_wgrad(self, name, X, dout, B, H, W, Ho, Wo, pro=None):
         cv = self.convs[name]
-        o, n = self._woff[name]
+        o, n = self.offsets[name + ".weight"], self._woff[name][1]
 
         def run():
-            ops.conv2d_wgrad(X, dout, self._gw[o:o + n], B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k,
+            ops.conv2d_wgrad(X, dout, self.grad[o:o + n], B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k,
                              KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None)
         if self._side is None:
             run()
@@ -265,7 +265,6 @@ class ResNet18:
                 run()
             X.record_stream(self._side)
             dout.record_stream(self._side)
-        # the (tap, c, m) results are re-laid into the OIHW gradient views by ONE launch at the end of backward()
 
     def _conv_dgrad(self, name, dout, B, H, W, Ho, Wo, **epi):
         """gradient w.r.t. the conv's input (H, W) from dout at (Ho, Wo)."""
@@ -284,19 +283,15 @@ class ResNet18:
         return b
 
     def _bucket_done(self, bi, cb):
-        """Every gradient of bucket bi has been ISSUED: its weight gradients on the side stream (re-laid to OIHW right behind
-        them, on that stream), its BatchNorm / fc gradients on the main stream.  cb(bi, flat slice, events) may start the
+        """Every gradient of bucket bi has been ISSUED: its weight gradients on the side stream, its BatchNorm / fc gradients
+        on the main stream.  cb(bi, flat slice, events) may start the
         slice's all-reduce as soon as the events have completed -- the main stream goes on with the earlier layers."""
         bk = self._buckets[bi]
         events = []
         if self._side is not None:
-            with torch.cuda.stream(self._side):
-                bk["perm"].run(self._gw, self.grad)
-                ev = torch.cuda.Event()
-                ev.record(self._side)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
             events.append(ev)
-        else:
-            bk["perm"].run(self._gw, self.grad)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         events.append(ev)
@@ -372,7 +367,6 @@ class ResNet18:
         else:
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
-            self._perm_grad.run(self._gw, self.grad)             # every conv weight gradient: (tap, c, m) -> OIHW
         dx = None
         if need_dx:
             cv = self.convs["conv1"]

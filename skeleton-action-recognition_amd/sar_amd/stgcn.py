@@ -172,6 +172,24 @@ class STGCN:
             if pk.items:
                 pk.finalize(dev)
                 self.packed = pk
+        # fp32 operands of the data-gradient GEMMs ((tap, f, c) / (k*F + f, c) / (f, c) transposes of the kernels): ONE
+        # re-layout launch at the start of backward() instead of one small dependent launch in front of every data gradient
+        # (22 per step, each on the critical chain)
+        self._wT_off, self._wT_perm, self._wT = {}, None, None
+        if not self.cn8:
+            pb, off, cin = ops.PermuteBatch(), 0, in_channels
+            for i, (f, s_, res) in enumerate(self.blocks):
+                pre = "l%d." % i
+                pb.add(self.offsets[pre + "tcn.kernel"], off, KT, f, f, f * f, 1, f)        # [tap][c][f] -> [tap][f][c]
+                self._wT_off[pre + "tcn"], off = off, off + KT * f * f
+                pb.add(self.offsets[pre + "gcn.kernel"], off, 1, KS * f, cin, 0, 1, KS * f)  # [c][k*F+f] -> [k*F+f][c]
+                self._wT_off[pre + "gcn"], off = off, off + KS * f * cin
+                if self.kinds[i] == "conv":
+                    pb.add(self.offsets[pre + "res.kernel"], off, 1, f, cin, 0, 1, f)       # [c][f] -> [f][c]
+                    self._wT_off[pre + "res"], off = off, off + f * cin
+                cin = f
+            pb.finalize(dev)
+            self._wT_perm, self._wT = pb, torch.zeros(off, dtype=torch.float32, device=dev)
         self.p = {k: self._view(self.flat, k) for k in self.shapes}
         self.g = {k: self._view(self.grad, k) for k in self.shapes}
         if self.dense_A:
@@ -372,6 +390,8 @@ class STGCN:
         sv = self._saved
         assert sv is not None, "backward() needs a preceding forward(training=True)"
         dev, V = dlogits.device, self.V
+        if self._wT_perm is not None:
+            self._wT_perm.run(self.flat, self._wT)      # every data-gradient operand of this step
         N, M = sv["N"], sv["M"]
         B = N * M
         c_last = self.C_last
@@ -435,8 +455,8 @@ class STGCN:
         wimg = self._img(pre + "tcn.b")
         wT = None
         if wimg is None:
-            wT = torch.empty((KT, f, f), dtype=torch.float32, device=dev)
-            ops.transpose(self.p[pre + "tcn.kernel"], wT, KT, f, f)      # [tap][c][f] -> [tap][f][c]
+            o = self._wT_off[pre + "tcn"]
+            wT = self._wT[o:o + KT * f * f]                               # [tap][f][c], re-laid at the start of backward()
         dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
         pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, du, dz1, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=KT,
                            stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g,
@@ -457,8 +477,8 @@ class STGCN:
         gimg = self._img(pre + "gcn.b")
         gT = None
         if gimg is None:
-            gT = torch.empty((KS * f, cin), dtype=torch.float32, device=dev)
-            ops.transpose(self.p[pre + "gcn.kernel"], gT, 1, cin, KS * f)    # [c][k*F+f] -> [k][f][c]
+            o = self._wT_off[pre + "gcn"]
+            gT = self._wT[o:o + KS * f * cin]                             # [k][f][c]
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
         ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
@@ -478,7 +498,10 @@ class STGCN:
             w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f), X, dr)
         rimg = self._img(pre + "res.b")
         rT = None
-        if rimg is None:
+        if rimg is None and pre + "res" in self._wT_off:
+            o = self._wT_off[pre + "res"]
+            rT = self._wT[o:o + f * cin]
+        elif rimg is None:             # engines without the batched re-layout (ST-GIN)
             rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
             ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
         dXres = torch.empty((cin, B * T * V), dtype=torch.float32, device=dev)
@@ -500,8 +523,8 @@ class STGCN:
             L.SAR_CONV_TEMPORAL, X, dy3, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=KS * f, taps=1, stride=1, pad=0,
             w_stride_tap=0, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f), X, dy3)
         dXres = self._residual_backward(i, sb, dr, B)
-        gT = torch.empty((KS * f, cin), dtype=torch.float32, device=dev)
-        ops.transpose(self.p[pre + "gcn.kernel"], gT, 1, cin, KS * f)
+        o = self._wT_off[pre + "gcn"]
+        gT = self._wT[o:o + KS * f * cin]
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
         ops.conv_gemm(L.SAR_CONV_TEMPORAL, dy3, dX, gT, 0, cin, B=B, V=V, T_src=T, T_out=T, Kc=KS * f, M=cin, taps=1, stride=1,

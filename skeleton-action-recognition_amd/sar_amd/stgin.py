@@ -34,6 +34,7 @@ class STGIN(STGCN):
         self.cn8 = self.bf16 = self.dense_A = False
         self.train_adjacency = False
         self.packed = None
+        self._wT_off, self._wT_perm, self._wT = {}, None, None      # STGCN's batched data-gradient operands: not used here
         self.device = torch.device(device)
         self.num_classes, self.C_in, self.V = num_classes, in_channels, num_node
         self.blocks = list(blocks if blocks is not None else BLOCKS)

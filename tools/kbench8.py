@@ -45,10 +45,32 @@ for (cin, f, s, T, cnt) in [(64, 64, 1, 300, 3), (64, 128, 2, 300, 1), (128, 128
         "g_wgrad": lambda: ops8.conv_wgrad(L.SAR_CONV_GRAPH, X, dG, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab, w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f),
     }
     line = "[%3d->%3d s%d T%3d x%d]" % (cin, f, s, T, cnt)
+    stamps = []
     for name, fn in K.items():
         if only and name not in only: continue
         us = timeit(fn)
         tot[name] = tot.get(name, 0.0) + us * cnt
         line += "  %s %6.1f us" % (name, us)
+        lib = L.load()
+        if hasattr(lib, "sar_debug_cn8_stamps") and name in ("t_fwd", "t_dgrad", "g_fwd", "g_dgrad"):   # diagnostic build (tools/stamps8.sh)
+            import ctypes
+            buf = (ctypes.c_ulonglong * 10)()
+            torch.cuda.synchronize(); lib.sar_debug_cn8_stamps(buf, 1)
+            fn(); torch.cuda.synchronize(); lib.sar_debug_cn8_stamps(buf, 1)
+            v = [float(x) for x in buf]
+            nwg, ghz = v[6], v[8] / max(v[7], 1) * 0.1
+            kc = f if name in ("t_fwd", "t_dgrad", "g_dgrad") else cin
+            nst = -(-kc // 16)
+            if name[0] == "t":
+                stamps.append("    %-8s %5d workgroups, lifetime %6.1f us at %.2f GHz | per stage (cycles): store %5.0f  barrier %5.0f  "
+                              "loads+MFMA %5.0f  barrier %5.0f | prologue %5.0f  epilogue %5.0f" %
+                              (name, nwg, v[7] / nwg / 100, ghz, v[0] / nwg / nst, v[1] / nwg / nst, v[2] / nwg / nst, v[3] / nwg / nst,
+                               v[4] / nwg, v[5] / nwg))
+            else:
+                stamps.append("    %-8s %5d workgroups, lifetime %6.1f us at %.2f GHz | per stage (cycles): store raw %5.0f  barrier %5.0f  "
+                              "gather %5.0f  barrier %5.0f  loads+MFMA %5.0f | prologue %5.0f  epilogue %5.0f" %
+                              (name, nwg, v[7] / nwg / 100, ghz, v[0] / nwg / nst, v[1] / nwg / nst, v[2] / nwg / nst, v[3] / nwg / nst,
+                               v[9] / nwg / nst, v[4] / nwg, v[5] / nwg))
     print(line)
+    for st in stamps: print(st)
 print("per step (9 of 10 blocks):", {k: round(v / 1e3, 2) for k, v in tot.items()}, "sum %.2f ms" % (sum(tot.values()) / 1e3))
