@@ -517,6 +517,17 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_spectrogram(4)
     else:
+        sec = None
+        if args.mfma == "fp32" and not args.no_secondary:
+            # configs[2] and configs[3] in the same process, driver-timed with the headline (VERDICT r02 #2).  bf16: the
+            # SUSTAINED rate (>= 3 s of untimed load first) is `value`; the cold-GPU rate of a short run is first_run_value.
+            # They run BEFORE the headline leg: the first process on a fresh box measures 4 % low for its first seconds
+            # (1 029 vs 1 071-1 074 clips/s for three bench.py invocations in a row, profiles/r03_fp32_first_process.txt), and
+            # the number a training job sees is the one of a GPU that has been under load.
+            b = stgcn_leg(args, "bf16", 120, 3, 3.0, rank, world, dev, False, first_run=True, instrument_steps=5)
+            p = spectrogram_leg(args, 250, 5, 1.0, rank, world, dev, instrument_steps=5)
+            if rank == 0:
+                sec = {"bf16": slim(b), "pathB": slim(p)}
         head = stgcn_leg(args, args.mfma, args.steps, args.warmup, args.warm_seconds, rank, world, dev, not args.no_isolated_pass)
         out = None
         if rank == 0:
@@ -525,15 +536,9 @@ def main():
                    "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                    "dtype": head["dtype"], "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
             out.update({k: v for k, v in head.items() if k not in out})
-        if args.mfma == "fp32" and not args.no_secondary:
-            # configs[2] and configs[3] in the same process, driver-timed with the headline (VERDICT r02 #2).  bf16: the
-            # SUSTAINED rate (>= 3 s of untimed load first) is `value`; the cold-GPU rate of a short run is first_run_value.
-            sec = {}
-            b = stgcn_leg(args, "bf16", 120, 3, 3.0, rank, world, dev, False, first_run=True, instrument_steps=5)
-            p = spectrogram_leg(args, 250, 5, 1.0, rank, world, dev, instrument_steps=5)
-            if rank == 0:
-                sec["bf16"], sec["pathB"] = slim(b), slim(p)
+            if sec is not None:
                 out["secondary"] = sec
+                out["legs_order"] = "secondary legs (bf16, Path B) first, the headline leg last, each with its own warm-up and timed steps"
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample)
     if rank == 0:
