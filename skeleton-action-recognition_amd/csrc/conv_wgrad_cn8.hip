@@ -43,6 +43,23 @@ struct WgradK8 {
   int Gs, Gd;   // CN8 planes of src / dout
 };
 
+// In-kernel phase stamps (diagnostic build -DSAR_CN8_STAMPS, tools/stamps8.sh; see conv_gemm_cn8.hip): wave 0 of every workgroup,
+// shader-clock cycles in [0] store (wait for the tile's loads, folded BN + ReLU, LDS stores), [1] the barrier behind it, [2] load
+// issue + MFMA phase, [3] the closing barrier, [4] prologue, [5] epilogue (slab stores); [6] workgroups, [7] lifetimes in 100 MHz
+// ticks, [8] lifetimes in cycles, [9] tiles.
+#ifdef SAR_CN8_STAMPS
+constexpr int WSTAMP_WG = 8192;
+__device__ unsigned g_wstamps8[WSTAMP_WG][10];
+#define WSTAMP8(i)                                               \
+  do {                                                           \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    st_acc[i] += t_ - st_last;                                   \
+    st_last = t_;                                                \
+  } while (0)
+#else
+#define WSTAMP8(i)
+#endif
+
 constexpr int pad_stride(int n) { return n + ((4 - n % 16) + 16) % 16; }   // smallest plane stride >= n that is 4 (mod 16)
 
 // 8 consecutive columns (k = 8h .. 8h+7 of the k-step) of this lane's channel: two transposed reads, 4 columns each
@@ -116,6 +133,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
   const int l31 = lane & 31, hi = lane >> 5;
   int split, by, bz;
   if (!xcd_split(d.nsplit, k.gy, k.gz, split, by, bz)) return;
+#ifdef SAR_CN8_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0;
+#endif
   const int m0 = by * 64, c0 = bz * C::CBLK;
   const int wmb = wave & 1;                 // this wave's 32-row block along m
   const int wc = C::TSPLIT ? 0 : wave >> 1;  // ... along c
@@ -246,9 +268,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
   const unsigned b_base = (unsigned)(uintptr_t)Dimg + tr_lane_bytes(lane, PS_D, 4 * wmb);
 
   if (tile_lo < tile_hi) issue_loads(tile_lo);
+  WSTAMP8(4);
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     store_lds();
+    WSTAMP8(0);
     __syncthreads();
+    WSTAMP8(1);
     if (tile + 1 < tile_hi) issue_loads(tile + 1);   // in flight during the MFMA phase
     // k-steps, software-pipelined BY HAND over two fragment sets: the transposed reads of k-step ks + 1 are issued before
     // the MFMAs of k-step ks.  (As one un-pipelined loop body the compiler emitted read, wait, multiply three times per
@@ -300,7 +325,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
     } else {
       frag_mma(fb[0], fa[0]);
     }
+    WSTAMP8(2);
     __syncthreads();
+    WSTAMP8(3);
   }
 
   // ---- this split's slab: rows c (registers), columns m (lanes: contiguous)
@@ -331,6 +358,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
       if (m0 + tid < d.M) slab[d.wsize + m0 + tid] = bred[pl & 3][(pl >> 2) * 8 + e];
     }
   }
+#ifdef SAR_CN8_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  WSTAMP8(5);
+  if (tid == 0 && blockIdx.x < WSTAMP_WG) {
+    unsigned* row = g_wstamps8[blockIdx.x];
+    for (int i2 = 0; i2 < 6; ++i2) row[i2] = (unsigned)st_acc[i2];
+    row[6] = 1u;
+    row[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    row[8] = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0);
+    row[9] = (unsigned)(tile_hi > tile_lo ? tile_hi - tile_lo : 0);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ graph
@@ -638,6 +677,23 @@ void launch_g(const WgradK8& k, bool id0, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SAR_CN8_STAMPS
+extern "C" int sar_debug_wgrad8_stamps(unsigned long long* out10, int reset) {
+  static unsigned host[WSTAMP_WG][10];
+  if (out10) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wstamps8), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 10; ++i) out10[i] = 0;
+    for (int w = 0; w < WSTAMP_WG; ++w)
+      for (int i = 0; i < 10; ++i) out10[i] += host[w][i];
+  }
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wstamps8)) != hipSuccess || hipMemset(p, 0, sizeof(host)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int sar_conv_wgrad_cn8_tile_frames(int mode) { return mode == SAR_CONV_GRAPH ? 5 : 7; }
 

@@ -52,6 +52,16 @@ for (cin, f, s, T, cnt) in [(64, 64, 1, 300, 3), (64, 128, 2, 300, 1), (128, 128
         tot[name] = tot.get(name, 0.0) + us * cnt
         line += "  %s %6.1f us" % (name, us)
         lib = L.load()
+        if hasattr(lib, "sar_debug_wgrad8_stamps") and name == "t_wgrad":
+            import ctypes
+            buf = (ctypes.c_ulonglong * 10)()
+            torch.cuda.synchronize(); lib.sar_debug_wgrad8_stamps(buf, 1)
+            fn(); torch.cuda.synchronize(); lib.sar_debug_wgrad8_stamps(buf, 1)
+            v = [float(x) for x in buf]
+            nwg, ghz, nt = v[6], v[8] / max(v[7], 1) * 0.1, max(v[9], 1)
+            stamps.append("    %-8s %5d workgroups x %.1f tiles, lifetime %6.1f us at %.2f GHz | per tile (cycles): store %5.0f  barrier %5.0f  "
+                          "loads+MFMA %5.0f  barrier %5.0f | prologue %5.0f  epilogue %5.0f" %
+                          (name, nwg, nt / nwg, v[7] / nwg / 100, ghz, v[0] / nt, v[1] / nt, v[2] / nt, v[3] / nt, v[4] / nwg, v[5] / nwg))
         if hasattr(lib, "sar_debug_cn8_stamps") and name in ("t_fwd", "t_dgrad", "g_fwd", "g_dgrad"):   # diagnostic build (tools/stamps8.sh)
             import ctypes
             buf = (ctypes.c_ulonglong * 10)()
