@@ -217,6 +217,22 @@ int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const float* sh, in
  * mu / mr (the batch means) may be NULL = 0 */
 int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
                                    const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n, int64_t ld, sar_stream_t s);
+/* The same reduction with the BatchNorm-backward finalisation folded in ("tail"): the LAST workgroup of every channel to
+ * finish (an integer ticket per channel, agent-scope release / acquire; no float atomics, every sum in a fixed order) adds the
+ * channel's partials in fp64 and writes what sar_bn_bwd_finalize_f32(centered) would: dgamma, dbeta, k1, k2, k3 of the
+ * block's BatchNorm and, when r != NULL, of the residual branch's -- one small dependent launch (or two) less on the critical
+ * chain of every block.  ticket: C (f32) / ceil(C/8) (cn8) ints, zero before the first use; the kernel leaves them zero. */
+typedef struct sar_bn_tail {
+  int32_t* ticket;
+  double count;                                   /* elements per channel (N*T*V) */
+  const float* gamma; const float* rstd;          /* BatchNorm of u (its mean is the reduce call's mu) */
+  float* dgamma; float* dbeta; float* k1; float* k2; float* k3;
+  const float* rgamma; const float* rrstd;        /* BatchNorm of the residual branch (r != NULL), mean = mr */
+  float* rdgamma; float* rdbeta; float* rk1; float* rk2; float* rk3;
+} sar_bn_tail;
+int sar_bn_add_relu_bwd_reduce_tail_f32(const float* dy, const float* y, const float* u, const float* r,
+                                        const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n, int64_t ld,
+                                        const sar_bn_tail* tail, sar_stream_t s);
 /* backward pass 2: du = k1*dz+k2*u+k3 ; dr = rk1*dz+rk2*r+rk3 (if dr != NULL) ; dz_out = dz (if != NULL) */
 int sar_bn_add_relu_bwd_apply_f32(const float* dy, const float* y, const float* u, const float* r,
                                   const float* k1, const float* k2, const float* k3,
@@ -483,6 +499,9 @@ int sar_bn_add_relu_fwd_cn8(const void* u, const float* scale, const float* shif
 int sar_bn_add_relu_bwd_reduce_cn8(const void* dy, const void* y, const void* u, const void* r, const float* mean_u,
                                    const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
                                    sar_stream_t s);
+int sar_bn_add_relu_bwd_reduce_tail_cn8(const void* dy, const void* y, const void* u, const void* r, const float* mean_u,
+                                        const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
+                                        const sar_bn_tail* tail, sar_stream_t s);
 int sar_bn_add_relu_bwd_apply_cn8(const void* dy, const void* y, const void* u, const void* r, const float* k1,
                                   const float* k2, const float* k3, const float* rk1, const float* rk2, const float* rk3,
                                   void* du, void* dr, void* dz_out, int C, int64_t n, int64_t ld, sar_stream_t s);

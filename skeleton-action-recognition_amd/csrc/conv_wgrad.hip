@@ -852,6 +852,106 @@ bool graph_fixed_supported(const sar_wgrad_desc& d) {
   return (d.nz[0] == 1 && d.nz[1] == 1 && d.nz[2] == 4) || (d.nz[0] == 1 && d.nz[2] == 1 && d.nz[1] == 4);
 }
 
+// ------------------------------------------------------------------------------------------------ graph weight gradient, Kc <= 4
+// The first layer's graph convolution has 3 input channels: 9 (c, k) weight rows per output channel, 3 bias rows.  As an MFMA
+// reduction (32-row blocks, 3 live) it ran at 3-7 TF and 400 us; it is 1.5 GFLOP of plain FMA work behind 246 MB of dout, i.e.
+// a streaming kernel: one workgroup = 32 output channels (wave w: channels 8 w .. 8 w + 7) x its share of the columns,
+// lanes = 64 consecutive columns (dout rows read as 256-byte segments), per lane the 3 x Kc gathered z values of its column
+// (<= 4-entry lists, the 46 MB src stays in L2) and 8 x (3 Kc + 3) accumulators (three waves per SIMD), reduced over the lanes once at the end.
+// Slabs as in every weight-gradient kernel (deterministic: fixed column order per lane, fixed lane tree, slabs in order).
+template <int KC>
+__global__ __launch_bounds__(256, KC <= 3 ? 3 : 2) void graph_wgrad_small_kernel(const sar_wgrad_desc d, int ncol, int cols_per_split) {
+  constexpr int MW = 8;   // output channels per wave
+  __shared__ int t_idx[3 * 64 * 4];     // gather tables [k][w][j] (V <= 64) and column sums: read per chunk, loaded once
+  __shared__ float t_wt[3 * 64 * 4];
+  __shared__ float t_cs[3 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x, m0 = blockIdx.y * 4 * MW + wave * MW;
+  const int V = d.V;
+  const bool do_bias = d.bsize > 0;
+  for (int i = tid; i < 3 * V * 4; i += 256) {
+    const int k = i / (V * 4), j = i & 3;
+    t_idx[i] = d.g_idx[i];
+    t_wt[i] = j < d.nz[k] ? d.g_wt[i] : 0.f;
+  }
+  for (int i = tid; i < 3 * V; i += 256) t_cs[i] = (do_bias && d.g_colsum) ? d.g_colsum[i] : 0.f;
+  __syncthreads();
+  const int col_lo = split * cols_per_split;
+  const int col_hi = (col_lo + cols_per_split < ncol) ? col_lo + cols_per_split : ncol;
+  float acc[MW][3 * KC], bacc[MW][3];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3 * KC; ++j) acc[i][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bacc[i][j] = 0.f;
+  }
+  for (int c0 = col_lo; c0 < col_hi; c0 += 64) {
+    const int col = c0 + lane;
+    const bool live = col < col_hi;
+    const int cc = live ? col : col_lo;
+    const int fr = cc / V, w = cc - fr * V;
+    // dout first (the long-latency stream), then z_k[c] of this column: the table-order fma chain of every gathering kernel
+    float dv[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) dv[i] = (live && m0 + i < d.M) ? d.dout[(int64_t)(m0 + i) * d.ld_dout + cc] : 0.f;
+    float z[3][KC], cs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      cs[k] = live ? t_cs[k * V + w] : 0.f;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) z[k][c] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < d.nz[k]) {   // uniform
+          const int vi = t_idx[(k * V + w) * 4 + j];
+          const float wt = live ? t_wt[(k * V + w) * 4 + j] : 0.f;
+#pragma unroll
+          for (int c = 0; c < KC; ++c)
+            if (c < d.Kc) {   // uniform
+              const float xv = d.src[(int64_t)c * d.ld_src + (int64_t)fr * V + vi];
+              z[k][c] = j == 0 ? wt * xv : fmaf(wt, xv, z[k][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) acc[i][k * KC + c] = fmaf(z[k][c], dv[i], acc[i][k * KC + c]);
+        bacc[i][k] = fmaf(cs[k], dv[i], bacc[i][k]);
+      }
+    }
+  }
+  float* slab = d.slab + (int64_t)split * (d.wsize + d.bsize);
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int m = m0 + i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float t = wave_sum(acc[i][k * KC + c]);
+        if (lane == 0 && m < d.M && c < d.Kc) slab[k * d.w_stride_tap + c * d.w_stride_c + m] = t;
+      }
+      if (do_bias) {   // uniform
+        const float t = wave_sum(bacc[i][k]);
+        if (lane == 0 && m < d.M) slab[d.wsize + (int64_t)k * d.M + m] = t;
+      }
+    }
+  }
+}
+
+int launch_graph_small(const sar_wgrad_desc& d, hipStream_t st) {
+  const int ncol = d.B * d.T_out * d.V;
+  const int cps = ((ncol + d.nsplit - 1) / d.nsplit + 63) / 64 * 64;   // whole 64-column chunks per slab
+  dim3 grid(d.nsplit, (d.M + 31) / 32);
+  if (d.Kc <= 3) hipLaunchKernelGGL(graph_wgrad_small_kernel<3>, grid, dim3(256), 0, st, d, ncol, cps);
+  else hipLaunchKernelGGL(graph_wgrad_small_kernel<4>, grid, dim3(256), 0, st, d, ncol, cps);
+  return 0;
+}
+
 template <int NZ0, int NZ1, int NZ2, int MB>
 int launch_graph_fixed_mb(const sar_wgrad_desc& d, hipStream_t st) {
   WgradK k;
@@ -903,7 +1003,8 @@ extern "C" int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s) {
         sar_set_error("sar_conv_wgrad: adjacency slice %d needs %d gather entries per column (max 4)", i, d->nz[i]);
         return SAR_E_UNSUP;
       }
-    if (d->V == 25 && d->Kc >= 32 && !d->pro_scale && graph_fixed_supported(*d)) rc = launch_graph_fixed(*d, st);
+    if (d->Kc <= 4 && !d->pro_scale) rc = launch_graph_small(*d, st);
+    else if (d->V == 25 && d->Kc >= 32 && !d->pro_scale && graph_fixed_supported(*d)) rc = launch_graph_fixed(*d, st);
     else if (d->nz[0] == 1 && d->nz[1] == 1) rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 1, 1, 4>(*d, st);
     else if (d->nz[0] == 1 && d->nz[2] == 1) rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 1, 4, 1>(*d, st);
     else rc = launch<SAR_CONV_GRAPH, 3, 2, 2, 1, 3, 4, 4, 4>(*d, st);

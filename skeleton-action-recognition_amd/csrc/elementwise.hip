@@ -355,11 +355,12 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
   }
 }
 
-template <int VEC>
+template <int VEC, bool TAIL = false>
 __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                      const float* __restrict__ u, const float* __restrict__ r,
                                                                      const float* __restrict__ mu_p, const float* __restrict__ mr_p,
-                                                                     float* __restrict__ partials, int64_t n, int64_t ldm) {
+                                                                     float* __restrict__ partials, int64_t n, int64_t ldm,
+                                                                     const sar_bn_tail tail = sar_bn_tail()) {
   const int c = blockIdx.y;
   const float mu = mu_p ? mu_p[c] : 0.f, mr = (r && mr_p) ? mr_p[c] : 0.f;
   const int64_t base = (int64_t)c * ldm;
@@ -382,10 +383,22 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_kernel(const float
   block_sum<3>(acc, red);
   if (threadIdx.x == 0) {
     float* pp = partials + ((int64_t)c * gridDim.x + blockIdx.x) * 4;
-    pp[0] = acc[0];
-    pp[1] = acc[1];
-    pp[2] = acc[2];
-    pp[3] = 0.f;
+    if constexpr (TAIL) {
+      bn_tail_store(pp, acc[0]);
+      bn_tail_store(pp + 1, acc[1]);
+      bn_tail_store(pp + 2, acc[2]);
+    } else {
+      pp[0] = acc[0];
+      pp[1] = acc[1];
+      pp[2] = acc[2];
+      pp[3] = 0.f;
+    }
+  }
+  if constexpr (TAIL) {   // the last workgroup of the channel finalises it (sar_bn_tail)
+    __shared__ int last;
+    if (threadIdx.x == 0) last = bn_tail_last_arriver(tail.ticket + c, (int)gridDim.x) ? 1 : 0;
+    __syncthreads();
+    if (last && threadIdx.x < 64) bn_tail_channel(partials, (int)gridDim.x, c, tail, mu_p, mr_p, r != nullptr);
   }
 }
 
@@ -747,6 +760,26 @@ extern "C" int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, c
                        mu, mr, partials, n, ldm);
   }
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_reduce_tail_f32(const float* dy, const float* y, const float* u, const float* r,
+                                                   const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n,
+                                                   int64_t ldm, const sar_bn_tail* tail, sar_stream_t s) {
+  SAR_REQUIRE(dy && y && u && partials && nparts > 0 && nparts <= 65535 && C > 0 && n > 0 && ldm >= n,
+              "sar_bn_add_relu_bwd_reduce_tail: bad arguments");
+  SAR_REQUIRE(tail && tail->ticket && tail->count > 0 && tail->rstd && tail->k1 && tail->k2 && tail->k3,
+              "sar_bn_add_relu_bwd_reduce_tail: ticket, count, rstd and k1..k3 are required");
+  SAR_REQUIRE(!r || (tail->rrstd && tail->rk1 && tail->rk2 && tail->rk3), "sar_bn_add_relu_bwd_reduce_tail: residual-branch outputs");
+  SAR_REQUIRE(((uintptr_t)partials & 15) == 0, "sar_bn_add_relu_bwd_reduce_tail: partials must be 16-byte aligned");
+  if (vec4_ok(n, ldm, {dy, y, u, r})) {
+    hipLaunchKernelGGL((bn_add_relu_bwd_reduce_kernel<4, true>), dim3(nparts, C), dim3(TPB), 0, as_stream(s), dy, y, u, r, mu, mr,
+                       partials, n, ldm, *tail);
+  } else {
+    hipLaunchKernelGGL((bn_add_relu_bwd_reduce_kernel<1, true>), dim3(nparts, C), dim3(TPB), 0, as_stream(s), dy, y, u, r, mu, mr,
+                       partials, n, ldm, *tail);
+  }
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_tail_f32");
   return 0;
 }
 

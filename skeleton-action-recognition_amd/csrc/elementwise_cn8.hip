@@ -45,12 +45,13 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_cn8_kernel(const uint4* _
 }
 
 // partials[C][nparts][4] = (sum dz, sum dz (u - mu), sum dz (r - mr), 0), dz = dy where y > 0
+template <bool TAIL>
 __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_cn8_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y,
                                                                          const uint4* __restrict__ u, const uint4* __restrict__ r,
                                                                          const float* __restrict__ mu_p,
                                                                          const float* __restrict__ mr_p,
                                                                          float* __restrict__ partials, int C, int64_t n,
-                                                                         int64_t ld) {
+                                                                         int64_t ld, const sar_bn_tail tail) {
   const int g = blockIdx.y;
   float mu[8], mr[8];
   cn8_params(mu_p, g, C, 0.f, mu);
@@ -91,8 +92,25 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_cn8_kernel(const u
     if (c < C) {
       const int k = threadIdx.x;
       float* pp = partials + ((int64_t)c * gridDim.x + blockIdx.x) * 4;
-      pp[q] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-      if (q == 0) pp[3] = 0.f;
+      const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+      if constexpr (TAIL) {
+        bn_tail_store(pp + q, v);
+      } else {
+        pp[q] = v;
+        if (q == 0) pp[3] = 0.f;
+      }
+    }
+  }
+  if constexpr (TAIL) {   // the last workgroup of the plane finalises its 8 channels, two per wave (sar_bn_tail)
+    __shared__ int last;  // (the 24 storing lanes are lanes of wave 0, as is the lane that takes the ticket)
+    if (threadIdx.x == 0) last = bn_tail_last_arriver(tail.ticket + g, (int)gridDim.x) ? 1 : 0;
+    __syncthreads();
+    if (last) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = 8 * g + 2 * wave + j;
+        if (c < C) bn_tail_channel(partials, (int)gridDim.x, c, tail, mu_p, mr_p, r != nullptr);
+      }
     }
   }
 }
@@ -258,9 +276,24 @@ extern "C" int sar_bn_add_relu_bwd_reduce_cn8(const void* dy, const void* y, con
   SAR_REQUIRE(dy && y && u && partials && nparts > 0 && nparts <= 65535 && C > 0 && n > 0 && ld >= n,
               "sar_bn_add_relu_bwd_reduce_cn8: bad arguments");
   SAR_REQUIRE(al16({dy, y, u, r}), "sar_bn_add_relu_bwd_reduce_cn8: CN8 tensors must be 16-byte aligned");
-  hipLaunchKernelGGL(bn_add_relu_bwd_reduce_cn8_kernel, dim3(nparts, CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)dy,
-                     (const uint4*)y, (const uint4*)u, (const uint4*)r, mean_u, mean_r, partials, C, n, ld);
+  hipLaunchKernelGGL(bn_add_relu_bwd_reduce_cn8_kernel<false>, dim3(nparts, CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)dy,
+                     (const uint4*)y, (const uint4*)u, (const uint4*)r, mean_u, mean_r, partials, C, n, ld, sar_bn_tail());
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_cn8");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_reduce_tail_cn8(const void* dy, const void* y, const void* u, const void* r, const float* mean_u,
+                                                   const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
+                                                   const sar_bn_tail* tail, sar_stream_t s) {
+  SAR_REQUIRE(dy && y && u && partials && nparts > 0 && nparts <= 65535 && C > 0 && n > 0 && ld >= n,
+              "sar_bn_add_relu_bwd_reduce_tail_cn8: bad arguments");
+  SAR_REQUIRE(al16({dy, y, u, r, partials}), "sar_bn_add_relu_bwd_reduce_tail_cn8: CN8 tensors and partials must be 16-byte aligned");
+  SAR_REQUIRE(tail && tail->ticket && tail->count > 0 && tail->rstd && tail->k1 && tail->k2 && tail->k3,
+              "sar_bn_add_relu_bwd_reduce_tail_cn8: ticket, count, rstd and k1..k3 are required");
+  SAR_REQUIRE(!r || (tail->rrstd && tail->rk1 && tail->rk2 && tail->rk3), "sar_bn_add_relu_bwd_reduce_tail_cn8: residual-branch outputs");
+  hipLaunchKernelGGL(bn_add_relu_bwd_reduce_cn8_kernel<true>, dim3(nparts, CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)dy,
+                     (const uint4*)y, (const uint4*)u, (const uint4*)r, mean_u, mean_r, partials, C, n, ld, *tail);
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_tail_cn8");
   return 0;
 }
 

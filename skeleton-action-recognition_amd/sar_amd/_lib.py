@@ -62,6 +62,13 @@ class Conv2dDesc(C.Structure):
 
 # name -> (restype, argtypes); every name must also be declared in include/sar_hip.h
 _i, _i64, _f, _d = C.c_int, C.c_int64, C.c_float, C.c_double
+
+
+class BnTail(C.Structure):
+    """sar_bn_tail (include/sar_hip.h): the BatchNorm-backward finalisation folded into the reduce kernel's last workgroup"""
+    _fields_ = [("ticket", _fp), ("count", C.c_double), ("gamma", _fp), ("rstd", _fp), ("dgamma", _fp), ("dbeta", _fp),
+                ("k1", _fp), ("k2", _fp), ("k3", _fp), ("rgamma", _fp), ("rrstd", _fp), ("rdgamma", _fp), ("rdbeta", _fp),
+                ("rk1", _fp), ("rk2", _fp), ("rk3", _fp)]
 SIGNATURES = {
     "sar_version": (_i, []),
     "sar_last_error_string": (C.c_char_p, []),
@@ -84,6 +91,7 @@ SIGNATURES = {
     "sar_data_bn_bwd_reduce_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _i64, _fp, _fp, _fp]),
     "sar_bn_add_relu_fwd_f32": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_reduce_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_reduce_tail_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, C.POINTER(BnTail), _fp]),
     "sar_bn_add_relu_bwd_apply_f32": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),
     "sar_affine2_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_pool_fwd_f32": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
@@ -138,6 +146,7 @@ SIGNATURES = {
     "sar_conv_wgrad_cn8": (_i, [C.POINTER(WgradDesc), _i, _fp]),
     "sar_bn_add_relu_fwd_cn8": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_reduce_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_reduce_tail_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, C.POINTER(BnTail), _fp]),
     "sar_bn_add_relu_bwd_apply_cn8": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),
     "sar_affine2_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_data_bn_apply_cn8": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _i64, _fp]),

@@ -153,6 +153,10 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
         ntiles = B * ((T_out + 7) // 8)
         cb = 64 if stride == 1 else 32
         nsplit = max(1, min(ntiles, 512 // (((M + 63) // 64) * ((Kc + cb - 1) // cb))))
+    if nsplit is None and mode == L.SAR_CONV_GRAPH and Kc <= 4 and pro is None:
+        # streaming kernel of the 3-channel first layer (conv_wgrad.hip: graph_wgrad_small_kernel): ~8 chunks of 64 columns per
+        # workgroup (its loop is latency-bound: many short workgroups, not few long ones)
+        nsplit = max(1, min(4096, (B * T_out * V + 511) // 512))
     if nsplit is None:
         ft = max(2, min((128 // V) & ~1, (T_out + 1) & ~1))
         bf = 64
@@ -235,10 +239,47 @@ def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y):
 _REDUCE_CHUNK = int(__import__("os").environ.get("SAR_BWD_REDUCE_CHUNK", "8192"))      # row elements per workgroup of the BN-backward reductions
 
 
-def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None):
+# SAR_BN_TAIL=1: the BatchNorm-backward finalisation of every block tail runs in the reduce kernel's last workgroup instead of in
+# its own launch(es).  Measured (three interleaved rounds each): fp32 59.44 vs 59.49 ms, bf16 13.37 vs 13.32, Path B 6.35 vs 6.37
+# -- the launches it removes were waiting beside useful work of the other stream, not in front of it.  OFF by default: the sc1
+# hand-off it relies on is measured behaviour of this part (MI355X_MICROARCH.md), not an architectural guarantee, and buys nothing.
+BN_TAIL = __import__("os").environ.get("SAR_BN_TAIL", "0") == "1"
+_tickets = {}
+
+
+def bn_tail_tickets(device):
+    """the ticket array of the folded finalisations, one per (device, stream): launches on ONE stream run one after the other and
+    share it (4096 ints, zero; every launch leaves it zero); two host threads on two streams never share one"""
+    key = (str(device), stream_ptr())
+    if key not in _tickets:
+        _tickets[key] = torch.zeros(4096, dtype=torch.int32, device=device)
+    return _tickets[key]
+
+
+def make_bn_tail(device, count, gamma, bn, dgamma, dbeta, rgamma=None, rbn=None, rdgamma=None, rdbeta=None):
+    """sar_bn_tail for a block tail: bn / rbn are _BN records (rstd, k1, k2, k3)"""
+    t = L.BnTail()
+    t.ticket, t.count = ptr(bn_tail_tickets(device)), float(count)
+    t.gamma, t.rstd, t.dgamma, t.dbeta = ptr(_f32(gamma)), ptr(bn.rstd), ptr(_f32(dgamma)), ptr(_f32(dbeta))
+    t.k1, t.k2, t.k3 = ptr(bn.k1), ptr(bn.k2), ptr(bn.k3)
+    if rbn is not None:
+        t.rgamma, t.rrstd, t.rdgamma, t.rdbeta = ptr(_f32(rgamma)), ptr(rbn.rstd), ptr(_f32(rdgamma)), ptr(_f32(rdbeta))
+        t.rk1, t.rk2, t.rk3 = ptr(rbn.k1), ptr(rbn.k2), ptr(rbn.k3)
+    return t
+
+
+def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None, tail=None):
+    """tail (make_bn_tail): the reduce kernel's last workgroup per channel also finalises (dgamma, dbeta, k1..k3): no
+    sar_bn_bwd_finalize launch behind it"""
     Cc, n = u.shape
     nparts = max(1, min(4096, (n + _REDUCE_CHUNK - 1) // _REDUCE_CHUNK))
     partials = torch.empty((Cc, nparts, 4), dtype=torch.float32, device=u.device)
+    if tail is not None:
+        assert Cc <= 4096
+        check(L.load().sar_bn_add_relu_bwd_reduce_tail_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(mu), ptr(mr), ptr(partials), nparts, Cc,
+                                                           n, u.stride(0), C.byref(tail), stream_ptr()),
+              "sar_bn_add_relu_bwd_reduce_tail_f32")
+        return partials, nparts
     check(L.load().sar_bn_add_relu_bwd_reduce_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(mu), ptr(mr), ptr(partials), nparts, Cc, n,
                                                   u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_reduce_f32")
     return partials, nparts

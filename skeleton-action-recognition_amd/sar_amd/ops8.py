@@ -135,10 +135,16 @@ def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, channels):
 _REDUCE_CHUNK = int(__import__("os").environ.get("SAR_BWD_REDUCE_CHUNK8", "8192"))     # units per workgroup of the BN-backward reduction
 
 
-def bn_add_relu_bwd_reduce(dy, y, u, r, channels, mu=None, mr=None):
+def bn_add_relu_bwd_reduce(dy, y, u, r, channels, mu=None, mr=None, tail=None):
     n = u.shape[1]
     nparts = max(1, min(4096, (n + _REDUCE_CHUNK - 1) // _REDUCE_CHUNK))
     partials = torch.empty((channels, nparts, 4), dtype=torch.float32, device=u.device)
+    if tail is not None:      # ops.make_bn_tail: the last workgroup of every plane finalises its channels
+        import ctypes
+        check(L.load().sar_bn_add_relu_bwd_reduce_tail_cn8(ptr(_cn8(dy)), ptr(_cn8(y)), ptr(_cn8(u)), ptr(_cn8(r)), ptr(mu), ptr(mr),
+                                                           ptr(partials), nparts, channels, n, n, ctypes.byref(tail), stream_ptr()),
+              "sar_bn_add_relu_bwd_reduce_tail_cn8")
+        return partials, nparts
     check(L.load().sar_bn_add_relu_bwd_reduce_cn8(ptr(_cn8(dy)), ptr(_cn8(y)), ptr(_cn8(u)), ptr(_cn8(r)), ptr(mu), ptr(mr),
                                                   ptr(partials), nparts, channels, n, n, stream_ptr()),
           "sar_bn_add_relu_bwd_reduce_cn8")

@@ -320,12 +320,17 @@ class ResNet18:
             n_out = B * Ho * Wo
             b1, b2 = self.bn[pre + "bn1"], self.bn[pre + "bn2"]
             bd = self.bn.get(pre + "downsample.1")
-            part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None)
-            self._bn_bwd(pre + "bn2", part, nparts, nparts * 4, 4, 1, n_out)
-            rk = None
-            if ds:
-                self._bn_bwd(pre + "downsample.1", part, nparts, nparts * 4, 4, 2, n_out)
-                rk = (bd.k1, bd.k2, bd.k3)
+            rk = (bd.k1, bd.k2, bd.k3) if ds else None
+            if ops.BN_TAIL:   # the reduce kernel's last workgroup per channel finalises bn2 (and the downsample BN)
+                n2, nd = pre + "bn2", pre + "downsample.1"
+                tail = ops.make_bn_tail(dY.device, n_out, self.p[n2 + ".weight"], b2, self.g[n2 + ".weight"], self.g[n2 + ".bias"],
+                                        *((self.p[nd + ".weight"], bd, self.g[nd + ".weight"], self.g[nd + ".bias"]) if ds else ()))
+                ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None, tail=tail)
+            else:
+                part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None)
+                self._bn_bwd(pre + "bn2", part, nparts, nparts * 4, 4, 1, n_out)
+                if ds:
+                    self._bn_bwd(pre + "downsample.1", part, nparts, nparts * 4, 4, 2, n_out)
             dc2 = torch.empty_like(c2)
             ddsc = torch.empty_like(dsc) if ds else None
             ops.bn_add_relu_bwd_apply(dY, y, c2, dsc, (b2.k1, b2.k2, b2.k3), rk, dc2, ddsc, None if ds else dY)

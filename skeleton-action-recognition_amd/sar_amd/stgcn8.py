@@ -132,14 +132,19 @@ def _block_backward(eng, i, sb, dY, B):
     conv = kind == "conv"
     img = eng.packed.image
     # ---- tail: y = relu(bn2(u) + res)
-    part, nparts = ops8.bn_add_relu_bwd_reduce(dY, y, u, r if conv else None, f, bn2.mean, rbn.mean if conv else None)
-    ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, eng.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
-                        eng.g[pre + "bn2.gamma"], eng.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
-    rk = None
-    if conv:
-        ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 2, f, n_out, eng.p[pre + "res_bn.gamma"], rbn.mean, rbn.rstd,
-                            eng.g[pre + "res_bn.gamma"], eng.g[pre + "res_bn.beta"], rbn.k1, rbn.k2, rbn.k3)
-        rk = (rbn.k1, rbn.k2, rbn.k3)
+    rk = (rbn.k1, rbn.k2, rbn.k3) if conv else None
+    if ops.BN_TAIL:          # the reduce kernel's last workgroup per plane finalises BN2 (and the residual BN): no launch between
+        tail = ops.make_bn_tail(dev, n_out, eng.p[pre + "bn2.gamma"], bn2, eng.g[pre + "bn2.gamma"], eng.g[pre + "bn2.beta"],
+                                *((eng.p[pre + "res_bn.gamma"], rbn, eng.g[pre + "res_bn.gamma"], eng.g[pre + "res_bn.beta"])
+                                  if conv else ()))
+        ops8.bn_add_relu_bwd_reduce(dY, y, u, r if conv else None, f, bn2.mean, rbn.mean if conv else None, tail=tail)
+    else:
+        part, nparts = ops8.bn_add_relu_bwd_reduce(dY, y, u, r if conv else None, f, bn2.mean, rbn.mean if conv else None)
+        ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, eng.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
+                            eng.g[pre + "bn2.gamma"], eng.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
+        if conv:
+            ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 2, f, n_out, eng.p[pre + "res_bn.gamma"], rbn.mean, rbn.rstd,
+                                eng.g[pre + "res_bn.gamma"], eng.g[pre + "res_bn.beta"], rbn.k1, rbn.k2, rbn.k3)
     du = ops8.empty(f, n_out, dev)
     dr = ops8.empty(f, n_out, dev) if conv else None
     dz = dY if kind == "identity" else None      # in place: dY becomes the pre-ReLU gradient for the skip path

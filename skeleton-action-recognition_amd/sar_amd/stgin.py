@@ -270,15 +270,21 @@ class STGIN(STGCN):
         new = lambda rows, n: torch.empty((rows, n), dtype=torch.float32, device=dev)
         rows = lambda t, k: t[k * h:(k + 1) * h]
         # ---- tail: y = relu(bn2(u) + res)
-        part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, u, r if kind == "conv" else None, bn2.mean,
-                                                  rbn.mean if kind == "conv" else None)
-        ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, self.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
-                            self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
-        rk = None
-        if kind == "conv":
-            ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 2, f, n_out, self.p[pre + "res_bn.gamma"], rbn.mean, rbn.rstd,
-                                self.g[pre + "res_bn.gamma"], self.g[pre + "res_bn.beta"], rbn.k1, rbn.k2, rbn.k3)
-            rk = (rbn.k1, rbn.k2, rbn.k3)
+        rk = (rbn.k1, rbn.k2, rbn.k3) if kind == "conv" else None
+        if ops.BN_TAIL:      # the reduce kernel's last workgroup per channel finalises BN2 (and the residual BN)
+            tail = ops.make_bn_tail(dev, n_out, self.p[pre + "bn2.gamma"], bn2, self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"],
+                                    *((self.p[pre + "res_bn.gamma"], rbn, self.g[pre + "res_bn.gamma"], self.g[pre + "res_bn.beta"])
+                                      if kind == "conv" else ()))
+            ops.bn_add_relu_bwd_reduce(dY, y, u, r if kind == "conv" else None, bn2.mean, rbn.mean if kind == "conv" else None,
+                                       tail=tail)
+        else:
+            part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, u, r if kind == "conv" else None, bn2.mean,
+                                                      rbn.mean if kind == "conv" else None)
+            ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, self.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
+                                self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
+            if kind == "conv":
+                ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 2, f, n_out, self.p[pre + "res_bn.gamma"], rbn.mean, rbn.rstd,
+                                    self.g[pre + "res_bn.gamma"], self.g[pre + "res_bn.beta"], rbn.k1, rbn.k2, rbn.k3)
         du = torch.empty_like(u)
         dr = torch.empty_like(r) if kind == "conv" else None
         dz = dY if kind == "identity" else None

@@ -200,6 +200,52 @@ def test_residual_conv_gradients(dev, B, cin, f, T, s):
     assert rel_err(from_cn(dx.cpu(), B, T, 25), gx) < TOL
 
 
+@pytest.mark.parametrize("C,n,res", [(64, 2 * 300 * 25, True), (128, 40000, False), (20, 777, True), (256, 9375 * 4, True)])
+def test_folded_bn_backward_finalisation(dev, C, n, res):
+    """sar_bn_add_relu_bwd_reduce_tail_f32 / _cn8 (the reduce kernel's last workgroup per channel finalises: dgamma, dbeta,
+    k1..k3 of the block's BatchNorm and of the residual branch's) against the separate sar_bn_bwd_finalize_f32 launches on the
+    same partials -- the same fp64 sums in another order: equal to 1e-6 -- run several times (the ticket array must come back
+    to zero; a stale partial would show as a wrong coefficient)."""
+    from sar_amd import ops, ops8
+    from sar_amd.stgcn import _BN
+    g = torch.Generator().manual_seed(C + n)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    for cn8 in (False, True):
+        cast = (lambda t: t.bfloat16().float()) if cn8 else (lambda t: t)
+        u, r, dy, y = cast(rnd(C, n)).to(dev), cast(rnd(C, n)).to(dev), cast(rnd(C, n)).to(dev), cast(rnd(C, n)).to(dev)
+        mu, mr = (0.1 * rnd(C)).to(dev), (0.1 * rnd(C)).to(dev)
+        gam, rgam = (1 + 0.2 * rnd(C)).to(dev), (1 + 0.2 * rnd(C)).to(dev)
+        bn, rbn, bn0, rbn0 = _BN(C, dev), _BN(C, dev), _BN(C, dev), _BN(C, dev)
+        for b in (bn, rbn, bn0, rbn0):
+            b.rstd.copy_(0.5 + torch.rand(C, generator=g).to(dev))
+        rbn0.rstd.copy_(rbn.rstd), bn0.rstd.copy_(bn.rstd)
+        z = lambda: torch.zeros(C, device=dev)
+        if cn8:
+            a8 = [ops8.from_cn(t) for t in (dy, y, u, r)]
+            red = lambda tail=None: ops8.bn_add_relu_bwd_reduce(a8[0], a8[1], a8[2], a8[3] if res else None, C, mu, mr if res else None,
+                                                                tail=tail)
+        else:
+            red = lambda tail=None: ops.bn_add_relu_bwd_reduce(dy, y, u, r if res else None, mu, mr if res else None, tail=tail)
+        part, nparts = red()
+        dg0, db0, rdg0, rdb0 = z(), z(), z(), z()
+        ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, C, n, gam, mu, bn0.rstd, dg0, db0, bn0.k1, bn0.k2, bn0.k3)
+        if res:
+            ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 2, C, n, rgam, mr, rbn0.rstd, rdg0, rdb0, rbn0.k1, rbn0.k2, rbn0.k3)
+        for rep in range(3):
+            dg, db, rdg, rdb = z(), z(), z(), z()
+            for b in (bn, rbn):
+                b.k1.zero_(), b.k2.zero_(), b.k3.zero_()
+            tail = ops.make_bn_tail(dev, n, gam, bn, dg, db, *((rgam, rbn, rdg, rdb) if res else ()))
+            red(tail)
+            torch.cuda.synchronize()
+            assert int(ops.bn_tail_tickets(dev).abs().sum().item()) == 0
+            pairs = [(dg, dg0), (db, db0), (bn.k1, bn0.k1), (bn.k2, bn0.k2), (bn.k3, bn0.k3)]
+            if res:
+                pairs += [(rdg, rdg0), (rdb, rdb0), (rbn.k1, rbn0.k1), (rbn.k2, rbn0.k2), (rbn.k3, rbn0.k3)]
+            for got, ref in pairs:
+                assert rel_err(got.cpu(), ref.cpu().double()) < 1e-6, (cn8, rep)
+
+
 def test_block_tail_forward_backward(dev):
     """y = relu(bn2(u) + bn_r(r)) and its backward (reductions, coefficients, apply)."""
     from sar_amd import ops
