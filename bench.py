@@ -228,12 +228,18 @@ class Leg:
             for i in range(10):
                 step(i)
             self.sync()
-            per = (time.perf_counter() - t0) / 10
-            n = max(0, int(warm_seconds / max(per, 1e-4)) - 10)
-            n = int(max(gather_over_ranks(float(n), self.dev)))
-            for i in range(n):
-                step(i)
-            self.sync()
+            done = 10
+            for _ in range(6):      # the first steps of a cold process are slow: re-estimate until the time has really passed
+                left = warm_seconds - (time.perf_counter() - t0)
+                left = min(gather_over_ranks(left, self.dev))            # every rank agrees on when to stop
+                if left <= 0:
+                    break
+                per = (time.perf_counter() - t0) / done
+                n = int(max(gather_over_ranks(float(max(1, int(left / max(per, 1e-4)))), self.dev)))
+                for i in range(n):
+                    step(i)
+                done += n
+                self.sync()
             warm_done = time.perf_counter() - t0
         if trainer is not None:
             trainer.comm_events = []
