@@ -217,7 +217,8 @@ int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const float* sh, in
  * mu / mr (the batch means) may be NULL = 0 */
 int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
                                    const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n, int64_t ld, sar_stream_t s);
-/* The same reduction with the BatchNorm-backward finalisation folded in ("tail"): the LAST workgroup of every channel to
+/* The same reduction (gradient of `relu(bn(u) + res)`, models/stgcn.py:37,56,62-63 and models/resnet18.py:46-63 under
+ * main_gnn.py:233 / loss.backward()) with the BatchNorm-backward finalisation folded in ("tail"): the LAST workgroup of every channel to
  * finish (an integer ticket per channel, agent-scope release / acquire; no float atomics, every sum in a fixed order) adds the
  * channel's partials in fp64 and writes what sar_bn_bwd_finalize_f32(centered) would: dgamma, dbeta, k1, k2, k3 of the
  * block's BatchNorm and, when r != NULL, of the residual branch's -- one small dependent launch (or two) less on the critical

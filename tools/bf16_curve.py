@@ -4,7 +4,7 @@ from oracle import stgcn as O
 from sar_amd.stgcn import STGCN
 import test_gpu_bf16_training as TT
 dev = torch.device("cuda:0")
-classes, steps, bs = 10, 400, 32
+classes, steps, bs = 10, int(os.environ.get("CURVE_STEPS", "400")), 32
 batch = TT._task(dev, classes)
 p = O.init_params(classes, seed=7, dtype=torch.float64)
 for lr in (0.02,):
@@ -15,7 +15,7 @@ for lr in (0.02,):
     for s in range(steps):
         x, y = batch(bs, s)
         logits, loss = eng.loss_and_grad(x, y)
-        eng.sgd_step(lr if s < 300 else lr / 10)
+        eng.sgd_step(lr if s < steps * 3 // 4 else lr / 10)
         losses.append(loss.reshape(())); correct.append((logits.argmax(1) == y).float().mean())
     L = torch.stack(losses).cpu(); C = torch.stack(correct).cpu()
     print(lr, mode, "loss per 50:", [round(L[i:i+50].mean().item(), 3) for i in range(0, steps, 50)], "acc last50 %.3f" % C[-50:].mean().item())
