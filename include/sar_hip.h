@@ -500,6 +500,18 @@ int sar_bn_add_relu_fwd_cn8(const void* u, const float* scale, const float* shif
 int sar_bn_add_relu_bwd_reduce_cn8(const void* dy, const void* y, const void* u, const void* r, const float* mean_u,
                                    const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
                                    sar_stream_t s);
+/* The block tail with a 1-bit ReLU mask: the forward also writes mask[g][col] (one byte per unit, bit j = stored channel 8 g + j
+ * is > 0; ld bytes per plane), and the two backward passes read that byte instead of the 16-byte unit of y -- the same
+ * results bit for bit, 115 MB less HBM traffic per pass at the NTU shapes (models/stgcn.py:37,62-63 and their gradients). */
+int sar_bn_add_relu_fwd_mask_cn8(const void* u, const float* scale, const float* shift, int res_kind, const void* r,
+                                 const float* res_scale, const float* res_shift, void* y, void* mask, int C, int64_t n, int64_t ld,
+                                 sar_stream_t s);
+int sar_bn_add_relu_bwd_reduce_mask_cn8(const void* dy, const void* mask, const void* u, const void* r, const float* mean_u,
+                                        const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
+                                        sar_stream_t s);
+int sar_bn_add_relu_bwd_apply_mask_cn8(const void* dy, const void* mask, const void* u, const void* r, const float* k1,
+                                       const float* k2, const float* k3, const float* rk1, const float* rk2, const float* rk3,
+                                       void* du, void* dr, void* dz_out, int C, int64_t n, int64_t ld, sar_stream_t s);
 int sar_bn_add_relu_bwd_reduce_tail_cn8(const void* dy, const void* y, const void* u, const void* r, const float* mean_u,
                                         const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
                                         const sar_bn_tail* tail, sar_stream_t s);

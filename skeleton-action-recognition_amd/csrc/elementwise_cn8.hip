@@ -18,11 +18,24 @@ inline int unit_blocks(int64_t n) {
   return (int)b;
 }
 
+// 8 bits of a unit: bit j = stored channel 8 g + j is > 0 (taken from the ROUNDED bfloat16 that is stored: a positive fp32
+// that rounds to +0 counts as 0, exactly as a test of the stored value would)
+__device__ __forceinline__ unsigned cn8_positive_bits(const uint4& p) {
+  const unsigned w[4] = {p.x, p.y, p.z, p.w};
+  unsigned m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    m |= ((short)(w[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
+    m |= ((short)(w[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+  }
+  return m;
+}
+
 __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_cn8_kernel(const uint4* __restrict__ u, const float* __restrict__ sc,
                                                                   const float* __restrict__ sh, int res_kind,
                                                                   const uint4* __restrict__ r, const float* __restrict__ rsc,
                                                                   const float* __restrict__ rsh, uint4* __restrict__ y, int C,
-                                                                  int64_t n, int64_t ld) {
+                                                                  int64_t n, int64_t ld, unsigned char* __restrict__ mask = nullptr) {
   const int g = blockIdx.y;
   float a[8], b[8], ra[8], rb[8];
   cn8_params(sc, g, C, 0.f, a);
@@ -40,18 +53,22 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_cn8_kernel(const uint4* _
       if (res_kind) z += fmaf(rv[j], ra[j], rb[j]);
       o[j] = fmaxf(z, 0.f);
     }
-    y[base + i] = cn8_pack(o);
+    const uint4 p = cn8_pack(o);
+    y[base + i] = p;
+    if (mask) mask[base + i] = (unsigned char)cn8_positive_bits(p);   // uniform
   }
 }
 
 // partials[C][nparts][4] = (sum dz, sum dz (u - mu), sum dz (r - mr), 0), dz = dy where y > 0
+// (y == nullptr: the ReLU mask comes from `mask`, one byte per unit written by the forward tail, instead of from the stored y)
 template <bool TAIL>
 __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_cn8_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y,
                                                                          const uint4* __restrict__ u, const uint4* __restrict__ r,
                                                                          const float* __restrict__ mu_p,
                                                                          const float* __restrict__ mr_p,
                                                                          float* __restrict__ partials, int C, int64_t n,
-                                                                         int64_t ld, const sar_bn_tail tail) {
+                                                                         int64_t ld, const sar_bn_tail tail,
+                                                                         const unsigned char* __restrict__ mask = nullptr) {
   const int g = blockIdx.y;
   float mu[8], mr[8];
   cn8_params(mu_p, g, C, 0.f, mu);
@@ -63,14 +80,16 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_cn8_kernel(const u
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    float gv[8], yv[8], uv[8], rv[8];
+    float gv[8], uv[8], rv[8];
     cn8_unpack(dy[base + i], gv);
-    cn8_unpack(y[base + i], yv);
+    unsigned mb;
+    if (mask) mb = mask[base + i];   // uniform
+    else mb = cn8_positive_bits(y[base + i]);
     cn8_unpack(u[base + i], uv);
     if (r) cn8_unpack(r[base + i], rv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float dz = yv[j] > 0.f ? gv[j] : 0.f;
+      const float dz = ((mb >> j) & 1u) ? gv[j] : 0.f;
       acc[0][j] += dz;
       acc[1][j] = fmaf(dz, uv[j] - mu[j], acc[1][j]);
       if (r) acc[2][j] = fmaf(dz, rv[j] - mr[j], acc[2][j]);
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_cn8_kernel(
     const uint4* __restrict__ dy, const uint4* __restrict__ y, const uint4* __restrict__ u, const uint4* __restrict__ r,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3, const float* __restrict__ rk1,
     const float* __restrict__ rk2, const float* __restrict__ rk3, uint4* du, uint4* dr, uint4* dz_out, int C, int64_t n,
-    int64_t ld) {
+    int64_t ld, const unsigned char* __restrict__ mask = nullptr) {
   const int g = blockIdx.y;
   float a1[8], a2[8], a3[8], b1[8], b2[8], b3[8];
   cn8_params(k1, g, C, 0.f, a1);
@@ -131,14 +150,16 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_cn8_kernel(
   cn8_params(dr ? rk3 : nullptr, g, C, 0.f, b3);
   const int64_t base = (int64_t)g * ld;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    float gv[8], yv[8], uv[8], rv[8], o1[8], o2[8], o3[8];
+    float gv[8], uv[8], rv[8], o1[8], o2[8], o3[8];
     cn8_unpack(dy[base + i], gv);
-    cn8_unpack(y[base + i], yv);
+    unsigned mb;
+    if (mask) mb = mask[base + i];   // uniform
+    else mb = cn8_positive_bits(y[base + i]);
     cn8_unpack(u[base + i], uv);
     if (dr) cn8_unpack(r[base + i], rv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float dz = yv[j] > 0.f ? gv[j] : 0.f;
+      const float dz = ((mb >> j) & 1u) ? gv[j] : 0.f;
       o3[j] = dz;
       o1[j] = fmaf(a1[j], dz, fmaf(a2[j], uv[j], a3[j]));
       if (dr) o2[j] = fmaf(b1[j], dz, fmaf(b2[j], rv[j], b3[j]));
@@ -270,6 +291,19 @@ extern "C" int sar_bn_add_relu_fwd_cn8(const void* u, const float* sc, const flo
   return 0;
 }
 
+extern "C" int sar_bn_add_relu_fwd_mask_cn8(const void* u, const float* sc, const float* sh, int res_kind, const void* r,
+                                            const float* rsc, const float* rsh, void* y, void* mask, int C, int64_t n, int64_t ld,
+                                            sar_stream_t s) {
+  SAR_REQUIRE(u && sc && sh && y && mask && C > 0 && n > 0 && ld >= n, "sar_bn_add_relu_fwd_mask_cn8: bad arguments");
+  SAR_REQUIRE(res_kind >= 0 && res_kind <= 2 && (res_kind == 0 || r) && (res_kind != 2 || (rsc && rsh)),
+              "sar_bn_add_relu_fwd_mask_cn8: residual arguments");
+  SAR_REQUIRE(al16({u, r, y}), "sar_bn_add_relu_fwd_mask_cn8: CN8 tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(bn_add_relu_fwd_cn8_kernel, dim3(unit_blocks(n), CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)u, sc,
+                     sh, res_kind, (const uint4*)r, rsc, rsh, (uint4*)y, C, n, ld, (unsigned char*)mask);
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_fwd_mask_cn8");
+  return 0;
+}
+
 extern "C" int sar_bn_add_relu_bwd_reduce_cn8(const void* dy, const void* y, const void* u, const void* r, const float* mean_u,
                                               const float* mean_r, float* partials, int nparts, int C, int64_t n, int64_t ld,
                                               sar_stream_t s) {
@@ -279,6 +313,19 @@ extern "C" int sar_bn_add_relu_bwd_reduce_cn8(const void* dy, const void* y, con
   hipLaunchKernelGGL(bn_add_relu_bwd_reduce_cn8_kernel<false>, dim3(nparts, CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)dy,
                      (const uint4*)y, (const uint4*)u, (const uint4*)r, mean_u, mean_r, partials, C, n, ld, sar_bn_tail());
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_cn8");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_reduce_mask_cn8(const void* dy, const void* mask, const void* u, const void* r,
+                                                   const float* mean_u, const float* mean_r, float* partials, int nparts, int C,
+                                                   int64_t n, int64_t ld, sar_stream_t s) {
+  SAR_REQUIRE(dy && mask && u && partials && nparts > 0 && nparts <= 65535 && C > 0 && n > 0 && ld >= n,
+              "sar_bn_add_relu_bwd_reduce_mask_cn8: bad arguments");
+  SAR_REQUIRE(al16({dy, u, r}), "sar_bn_add_relu_bwd_reduce_mask_cn8: CN8 tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(bn_add_relu_bwd_reduce_cn8_kernel<false>, dim3(nparts, CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)dy,
+                     (const uint4*)nullptr, (const uint4*)u, (const uint4*)r, mean_u, mean_r, partials, C, n, ld, sar_bn_tail(),
+                     (const unsigned char*)mask);
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_mask_cn8");
   return 0;
 }
 
@@ -308,6 +355,20 @@ extern "C" int sar_bn_add_relu_bwd_apply_cn8(const void* dy, const void* y, cons
                      (const uint4*)dy, (const uint4*)y, (const uint4*)u, (const uint4*)r, k1, k2, k3, rk1, rk2, rk3, (uint4*)du,
                      (uint4*)dr, (uint4*)dz_out, C, n, ld);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_cn8");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_apply_mask_cn8(const void* dy, const void* mask, const void* u, const void* r, const float* k1,
+                                                  const float* k2, const float* k3, const float* rk1, const float* rk2,
+                                                  const float* rk3, void* du, void* dr, void* dz_out, int C, int64_t n, int64_t ld,
+                                                  sar_stream_t s) {
+  SAR_REQUIRE(dy && mask && u && k1 && k2 && k3 && du && C > 0 && n > 0 && ld >= n, "sar_bn_add_relu_bwd_apply_mask_cn8: bad arguments");
+  SAR_REQUIRE(!dr || (r && rk1 && rk2 && rk3), "sar_bn_add_relu_bwd_apply_mask_cn8: residual-branch arguments");
+  SAR_REQUIRE(al16({dy, u, r, du, dr, dz_out}), "sar_bn_add_relu_bwd_apply_mask_cn8: CN8 tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(bn_add_relu_bwd_apply_cn8_kernel, dim3(unit_blocks(n), CN8_G(C)), dim3(TPB), 0, as_stream(s),
+                     (const uint4*)dy, (const uint4*)nullptr, (const uint4*)u, (const uint4*)r, k1, k2, k3, rk1, rk2, rk3, (uint4*)du,
+                     (uint4*)dr, (uint4*)dz_out, C, n, ld, (const unsigned char*)mask);
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_mask_cn8");
   return 0;
 }
 

@@ -146,6 +146,9 @@ SIGNATURES = {
     "sar_conv_wgrad_cn8": (_i, [C.POINTER(WgradDesc), _i, _fp]),
     "sar_bn_add_relu_fwd_cn8": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_reduce_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_fwd_mask_cn8": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_reduce_mask_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_apply_mask_cn8": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),
     "sar_bn_add_relu_bwd_reduce_tail_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i64, _i64, C.POINTER(BnTail), _fp]),
     "sar_bn_add_relu_bwd_apply_cn8": (_i, [_fp] * 13 + [_i, _i64, _i64, _fp]),
     "sar_affine2_cn8": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),

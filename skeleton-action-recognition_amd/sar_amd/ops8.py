@@ -127,7 +127,17 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
           "sar_slab_reduce_f32")
 
 
-def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, channels):
+def relu_mask(channels, n, device):
+    """one byte per unit: the ReLU mask of a block tail's output (sar_bn_add_relu_fwd_mask_cn8)"""
+    return torch.empty(((channels + 7) // 8, n), dtype=torch.uint8, device=device)
+
+
+def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, channels, mask=None):
+    if mask is not None:
+        check(L.load().sar_bn_add_relu_fwd_mask_cn8(ptr(_cn8(u)), ptr(sc), ptr(sh), res_kind, ptr(_cn8(r)), ptr(rsc), ptr(rsh),
+                                                    ptr(_cn8(y)), ptr(mask), channels, u.shape[1], u.shape[1], stream_ptr()),
+              "sar_bn_add_relu_fwd_mask_cn8")
+        return
     check(L.load().sar_bn_add_relu_fwd_cn8(ptr(_cn8(u)), ptr(sc), ptr(sh), res_kind, ptr(_cn8(r)), ptr(rsc), ptr(rsh), ptr(_cn8(y)),
                                            channels, u.shape[1], u.shape[1], stream_ptr()), "sar_bn_add_relu_fwd_cn8")
 
@@ -135,10 +145,17 @@ def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, channels):
 _REDUCE_CHUNK = int(__import__("os").environ.get("SAR_BWD_REDUCE_CHUNK8", "8192"))     # units per workgroup of the BN-backward reduction
 
 
-def bn_add_relu_bwd_reduce(dy, y, u, r, channels, mu=None, mr=None, tail=None):
+def bn_add_relu_bwd_reduce(dy, y, u, r, channels, mu=None, mr=None, tail=None, mask=None):
+    """mask (relu_mask written by bn_add_relu_fwd): read instead of y"""
     n = u.shape[1]
     nparts = max(1, min(4096, (n + _REDUCE_CHUNK - 1) // _REDUCE_CHUNK))
     partials = torch.empty((channels, nparts, 4), dtype=torch.float32, device=u.device)
+    if mask is not None:
+        assert tail is None
+        check(L.load().sar_bn_add_relu_bwd_reduce_mask_cn8(ptr(_cn8(dy)), ptr(mask), ptr(_cn8(u)), ptr(_cn8(r)), ptr(mu), ptr(mr),
+                                                           ptr(partials), nparts, channels, n, n, stream_ptr()),
+              "sar_bn_add_relu_bwd_reduce_mask_cn8")
+        return partials, nparts
     if tail is not None:      # ops.make_bn_tail: the last workgroup of every plane finalises its channels
         import ctypes
         check(L.load().sar_bn_add_relu_bwd_reduce_tail_cn8(ptr(_cn8(dy)), ptr(_cn8(y)), ptr(_cn8(u)), ptr(_cn8(r)), ptr(mu), ptr(mr),
@@ -151,9 +168,15 @@ def bn_add_relu_bwd_reduce(dy, y, u, r, channels, mu=None, mr=None, tail=None):
     return partials, nparts
 
 
-def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, channels):
+def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, channels, mask=None):
     rk = rk or (None, None, None)
     n = u.shape[1]
+    if mask is not None:
+        check(L.load().sar_bn_add_relu_bwd_apply_mask_cn8(ptr(_cn8(dy)), ptr(mask), ptr(_cn8(u)), ptr(_cn8(r)), ptr(k[0]), ptr(k[1]),
+                                                          ptr(k[2]), ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(_cn8(du)), ptr(_cn8(dr)),
+                                                          ptr(_cn8(dz_out)), channels, n, n, stream_ptr()),
+              "sar_bn_add_relu_bwd_apply_mask_cn8")
+        return
     check(L.load().sar_bn_add_relu_bwd_apply_cn8(ptr(_cn8(dy)), ptr(_cn8(y)), ptr(_cn8(u)), ptr(_cn8(r)), ptr(k[0]), ptr(k[1]),
                                                  ptr(k[2]), ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(_cn8(du)), ptr(_cn8(dr)),
                                                  ptr(_cn8(dz_out)), channels, n, n, stream_ptr()), "sar_bn_add_relu_bwd_apply_cn8")

@@ -12,6 +12,8 @@ from . import _lib as L
 from . import ops, ops8
 from .stgcn import BN_EPS, BN_MOMENTUM, KS, KT, same_pad  # noqa: F401
 
+RELU_MASK = __import__("os").environ.get("SAR_CN8_RELU_MASK", "1") == "1"
+
 
 def forward(eng, x, training=True, keep=None):
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
@@ -84,10 +86,13 @@ def _block_forward(eng, i, X, cin, f, s, B, T, training, saved, keep):
         rbn = eng.bn[pre + "res_bn"]
     y = ops8.empty(f, n_out, dev)
     res_kind = {"none": 0, "identity": 1, "conv": 2}[kind]
+    # training: the tail also writes its ReLU mask, one BYTE per 16-byte unit; the two BatchNorm-backward passes read that
+    # instead of y (SAR_CN8_RELU_MASK=0: they read y)
+    ymask = ops8.relu_mask(f, n_out, dev) if (training and RELU_MASK) else None
     ops8.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r, rbn.scale if rbn else None,
-                         rbn.shift if rbn else None, y, f)
+                         rbn.shift if rbn else None, y, f, mask=ymask)
     if training:
-        saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind))
+        saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, ymask=ymask, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind))
     if keep is not None:
         keep[pre + "g"], keep[pre + "u"], keep[pre + "y"] = g, u, y
     return y, To
@@ -139,7 +144,8 @@ def _block_backward(eng, i, sb, dY, B):
                                   if conv else ()))
         ops8.bn_add_relu_bwd_reduce(dY, y, u, r if conv else None, f, bn2.mean, rbn.mean if conv else None, tail=tail)
     else:
-        part, nparts = ops8.bn_add_relu_bwd_reduce(dY, y, u, r if conv else None, f, bn2.mean, rbn.mean if conv else None)
+        part, nparts = ops8.bn_add_relu_bwd_reduce(dY, y, u, r if conv else None, f, bn2.mean, rbn.mean if conv else None,
+                                                   mask=sb.get("ymask"))
         ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, eng.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
                             eng.g[pre + "bn2.gamma"], eng.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
         if conv:
@@ -148,7 +154,7 @@ def _block_backward(eng, i, sb, dY, B):
     du = ops8.empty(f, n_out, dev)
     dr = ops8.empty(f, n_out, dev) if conv else None
     dz = dY if kind == "identity" else None      # in place: dY becomes the pre-ReLU gradient for the skip path
-    ops8.bn_add_relu_bwd_apply(dY, y, u, r if conv else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz, f)
+    ops8.bn_add_relu_bwd_apply(dY, y, u, r if conv else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz, f, mask=sb.get("ymask"))
     # ---- temporal conv: weight / bias gradient, then data gradient fused with the ReLU mask and the BN1 reductions
     flat_w = eng.grad[eng.offsets[pre + "tcn.kernel"]:eng.offsets[pre + "tcn.bias"] + f]
     eng._off_critical_path(lambda: ops8.conv_wgrad(

@@ -222,6 +222,43 @@ def test_graph_conv_data_gradient(dev, B, cin, f, T):
 
 
 @pytest.mark.parametrize("C,n,kind", [(64, 5000, 1), (128, 3001, 2), (20, 777, 0), (256, 9375, 2)])
+def test_block_tail_relu_mask_is_bit_identical(dev, C, n, kind):
+    """sar_bn_add_relu_fwd_mask_cn8 / _bwd_reduce_mask_cn8 / _bwd_apply_mask_cn8: the forward tail's one-byte-per-unit ReLU mask
+    (bit j = stored channel 8 g + j > 0) replaces the reads of y in both backward passes -- every output bit for bit equal to
+    the y-reading kernels, and the mask equal to its definition."""
+    from sar_amd import ops8
+    g = torch.Generator().manual_seed(3 * C + n)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    u, r, dy = (ops8.from_cn(rnd(C, n).bfloat16().float().to(dev)) for _ in range(3))
+    sc, sh, rsc, rsh = (t.to(dev) for t in (1 + 0.2 * rnd(C), 0.3 * rnd(C), 1 + 0.2 * rnd(C), 0.3 * rnd(C)))
+    mu, mr = (0.1 * rnd(C)).to(dev), (0.1 * rnd(C)).to(dev)
+    k = [rnd(C).to(dev) for _ in range(6)]
+    y0, y1 = ops8.empty(C, n, dev), ops8.empty(C, n, dev)
+    mask = ops8.relu_mask(C, n, dev)
+    res = r if kind else None
+    ops8.bn_add_relu_fwd(u, sc, sh, kind, res, rsc if kind == 2 else None, rsh if kind == 2 else None, y0, C)
+    ops8.bn_add_relu_fwd(u, sc, sh, kind, res, rsc if kind == 2 else None, rsh if kind == 2 else None, y1, C, mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    bits = (y0.float() > 0).to(torch.int32)                                   # (G, n, 8)
+    want = (bits * (2 ** torch.arange(8, device=dev, dtype=torch.int32))).sum(dim=2).to(torch.uint8)
+    assert torch.equal(mask, want)
+    rr = r if kind == 2 else None
+    p0, np0 = ops8.bn_add_relu_bwd_reduce(dy, y0, u, rr, C, mu, mr if rr is not None else None)
+    p1, np1 = ops8.bn_add_relu_bwd_reduce(dy, None, u, rr, C, mu, mr if rr is not None else None, mask=mask)
+    torch.cuda.synchronize()
+    assert np0 == np1 and torch.equal(p0[:, :, :3], p1[:, :, :3])
+    outs = []
+    for m in (None, mask):
+        du, dr, dz = ops8.empty(C, n, dev), (ops8.empty(C, n, dev) if rr is not None else None), ops8.empty(C, n, dev)
+        ops8.bn_add_relu_bwd_apply(dy, y0 if m is None else None, u, rr, k[:3], k[3:] if rr is not None else None, du, dr, dz, C, mask=m)
+        outs.append((du, dr, dz))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,n,kind", [(64, 5000, 1), (128, 3001, 2), (20, 777, 0), (256, 9375, 2)])
 def test_block_tail_forward_backward(dev, C, n, kind):
     """y = relu(bn2(u) + res) and its backward passes (sar_bn_add_relu_*_cn8, sar_affine2_cn8) against float64 arithmetic on
     the same bf16 inputs."""
