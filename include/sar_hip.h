@@ -217,6 +217,19 @@ int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const float* sh, in
  * mu / mr (the batch means) may be NULL = 0 */
 int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
                                    const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n, int64_t ld, sar_stream_t s);
+/* The block tail with a 1-bit ReLU mask (fp32 rows of 4-element groups: n and ld multiples of 4, 16-byte aligned pointers, else
+ * SAR_E_UNSUP): the forward also writes mask[c][i / 4] (one byte per float4 of y, bit j = element j > 0; ld / 4 bytes per row)
+ * and the two backward passes read it instead of y: the same results bit for bit, a third less HBM traffic in the reduce. */
+int sar_bn_add_relu_fwd_mask_f32(const float* u, const float* scale, const float* shift, int res_kind, const float* r,
+                                 const float* res_scale, const float* res_shift, float* y, void* mask, int C, int64_t n, int64_t ld,
+                                 sar_stream_t s);
+int sar_bn_add_relu_bwd_reduce_mask_f32(const float* dy, const void* mask, const float* u, const float* r,
+                                        const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n, int64_t ld,
+                                        sar_stream_t s);
+int sar_bn_add_relu_bwd_apply_mask_f32(const float* dy, const void* mask, const float* u, const float* r,
+                                       const float* k1, const float* k2, const float* k3,
+                                       const float* rk1, const float* rk2, const float* rk3,
+                                       float* du, float* dr, float* dz_out, int C, int64_t n, int64_t ld, sar_stream_t s);
 /* The same reduction (gradient of `relu(bn(u) + res)`, models/stgcn.py:37,56,62-63 and models/resnet18.py:46-63 under
  * main_gnn.py:233 / loss.backward()) with the BatchNorm-backward finalisation folded in ("tail"): the LAST workgroup of every channel to
  * finish (an integer ticket per channel, agent-scope release / acquire; no float atomics, every sum in a fixed order) adds the

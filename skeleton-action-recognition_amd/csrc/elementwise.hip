@@ -331,12 +331,14 @@ template <int VEC> __device__ __forceinline__ void st(float* p, const float (&r)
   else *p = r[0];
 }
 
+// mask (VEC == 4 only): one byte per float4 of y, bit j = element j > 0, row stride ldm / 4 bytes -- read by the two backward
+// passes instead of y (sar_bn_add_relu_*_mask_f32)
 template <int VEC>
 __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __restrict__ u, const float* __restrict__ sc,
                                                               const float* __restrict__ sh, int res_kind,
                                                               const float* __restrict__ r, const float* __restrict__ rsc,
                                                               const float* __restrict__ rsh, float* __restrict__ y,
-                                                              int64_t n, int64_t ldm) {
+                                                              int64_t n, int64_t ldm, unsigned char* __restrict__ mask = nullptr) {
   const int c = blockIdx.y;
   const float a = sc[c], b = sh[c];
   const float ra = (res_kind == 2) ? rsc[c] : 1.f, rb = (res_kind == 2) ? rsh[c] : 0.f;
@@ -352,6 +354,12 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
       o[j] = fmaxf(z, 0.f);
     }
     st<VEC>(y + base + i, o);
+    if (VEC == 4 && mask) {   // uniform
+      unsigned mb = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) mb |= (o[j] > 0.f ? 1u : 0u) << j;
+      mask[(base + i) >> 2] = (unsigned char)mb;
+    }
   }
 }
 
@@ -360,7 +368,8 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_kernel(const float
                                                                      const float* __restrict__ u, const float* __restrict__ r,
                                                                      const float* __restrict__ mu_p, const float* __restrict__ mr_p,
                                                                      float* __restrict__ partials, int64_t n, int64_t ldm,
-                                                                     const sar_bn_tail tail = sar_bn_tail()) {
+                                                                     const sar_bn_tail tail = sar_bn_tail(),
+                                                                     const unsigned char* __restrict__ mask = nullptr) {
   const int c = blockIdx.y;
   const float mu = mu_p ? mu_p[c] : 0.f, mr = (r && mr_p) ? mr_p[c] : 0.f;
   const int64_t base = (int64_t)c * ldm;
@@ -368,12 +377,19 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_reduce_kernel(const float
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float g[VEC], yv[VEC], uv[VEC], rv[VEC];
     ld<VEC>(dy + base + i, g);
-    ld<VEC>(y + base + i, yv);
+    unsigned mb = 0;
+    if (VEC == 4 && mask) {   // uniform
+      mb = mask[(base + i) >> 2];
+    } else {
+      ld<VEC>(y + base + i, yv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) mb |= (yv[j] > 0.f ? 1u : 0u) << j;
+    }
     ld<VEC>(u + base + i, uv);
     if (r) ld<VEC>(r + base + i, rv);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const float dz = yv[j] > 0.f ? g[j] : 0.f;
+      const float dz = ((mb >> j) & 1u) ? g[j] : 0.f;
       acc[0] += dz;
       acc[1] = fmaf(dz, uv[j] - mu, acc[1]);
       if (r) acc[2] = fmaf(dz, rv[j] - mr, acc[2]);
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ u, const float* __restrict__ r,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3, const float* __restrict__ rk1,
     const float* __restrict__ rk2, const float* __restrict__ rk3, float* du, float* dr, float* dz_out, int64_t n,
-    int64_t ldm) {
+    int64_t ldm, const unsigned char* __restrict__ mask = nullptr) {
   const int c = blockIdx.y;
   const int64_t base = (int64_t)c * ldm;
   const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
@@ -415,12 +431,19 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float g[VEC], yv[VEC], uv[VEC], rv[VEC], o1[VEC], o2[VEC], o3[VEC];
     ld<VEC>(dy + base + i, g);
-    ld<VEC>(y + base + i, yv);
+    unsigned mb = 0;
+    if (VEC == 4 && mask) {   // uniform
+      mb = mask[(base + i) >> 2];
+    } else {
+      ld<VEC>(y + base + i, yv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) mb |= (yv[j] > 0.f ? 1u : 0u) << j;
+    }
     ld<VEC>(u + base + i, uv);
     if (dr) ld<VEC>(r + base + i, rv);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const float dz = yv[j] > 0.f ? g[j] : 0.f;
+      const float dz = ((mb >> j) & 1u) ? g[j] : 0.f;
       o3[j] = dz;
       o1[j] = fmaf(a1, dz, fmaf(a2, uv[j], a3));
       if (dr) o2[j] = fmaf(b1, dz, fmaf(b2, rv[j], b3));
@@ -745,6 +768,54 @@ extern "C" int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const fl
                        res_kind, r, rsc, rsh, y, n, ldm);
   }
   SAR_LAUNCH_CHECK("sar_bn_add_relu_fwd_f32");
+  return 0;
+}
+
+// the block tail with a 1-bit ReLU mask (include/sar_hip.h): rows of 4-element groups only (n, ld multiples of 4, 16-byte aligned)
+extern "C" int sar_bn_add_relu_fwd_mask_f32(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
+                                            const float* rsc, const float* rsh, float* y, void* mask, int C, int64_t n, int64_t ldm,
+                                            sar_stream_t s) {
+  SAR_REQUIRE(u && sc && sh && y && mask && C > 0 && n > 0 && ldm >= n, "sar_bn_add_relu_fwd_mask: bad arguments");
+  SAR_REQUIRE(res_kind >= 0 && res_kind <= 2 && (res_kind == 0 || r) && (res_kind != 2 || (rsc && rsh)),
+              "sar_bn_add_relu_fwd_mask: residual arguments");
+  if (!vec4_ok(n, ldm, {u, r, y})) {
+    sar_set_error("sar_bn_add_relu_fwd_mask: rows must be 16-byte aligned multiples of 4 elements (n=%lld, ld=%lld)", (long long)n, (long long)ldm);
+    return SAR_E_UNSUP;
+  }
+  hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), u, sc, sh, res_kind, r, rsc,
+                     rsh, y, n, ldm, (unsigned char*)mask);
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_fwd_mask_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_reduce_mask_f32(const float* dy, const void* mask, const float* u, const float* r,
+                                                   const float* mu, const float* mr, float* partials, int nparts, int C, int64_t n,
+                                                   int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(dy && mask && u && partials && nparts > 0 && nparts <= 65535 && C > 0 && n > 0 && ldm >= n,
+              "sar_bn_add_relu_bwd_reduce_mask: bad arguments");
+  if (!vec4_ok(n, ldm, {dy, u, r})) {
+    sar_set_error("sar_bn_add_relu_bwd_reduce_mask: rows must be 16-byte aligned multiples of 4 elements");
+    return SAR_E_UNSUP;
+  }
+  hipLaunchKernelGGL((bn_add_relu_bwd_reduce_kernel<4, false>), dim3(nparts, C), dim3(TPB), 0, as_stream(s), dy, (const float*)nullptr,
+                     u, r, mu, mr, partials, n, ldm, sar_bn_tail(), (const unsigned char*)mask);
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_reduce_mask_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_add_relu_bwd_apply_mask_f32(const float* dy, const void* mask, const float* u, const float* r,
+                                                  const float* k1, const float* k2, const float* k3, const float* rk1,
+                                                  const float* rk2, const float* rk3, float* du, float* dr, float* dz_out,
+                                                  int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(dy && mask && u && k1 && k2 && k3 && du && C > 0 && n > 0 && ldm >= n, "sar_bn_add_relu_bwd_apply_mask: bad arguments");
+  SAR_REQUIRE(!dr || (r && rk1 && rk2 && rk3), "sar_bn_add_relu_bwd_apply_mask: residual arguments");
+  if (!vec4_ok(n, ldm, {dy, u, r, du, dr, dz_out})) {
+    sar_set_error("sar_bn_add_relu_bwd_apply_mask: rows must be 16-byte aligned multiples of 4 elements");
+    return SAR_E_UNSUP;
+  }
+  hipLaunchKernelGGL(bn_add_relu_bwd_apply_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), dy, (const float*)nullptr,
+                     u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, n, ldm, (const unsigned char*)mask);
+  SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_mask_f32");
   return 0;
 }
 

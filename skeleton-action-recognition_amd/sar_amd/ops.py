@@ -231,7 +231,22 @@ def data_bn_bwd_reduce(x, bone_parent, dy, mean, partials, motion=False):
                                               ptr(partials), stream_ptr()), "sar_data_bn_bwd_reduce_f32")
 
 
-def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y):
+RELU_MASK = __import__("os").environ.get("SAR_RELU_MASK", "1") == "1"   # block tails write / read a 1-bit ReLU mask (A/B switch)
+
+
+def relu_mask(u):
+    """the mask tensor of a (C, n) fp32 block-tail output: one byte per float4, or None when the rows are not 4-element groups"""
+    Cc, n = u.shape
+    if not RELU_MASK or n % 4 or u.stride(0) % 4:
+        return None
+    return torch.empty((Cc, u.stride(0) // 4), dtype=torch.uint8, device=u.device)
+
+
+def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, mask=None):
+    if mask is not None:
+        check(L.load().sar_bn_add_relu_fwd_mask_f32(ptr(u), ptr(sc), ptr(sh), res_kind, ptr(r), ptr(rsc), ptr(rsh), ptr(y), ptr(mask),
+                                                    u.shape[0], u.shape[1], u.stride(0), stream_ptr()), "sar_bn_add_relu_fwd_mask_f32")
+        return
     check(L.load().sar_bn_add_relu_fwd_f32(ptr(u), ptr(sc), ptr(sh), res_kind, ptr(r), ptr(rsc), ptr(rsh), ptr(y),
                                            u.shape[0], u.shape[1], u.stride(0), stream_ptr()), "sar_bn_add_relu_fwd_f32")
 
@@ -268,12 +283,16 @@ def make_bn_tail(device, count, gamma, bn, dgamma, dbeta, rgamma=None, rbn=None,
     return t
 
 
-def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None, tail=None):
+def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None, tail=None, mask=None):
     """tail (make_bn_tail): the reduce kernel's last workgroup per channel also finalises (dgamma, dbeta, k1..k3): no
-    sar_bn_bwd_finalize launch behind it"""
+    sar_bn_bwd_finalize launch behind it.  mask (relu_mask, written by bn_add_relu_fwd): read instead of y."""
     Cc, n = u.shape
     nparts = max(1, min(4096, (n + _REDUCE_CHUNK - 1) // _REDUCE_CHUNK))
     partials = torch.empty((Cc, nparts, 4), dtype=torch.float32, device=u.device)
+    if mask is not None and tail is None:
+        check(L.load().sar_bn_add_relu_bwd_reduce_mask_f32(ptr(dy), ptr(mask), ptr(u), ptr(r), ptr(mu), ptr(mr), ptr(partials), nparts,
+                                                           Cc, n, u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_reduce_mask_f32")
+        return partials, nparts
     if tail is not None:
         assert Cc <= 4096
         check(L.load().sar_bn_add_relu_bwd_reduce_tail_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(mu), ptr(mr), ptr(partials), nparts, Cc,
@@ -285,9 +304,14 @@ def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None, tail=None):
     return partials, nparts
 
 
-def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out):
+def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask=None):
     Cc, n = u.shape
     rk = rk or (None, None, None)
+    if mask is not None:
+        check(L.load().sar_bn_add_relu_bwd_apply_mask_f32(ptr(dy), ptr(mask), ptr(u), ptr(r), ptr(k[0]), ptr(k[1]), ptr(k[2]),
+                                                          ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(du), ptr(dr), ptr(dz_out), Cc, n,
+                                                          u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_apply_mask_f32")
+        return
     check(L.load().sar_bn_add_relu_bwd_apply_f32(ptr(dy), ptr(y), ptr(u), ptr(r), ptr(k[0]), ptr(k[1]), ptr(k[2]),
                                                  ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(du), ptr(dr), ptr(dz_out), Cc, n,
                                                  u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_apply_f32")

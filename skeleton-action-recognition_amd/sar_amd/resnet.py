@@ -232,10 +232,11 @@ class ResNet18:
                 dsc, rd, _, _ = self._conv_fwd(pre + "downsample.0", h, B, Hc, Wc, training)
                 bd = self._bn_stats(pre + "downsample.1", rd, B * Ho * Wo, training)
             y = torch.empty_like(c2)
+            ymask = ops.relu_mask(y) if training else None  # 1 bit per element: what the BatchNorm-backward passes read instead of y
             ops.bn_add_relu_fwd(c2, b2.scale, b2.shift, 2 if ds else 1, dsc if ds else h, bd.scale if ds else None,
-                                bd.shift if ds else None, y)
+                                bd.shift if ds else None, y, mask=ymask)
             if training:
-                saved["blocks"].append(dict(X=h, c1=c1, c2=c2, dsc=dsc, y=y, H=Hc, W=Wc, Ho=Ho, Wo=Wo))
+                saved["blocks"].append(dict(X=h, c1=c1, c2=c2, dsc=dsc, y=y, ymask=ymask, H=Hc, W=Wc, Ho=Ho, Wo=Wo))
             if keep is not None:
                 keep[pre + "out"], keep[pre + "c1"] = y, c1
             h, Hc, Wc = y, Ho, Wo
@@ -327,13 +328,13 @@ class ResNet18:
                                         *((self.p[nd + ".weight"], bd, self.g[nd + ".weight"], self.g[nd + ".bias"]) if ds else ()))
                 ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None, tail=tail)
             else:
-                part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None)
+                part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None, mask=sb.get("ymask"))
                 self._bn_bwd(pre + "bn2", part, nparts, nparts * 4, 4, 1, n_out)
                 if ds:
                     self._bn_bwd(pre + "downsample.1", part, nparts, nparts * 4, 4, 2, n_out)
             dc2 = torch.empty_like(c2)
             ddsc = torch.empty_like(dsc) if ds else None
-            ops.bn_add_relu_bwd_apply(dY, y, c2, dsc, (b2.k1, b2.k2, b2.k3), rk, dc2, ddsc, None if ds else dY)
+            ops.bn_add_relu_bwd_apply(dY, y, c2, dsc, (b2.k1, b2.k2, b2.k3), rk, dc2, ddsc, None if ds else dY, mask=sb.get("ymask"))
             # conv2 (input = relu(bn1(c1)), folded)
             self._conv_wgrad(pre + "conv2", c1, dc2, B, Ho, Wo, Ho, Wo, pro=(b1.scale, b1.shift))
             dz1, pm = self._conv_dgrad(pre + "conv2", dc2, B, Ho, Wo, Ho, Wo, epi=L.SAR_EPI_MASK, aux=c1,

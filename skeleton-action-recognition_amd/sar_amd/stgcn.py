@@ -350,10 +350,11 @@ class STGCN:
             rbn = self.bn[pre + "res_bn"]
         y = torch.empty((f, n_out), dtype=torch.float32, device=dev)
         res_kind = {"none": 0, "identity": 1, "conv": 2}[kind]
+        ymask = ops.relu_mask(y) if training else None     # 1 bit per element: what the BatchNorm-backward passes read instead of y
         ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r,
-                            rbn.scale if rbn else None, rbn.shift if rbn else None, y)
+                            rbn.scale if rbn else None, rbn.shift if rbn else None, y, mask=ymask)
         if training:
-            saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind, y3=y3))
+            saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, ymask=ymask, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind, y3=y3))
         if keep is not None:
             keep[pre + "g"], keep[pre + "u"], keep[pre + "y"] = g, u, y
         return y, To
@@ -440,7 +441,7 @@ class STGCN:
                                        tail=tail)
         else:
             part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, u, r if kind == "conv" else None, bn2.mean,
-                                                      rbn.mean if kind == "conv" else None)
+                                                      rbn.mean if kind == "conv" else None, mask=sb.get("ymask"))
             ops.bn_bwd_finalize(part, nparts, nparts * 4, 4, 0, 1, f, n_out, self.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
                                 self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
             if kind == "conv":
@@ -450,7 +451,8 @@ class STGCN:
         du = torch.empty_like(u)
         dr = torch.empty_like(r) if kind == "conv" else None
         dz = dY if kind == "identity" else None  # in place: dY becomes the pre-ReLU gradient for the skip path
-        ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz)
+        ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz,
+                                  mask=sb.get("ymask"))
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
         wt = self.g[pre + "tcn.kernel"]
         flat_w = self.grad[self.offsets[pre + "tcn.kernel"]:self.offsets[pre + "tcn.bias"] + f]

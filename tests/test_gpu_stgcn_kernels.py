@@ -246,6 +246,41 @@ def test_folded_bn_backward_finalisation(dev, C, n, res):
                 assert rel_err(got.cpu(), ref.cpu().double()) < 1e-6, (cn8, rep)
 
 
+@pytest.mark.parametrize("C,n,kind", [(64, 5000, 1), (128, 3000, 2), (20, 776, 0), (256, 9376, 2)])
+def test_block_tail_relu_mask_is_bit_identical_f32(dev, C, n, kind):
+    """sar_bn_add_relu_{fwd,bwd_reduce,bwd_apply}_mask_f32: one byte per float4 of y written by the forward tail, read by both
+    backward passes instead of y -- every output bit for bit equal to the y-reading kernels, the mask equal to its definition."""
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(3 * C + n)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    u, r, dy = rnd(C, n), rnd(C, n), rnd(C, n)
+    sc, sh, rsc, rsh, mu, mr = 1 + 0.2 * rnd(C), 0.3 * rnd(C), 1 + 0.2 * rnd(C), 0.3 * rnd(C), 0.1 * rnd(C), 0.1 * rnd(C)
+    k = [rnd(C) for _ in range(6)]
+    y0, y1 = torch.empty_like(u), torch.empty_like(u)
+    mask = ops.relu_mask(y1)
+    assert mask is not None
+    res = r if kind else None
+    ops.bn_add_relu_fwd(u, sc, sh, kind, res, rsc if kind == 2 else None, rsh if kind == 2 else None, y0)
+    ops.bn_add_relu_fwd(u, sc, sh, kind, res, rsc if kind == 2 else None, rsh if kind == 2 else None, y1, mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    want = ((y0 > 0).view(C, n // 4, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], device=dev, dtype=torch.int32)).sum(dim=2)
+    assert torch.equal(mask, want.to(torch.uint8))
+    rr = r if kind == 2 else None
+    p0, n0 = ops.bn_add_relu_bwd_reduce(dy, y0, u, rr, mu, mr if rr is not None else None)
+    p1, n1 = ops.bn_add_relu_bwd_reduce(dy, None, u, rr, mu, mr if rr is not None else None, mask=mask)
+    torch.cuda.synchronize()
+    assert n0 == n1 and torch.equal(p0[:, :, :3], p1[:, :, :3])
+    outs = []
+    for m in (None, mask):
+        du, dr, dz = torch.empty_like(u), (torch.empty_like(u) if rr is not None else None), torch.empty_like(u)
+        ops.bn_add_relu_bwd_apply(dy, y0 if m is None else None, u, rr, k[:3], k[3:] if rr is not None else None, du, dr, dz, mask=m)
+        outs.append((du, dr, dz))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
 def test_block_tail_forward_backward(dev):
     """y = relu(bn2(u) + bn_r(r)) and its backward (reductions, coefficients, apply)."""
     from sar_amd import ops
