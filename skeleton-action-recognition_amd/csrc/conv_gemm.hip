@@ -296,6 +296,11 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
         else acc[ms][ns][r] = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
       }
     }
+  // The bias rows live in buffer 1, which the FIRST wave to finish stage 0 overwrites: every wave must have read them before
+  // any wave gets there.  (Without this barrier a wave that the SIMD arbitration held back for a whole MFMA phase initialised
+  // its accumulators from the next stage's weights: one wrong tile in ~1 of 1 000 launches, found by tools/trace_divergence.py
+  // in round 3 -- the fp32 step was not repeatable in 1-4 % of its runs, in round 2 as well.)
+  __syncthreads();
   // one main-loop stage on LDS buffer IT (compile-time, so every LDS address is register + immediate)
   auto stage = [&](int c0, auto IT) {
     constexpr int it = decltype(IT)::value;

@@ -20,17 +20,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--modes", default="fp32,bf16")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    x, y = synthetic_clips(a.batch, dev, seed=3, num_classes=60)
-    bad = 0
-    for mode in ("fp32", "bf16"):
-        eng = STGCN(num_classes=60, device=dev, seed=0, mfma=mode)
+    total_bad = 0
+    for mode in a.modes.split(","):
+        bad = 0
+        if mode == "resnet":      # Path B's classifier at its bench shape (bs 32, 256 x 256 spectrograms)
+            from sar_amd.resnet import ResNet18
+            eng = ResNet18(num_classes=60, num_filters=64, device=dev, seed=0)
+            g = torch.Generator(device=dev).manual_seed(5)
+            x, y = torch.randn((32, 1, 256, 256), generator=g, device=dev), torch.randint(0, 60, (32,), generator=g, device=dev)
+        elif mode == "stgin":
+            from sar_amd.stgin import STGIN
+            eng = STGIN(num_classes=60, device=dev, seed=0)
+            x, y = synthetic_clips(a.batch, dev, seed=3, num_classes=60)
+        else:
+            eng = STGCN(num_classes=60, device=dev, seed=0, mfma=mode)
+            x, y = synthetic_clips(a.batch, dev, seed=3, num_classes=60)
         state = {k: v.clone() for k, v in eng.state_dict().items()}
         ref = None
         for r in range(a.reps):
             eng.load_params(state)
-            logits, loss = eng.loss_and_grad(x, y)
+            logits, loss = eng.loss_and_grad(x, y)[:2]
             torch.cuda.synchronize()
             cur = (logits.clone(), loss.clone(), eng.grad.clone())
             if ref is None:
@@ -40,9 +52,19 @@ def main():
                 if not same:
                     bad += 1
                     d = (ref[2] - cur[2]).abs().max().item()
-                    print("%s rep %d: MISMATCH (max |grad diff| %.3e)" % (mode, r, d))
-        print("%s: %d repetitions, loss %.6f, %s" % (mode, a.reps, ref[1].item(), "bitwise identical" if bad == 0 else "NOT deterministic"))
-    sys.exit(1 if bad else 0)
+                    names = []
+                    for k in eng.shapes:      # which tensors differ
+                        o, n = eng.offsets[k], 1
+                        for v in eng.shapes[k]:
+                            n *= v
+                        dk = (ref[2][o:o + n] - cur[2][o:o + n]).abs().max().item()
+                        if dk > 0:
+                            names.append("%s %.2e" % (k, dk))
+                    print("%s rep %d: MISMATCH (max |grad diff| %.3e; logits equal %s) %s" %
+                          (mode, r, d, torch.equal(ref[0], cur[0]), ", ".join(names[:12]) + (" ... %d tensors" % len(names) if len(names) > 12 else "")))
+        print("%s: %d repetitions, loss %.6f, %s" % (mode, a.reps, ref[1].item(), "bitwise identical" if bad == 0 else "NOT deterministic (%d)" % bad))
+        total_bad += bad
+    sys.exit(1 if total_bad else 0)
 
 
 if __name__ == "__main__":
