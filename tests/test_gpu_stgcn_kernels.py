@@ -105,6 +105,7 @@ def test_residual_conv_forward(dev, B, cin, f, T, s):
 
 
 @pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (3, 3, 64, 9), (4, 256, 256, 75),
+                                       (2, 3, 40, 5), (1, 2, 72, 4), (5, 3, 64, 300), (2, 4, 100, 7),
                                        (2, 40, 72, 9), (1, 72, 200, 5), (2, 44, 40, 6)])
 def test_graph_conv_gradients(dev, B, cin, f, T):
     """data gradient (A^T gather lists + W^T) and weight/bias gradients of GraphConvTD."""
