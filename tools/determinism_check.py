@@ -35,6 +35,11 @@ def main():
             from sar_amd.stgin import STGIN
             eng = STGIN(num_classes=60, device=dev, seed=0)
             x, y = synthetic_clips(a.batch, dev, seed=3, num_classes=60)
+        elif mode in ("dense", "bone_motion"):     # trainable adjacency (dense contraction kernels) / bone + motion input streams
+            from sar_amd.bone import NTU_BONE_PAIRS
+            kw = dict(trainable_adjacency=True) if mode == "dense" else dict(bone_pairs=NTU_BONE_PAIRS, motion=True)
+            eng = STGCN(num_classes=60, device=dev, seed=0, mfma="fp32", **kw)
+            x, y = synthetic_clips(a.batch, dev, seed=3, num_classes=60)
         else:
             eng = STGCN(num_classes=60, device=dev, seed=0, mfma=mode)
             x, y = synthetic_clips(a.batch, dev, seed=3, num_classes=60)
