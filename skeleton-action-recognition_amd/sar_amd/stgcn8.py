@@ -113,6 +113,8 @@ def backward(eng, dlogits):
     ops8.pool_bwd(dfeat, c_last, B, sv["T_last"] * V, M, dY)
     for i in reversed(range(len(eng.blocks))):
         dY = _block_backward(eng, i, sv["blocks"][i], dY, B)
+        if getattr(eng, "_deferred", None):
+            eng._flush_deferred()
     # data_bn gamma / beta need the input gradient of block 0 (the input itself needs none)
     x = sv["x"]
     nch = V * eng.C_in
