@@ -25,6 +25,11 @@ for _p in (ROOT, os.path.join(ROOT, "skeleton-action-recognition_amd")):
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
 BYTES_PER_CLIP_TRAIN_BF16 = 427.3e6   # block-fused algorithmic HBM traffic per clip and train step, bf16 storage
+# What the build EXECUTES per clip and train step: SURVEY's 102.56 GFLOP prices the dense 'nkctv,kvw->nctw' einsum (432
+# MMAC / sequence); the kernels apply the 73 non-zeros of A on the Cin side (16.8 MMAC / sequence), so the executed, useful work is
+# (1 939.7 + 16.8 + 6 082.6 + 92.2) MMAC / sequence x 2 sequences x 2 FLOP x 3 (fwd + data grad + weight grad) = 97.58 GFLOP.
+EXECUTED_FLOP_PER_CLIP_TRAIN = (1939.7 + 16.8 + 6082.6 + 92.2) * 1e6 * 2 * 2 * 3
+PEAK_FP64_VALU_TFLOPS = 78.6       # MI355X: packed-free fp64 vector FMA, half the fp32 vector rate of MI355X_MICROARCH.md (157.3 TF)
 
 
 FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<"),
@@ -71,17 +76,17 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(batch=64, fallback_clips=8, budget_s=150.0):
-    """SURVEY.md 8(d) protocol: the CPU oracle (oracle/stgcn.py: torch CPU ops, fp32) -- fwd + bwd + Nesterov SGD -- on
-    the bs = `batch` synthetic batch, all physical cores.  One short warm-up step on `fallback_clips` clips (thread pool,
-    allocator) also predicts the cost of a full-batch step: if one would not fit `budget_s`, the small batch is timed
-    instead and the sample string says so.  Otherwise 1 untimed + up to 2 timed full-batch steps (the second only while
-    inside the budget).  The oracle is used here ONLY as the reported CPU baseline."""
+def cpu_baseline(batch=64, fallback_clips=8, budget_s=80.0, classes=60):
+    """The CPU oracle (oracle/stgcn.py: torch CPU ops, fp32) -- fwd + bwd + Nesterov SGD -- on the bs = `batch` synthetic batch,
+    all physical cores.  A BOUNDED sample: two short steps on `fallback_clips` clips (thread pool / allocator warm-up; the
+    second predicts the cost of a full-batch step), then ONE timed full-batch step when it is predicted to fit `budget_s`
+    (the GPU box's 128 cores take ~55 s for it), else up to 5 timed small-batch steps; the sample string says which.  (Rounds
+    1-3 timed 1 + 2 full-batch steps: 165 s of a 190 s bench run.)  The oracle is used here ONLY as the reported CPU baseline."""
     import torch
     from oracle import stgcn as O
     cores = physical_cores()
     torch.set_num_threads(cores)
-    p = O.init_params(60, seed=0)
+    p = O.init_params(classes, seed=0)
     vel = {}
 
     def one(x, y):
@@ -89,22 +94,17 @@ def cpu_baseline(batch=64, fallback_clips=8, budget_s=150.0):
         O.sgd_nesterov_step(p, grads, vel, 0.1)
         p.update(new)
 
-    xs, ys = O.synthetic_batch(fallback_clips, seed=0, T=300, num_classes=60)
+    xs, ys = O.synthetic_batch(fallback_clips, seed=0, T=300, num_classes=classes)
     one(xs, ys)                            # thread-pool / allocator warm-up
     t0 = time.time()
     one(xs, ys)
     small_rate = fallback_clips / (time.time() - t0)
-    full = batch / small_rate * 3 <= budget_s * 1.5          # 1 warm-up + 2 timed steps predicted to fit
-    if full:
-        x, y = O.synthetic_batch(batch, seed=0, T=300, num_classes=60)
-        one(x, y)                          # untimed
+    if 0.75 * batch / small_rate <= budget_s:     # a full batch runs ~1.4x the small batch's rate (better core utilisation)
+        x, y = O.synthetic_batch(batch, seed=0, T=300, num_classes=classes)
         t0 = time.time()
-        n = 0
-        while n < 2 and (n == 0 or time.time() - t0 < budget_s / 2):
-            one(x, y)
-            n += 1
-        dt = time.time() - t0
-        clips, what = batch, "SURVEY 8(d) protocol: 1 warm-up + %d timed steps" % n
+        one(x, y)
+        dt, n = time.time() - t0, 1
+        clips, what = batch, "2 warm-up steps on %d clips + 1 timed full-batch step" % fallback_clips
     else:
         t0 = time.time()
         n = 0
@@ -118,9 +118,10 @@ def cpu_baseline(batch=64, fallback_clips=8, budget_s=150.0):
                       % (what, clips, cores)}
 
 
-def cpu_baseline_spectrogram(sample_clips, budget_s=25.0):
-    """The CPU oracle of Path B (oracle/radar.py numpy + oracle/resnet.py torch CPU ops): spectrogram, resnet18
-    fwd + bwd, Adam -- as the reported CPU baseline only."""
+def cpu_baseline_spectrogram(sample_clips, budget_s=12.0, num_pad_frames=0):
+    """The CPU oracle of Path B (oracle/radar.py numpy + oracle/resnet.py torch CPU ops): [the loader's up-sampling,
+    utils.py:134-140 restated in oracle/radar.py:pad_frames, when num_pad_frames > 0,] spectrogram, resnet18 fwd + bwd, Adam
+    -- as the reported CPU baseline only."""
     import numpy as np
     import torch
     from oracle import radar as RO
@@ -131,11 +132,15 @@ def cpu_baseline_spectrogram(sample_clips, budget_s=25.0):
     g = torch.Generator().manual_seed(0)
     x = (0.12 * torch.randn((sample_clips, 3, 300, 25, 2), generator=g)).clamp_(-1.1, 0.75)
     y = torch.randint(0, 60, (sample_clips,), generator=g)
-    cols = RO.nearest_columns(300 // 16 + 1, 256)
+    T = 300 * num_pad_frames if num_pad_frames else 300
+    cols = RO.nearest_columns(T // 16 + 1, 256)
     state = {}
 
     def one():
-        spec = RO.virtual_radar(x.numpy(), wavelength=5e-4)
+        xin = x.numpy()
+        if num_pad_frames:       # the reference's loader step, per clip (utils.py:134-140)
+            xin = np.stack([RO.pad_frames(c, num_pad_frames) for c in xin])
+        spec = RO.virtual_radar(xin, wavelength=5e-4)
         img = torch.from_numpy(np.ascontiguousarray(spec[:, :, cols]))[:, None]
         _, _, grads, new, _ = RN.loss_and_grads(p, img, y)
         RN.adam_step(p, grads, state, 1e-3)
@@ -151,8 +156,9 @@ def cpu_baseline_spectrogram(sample_clips, budget_s=25.0):
             break
     dt = time.time() - t0
     return {"value": round(sample_clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
-            "sample": "%d timed steps of VirtualRadar + resnet18 fwd+bwd+Adam on %d (3,300,25,2) clips, numpy / torch CPU ops, "
-                      "%d threads" % (n, sample_clips, cores)}
+            "sample": "%d timed steps of %sVirtualRadar + resnet18 fwd+bwd+Adam on %d (3,300,25,2) clips, numpy / scipy / torch CPU "
+                      "ops, %d threads" % (n, "the loader's x%d up-sampling + " % num_pad_frames if num_pad_frames else "",
+                                           sample_clips, cores)}
 
 
 def launch_ranks(n):
@@ -181,8 +187,17 @@ def rank_setup(args):
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    rank, world = init_distributed(dev, backend="gloo" if share else "nccl")
+    rank, world = init_distributed(dev, backend="gloo" if share else "nccl")    # SAR_FORCE_DDP=1: also for ONE rank
     return rank, world, dev
+
+
+def dist_info():
+    """what the line reports about the LIVE communicator (not about the arguments)"""
+    import torch.distributed as dist
+    from sar_amd.train import force_ddp
+    live = dist.is_available() and dist.is_initialized()
+    return {"rccl_ranks": dist.get_world_size() if live else 1, "dist_backend": dist.get_backend() if live else None,
+            "forced_ddp": bool(force_ddp() and live)}
 
 
 def gather_over_ranks(value, dev):
@@ -210,8 +225,9 @@ class Leg:
     def sync(self):
         import torch
         import torch.distributed as dist
+        from sar_amd.train import ddp_active
         torch.cuda.synchronize()
-        if self.world > 1:
+        if ddp_active():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -260,7 +276,8 @@ class Leg:
                 "allreduce_ms": None if comm_ms is None else round(comm_ms, 4), "warm_s": round(warm_done, 2), "last": last}
 
 
-def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolated_pass, first_run=False, instrument_steps=0):
+def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolated_pass, first_run=False, instrument_steps=0,
+              classes=None, stream="joint", sustained_steps=0):
     """ST-GCN train step (main_gnn.py:219-239) in one arithmetic mode; returns the result dict of rank 0 (None elsewhere).
     instrument_steps = 0: the per-kernel HIP events are recorded inside the timed region (the headline leg, as in every
     round); > 0: the timed region runs bare and that many extra steps are instrumented afterwards (long secondary legs:
@@ -270,10 +287,15 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
     from sar_amd import profiler
     from sar_amd.stgcn import STGCN
     from sar_amd.train import Trainer, synthetic_clips
-    eng = STGCN(num_classes=args.classes, device=dev, seed=0, mfma=mfma)  # identical init on every rank
+    classes = classes or args.classes
+    bone = None
+    if stream == "bone":       # data_gen/gen_bone_data.py:7-41, applied on the fly in the data_bn prologue (config 5's second stream)
+        from sar_amd.bone import NTU_BONE_PAIRS
+        bone = NTU_BONE_PAIRS
+    eng = STGCN(num_classes=classes, device=dev, seed=0, mfma=mfma, bone_pairs=bone)  # identical init on every rank
     trainer = Trainer(eng, batch_size=args.batch, world_size=world)
     nb = 4     # a few distinct batches resident in HBM, cycled (per-rank seeds: each rank trains on its own shard)
-    batches = [synthetic_clips(args.batch, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(nb)]
+    batches = [synthetic_clips(args.batch, dev, seed=1000 * rank + i, num_classes=classes) for i in range(nb)]
     leg = Leg(world, dev)
 
     def step(i):
@@ -301,6 +323,11 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
     dt = res["dt"]
     loss_val = float(res["last"].item())
     assert loss_val == loss_val, "loss is NaN"
+    sustained = None
+    if sustained_steps > 0:      # the same protocol over a longer region, right behind the contract's K steps (bare: no per-kernel events)
+        r2 = leg.run(step, sustained_steps, 0, 0.0, None)
+        sustained = {"steps": sustained_steps, "value": round(args.batch * world * sustained_steps / r2["dt"], 2),
+                     "ms_per_step": round(r2["dt"] / sustained_steps * 1e3, 3)}
     # The timed region is the production schedule: weight-gradient kernels run on a second stream and overlap the main
     # chain, which inflates the HIP-event duration of whatever they overlap.  A short untimed pass with that stream off
     # measures the dominant family in isolation (kernel quality); both are reported.
@@ -339,12 +366,15 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
                    (", weight-gradient kernels running concurrently on a second stream (inflates the bracketed time; "
                     "roofline.isolated = the same kernels alone)" if overl else ", single stream"))
         out = {
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, **dist_info(),
+            "grad_buckets": trainer.buckets_last_step,
             "steps": steps, "warmup": warmup, "warm_s": res["warm_s"],
             "ms_per_step": round(dt / steps * 1e3, 3), "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"],
             "dtype": "bf16" if bf16 else "f32",
             "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
-                                   "(3,300,25,2), %d classes, bs=%d/GPU" % (desc, args.classes, args.batch),
+                                   "(3,300,25,2)%s, %d classes, bs=%d/GPU"
+                                   % (desc, " as the BONE stream (joint -> bone in the data_bn prologue)" if bone else "", classes,
+                                      args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches); " + in_step,
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -353,11 +383,16 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
                                          if traffic else None,
                          "algorithmic_bytes_per_launch": int(sum(summ[k]["bytes"] for k in fam) / max(calls, 1)),
                          "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
-                         "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
+                         "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                         # the same step priced on the FLOPs the kernels execute (the dense 432-MMAC einsum is never executed)
+                         "step_frac_executed_flops": round(value / world * EXECUTED_FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
+            "executed_flops_per_clip": EXECUTED_FLOP_PER_CLIP_TRAIN, "survey_flops_per_clip": FLOP_PER_CLIP_TRAIN,
             "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),
         }
         if first is not None:
             out["first_run_value"] = round(first, 2)
+        if sustained is not None:
+            out["sustained"] = sustained
         if iso is not None:
             ims = sum(iso[k]["ms"] for k in fam if k in iso)
             ifl = sum(iso[k]["flops"] for k in fam if k in iso)
@@ -393,7 +428,7 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
     return out                   #  hipMalloc for every tensor of its first steps)
 
 
-def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrument_steps=0):
+def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrument_steps=0, num_pad_frames=None):
     """Path B: VirtualRadar (signal + STFT/log-magnitude/column select) -> resnet18 fwd+bwd -> Adam; bs = --batch per GPU
     (configs[3] uses 32)."""
     import torch
@@ -402,7 +437,8 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
     from sar_amd.train import SpectrogramTrainer, synthetic_clips
     from models.resnet import Model
     bs = 32 if args.batch == 64 else args.batch
-    model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=args.num_pad_frames)
+    pad = args.num_pad_frames if num_pad_frames is None else num_pad_frames
+    model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=pad)
     trainer = SpectrogramTrainer(model, 1e-3, world_size=world)      # the product step of main_spectrogram.py
     batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
     leg = Leg(world, dev)
@@ -449,18 +485,18 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
         calls = sum(summ[k]["calls"] for k in fam)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         value = bs * world * steps / dt
-        traffic, traffic_src = measured_traffic("pathB") if not args.num_pad_frames else (None, None)
+        traffic, traffic_src = measured_traffic("pathB") if not pad else (None, None)
         out = {
             "metric": "spectrogram clips/sec training (VirtualRadar + resnet18, bs=%d/GPU)" % bs,
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, **dist_info(),
             "steps": steps, "warmup": warmup, "warm_s": warm_s,
             "ms_per_step": round(dt / steps * 1e3, 3), "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VirtualRadar -> (B,1,256,256) log-spectrogram -> resnet18 fp32 training step (fwd+bwd+Adam), "
                                    "synthetic NTU clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
-                                   % (" up-sampled x%d on the GPU" % args.num_pad_frames if args.num_pad_frames else "",
-                                      args.classes, bs),
+                                   % (" up-sampled x%d on the GPU (the reference loader's default, utils.py:105,134-140)" % pad
+                                      if pad else "", args.classes, bs),
                        "global_batch": bs * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches); IN-STEP "
                                                     "figure: HIP events over the timed region, weight-gradient kernels on a second stream",
@@ -475,6 +511,27 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
             "final_loss": round(float(loss.item()), 5),
         }
+        if pad:
+            # The front end that only this variant has: per-clip smoothing + spline pieces, then the radar signal of 300 x pad
+            # frames with every frame's 150 coordinates evaluated from the cubic pieces in float64.  Its binding unit is the
+            # vector ALU: 48 (edge, body) terms per frame, each with IEEE square roots / divisions and an accurately reduced
+            # sin / cos of a ~1e5 rad phase; the float64 spline evaluation is 450 DFMA per frame beside it.
+            sig, prep = summ.get("radar_signal_upsampled"), summ.get("radar_upsample_prepare")
+            if sig and sig["ms"] > 0:
+                frames = bs * 300 * pad
+                terms = frames * 24 * 2
+                per = sig["ms"] / sig["calls"]
+                out["radar_roofline"] = {
+                    "bound": "valu", "kernel": "vr_signal_kernel<SPLINE> (+ upsample_prepare_kernel)",
+                    "avg_launch_ms": round(per, 4),
+                    "prepare_avg_launch_ms": round(prep["ms"] / prep["calls"], 4) if prep and prep["calls"] else None,
+                    "achieved": round(terms / (per * 1e-3) / 1e9, 2), "unit": "G (edge, body) terms/s",
+                    "spline_f64_tflops": round(sig["flops"] / sig["calls"] / (per * 1e-3) / 1e12, 3),
+                    "peak_f64_valu_tflops": PEAK_FP64_VALU_TFLOPS,
+                    "frac_of_f64_valu_peak": round(sig["flops"] / sig["calls"] / (per * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 4),
+                    "share_of_step": round((per + (prep["ms"] / prep["calls"] if prep and prep["calls"] else 0.0)) / (dt / steps * 1e3), 4),
+                    "note": "the float64 spline evaluation uses a few per cent of the fp64 vector peak: the kernel is bound by its "
+                            "fp32 transcendental / IEEE-division VALU work, see profiles/r04_pathB_pad250_* (SQ_INSTS_VALU)"}
     del trainer, model, batches
     return out
 
@@ -487,7 +544,7 @@ def slim(leg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU (reference --batch-size)")
     ap.add_argument("--classes", type=int, default=60)
@@ -503,13 +560,23 @@ def main():
     ap.add_argument("--no-isolated-pass", action="store_true",
                     help="skip the 3 extra untimed steps that measure the dominant kernel family with the side stream off "
                          "(profile runs: keeps the launch counts at warmup + steps)")
-    ap.add_argument("--no-secondary", action="store_true",
-                    help="headline line only (profile runs); by default the fp32 headline is followed, in the same process, by "
-                         "~2 s each of configs[2] (--mfma bf16, after >= 3 s of untimed load) and configs[3] (Path B), reported "
-                         "under 'secondary'")
-    ap.add_argument("--warm-seconds", type=float, default=0.0,
-                    help="untimed load before the timed steps of the selected workload (the bf16 step's clocks settle after the "
-                         "first second of load; the secondary bf16 leg always uses 3 s)")
+    ap.add_argument("--no-secondary", action="store_true", help="headline line only (profile runs)")
+    ap.add_argument("--secondary", default="bf16,pathB,pathB_pad250,config5",
+                    help="comma list of the secondary legs run in the same process BEFORE the fp32 headline and reported under "
+                         "'secondary': bf16 = configs[2] (sustained: >= 3 s of untimed load first), pathB = configs[3], pathB_pad250 = "
+                         "configs[3] on the reference loader's real input (x250 up-sampling on the GPU), config5 = configs[4] (120 "
+                         "classes, bone stream)")
+    ap.add_argument("--quick", action="store_true", help="tests: secondary legs of a few steps without warm-up seconds")
+    ap.add_argument("--stream", default="joint", choices=["joint", "bone"],
+                    help="input stream of the stgcn workload (bone = data_gen/gen_bone_data.py on the fly; config 5 = --classes 120 "
+                         "--stream bone)")
+    ap.add_argument("--sustained-steps", type=int, default=100,
+                    help="fp32 headline: after the K timed steps of the contract, time this many more with the same protocol and report "
+                         "them as 'sustained' (0 = off; skipped when K is already >= this)")
+    ap.add_argument("--warm-seconds", type=float, default=3.0,
+                    help="untimed load in front of the timed steps of the selected workload, in EVERY mode (with or without secondary "
+                         "legs the headline is timed on a GPU that has been under its own load for this long: a cold first process "
+                         "measures ~4 %% low, profiles/r03_fp32_first_process.txt; the time really spent is reported as warm_s)")
     ap.add_argument("--cpu-sample", type=int, default=8,
                     help="clips in the CPU-baseline fallback batch (used only when a full --batch step does not fit the budget)")
     args = ap.parse_args()
@@ -518,23 +585,51 @@ def main():
 
     import torch.distributed as dist
     rank, world, dev = rank_setup(args)
+    cpu_ok = rank == 0 and world == 1 and not args.no_cpu_baseline
     if args.workload == "spectrogram":
         out = spectrogram_leg(args, args.steps, args.warmup, args.warm_seconds, rank, world, dev)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_spectrogram(4)
+        if cpu_ok:
+            out["cpu_baseline"] = cpu_baseline_spectrogram(2 if args.num_pad_frames else 4, num_pad_frames=args.num_pad_frames)
     else:
         sec = None
-        if args.mfma == "fp32" and not args.no_secondary:
-            # configs[2] and configs[3] in the same process, driver-timed with the headline.  bf16: the
-            # SUSTAINED rate (>= 3 s of untimed load first) is `value`; the cold-GPU rate of a short run is first_run_value.
-            # They run BEFORE the headline leg: the first process on a fresh box measures 4 % low for its first seconds
-            # (1 029 vs 1 071-1 074 clips/s for three bench.py invocations in a row, profiles/r03_fp32_first_process.txt), and
-            # the number a training job sees is the one of a GPU that has been under load.
-            b = stgcn_leg(args, "bf16", 120, 3, 3.0, rank, world, dev, False, first_run=True, instrument_steps=5)
-            p = spectrogram_leg(args, 250, 5, 1.0, rank, world, dev, instrument_steps=5)
-            if rank == 0:
-                sec = {"bf16": slim(b), "pathB": slim(p)}
-        head = stgcn_leg(args, args.mfma, args.steps, args.warmup, args.warm_seconds, rank, world, dev, not args.no_isolated_pass)
+        names = [] if args.no_secondary or args.mfma != "fp32" or args.stream != "joint" else [n for n in args.secondary.split(",") if n]
+        if names:
+            # The other BASELINE configs in the same process, driver-timed with the headline.  bf16: the SUSTAINED rate (>= 3 s of
+            # untimed load first) is `value`; the cold-GPU rate of a short run is first_run_value.  They run BEFORE the headline
+            # leg; the headline has its own --warm-seconds of load either way, so its thermal state does not depend on them.
+            q = args.quick
+            sec = {}
+            for n in names:
+                if n == "bf16":
+                    r = stgcn_leg(args, "bf16", 4 if q else 150, 3, 0.0 if q else 3.0, rank, world, dev, False, first_run=not q,
+                                  instrument_steps=2 if q else 5)
+                elif n == "pathB":
+                    r = spectrogram_leg(args, 4 if q else 250, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
+                                        num_pad_frames=0)
+                    if r is not None and cpu_ok and not q:
+                        r["cpu_baseline"] = cpu_baseline_spectrogram(4)
+                elif n == "pathB_pad250":
+                    r = spectrogram_leg(args, 4 if q else 120, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
+                                        num_pad_frames=250)
+                    if r is not None and cpu_ok and not q:
+                        r["cpu_baseline"] = cpu_baseline_spectrogram(2, budget_s=8.0, num_pad_frames=250)
+                elif n == "config5":
+                    # configs[4]: two independently trained ST-GCNs (joint, bone), 120 classes.  The joint stream differs from the
+                    # headline only by the 120-class head; the leg times the BONE stream (joint -> bone fused into the data_bn
+                    # prologue) in the reference's precision, and the bf16 engine on the same stream beside it.
+                    r = stgcn_leg(args, "fp32", 4 if q else 30, 3, 0.0 if q else 1.0, rank, world, dev, False, classes=120, stream="bone",
+                                  instrument_steps=2 if q else 3)
+                    rb = stgcn_leg(args, "bf16", 4 if q else 100, 3, 0.0 if q else 2.0, rank, world, dev, False, classes=120,
+                                   stream="bone", instrument_steps=2 if q else 3)
+                    if r is not None:
+                        r["bf16"] = {k: rb[k] for k in ("value", "ms_per_step", "warm_s", "steps", "dtype", "per_rank_ms", "allreduce_ms")}
+                else:
+                    raise SystemExit("unknown secondary leg %r" % n)
+                if rank == 0:
+                    sec[n] = slim(r)
+        sust = args.sustained_steps if args.steps < args.sustained_steps else 0
+        head = stgcn_leg(args, args.mfma, args.steps, args.warmup, args.warm_seconds, rank, world, dev, not args.no_isolated_pass,
+                         stream=args.stream, sustained_steps=sust)
         out = None
         if rank == 0:
             out = {"metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)", "value": head["value"], "unit": "clips/s",
@@ -542,11 +637,12 @@ def main():
                    "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                    "dtype": head["dtype"], "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
             out.update({k: v for k, v in head.items() if k not in out})
-            if sec is not None:
+            if sec:
                 out["secondary"] = sec
-                out["legs_order"] = "secondary legs (bf16, Path B) first, the headline leg last, each with its own warm-up and timed steps"
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample)
+                out["legs_order"] = ("secondary legs (%s) first, the headline leg last; every leg has its own warm-up, untimed load "
+                                     "(warm_s) and timed steps" % ", ".join(names))
+        if cpu_ok:
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample, classes=args.classes)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from sar_amd import _lib as L
+from sar_amd import profiler
 from sar_amd._lib import check, ptr, stream_ptr
 
 # layers/virtual_radar.py:10-13: the skeleton's bones without the hand-tip / thumb / foot-tip stubs the reference
@@ -180,8 +181,10 @@ class VirtualRadar(torch.nn.Module):
         w_dev = torch.from_numpy(w).to(x.device)
         ws = torch.empty(lib.sar_upsample_workspace_bytes(B, T, V, M), dtype=torch.uint8, device=x.device)
         coef = torch.empty(lib.sar_upsample_coef_doubles(B, T, V, M), dtype=torch.float64, device=x.device)
-        check(lib.sar_upsample_prepare_f64(ptr(x), B, T, V, M, ptr(w_dev), radius, ptr(ws), ptr(coef), stream_ptr()),
-              "sar_upsample_prepare_f64")
+        # algorithmic float64 work: (2 radius + 1)-tap smoothing + ~8 T flops of the tridiagonal solve per series
+        with profiler.region("radar_upsample_prepare", B * 3.0 * V * M * T * (2.0 * (2 * radius + 1) + 8.0)):
+            check(lib.sar_upsample_prepare_f64(ptr(x), B, T, V, M, ptr(w_dev), radius, ptr(ws), ptr(coef), stream_ptr()),
+                  "sar_upsample_prepare_f64")
         return coef
 
     def signal(self, x, num_pad_frames=0, coef=None, sigma=3):
@@ -195,10 +198,12 @@ class VirtualRadar(torch.nn.Module):
         zi = torch.empty_like(zr)
         if num_pad_frames:
             coef = coef if coef is not None else self.spline_pieces(x, sigma)
-            check(L.load().sar_vr_signal_upsampled_f32(ptr(coef), B, T, num_pad_frames, V, M, ptr(self._src), ptr(self._dst),
-                                                       len(self.src), ptr(self.radar_location.data),
-                                                       ptr(self.wavelength.data.reshape(1)), ptr(zr), ptr(zi), stream_ptr()),
-                  "sar_vr_signal_upsampled_f32")
+            # float64 work of the on-the-fly up-sampling: one cubic (3 DFMA) per coordinate and up-sampled frame
+            with profiler.region("radar_signal_upsampled", 6.0 * B * Tz * 3 * V * M):
+                check(L.load().sar_vr_signal_upsampled_f32(ptr(coef), B, T, num_pad_frames, V, M, ptr(self._src), ptr(self._dst),
+                                                           len(self.src), ptr(self.radar_location.data),
+                                                           ptr(self.wavelength.data.reshape(1)), ptr(zr), ptr(zi), stream_ptr()),
+                      "sar_vr_signal_upsampled_f32")
         else:
             check(L.load().sar_vr_signal_f32(ptr(x), B, T, V, M, ptr(self._src), ptr(self._dst), len(self.src),
                                              ptr(self.radar_location.data), ptr(self.wavelength.data.reshape(1)), ptr(zr),

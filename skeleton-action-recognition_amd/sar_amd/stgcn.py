@@ -205,6 +205,61 @@ class STGCN:
                 self.bn["l%d.res_bn" % i] = _BN(f, dev)
         self._init_params(seed)
         self._saved = None
+        self._deferred, self._flushing = [], False
+        self._buckets = self._make_buckets(total)
+
+    # ------------------------------------------------------------------ gradient buckets (data-parallel exchange)
+    def _make_buckets(self, total):
+        """Contiguous slices of the flat gradient buffer in the order backward() completes them (main_gnn.py:234,239: the
+        all-reduce inside apply_gradients).  Parameters are laid out data_bn, l0 .. l9, logits(, adjacency_matrix); backward
+        produces logits, l9 .. l0, data_bn(, adjacency): bucket 0 = [first block of the last stage .. logits], one bucket per
+        earlier stage boundary (a stride-2 block), the last bucket = [data_bn .. end of the first stage]; a trainable
+        adjacency is summed over the blocks at the very end and forms its own slice.  Each entry: (block index after whose
+        backward the slice is complete, or -1 = at the end of backward; lo; hi)."""
+        nb = len(self.blocks)
+        starts = [i for i, (f, s, res) in enumerate(self.blocks) if s != 1 and i > 0]     # a new stage begins here
+        hi = self.offsets.get("adjacency_matrix", total)
+        out = []
+        for i in reversed(starts):
+            lo = min(o for k, o in self.offsets.items() if k.startswith("l%d." % i))
+            if lo < hi:
+                out.append((i, lo, hi))
+                hi = lo
+        out.append((-1, 0, hi))
+        if "adjacency_matrix" in self.offsets:
+            out.append((-1, self.offsets["adjacency_matrix"], total))
+        assert sum(h - l for _, l, h in out) == total and nb > 0
+        return out
+
+    def _bucket_done(self, bi, cb):
+        """Every gradient of bucket bi has been ISSUED: weight gradients on the side stream, BatchNorm / bias gradients on the
+        main stream.  cb(bi, flat slice, events) may start the slice's all-reduce once the events have completed."""
+        _, lo, hi = self._buckets[bi]
+        events = []
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            events.append(ev)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        events.append(ev)
+        cb(bi, self.grad[lo:hi], events)
+
+    def _buckets_after_block(self, i, cb):
+        if cb is not None:
+            for bi, (blk, _, _) in enumerate(self._buckets):
+                if blk == i:
+                    self._bucket_done(bi, cb)
+
+    def _finish_backward(self, cb):
+        """common tail of backward(): nothing deferred is left behind, the side stream is joined, the remaining buckets go"""
+        if self._deferred:
+            self._flush_deferred()
+        if cb is not None:
+            self._buckets_after_block(-1, cb)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)      # every weight gradient is in self.grad
+        self._saved = None
 
     # ------------------------------------------------------------------ parameters
     def _add(self, name, shape):
@@ -379,8 +434,8 @@ class STGCN:
         if self._side is None:
             fn()
             return
-        if self._wgrad_defer() and not getattr(self, "_flushing", False):   # see _WGRAD_DEFER_ENV above
-            self.__dict__.setdefault("_deferred", []).append((fn, tensors))
+        if self._wgrad_defer() and not self._flushing:   # see _WGRAD_DEFER_ENV above
+            self._deferred.append((fn, tensors))
             return
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
@@ -394,17 +449,20 @@ class STGCN:
         return (not self.cn8) if _WGRAD_DEFER_ENV is None else _WGRAD_DEFER_ENV == "1"
 
     def _flush_deferred(self):
-        q, self._deferred = getattr(self, "_deferred", []), []
+        q, self._deferred = self._deferred, []
         self._flushing = True
-        for fn, tensors in q:
-            self._off_critical_path(fn, *tensors)
-        self._flushing = False
+        try:
+            for fn, tensors in q:
+                self._off_critical_path(fn, *tensors)
+        finally:
+            self._flushing = False
 
-    def backward(self, dlogits):
-        """dlogits (N, classes) -> fills self.grad (every trainable parameter).  main_gnn.py:233."""
+    def backward(self, dlogits, bucket_cb=None):
+        """dlogits (N, classes) -> fills self.grad (every trainable parameter).  main_gnn.py:233.  bucket_cb: see
+        _bucket_done (the data-parallel exchange starts per bucket while backward is still running)."""
         if self.cn8:
             from . import stgcn8
-            return stgcn8.backward(self, dlogits)
+            return stgcn8.backward(self, dlogits, bucket_cb)
         sv = self._saved
         assert sv is not None, "backward() needs a preceding forward(training=True)"
         dev, V = dlogits.device, self.V
@@ -423,8 +481,9 @@ class STGCN:
             self._dA_layers = torch.zeros((len(self.blocks), KS * V * V), dtype=torch.float32, device=dev)
         for i in reversed(range(len(self.blocks))):
             dY = self._block_backward(i, sv["blocks"][i], dY, B)
-            if getattr(self, "_deferred", None):
+            if self._deferred:
                 self._flush_deferred()
+            self._buckets_after_block(i, bucket_cb)
         if self.dense_A:       # the adjacency is shared by all blocks: dA = sum over the layers (fixed order); zero while frozen
             n = KS * V * V
             ops.check(L.load().sar_slab_reduce_f32(ops.ptr(self._dA_layers), len(self.blocks), n, n,
@@ -438,9 +497,7 @@ class STGCN:
         ops.data_bn_bwd_reduce(x, self.bone_parent, dY, dbn.mean, part, self.motion)
         ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, nch, N * M * sv["T"], self.p["data_bn.gamma"], dbn.mean, dbn.rstd,
                             self.g["data_bn.gamma"], self.g["data_bn.beta"])
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)      # every weight gradient is in self.grad
-        self._saved = None
+        self._finish_backward(bucket_cb)
 
     def _block_backward(self, i, sb, dY, B):
         V, dev = self.V, dY.device
@@ -559,15 +616,15 @@ class STGCN:
         return dX
 
     # ------------------------------------------------------------------ training step
-    def loss_and_grad(self, x, labels, global_batch_size=None):
-        """main_gnn.py:221-233: loss = sum CE / global_batch; gradients of every trainable variable."""
+    def loss_and_grad(self, x, labels, global_batch_size=None, bucket_cb=None):
+        """main_gnn.py:221-233: loss = sum CE / global_batch; gradients of every trainable variable.  bucket_cb: backward()."""
         logits = self.forward(x, training=True)
         N = x.shape[0]
         gbs = global_batch_size or N
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlogits = torch.empty_like(logits)
         ops.softmax_ce(logits, labels, 1.0 / gbs, loss, dlogits)
-        self.backward(dlogits)
+        self.backward(dlogits, bucket_cb)
         return logits, loss
 
     def sgd_step(self, lr, momentum=0.9):

@@ -98,7 +98,7 @@ def _block_forward(eng, i, X, cin, f, s, B, T, training, saved, keep):
     return y, To
 
 
-def backward(eng, dlogits):
+def backward(eng, dlogits, bucket_cb=None):
     sv = eng._saved
     assert sv is not None, "backward() needs a preceding forward(training=True)"
     dev, V = dlogits.device, eng.V
@@ -113,8 +113,9 @@ def backward(eng, dlogits):
     ops8.pool_bwd(dfeat, c_last, B, sv["T_last"] * V, M, dY)
     for i in reversed(range(len(eng.blocks))):
         dY = _block_backward(eng, i, sv["blocks"][i], dY, B)
-        if getattr(eng, "_deferred", None):
+        if eng._deferred:
             eng._flush_deferred()
+        eng._buckets_after_block(i, bucket_cb)
     # data_bn gamma / beta need the input gradient of block 0 (the input itself needs none)
     x = sv["x"]
     nch = V * eng.C_in
@@ -123,9 +124,7 @@ def backward(eng, dlogits):
     ops8.data_bn_bwd_reduce(x, eng.bone_parent, dY, dbn.mean, part, eng.motion)
     ops.bn_bwd_finalize(part, N, N * 2, 2, 0, 1, nch, N * M * sv["T"], eng.p["data_bn.gamma"], dbn.mean, dbn.rstd,
                         eng.g["data_bn.gamma"], eng.g["data_bn.beta"])
-    if eng._side is not None:
-        torch.cuda.current_stream().wait_stream(eng._side)
-    eng._saved = None
+    eng._finish_backward(bucket_cb)
 
 
 def _block_backward(eng, i, sb, dY, B):

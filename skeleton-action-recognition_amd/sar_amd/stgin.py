@@ -125,6 +125,8 @@ class STGIN(STGCN):
         self._zeros = torch.zeros(cmax, dtype=torch.float32, device=dev)
         self._init_params(seed)
         self._saved = None
+        self._deferred, self._flushing = [], False
+        self._buckets = self._make_buckets(total)
 
     # ------------------------------------------------------------------ parameters
     @staticmethod

@@ -3,13 +3,33 @@ tf.distribute.MirroredStrategy, main_gnn.py:257-258,295).
 
 Per step every rank runs the full forward/backward on its own `batch_size` clips with LOCAL BatchNorm
 statistics (MirroredStrategy does not sync BN), the loss is scaled by 1/global_batch (main_gnn.py:226),
-then ONE all-reduce(SUM) of the flat fp32 gradient buffer (12.3 MB for ST-GCN-60) over RCCL/xGMI and an
-identical fused Nesterov-SGD update on every rank.  The exchange is a single collective because the
-whole gradient lives in one contiguous buffer; at >= 50 ms of compute per step a 12 MB all-reduce over
-7 xGMI links (~20-140 us) needs no bucketing/overlap machinery.
+then the flat fp32 gradient buffer (12.3 MB for ST-GCN-60) is summed over RCCL/xGMI and every rank applies the
+identical fused Nesterov-SGD update.  The buffer is exchanged in three contiguous BUCKETS in the order backward
+finishes them (last stage l7-l9 + classifier = 75 % of the bytes, l4-l6 = 19 %, the rest): each bucket's all-reduce is issued
+asynchronously on a communication stream as soon as its gradients have been issued, so only the last (smallest)
+bucket's collective is exposed -- at 58 ms per fp32 step that is irrelevant, at 12 ms per bf16 step it is the
+difference between 1-2 % and ~0.3 % of the step.
+
+SAR_FORCE_DDP=1 makes a ONE-rank job take every data-parallel branch (process group on the "nccl" = RCCL backend with
+device_id, bucketed asynchronous all-reduces on the communication stream, their events and waits): the rehearsal
+of the RCCL path on a one-GPU box (tests/test_gpu_rccl.py).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def force_ddp():
+    return os.environ.get("SAR_FORCE_DDP", "0") == "1"
+
+
+def ddp_active(world_size=None):
+    """True when gradients have to be exchanged: a process group exists and it has more than one rank (or the one-rank
+    rehearsal switch is set)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or force_ddp()
 
 
 def lr_schedule(iteration, base_lr=0.1, steps=(10, 50), batch_size=64):
@@ -41,7 +61,7 @@ def allreduce_sum_(flat, group=None):
     the HIP kernels that produced it and before the optimizer kernel that consumes it (both are launched on that same
     stream, sar_amd/_lib.py:stream_ptr).  Under "gloo" (ranks that share one GPU, CPU-only rendezvous) the bucket is
     staged through host memory: the .cpu() copy synchronises with the producing stream."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_ddp()):
         if flat.is_cuda and dist.get_backend(group) == "gloo":
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -55,11 +75,18 @@ def init_distributed(device, backend=None):
     """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns
     (rank, world).  backend: "nccl" (RCCL) by default; SAR_DIST_BACKEND / the argument select "gloo" for ranks that
     share a device."""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_ddp()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:            # SAR_FORCE_DDP=1 without a launcher: a one-rank rendezvous on a free local port
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         backend = backend or os.environ.get("SAR_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -68,27 +95,99 @@ def init_distributed(device, backend=None):
     return rank, world
 
 
+class RunAhead:
+    """Bounds how far the host may run ahead of the GPU: at most `depth` train steps in flight (SAR_MAX_STEPS_IN_FLIGHT,
+    default 2; 0 = unbounded).  A step is ~200 asynchronous launches that the host issues in 1-2 ms while the GPU needs
+    13-60 ms for them; nothing in the step synchronises, so a loop without a per-step read-back queues hundreds of steps.
+    Every step's activations that the weight-gradient stream reads are `record_stream`-ed and cannot be reused by the caching
+    allocator before the GPU has passed them: tens of GB per queued fp32 step -- the allocator runs out of the 288 GB, falls
+    into its synchronise-and-free retry path and the rate collapses (measured: 100 un-synchronised fp32 steps at bs = 64 ran at
+    291 clips/s instead of 1 076; profiles/r04_runahead.txt).  Waiting on the event of the step before the previous one costs
+    the GPU nothing (its queue still holds a full step)."""
+
+    def __init__(self):
+        self.depth = int(os.environ.get("SAR_MAX_STEPS_IN_FLIGHT", "2"))
+        self._events = []
+
+    def step_issued(self):
+        if self.depth <= 0:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events.append(ev)
+        if len(self._events) > self.depth:
+            self._events.pop(0).synchronize()
+
+
+class GradExchange:
+    """SUM all-reduce of gradient buckets, overlapped with the backward pass that is still producing the earlier layers'
+    gradients.  RCCL: each bucket's collective is issued asynchronously on ONE communication stream that waits for just the
+    events that mark the bucket complete (weight gradients on the engine's side stream, BatchNorm / bias gradients on the
+    main stream); `wait()` makes the main stream -- not the host -- wait for all of them before the optimizer kernel.
+    gloo (ranks that share one device, tests): staged through the host, synchronous."""
+
+    def __init__(self):
+        self._stream, self._works = None, []
+
+    def submit(self, flat, events=()):
+        if dist.get_backend() == "gloo":
+            for e in events:
+                torch.cuda.current_stream().wait_event(e)
+            allreduce_sum_(flat)
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        for e in events:
+            self._stream.wait_event(e)
+        with torch.cuda.stream(self._stream):
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        works, self._works = self._works, []
+        for w in works:
+            w.wait()                                 # the current stream waits for the collective, the host does not
+        return len(works)
+
+
 class Trainer:
     def __init__(self, engine, batch_size=64, base_lr=0.1, steps=(10, 50), momentum=0.9, world_size=1):
         self.engine, self.batch_size, self.base_lr, self.steps = engine, batch_size, base_lr, tuple(steps)
         self.momentum, self.world_size = momentum, world_size
         self.iteration = 0
-        self.comm_events = None     # a list while a bench times the collective: (start, end) events around the all-reduce
+        self.comm_events = None     # a list while a bench times the exchange: (start, end) events around it
+        self.exchange = GradExchange()
+        self.run_ahead = RunAhead()
+        self.buckets_last_step = 0  # collectives issued by the last step (tests, bench)
 
     def step(self, x, labels):
         """One train_step (main_gnn.py:219-239).  Returns (logits, loss) as device tensors (no host sync)."""
         gbs = x.shape[0] * self.world_size
-        logits, loss = self.engine.loss_and_grad(x, labels, gbs)
-        if self.comm_events is not None and self.world_size > 1:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            allreduce_sum_(self.engine.grad)
-            e1.record()
-            self.comm_events.append((e0, e1))
+        ddp = ddp_active()
+        timing = self.comm_events is not None and ddp
+        if not ddp:
+            logits, loss = self.engine.loss_and_grad(x, labels, gbs)
+            self.buckets_last_step = 0
         else:
-            allreduce_sum_(self.engine.grad)
+            if timing:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = [0]
+
+            def on_bucket(bi, flat, events):
+                if timing and n[0] == 0:
+                    t0.record()
+                n[0] += 1
+                self.exchange.submit(flat, events)
+
+            logits, loss = self.engine.loss_and_grad(x, labels, gbs, bucket_cb=on_bucket)
+            self.exchange.wait()
+            self.buckets_last_step = n[0]
+            if timing:
+                t1.record()
+                self.comm_events.append((t0, t1))    # first bucket ready -> last collective done (overlaps backward)
         self.engine.sgd_step(lr_schedule(self.iteration, self.base_lr, self.steps, self.batch_size), self.momentum)
         self.iteration += 1
+        if x.is_cuda:
+            self.run_ahead.step_issued()
         return logits, loss
 
 
@@ -104,7 +203,8 @@ class SpectrogramTrainer:
         self.radar_params = list(model.virtual_radar.parameters())
         self.radar_opt = torch.optim.Adam(self.radar_params, lr=base_lr)   # main_spectrogram.py:106 hyper-parameters
         self.comm_events = None      # a list while a bench times the exchange: (start, end) events around it
-        self._comm_stream = None
+        self.exchange = GradExchange()
+        self.run_ahead = RunAhead()
         self._radar_key, self._radar_bucket = None, None
 
     def train_radar(self):
@@ -118,27 +218,18 @@ class SpectrogramTrainer:
         if key != self._radar_key:
             n = sum(p.numel() for p in live)
             self._radar_bucket = torch.zeros(n, dtype=torch.float32, device=live[0].device) if live else None
-            o = 0
-            for p in live:
-                p.grad = self._radar_bucket[o:o + p.numel()].view_as(p)
-                o += p.numel()
             self._radar_key = key
+        # every step: a p.grad that no longer aliases the bucket (zero_grad(set_to_none=True), a user assignment) is re-bound,
+        # otherwise the exchange would reduce a stale bucket while the optimizer steps on the un-reduced gradient
+        o, base = 0, self._radar_bucket.data_ptr() if self._radar_bucket is not None else 0
+        for p in live:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o or p.grad.shape != p.shape:
+                view = self._radar_bucket[o:o + p.numel()].view_as(p)
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view
+            o += p.numel()
         return self._radar_bucket
-
-    def _exchange(self, flat, events=()):
-        """SUM all-reduce of one gradient bucket once `events` have completed.  RCCL: asynchronously on a communication
-        stream (returns the work handle); gloo (ranks sharing a device, tests): staged through the host, synchronous."""
-        if dist.get_backend() == "gloo":
-            for e in events:
-                torch.cuda.current_stream().wait_event(e)
-            allreduce_sum_(flat)
-            return None
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=flat.device)
-        for e in events:
-            self._comm_stream.wait_event(e)
-        with torch.cuda.stream(self._comm_stream):
-            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def step(self, x, labels, lr):
         """Returns (logits, loss) device tensors; no host synchronisation.  Under data parallelism every gradient is
@@ -147,8 +238,7 @@ class SpectrogramTrainer:
         weight gradients come off the second stream), and the trainable radar parameters share one more small bucket."""
         model, eng, world = self.model, self.eng, self.world_size
         train_radar = self.train_radar()
-        ddp = world > 1 and dist.is_available() and dist.is_initialized()
-        works = []
+        ddp = ddp_active()
         timing = self.comm_events is not None and ddp
         if timing:
             t0 = torch.cuda.Event(enable_timing=True)
@@ -156,7 +246,7 @@ class SpectrogramTrainer:
         def on_bucket(bi, flat, events):
             if timing and bi == 0:
                 t0.record()
-            works.append(self._exchange(flat, events))
+            self.exchange.submit(flat, events)
 
         kw = dict(grad_scale=1.0 / world, bucket_cb=on_bucket) if ddp else {}
         with torch.set_grad_enabled(train_radar):
@@ -169,12 +259,10 @@ class SpectrogramTrainer:
             if ddp and bucket is not None:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())   # after autograd's kernels on this stream
-                works.append(self._exchange(bucket, [ev]))
+                self.exchange.submit(bucket, [ev])
         else:
             logits, loss = eng.loss_and_grad(img, labels, **kw)
-        for w in works:
-            if w is not None:
-                w.wait()                                 # the main stream waits for the collectives, the host does not
+        self.exchange.wait()                             # the main stream waits for the collectives, the host does not
         if timing:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
@@ -184,6 +272,7 @@ class SpectrogramTrainer:
             for g in self.radar_opt.param_groups:
                 g['lr'] = lr
             self.radar_opt.step()
+        self.run_ahead.step_issued()
         return logits, loss
 
 

@@ -70,3 +70,89 @@ def test_allreduce_is_identity_without_process_group():
     from sar_amd.train import allreduce_sum_
     t = torch.arange(5.0)
     assert allreduce_sum_(t) is t and torch.equal(t, torch.arange(5.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the bucketed, overlapped exchange of the ST-GCN gradient buffer (sar_amd/train.py GradExchange, Trainer.step)
+
+def test_gradient_buckets_partition_the_flat_buffer_in_backward_order():
+    """Buckets are contiguous, disjoint, cover the buffer, and are listed in the order backward() completes them (late
+    layers first); the trainable adjacency (summed over the blocks at the end of backward) is its own last slice."""
+    sys.path.insert(0, os.path.join(ROOT, "skeleton-action-recognition_amd"))
+    from sar_amd.stgcn import STGCN
+    from sar_amd.stgin import STGIN
+    for cls, kw in ((STGCN, {}), (STGCN, dict(mfma="bf16")), (STGCN, dict(trainable_adjacency=True)), (STGIN, {}),
+                    (STGCN, dict(blocks=[(64, 1, False), (64, 1, True)]))):
+        eng = cls(device="cpu", num_classes=7, **kw)
+        n = eng.grad.numel()
+        cover = torch.zeros(n, dtype=torch.int32)
+        for blk, lo, hi in eng._buckets:
+            assert 0 <= lo < hi <= n and lo % 4 == 0
+            cover[lo:hi] += 1
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
+        done_at = [blk if blk >= 0 else -1 for blk, _, _ in eng._buckets]
+        # completion order: block indices descending, then the end-of-backward buckets
+        real = [b for b in done_at if b >= 0]
+        assert real == sorted(real, reverse=True) and done_at[len(real):] == [-1] * (len(done_at) - len(real))
+        for blk, lo, hi in eng._buckets:
+            if blk >= 0:      # everything in the slice belongs to blocks >= blk or the classifier
+                for k, o in eng.offsets.items():
+                    if lo <= o < hi:
+                        assert k.startswith("logits.") or int(k.split(".")[0][1:]) >= blk, (k, blk)
+        if "adjacency_matrix" in eng.offsets:
+            assert eng._buckets[-1][1] == eng.offsets["adjacency_matrix"] and eng._buckets[-1][0] == -1
+
+
+class _FakeEngine:
+    """stands in for the HIP engine on the CPU: 'backward' fills three slices of the flat gradient in backward order and
+    announces each through bucket_cb, exactly like STGCN.backward"""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.flat, self.grad = torch.zeros(40), torch.zeros(40)
+        self.lr = None
+
+    def loss_and_grad(self, x, labels, gbs, bucket_cb=None):
+        for bi, (lo, hi) in enumerate(((24, 40), (8, 24), (0, 8))):
+            self.grad[lo:hi] = torch.arange(lo, hi, dtype=torch.float32) * (self.rank + 1) / gbs
+            if bucket_cb is not None:
+                bucket_cb(bi, self.grad[lo:hi], [])
+        return x, torch.tensor([float(gbs)])
+
+    def sgd_step(self, lr, momentum):
+        self.flat -= lr * self.grad
+
+
+def _bucket_worker(rank, world, port, out, force):
+    sys.path.insert(0, os.path.join(ROOT, "skeleton-action-recognition_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if force:
+        os.environ["SAR_FORCE_DDP"] = "1"
+    from sar_amd.train import Trainer, init_distributed
+    r, w = init_distributed(torch.device("cpu"), backend="gloo")
+    assert (r, w) == (rank, world) and dist.is_initialized() and dist.get_world_size() == world
+    eng = _FakeEngine(rank)
+    tr = Trainer(eng, batch_size=4, world_size=world)
+    tr.step(torch.zeros(4, 1), None)
+    assert tr.buckets_last_step == 3
+    torch.save(dict(grad=eng.grad.clone(), flat=eng.flat.clone()), out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_step_exchanges_every_bucket(tmp_path):
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_bucket_worker, args=(2, 31500 + os.getpid() % 2000, out, False), nprocs=2, join=True)
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    want = torch.arange(40, dtype=torch.float32) * 3 / 8          # (1 + 2) / global batch 8
+    assert torch.equal(a["grad"], want) and torch.equal(b["grad"], want) and torch.equal(a["flat"], b["flat"])
+    assert torch.equal(a["flat"], -0.1 * want)
+
+
+def test_forced_one_rank_process_group_takes_the_ddp_branches(tmp_path):
+    """SAR_FORCE_DDP=1: a single rank initialises a process group and Trainer.step goes through the bucket exchange (the
+    rehearsal switch of tests/test_gpu_rccl.py, here over gloo)."""
+    out = str(tmp_path / "f%d.pt")
+    mp.spawn(_bucket_worker, args=(1, 33500 + os.getpid() % 2000, out, True), nprocs=1, join=True)
+    a = torch.load(out % 0)
+    assert torch.equal(a["grad"], torch.arange(40, dtype=torch.float32) / 4)

@@ -91,7 +91,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--secondary", "bf16,pathB", "--sustained-steps", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)

@@ -3,7 +3,7 @@
 #   tools/instep8.sh [lib.so]
 cd "$(dirname "$0")/.."
 [ -n "$1" ] && export SAR_HIP_LIB=$PWD/$1
-SAR_WGRAD_STREAM=0 python bench.py --mfma bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-isolated-pass --no-secondary 2>&1 | tail -1 | python3 -c "
+SAR_WGRAD_STREAM=0 python bench.py --mfma bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 2>&1 | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print('value', d['value'], 'ms/step', d['ms_per_step'])

@@ -8,7 +8,7 @@ export SAR_WGRAD_STREAM=${SAR_WGRAD_STREAM:-0}
 O=$R/gpurun_out/trace8_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --mfma bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary "$@" > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --mfma bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 "$@" > $O/bench.log 2>&1
 python3 - $O <<'PY'
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
