@@ -88,6 +88,13 @@ enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3 };
  * (z_k = x . A_k as a 16 x 16 x 32 MFMA per frame, exact products, fp32 accumulation) instead of in the vector ALU; without
  * the flag they keep the fp32 gather.  Ignored by the fp32 kernels. */
 #define SAR_GRAPH_WT_BF16_EXACT 1
+/* g_flags: the caller asserts that at most n = (g_flags >> SAR_GRAPH_FEW_DENSE_SHIFT) & 0xff of the 3 V gather lists are
+ * anything else than {one entry of weight 1} or empty (NTU 'spatial' adjacency, graph/tools.py:11-30: 2 of 75 forward, 8 of 75
+ * transposed).  The bf16 (CN8) graph convolution then reads the operand of such a trivial list straight from the raw tile at
+ * the listed joint and builds only the n remaining lists per frame (csrc/conv_graph_cn8.hip), bit-identical with the kernel
+ * that builds every gathered tile.  A count that is too small makes the excess lists read as empty (wrong result, no fault). */
+#define SAR_GRAPH_FEW_DENSE 4
+#define SAR_GRAPH_FEW_DENSE_SHIFT 8
 typedef struct sar_conv_desc {
   int32_t mode;        /* SAR_CONV_* */
   int32_t transposed;  /* TEMPORAL only */

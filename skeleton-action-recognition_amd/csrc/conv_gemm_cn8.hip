@@ -13,224 +13,9 @@
 //  * the graph gather z_k = x . A_k reads whole units (8 channels per ds_read_b128) of the raw tile;
 //  * the epilogue stores the 4 consecutive channels a lane holds in registers 4q .. 4q+3 as ONE 8-byte half unit:
 //    512 contiguous bytes per wave instruction, 4 stores per 32x32 accumulator tile (fp32 CN layout: 16).
-#include "cn8.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "conv_cn8_common.h"
 
 namespace {
-
-constexpr int KC16 = 16;   // src channels per main-loop stage = one MFMA k-step = two CN8 planes
-
-#ifndef SAR_ABLATE8
-#define SAR_ABLATE8 0   // diagnostic builds only (tools/ablate8.sh): 1 no MFMA, 2 global loads of stage 0 only, 4 no epilogue, 8 LDS stores of stage 0 only
-#endif
-
-// In-kernel phase stamps of conv_gemm_cn8_kernel (diagnostic build -DSAR_CN8_STAMPS, tools/stamps8.sh): wave 0 of every
-// workgroup adds the shader-clock cycles it spent in [0] store_lds, [1] the wait at the barrier behind it, [2] load issue +
-// MFMA phase, [3] the wait at the closing barrier, [4] the prologue, [5] the epilogue; [6] = workgroups, [7] = their
-// lifetimes in 100 MHz ticks (s_memrealtime), [8] = the same in shader-clock cycles, [9] = the graph kernel's loads + MFMA phase.
-#ifdef SAR_CN8_STAMPS
-constexpr int STAMP_WG = 8192;
-__device__ unsigned g_stamps8[STAMP_WG][10];   // one row per workgroup (plain stores: same-address atomics would stall the L2 channel)
-#define STAMP8_(i)                                               \
-  do {                                                           \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-    st_acc[i] += t_ - st_last;                                   \
-    st_last = t_;                                                \
-  } while (0)
-#if SAR_CN8_STAMPS == 2   // the graph kernel's prologue in pieces ([0] geometry + colsum, [1] gather tables, [2] B fragments + zero fill, [3] loads + barrier + bias)
-#define STAMP8(i)
-#define STAMP8P(i) STAMP8_(i)
-#else
-#define STAMP8(i) STAMP8_(i)
-#define STAMP8P(i)
-#endif
-#else
-#define STAMP8(i)
-#define STAMP8P(i)
-#endif
-
-struct ConvK8 {
-  sar_conv_desc d;
-  const uint4* wp;   // packed weights [taps][G][M] units of 8 bf16 (sar_pack_weights_bf16_batch)
-  int G;             // channel groups of 8 in the packed weights (even)
-  int Gs, Go;        // CN8 planes of src / out (= aux)
-  int FT, TPS, NF, RW, nparts, ntiles, ny;
-  int stagger, stagger_shift;   // experiment (SAR_CN8_STAGGER): first-round workgroups start (id >> shift) % 3 * stagger x 1024 cycles late
-};
-
-template <int TAPS, int MS, int NS, int WM, int WN>
-struct TileCfg8 {
-  static constexpr int BM = 32 * MS * WM;
-  static constexpr int TN = 32 * NS * WN;
-  static constexpr int RWMAX = (TN == 128 ? 448 : 704);   // staged columns: (FT - 1) * stride + taps frames of V joints
-  static constexpr int SCOLS = RWMAX + 8;                 // + the always-zero column
-  static constexpr int WUNITS = TAPS * 2 * BM;            // [tap][h][m]
-  static constexpr int SUNITS = 2 * SCOLS;                // [h][col]
-  static constexpr int CJ = (RWMAX + 255) / 256;          // S units per lane and plane
-  static constexpr int WIT = (WUNITS + 255) / 256;        // W units per lane
-  static constexpr int UNITS = WUNITS + SUNITS;
-};
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-constexpr int pad_stride8(int n) { return n + ((4 - n % 16) + 16) % 16; }   // smallest plane stride >= n that is 4 (mod 16)
-
-// ---- epilogue: mask / add, BatchNorm partial sums from the fp32 accumulators, bf16 half-unit stores.  Every wave is
-// past its last MFMA phase and the closing barrier: the transpose area aliases the operand image.
-// PRE: the caller has already (a) loaded the aux half units into axr[((ms * 2 + rb) * 2 + q2) * NS + ns] (issued before
-// its last MFMA phase, so their HBM latency is hidden) and (b) staged the MASK parameters (scale, shift, mean) in rowp.
-struct Epi8Desc {
-  __amdgpu_buffer_rsrc_t ro, ra;
-  int so_out, so_aux, g_w, rows_w;
-};
-
-template <int MS>
-__device__ __forceinline__ Epi8Desc epi8_desc(const ConvK8& k, int wm, int m0, bool has_aux) {
-  const sar_conv_desc& d = k.d;
-  Epi8Desc e;
-  e.rows_w = m0 + wm * MS * 32;          // first output row of this wave (multiple of 32)
-  e.g_w = e.rows_w >> 3;                 // its first CN8 plane
-  auto plane_bytes = [&](int64_t ld) {   // bytes from plane g_w to the end of the tensor (clamped to 2 GiB)
-    const int64_t n = (int64_t)(k.Go - e.g_w) * ld * 16;
-    return (unsigned)(n <= 0 ? 0 : (n > 0x7fffffffll ? 0x7fffffffll : n));
-  };
-  e.ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)d.out + (int64_t)e.g_w * d.ld_out * 16), 0, plane_bytes(d.ld_out),
-                                           0x00020000);
-  e.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(has_aux ? (char*)d.aux + (int64_t)e.g_w * d.ld_aux * 16 : (char*)d.out), 0,
-                                           has_aux ? plane_bytes(d.ld_aux) : 0u, 0x00020000);
-  e.so_out = (int)(d.ld_out * 16), e.so_aux = (int)(d.ld_aux * 16);   // one plane
-  return e;
-}
-
-template <int MS, int NS, int WN, int BM, bool PRE = false>
-__device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int wn, int m0, const unsigned (&vo)[NS],
-                                          f32x16 (&acc)[MS][NS], float4* rowp, float* smem,
-                                          const u32x2* axr = nullptr) {
-  const sar_conv_desc& d = k.d;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int part = tile * WN + wn;
-  auto run = [&](auto EPI_) {
-    constexpr int EPI = decltype(EPI_)::value;
-    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
-    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
-    if (EPI == SAR_EPI_MASK && !PRE) {
-      if (tid < BM) {
-        const int row = m0 + tid;
-        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < d.M) {
-          ap.x = d.aux_scale[row];
-          ap.y = d.aux_shift[row];
-          if (d.aux_mean) ap.z = d.aux_mean[row];
-        }
-        rowp[tid] = ap;
-      }
-      __syncthreads();
-    }
-    const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, has_aux);
-    const int rows_w = e8.rows_w, g_w = e8.g_w;
-    const __amdgpu_buffer_rsrc_t ro = e8.ro, ra = e8.ra;
-    // vo[ns]: byte offset of this lane's half unit inside a plane (0x80000000 = off-tile column: rejected)
-    const int so_out = e8.so_out, so_aux = e8.so_aux;
-    float* P = smem + wave * (16 * 65);
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        // registers 8 rb .. 8 rb + 7 = two groups of 4 consecutive channels: planes 4 ms + 2 rb + {0, 1}
-        float ax[NS][8];
-        if (has_aux) {
-#pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-              u32x2 a;
-              if constexpr (PRE) a = axr[((ms * 2 + rb) * 2 + q2) * NS + ns];
-              else a = __builtin_amdgcn_raw_buffer_load_b64(ra, vo[ns], (4 * ms + 2 * rb + q2) * so_aux, 0);
-              float f[4];
-              cn8_unpack4(make_uint2(a[0], a[1]), f);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) ax[ns][4 * q2 + i] = f[i];
-            }
-        }
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-          const int r = rb * 8 + r8;
-          float s1 = 0.f, s2 = 0.f;
-          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns) {
-            float val = acc[ms][ns][r];
-            if (EPI == SAR_EPI_STATS) {
-              s1 += val;
-              s2 = fmaf(val, val, s2);
-            } else if (EPI == SAR_EPI_MASK) {
-              val = (fmaf(ax[ns][r8], ap.x, ap.y) > 0.f) ? val : 0.f;
-              s1 += val;
-              s2 = fmaf(val, ax[ns][r8] - ap.z, s2);
-            } else if (EPI == SAR_EPI_ADD) {
-              val += ax[ns][r8];
-            }
-            acc[ms][ns][r] = val;
-          }
-          if (stats) {
-            P[(2 * r8) * 65 + lane] = s1;
-            P[(2 * r8 + 1) * 65 + lane] = s2;
-          }
-        }
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-          const int gq = 4 * ms + 2 * rb + q2;
-          if (g_w + gq < k.Go) {   // wave-uniform
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-              const int r0 = rb * 8 + 4 * q2;
-              u32x2 o;
-              o[0] = cn8_pack2(acc[ms][ns][r0], acc[ms][ns][r0 + 1]);
-              o[1] = cn8_pack2(acc[ms][ns][r0 + 2], acc[ms][ns][r0 + 3]);
-              __builtin_amdgcn_raw_buffer_store_b64(o, ro, vo[ns], gq * so_out, 0);
-            }
-          }
-        }
-        if (stats) {
-          __builtin_amdgcn_wave_barrier();
-          const int q = lane & 15, sub = (lane >> 4) & 1;
-          const float* pr = P + q * 65 + hi * 32 + sub * 16;
-          float t = 0.f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) t += pr[i];
-          t += __shfl_xor(t, 16);
-          __builtin_amdgcn_wave_barrier();
-          const int r = rb * 8 + (q >> 1);
-          const int row = rows_w + ms * 32 + mfma_row(r, hi);
-          if (sub == 0 && row < d.M) d.partials[((int64_t)row * k.nparts + part) * 2 + (q & 1)] = t;
-        }
-      }
-    }
-  };
-  switch (d.epi) {
-    case SAR_EPI_STATS: run(std::integral_constant<int, SAR_EPI_STATS>()); break;
-    case SAR_EPI_MASK: run(std::integral_constant<int, SAR_EPI_MASK>()); break;
-    case SAR_EPI_ADD: run(std::integral_constant<int, SAR_EPI_ADD>()); break;
-    default: run(std::integral_constant<int, SAR_EPI_NONE>()); break;
-  }
-}
-
-// workgroup id -> work item, XCD-aware (conv_gemm.hip): consecutive ids go to consecutive XCDs; each XCD walks a
-// contiguous range of tiles so that the temporal halo and the row blocks of a tile share one L2
-__device__ __forceinline__ int xcd_work(int nwork) {
-  const int per = (nwork + 7) / 8;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int w = xcd * per + slot;
-  return (w >= nwork || slot >= per) ? -1 : w;
-}
 
 // TR: 0 forward; 1 data gradient, stride 1; 2 data gradient, generic stride (tap validity mask); 3 data gradient,
 // stride 2, parity-split column map (see conv_gemm.hip)
@@ -1165,43 +950,6 @@ __global__ __launch_bounds__(256, (NZ0 + NZ1 + NZ2 > 6) ? 2 : 3) void conv_graph
 #endif
 }
 
-template <int WN>
-int tile_geometry8(const sar_conv_desc& d, int NSv, bool parity, ConvK8& k, int rwmax_db = 0) {
-  const int tile_n = 32 * NSv * WN;
-  if (parity) {
-    k.FT = 2 * ((tile_n / 2) / d.V);
-    const int t_even = d.T_out + (d.T_out & 1);
-    if (k.FT > t_even) k.FT = t_even;
-  } else {
-    k.FT = tile_n / d.V;
-    if (k.FT > d.T_out) k.FT = d.T_out;
-  }
-  if (k.FT < 1) return -1;
-  const int rwmax = rwmax_db ? rwmax_db : (d.mode == SAR_CONV_GRAPH) ? tile_n : (NSv * WN == 4 ? 448 : 704);
-  for (;; k.FT -= parity ? 2 : 1) {      // as many frames as the staged window allows
-    if (d.mode == SAR_CONV_GRAPH) k.NF = k.FT;
-    else if (!d.transposed) k.NF = (k.FT - 1) * d.stride + d.taps;
-    else k.NF = (k.FT - 1 + d.taps - 1) / d.stride + 2;
-    k.RW = k.NF * d.V;
-    if (k.RW <= rwmax || k.FT <= (parity ? 2 : 1)) break;
-  }
-  if (k.RW > rwmax) return -2;
-  k.TPS = (d.T_out + k.FT - 1) / k.FT;
-  k.nparts = d.B * k.TPS * WN;
-  return 0;
-}
-
-void fill_common(const sar_conv_desc& d, const uint4* wp, ConvK8& k) {
-  static const int stg = [] { const char* e = getenv("SAR_CN8_STAGGER"); return e ? atoi(e) : 0; }();
-  static const int stg_sh = [] { const char* e = getenv("SAR_CN8_STAGGER_SHIFT"); return e ? atoi(e) : 8; }();
-  k.stagger = stg, k.stagger_shift = stg_sh;
-  k.d = d;
-  k.wp = wp;
-  k.G = 2 * ((d.Kc + 15) / 16);
-  k.Gs = (d.Kc + 7) / 8;
-  k.Go = (d.M + 7) / 8;
-}
-
 template <int TR, int TAPS, int MS, int NS, int WM, int WN>
 int launch_cfg8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* nparts_only) {
   ConvK8 k;
@@ -1315,6 +1063,8 @@ int launch_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* n
 
 int dispatch8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) {
   if (d.mode == SAR_CONV_GRAPH) {
+    const int rc2 = sar_graph2_cn8_dispatch(d, wp, st, np);   // gather at operand-read time (power-of-two gather weights)
+    if (rc2 != SAR_GRAPH2_NOT_APPLICABLE) return rc2;
     if (d.nz[0] == 1 && d.nz[1] == 1) return launch_graph_by_m8<1, 1, 4>(d, wp, st, np);
     if (d.nz[0] == 1 && d.nz[2] == 1) return launch_graph_by_m8<1, 4, 1>(d, wp, st, np);
     return launch_graph_by_m8<4, 4, 4>(d, wp, st, np);

@@ -1,0 +1,340 @@
+// conv_graph_cn8.hip -- GraphConvTD (models/gcn.py:199-209) and its data gradient on bf16 CN8 activations with the
+// adjacency applied WHEN THE MATRIX OPERAND IS READ (round 4; replaces the unit builder of conv_graph_cn8_kernel in
+// conv_gemm_cn8.hip for adjacencies with few non-trivial gather lists -- SAR_GRAPH_FEW_DENSE, the NTU graph).
+//
+//   out[m, (t,w)] = sum_k sum_c bf16(W_k[c][m]) * bf16(z_k)[c, (t,w)] + sum_k b_k[m] colsum(A_k)[w]
+//   z_k[c, (t,w)] = sum_j wt_kj(w) * x[c, (t, idx_kj(w))]                    (<= 4 entries per column of A_k)
+//
+// conv_graph_cn8_kernel BUILDS the three z_k tiles in LDS every stage (gather, weight in fp32, round, store, barrier): 1 750
+// of the 3 360 cycles of a 16-channel stage (profiles/r03_bf16_phase_stamps.txt).  But of the 75 (slice, joint) gather lists
+// of the NTU graph 25 are the identity, 44 are ONE entry of weight 1 (z_k[., w] IS the raw column of another joint), 4 are
+// empty and only 2 (fwd) / 8 (transposed) need arithmetic.  So:
+//  * a B fragment of slice k for column (t, w) is read STRAIGHT from the raw tile at the per-lane address of joint idx_k(w)
+//    (a ds_read_b128 with a per-lane address costs what the un-gathered read costs), an empty list reads an always-zero unit;
+//  * the few lists that need arithmetic become VIRTUAL joints V .. V + NV - 1 appended to every frame of the raw tile, built
+//    by a mini-builder (<= 1 unit per thread and stage: the same fp32 fma chain in table order, rounded once -- the values the
+//    unit builder produces, so the two kernels agree BIT FOR BIT);
+//  * no z image: the LDS it frees double-buffers the raw tile and the weights, which removes the stage's closing barrier.
+// Stage = 16 source channels: W units [slice][plane][BM] + raw tile [plane][frame][V + NV] -> LDS buffer s & 1 (register
+// staging: the loads of stage s + 1 are in flight during the MFMA phase of stage s), barrier, mini-builder, barrier,
+// 3 x MS x NS MFMAs per wave; epilogue = conv_cn8_common.h (STATS / ADD / NONE).
+#include "conv_cn8_common.h"
+
+namespace {
+
+constexpr int NVMAX = 16;   // virtual joints per frame the tables may ask for
+
+template <int MS, int NS, int WM, int WN>
+__global__ __launch_bounds__(256, 3) void conv_graph2_cn8_kernel(const ConvK8 k, const int nv_asserted) {
+  constexpr int BM = 32 * MS * WM, TN = 32 * NS * WN;
+  constexpr int PL = 2;                      // CN8 planes per stage (16 source channels = one MFMA k-step)
+  constexpr int XS = TN + TN / 2 + 8;        // plane stride (units) >= FT * (V + NV) + 1; the LAST unit of a plane is never written: zero
+  constexpr int ZUNIT = XS - 1;
+  constexpr int WUNITS = 3 * PL * BM;        // [slice][plane][m]
+  constexpr int RUNITS = PL * XS;            // [plane][frame][V + NV]
+  constexpr int BUF = WUNITS + RUNITS;
+  constexpr int WIT = (WUNITS + 255) / 256;
+  constexpr int XJ = (PL * TN) / 256;        // raw units per thread and stage
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area aliases the image
+  constexpr int IMG_U = 2 * BUF > PAREA_U ? 2 * BUF : PAREA_U;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ uint4 smem_u[IMG_U + BM];
+  __shared__ int vmap[3 * 64];               // (slice, joint) -> raw joint | V + virtual id | -1 (empty list)
+  __shared__ int vl_idx[NVMAX][4];           // gather entries of the virtual joints
+  __shared__ float vl_wt[NVMAX][4];
+  __shared__ int nv_s;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int V = d.V;
+  const int ny = k.ny;
+  const int w = xcd_work(k.ntiles * ny);
+  if (w < 0) return;
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+  const int nfr = (t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0;   // live frames of this tile
+  const int ncols = nfr * V;
+
+  // ---- prologue: everything that comes from global memory is ISSUED first (one round trip)
+  f32x16 acc[MS][NS];
+  const int seq_left = (d.T_src - t0) * V;   // columns from the tile start to the end of the sequence
+  const char* src_b = (const char*)d.src + ((int64_t)b * d.T_src + t0) * V * 16;
+  int xvo[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int u = tid + 256 * j;
+    const int xc = u % TN;
+    xvo[j] = xc < ncols ? xc * 16 : 0x7fffffff;   // rejected by the range check -> 0
+  }
+  unsigned wvo[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int u = tid + 256 * i;
+    const int m = u % BM, p = (u / BM) % PL, tp = u / (BM * PL);
+    const bool ok = u < WUNITS && (m0 + m) < d.M;
+    wvo[i] = ok ? (unsigned)((((int64_t)tp * k.G + p) * d.M + m0 + m) * 16) : 0x80000000u;
+  }
+  const unsigned wbytes = (unsigned)((int64_t)3 * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  uint4 wreg[WIT];
+  uint4 xreg[XJ];
+  auto issue_loads = [&](int c0) {
+    const int wso = (c0 / 8) * d.M * 16;   // planes beyond G lie past the image: range check -> 0
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], wso, 0);
+      wreg[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int g = c0 / 8 + (tid + 256 * j) / TN;   // wave-uniform (TN is a multiple of 64)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(src_b + (int64_t)(g < k.Gs ? g : 0) * d.ld_src * 16), 0, g < k.Gs ? (unsigned)seq_left * 16u : 0u, 0x00020000);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xvo[j], 0, 0);
+      xreg[j] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  issue_loads(0);
+
+  // classify the 3 V gather lists (wave 0; 64 lists per pass): a list with ONE entry of weight 1 is the raw column of that
+  // joint, an empty list the zero unit, everything else a virtual joint (ranked in (slice, joint) order)
+  if (wave == 0) {
+    int base = 0;
+    for (int p0 = 0; p0 < 3 * V; p0 += 64) {
+      const int p = p0 + lane;
+      const bool in = p < 3 * V;
+      const int tp = in ? p / V : 0;
+      const int nzl = d.nz[tp];
+      int cnt = 0, first = 0;
+      float wfirst = 0.f;
+      int ei[4];
+      float ew[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ei[j] = 0, ew[j] = 0.f;
+        if (in && j < nzl) {
+          ei[j] = d.g_idx[p * 4 + j];
+          ew[j] = d.g_wt[p * 4 + j];
+          if (ew[j] != 0.f) {
+            if (cnt == 0) first = ei[j], wfirst = ew[j];
+            ++cnt;
+          }
+        }
+      }
+      const bool virt = in && (cnt > 1 || (cnt == 1 && wfirst != 1.0f));
+      const unsigned long long bal = __ballot(virt);
+      const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (in) vmap[p] = virt ? (rank < nv_asserted ? V + rank : -1) : (cnt == 1 ? first : -1);
+      if (virt && rank < nv_asserted && rank < NVMAX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vl_idx[rank][j] = ei[j], vl_wt[rank][j] = ew[j];
+      }
+      base += __popcll(bal);
+    }
+    if (lane == 0) nv_s = base < nv_asserted ? base : nv_asserted;
+  }
+  float gcs[3][NS];   // column sums of A_k at this lane's joints (bias term; masked by colok at the use)
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    const int v = (p < ncols ? p : 0) % V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) gcs[tp][ns] = d.g_colsum ? d.g_colsum[tp * V + v] : 0.f;
+  }
+  float4 bias_row = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < BM && d.bias && m0 + tid < d.M) {
+    bias_row.x = d.bias[m0 + tid];
+    bias_row.y = d.bias[d.M + m0 + tid];
+    bias_row.z = d.bias[2 * d.M + m0 + tid];
+  }
+  if (tid < BM) rowp[tid] = bias_row;
+  if (tid < 2 * PL) smem_u[(tid >> 1) * BUF + WUNITS + (tid & 1) * XS + ZUNIT] = make_uint4(0u, 0u, 0u, 0u);   // the zero units
+  __syncthreads();   // rowp, vmap, nv_s
+
+  const int NV = nv_s;
+  const int FS = V + NV;   // units per frame of the raw tile
+  int xdst[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int u = tid + 256 * j;
+    const int xh = u / TN, xc = u - xh * TN;
+    const int f = xc / V, v = xc - f * V;
+    xdst[j] = xc < k.FT * V ? WUNITS + xh * XS + f * FS + v : -1;   // columns beyond the tile's frames are not stored
+  }
+  bool colok[NS];
+  unsigned vo[NS];
+  int boff[3][NS];   // unit (inside a buffer) of this lane's B fragment of slice tp for column block ns
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    colok[ns] = p < ncols;
+    const int pv = colok[ns] ? p : 0;
+    vo[ns] = colok[ns] ? (unsigned)((((int64_t)b * d.T_out + t0) * V + pv) * 16 + 8 * hi) : 0x80000000u;
+    const int fo = pv / V, v = pv - fo * V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      const int vm = vmap[tp * V + v];
+      boff[tp][ns] = WUNITS + hi * XS + ((colok[ns] && vm >= 0) ? fo * FS + vm : ZUNIT);
+    }
+    // bias term sum_k b_k[m] colsum(A_k)[w]
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+        acc[ms][ns][r] = colok[ns] ? fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns])) : 0.f;
+      }
+  }
+  // mini-builder geometry: item = (plane, frame, virtual joint), at most ONE per thread (PL * FT * NV <= 256 is checked by the host)
+  const int nitems = PL * k.FT * NV;
+  int vb_dst = -1, vb_src[4] = {0, 0, 0, 0};
+  float vb_wt[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tid < nitems) {
+    const int pl = tid / (k.FT * NV), rem = tid - pl * (k.FT * NV);
+    const int f = rem / NV, r = rem - f * NV;
+    vb_dst = WUNITS + pl * XS + f * FS + V + r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vb_src[j] = WUNITS + pl * XS + f * FS + vl_idx[r][j];
+      vb_wt[j] = vl_wt[r][j];
+    }
+  }
+
+  auto store_images = [&](uint4* buf) {
+#pragma unroll
+    for (int i = 0; i < WIT; ++i)
+      if ((i + 1) * 256 <= WUNITS || tid + 256 * i < WUNITS) buf[tid + 256 * i] = wreg[i];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j)
+      if (xdst[j] >= 0) buf[xdst[j]] = xreg[j];
+  };
+  auto build_virtual = [&](uint4* buf) {
+    if (vb_dst >= 0) {
+      float z[8], x[8];
+      cn8_unpack(buf[vb_src[0]], x);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) z[c] = vb_wt[0] * x[c];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        cn8_unpack(buf[vb_src[j]], x);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) z[c] = vb_wt[j] != 0.f ? fmaf(vb_wt[j], x[c], z[c]) : z[c];   // a missing entry adds nothing, whatever its source holds
+      }
+      buf[vb_dst] = cn8_pack(z);
+    }
+  };
+  auto mma_phase = [&](const uint4* buf) {
+    const uint4* Wa = buf + hi * BM + wm * MS * 32 + l31;
+    uint4 fa[2][MS], fb[2][NS];
+    auto frag_load = [&](int tp, uint4 (&a)[MS], uint4 (&bq)[NS]) {
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[ms] = Wa[tp * PL * BM + ms * 32];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) bq[ns] = buf[boff[tp][ns]];
+    };
+    frag_load(0, fa[0], fb[0]);
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      if (tp + 1 < 3) frag_load(tp + 1, fa[(tp + 1) & 1], fb[(tp + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // the reads of the next slice stay AHEAD of this slice's MFMAs
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&fa[tp & 1][ms]),
+                                                                *reinterpret_cast<bf16x8*>(&fb[tp & 1][ns]), acc[ms][ns], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the ADD epilogue's aux half units (skip-path / residual gradient of the data gradient) are loaded before the last MFMA
+  // phase, not inside the epilogue (conv_gemm_cn8_kernel)
+  const bool pre_aux = d.epi == SAR_EPI_ADD;
+  u32x2 axr[MS * 4 * NS];
+  auto issue_aux = [&]() {
+    const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            axr[((ms * 2 + rb) * 2 + q2) * NS + ns] =
+                __builtin_amdgcn_raw_buffer_load_b64(e8.ra, vo[ns], (4 * ms + 2 * rb + q2) * e8.so_aux, 0);
+  };
+  // Happens-before of the two buffers (no closing barrier): stage s stores into buffer s & 1, last READ by the MFMA phase of
+  // stage s - 2; a wave reaches store(s) only after barrier B of stage s - 1, which every wave joins after ITS MFMA phase of
+  // stage s - 2 (program order: MFMA(s-2), store(s-1), A(s-1), build, B(s-1)).  The mini-builder of stage s reads raw units
+  // of buffer s & 1 written before barrier A(s) and writes virtual units nobody reads before barrier B(s).
+  int c0 = 0, par = 0;
+  for (; c0 + KC16 < d.Kc; c0 += KC16, par ^= 1) {
+    uint4* buf = smem_u + par * BUF;
+    store_images(buf);
+    __syncthreads();         // A: raw tile + weights of this stage complete
+    issue_loads(c0 + KC16);  // in flight during the builder and the MFMA phase
+    build_virtual(buf);
+    __syncthreads();         // B: virtual joints complete
+    mma_phase(buf);
+  }
+  {
+    uint4* buf = smem_u + par * BUF;
+    store_images(buf);       // last stage (peeled: the aux registers take the place of the staging registers)
+    __syncthreads();
+    if (pre_aux) issue_aux();   // uniform
+    build_virtual(buf);
+    __syncthreads();
+    mma_phase(buf);
+  }
+  __syncthreads();           // the epilogue's transpose area aliases the image
+  if (pre_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
+  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+}
+
+template <int MS, int NS, int WM, int WN>
+int launch_graph2_cfg(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* nparts_only, int nv) {
+  ConvK8 k;
+  fill_common(d, wp, k);
+  if (int g = tile_geometry8<WN>(d, NS, false, k)) {
+    sar_set_error("sar_conv_gemm_cn8: unsupported tile geometry (V=%d)", d.V);
+    return g == -2 ? SAR_E_UNSUP : SAR_E_ARG;
+  }
+  constexpr int BM = 32 * MS * WM, TN = 32 * NS * WN;
+  // the raw tile with its virtual joints must fit a plane, the mini-builder handles one unit per thread
+  if (k.FT * (d.V + nv) + 1 > TN + TN / 2 + 8 || 2 * k.FT * nv > 256) return SAR_GRAPH2_NOT_APPLICABLE;
+  if (nparts_only) {
+    *nparts_only = k.nparts;
+    return 0;
+  }
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + BM - 1) / BM;
+  const int nwork = k.ntiles * k.ny;
+  hipLaunchKernelGGL((conv_graph2_cn8_kernel<MS, NS, WM, WN>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k, nv);
+  return 0;
+}
+
+}  // namespace
+
+// Called by sar_conv_gemm_cn8 / sar_conv_gemm_cn8_nparts (conv_gemm_cn8.hip) for SAR_CONV_GRAPH descriptors.  Returns
+// SAR_GRAPH2_NOT_APPLICABLE when the caller has not asserted SAR_GRAPH_FEW_DENSE or the tile cannot hold the virtual joints
+// (the caller then keeps the unit builder; both kernels use the same tiles, i.e. the same partial-sum geometry).
+int sar_graph2_cn8_dispatch(const sar_conv_desc& d, const void* wp_, hipStream_t st, int* np) {
+  static const bool on = [] {
+    const char* e = getenv("SAR_GRAPH_READ_GATHER");
+    return !(e && e[0] == '0');
+  }();
+  if (!on || !(d.g_flags & SAR_GRAPH_FEW_DENSE) || d.V > 64) return SAR_GRAPH2_NOT_APPLICABLE;
+  const int nv = (d.g_flags >> SAR_GRAPH_FEW_DENSE_SHIFT) & 0xff;
+  if (nv > NVMAX) return SAR_GRAPH2_NOT_APPLICABLE;
+  const uint4* wp = (const uint4*)wp_;
+  if (d.M > 64) return launch_graph2_cfg<2, 2, 2, 2>(d, wp, st, np, nv);
+  if (d.M > 32) return launch_graph2_cfg<2, 2, 1, 4>(d, wp, st, np, nv);
+  return launch_graph2_cfg<1, 2, 1, 4>(d, wp, st, np, nv);
+}

@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("SAR_HIP_LIB") or os.path.join(_HERE, "libsar_hip.so")
 SAR_CONV_GRAPH, SAR_CONV_TEMPORAL = 0, 1
 SAR_EPI_NONE, SAR_EPI_STATS, SAR_EPI_MASK, SAR_EPI_ADD = 0, 1, 2, 3
 SAR_GRAPH_WT_BF16_EXACT = 1
+SAR_GRAPH_FEW_DENSE = 4
+SAR_GRAPH_FEW_DENSE_SHIFT = 8
 SAR_C2D_AUX_EVEN_PIXELS = 1
 
 _fp = C.c_void_p  # every device pointer crosses the ABI as void*

@@ -38,6 +38,14 @@ class GraphTables:
         # slice on the matrix cores (SAR_GRAPH_WT_BF16_EXACT, include/sar_hip.h)
         w32 = torch.from_numpy(np.ascontiguousarray(wt, dtype=np.float32))
         self.g_flags = L.SAR_GRAPH_WT_BF16_EXACT if bool(torch.equal(w32.to(torch.bfloat16).to(torch.float32), w32)) else 0
+        # gather lists that are neither {one entry of weight 1} nor empty: the CN8 graph convolution builds only those and reads
+        # every other operand straight from the raw tile (SAR_GRAPH_FEW_DENSE, csrc/conv_graph_cn8.hip)
+        wnp = np.asarray(wt, dtype=np.float32)
+        cnt = (wnp != 0).sum(axis=2)
+        first = np.take_along_axis(wnp, np.argmax(wnp != 0, axis=2)[..., None], axis=2)[..., 0]
+        self.n_dense_lists = int(((cnt > 1) | ((cnt == 1) & (first != 1.0))).sum())
+        if self.n_dense_lists <= 16:
+            self.g_flags |= L.SAR_GRAPH_FEW_DENSE | (self.n_dense_lists << L.SAR_GRAPH_FEW_DENSE_SHIFT)
 
 
 class PackedWeights:

@@ -4,6 +4,8 @@ exact, contraction in float64 here / fp32 on the GPU, outputs rounded to bfloat1
 sums (taken from the fp32 accumulators) 1e-4; stored outputs within one bfloat16 rounding (2^-8 relative per element plus
 1e-5 of the tensor scale for the accumulation order)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -500,3 +502,61 @@ def test_cn8_kernels_repeat_bit_for_bit(dev, cin, f, s, T):
                 ref = res
             else:
                 assert all(torch.equal(a, b) for a, b in zip(ref, res)), "%s is not repeatable (rep %d)" % (name, rep)
+
+
+def _run_in_env(code, env_extra):
+    """a fresh interpreter with `env_extra` (the switch is read once per process); returns what the snippet saved"""
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.pkl")
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                           timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+        return pickle.load(open(out, "rb"))
+
+
+_GRAPH_AB = r'''
+import sys, pickle, torch
+sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "skeleton-action-recognition_amd")
+import test_gpu_cn8 as T
+from sar_amd import ops8, _lib as L
+dev = torch.device("cuda", 0)
+res = {}
+for (B, cin, f, Tt) in [(3, 3, 64, 13), (2, 64, 64, 23), (2, 64, 128, 7), (1, 128, 256, 5), (4, 256, 256, 75), (2, 40, 72, 9)]:
+    g = torch.Generator().manual_seed(B * 1000 + cin)
+    x = torch.randn(B, cin, Tt, 25, generator=g).bfloat16()
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    bias = torch.randn(3 * f, generator=g) * 0.1
+    dout = torch.randn(B, f, Tt, 25, generator=g).bfloat16()
+    add = torch.randn(B, cin, Tt, 25, generator=g).bfloat16()
+    tab, tabT = T._tables(dev), T._tables(dev, True)
+    out = ops8.empty(f, B * Tt * 25, dev)
+    r = ops8.conv_gemm(L.SAR_CONV_GRAPH, T._cn8(x, dev), out, T._pack(dev, kernel, f, 3 * f, 1, 3, cin, f), B=B, V=25, T_src=Tt, T_out=Tt,
+                       Kc=cin, M=f, taps=3, bias=bias.to(dev), tables=tab, epi=L.SAR_EPI_STATS)
+    dx = ops8.empty(cin, B * Tt * 25, dev)
+    ops8.conv_gemm(L.SAR_CONV_GRAPH, T._cn8(dout, dev), dx, T._pack(dev, kernel, f, 1, 3 * f, 3, f, cin), B=B, V=25, T_src=Tt, T_out=Tt,
+                   Kc=f, M=cin, taps=3, tables=tabT, epi=L.SAR_EPI_ADD, aux=T._cn8(add, dev))
+    torch.cuda.synchronize()
+    res[(B, cin, f, Tt)] = (out.cpu(), r[0].cpu(), dx.cpu(), tab.g_flags, tabT.g_flags)
+pickle.dump(res, open(sys.argv[1], "wb"))
+'''
+
+
+def test_graph_conv_read_gather_equals_the_unit_builder_bit_for_bit(dev):
+    """csrc/conv_graph_cn8.hip (operands of trivial gather lists read straight from the raw tile, the few others built as
+    virtual joints) against conv_graph_cn8_kernel (every gathered tile built): same tiles, same fp32 chains, same MFMA order --
+    outputs, BatchNorm partial sums and data gradients must agree bit for bit.  NTU: 2 dense lists forward, 8 transposed."""
+    from sar_amd import _lib as L
+    new = _run_in_env(_GRAPH_AB, {"SAR_GRAPH_READ_GATHER": "1"})
+    old = _run_in_env(_GRAPH_AB, {"SAR_GRAPH_READ_GATHER": "0"})
+    for key in new:
+        o1, p1, d1, fl, flT = new[key]
+        o0, p0, d0, _, _ = old[key]
+        assert fl & L.SAR_GRAPH_FEW_DENSE and (fl >> L.SAR_GRAPH_FEW_DENSE_SHIFT) & 0xff == 2
+        assert flT & L.SAR_GRAPH_FEW_DENSE and (flT >> L.SAR_GRAPH_FEW_DENSE_SHIFT) & 0xff == 8
+        assert torch.equal(o1, o0), key
+        assert torch.equal(p1, p0), key
+        assert torch.equal(d1, d0), key
