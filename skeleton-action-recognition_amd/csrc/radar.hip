@@ -14,6 +14,7 @@
 //   (k + n_fft/2) % n_fft (the reference's roll) -- and only for the frames the nearest-neighbour
 //   F.interpolate of models/resnet.py:26 actually consumes when out_cols > 0.
 #include "sar_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -126,6 +127,139 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_kernel(const float* __restri
   }
   z_re[(int64_t)b * To + t0 + tt] = zr;
   z_im[(int64_t)b * To + t0 + tt] = zi;
+}
+
+// ---- the up-sampled signal (sar_vr_signal_upsampled_f32): 75 000 frames per clip instead of 300, i.e. where this kernel is 30 %
+// of the Path B step (profiles/r02_pathB_pad250_*).  Same frame-per-lane scheme, three changes (round 4):
+//  * ONE BODY AT A TIME through the LDS slab: 19 KB instead of 39 KB per wave, two waves per SIMD instead of one (the
+//    kernel is a chain of dependent vector instructions: a second wave hides half of every latency);
+//  * the aspect angles never leave the algebra: sin^2(theta) cos^2(phi) + sin^2(theta) sin^2(phi) = sin^2(theta) = 1 - q^2 with
+//    q = <A,B> / (|A||B| + 1e-6) = cos(theta), so  den = (1 - q)(1 + q) + c q^2  -- no acos / asin / 4 x sin, cos per term
+//    (phi drops out of layers/virtual_radar.py:114-116 altogether); q itself keeps the oracle's roundings.  Measured against the
+//    oracle's literal evaluation in tests/test_gpu_radar.py;
+//  * RANGE AND PHASE keep the oracle's float32 operation order bit for bit (IEEE sqrt and division: one ulp of range is
+//    0.02 rad of phase at lambda = 5e-4), but cos / sin of the ~1e5 rad phase share ONE argument reduction done in float64
+//    (psi is exact in float64; n = rint(psi 2/pi), r = psi - n pi/2 with a two-term pi/2: |error| < 1e-11 rad) followed by
+//    the Cephes minimax polynomials on [-pi/4, pi/4] -- instead of two Payne-Hanek reductions in ocml's sinf / cosf.
+__device__ __forceinline__ void sincos_phase(float psi, float& sn, float& cs) {
+  const double x = (double)psi;
+  const double n = __builtin_rint(x * 0.63661977236758134308);
+  double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);
+  r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
+  const float rf = (float)r;
+  const int q = (int)n;
+  const float z = rf * rf;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, rf, rf);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                        fmaf(-0.5f, z, 1.0f));
+  const bool swap = q & 1;
+  const float a = swap ? cp : sp, b = swap ? sp : cp;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
+template <int SPLINE>
+__global__ __launch_bounds__(FRAMES) void vr_signal_fast_kernel(const float* __restrict__ x, const double* __restrict__ coef,
+                                                                int T, int Tup, int V, int M,
+                                                                const int* __restrict__ e_src, const int* __restrict__ e_dst,
+                                                                int E, const float* __restrict__ loc_p,
+                                                                const float* __restrict__ lam_p, float* __restrict__ z_re,
+                                                                float* __restrict__ z_im) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int VM = V * M;
+  const int RS = V | 1;                      // odd row stride
+  float* xs = smem;                          // [3][FRAMES][RS]: ONE body
+  int* es = (int*)(xs + 3 * FRAMES * RS);    // [E] src joints
+  int* ed = es + E;                          // [E] dst joints
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * FRAMES;
+  const int To = SPLINE ? Tup : T;           // frames of the signal
+  const int nt = min(FRAMES, To - t0);
+  const int tt = threadIdx.x;
+  for (int i = tt; i < E; i += FRAMES) {
+    es[i] = e_src[i];
+    ed[i] = e_dst[i];
+  }
+  const float lx = loc_p[0], ly = loc_p[1], lz = loc_p[2];
+  const float lam = lam_p[0];
+  const float PI_F = 3.14159274101257324f;        // float32(np.pi)
+  const float FOURPI_F = 12.5663706143591725f;    // rounds to float32(4*np.pi)
+  // spline piece of this lane's frame (fill_slab<1>)
+  double sdx = 0.0;
+  const double* cf = nullptr;
+  if (SPLINE && tt < nt) {
+    const int j = t0 + tt;
+    const double xn = (double)j / (double)(Tup - 1);
+    int i = (int)floor(xn * (double)(T - 1));
+    if (i > T - 2) i = T - 2;
+    sdx = xn - (double)i / (double)(T - 1);
+    cf = coef + ((int64_t)b * (T - 1) + i) * (3 * VM * 4);
+  }
+  float zr = 0.f, zi = 0.f;
+  for (int m = 0; m < M; ++m) {
+    __syncthreads();   // the previous body's slab has been consumed (and es / ed are visible)
+    if (!SPLINE) {
+      for (int c = 0; c < 3; ++c) {
+        const float* g = x + (((int64_t)b * 3 + c) * T + t0) * VM;   // nt*VM contiguous floats
+        for (int i = tt; i < nt * V; i += FRAMES) {
+          const int f = i / V, v = i - f * V;
+          xs[(c * FRAMES + f) * RS + v] = g[f * VM + v * M + m];
+        }
+      }
+    } else if (tt < nt) {
+      for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < V; ++v) {
+          const double* q = cf + (c * VM + v * M + m) * 4;
+          const double val = q[0] + sdx * (q[1] + sdx * (q[2] + sdx * q[3]));
+          xs[(c * FRAMES + tt) * RS + v] = (float)val;
+        }
+    }
+    __syncthreads();
+    if (tt < nt) {
+      const float* X0 = xs + (0 * FRAMES + tt) * RS;
+      const float* X1 = xs + (1 * FRAMES + tt) * RS;
+      const float* X2 = xs + (2 * FRAMES + tt) * RS;
+      // c = (mean_e |S - D|)^2, layers/virtual_radar.py:110-113 (mean over the edge axis); amplitude only: 1-ulp square root
+      float acc = 0.f;
+      for (int e = 0; e < E; ++e) {
+        const int js = es[e], jd = ed[e];
+        const float dx = X0[js] - X0[jd], dy = X1[js] - X1[jd], dz = X2[js] - X2[jd];
+        acc = acc + __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz);
+      }
+      float c = acc / (float)E;
+      c = c * c;
+      const float spc = __builtin_amdgcn_sqrtf(PI_F * c);
+      for (int e = 0; e < E; ++e) {
+        const int js = es[e], jd = ed[e];
+        const float sx = X0[js], sy = X1[js], sz = X2[js];
+        const float dx = X0[jd], dy = X1[jd], dz = X2[jd];
+        // range and phase: the oracle's operation order, IEEE sqrt and division
+        const float rx = fabsf(sx - lx), ry = fabsf(sy - ly), rz = fabsf(sz - lz);
+        const float rxy2 = rx * rx + ry * ry;
+        const float dist = sqrtf(rxy2 + rz * rz);
+        const float psi = ((FOURPI_F * dist) / (lam));
+        // amplitude: q = cos(theta), den = sin^2(theta) + c cos^2(theta)
+        const float ax = lx - ((sx + dx) * 0.5f), ay = ly - ((sy + dy) * 0.5f), az = lz - ((sz + dz) * 0.5f);
+        const float bx = dx - sx, by = dy - sy, bz = dz - sz;
+        const float dot = (ax * bx + ay * by) + az * bz;
+        const float nA2 = (ax * ax + ay * ay) + az * az;
+        const float nB2 = (bx * bx + by * by) + bz * bz;
+        // q with the oracle's roundings (IEEE sqrt and division): near |q| = 1 the denominator is a cancellation, and agreement
+        // with the reference there means the SAME q, not merely an accurate one (an rcp-based q: 6e-5 of the signal's scale)
+        const float q = dot / (sqrtf(nA2) * sqrtf(nB2) + 1e-6f);
+        const float den = fmaf(c * q, q, (1.f - q) * (1.f + q));
+        const float amp = spc * __builtin_amdgcn_rcpf(fabsf(den));
+        float sn, cs;
+        sincos_phase(psi, sn, cs);
+        zr = zr + amp * cs;
+        zi = zi + amp * sn;
+      }
+    }
+  }
+  if (tt < nt) {
+    z_re[(int64_t)b * To + t0 + tt] = zr;
+    z_im[(int64_t)b * To + t0 + tt] = zi;
+  }
 }
 
 __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ z_re, const float* __restrict__ z_im,
@@ -421,28 +555,37 @@ __global__ __launch_bounds__(FRAMES) void vr_signal_bwd_kernel(const float* __re
 //      (m[1] = r[1]/6, m[T-2] = r[T-2]/6 from the not-a-knot conditions, m[0] = 2 m[1] - m[2], ...), then the
 //      per-interval cubic pieces  a + b dx + c dx^2 + d dx^3  (dx in units of x, knot spacing h = 1/(T-1)).
 // One thread per series (150 per clip); scratch [T][nseries] so that neighbouring threads touch neighbouring words.
-__global__ __launch_bounds__(64) void upsample_prepare_kernel(const float* __restrict__ x, int B, int T, int VM,
-                                                              const double* __restrict__ w, int radius,
-                                                              float* __restrict__ sm, double* __restrict__ m2,
-                                                              double* __restrict__ cp, double* __restrict__ coef) {
+// Step 1 as its own launch (round 4): one thread per (frame, series) -- the 2 radius + 1 taps of one output are independent of
+// every other output, and inside the per-series kernel they were 7 500 serial iterations in front of the spline solve
+// (0.6 of its 0.89 ms at bs = 32).  Same summation order, same float64 accumulation, same float32 result.
+__global__ __launch_bounds__(256) void upsample_smooth_kernel(const float* __restrict__ x, int B, int T, int VM,
+                                                              const double* __restrict__ w, int radius, float* __restrict__ sm) {
+  const int nser = B * 3 * VM;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)nser * T) return;
+  const int sidx = (int)(gid % nser), t = (int)(gid / nser);
+  const int vm = sidx % VM, c = (sidx / VM) % 3, b = sidx / (3 * VM);
+  const float* xs = x + ((int64_t)(b * 3 + c) * T) * VM + vm;        // element t at xs[t * VM]
+  auto refl = [&](int q) {                                          // scipy 'reflect': (d c b a | a b c d | d c b a)
+    while (q < 0 || q >= T) {
+      if (q < 0) q = -q - 1;
+      if (q >= T) q = 2 * T - 1 - q;
+    }
+    return q;
+  };
+  double tmp = (double)xs[(int64_t)t * VM] * w[0];
+  for (int k = radius; k >= 1; --k)
+    tmp += ((double)xs[(int64_t)refl(t - k) * VM] + (double)xs[(int64_t)refl(t + k) * VM]) * w[k];
+  sm[(int64_t)t * nser + sidx] = (float)tmp;
+}
+
+__global__ __launch_bounds__(64) void upsample_prepare_kernel(int B, int T, int VM, const float* __restrict__ sm,
+                                                              double* __restrict__ m2, double* __restrict__ cp,
+                                                              double* __restrict__ coef) {
   const int nser = B * 3 * VM;
   const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (sidx >= nser) return;
   const int vm = sidx % VM, c = (sidx / VM) % 3, b = sidx / (3 * VM);
-  const float* xs = x + ((int64_t)(b * 3 + c) * T) * VM + vm;        // element t at xs[t * VM]
-  auto refl = [&](int t) {                                          // scipy 'reflect': (d c b a | a b c d | d c b a)
-    while (t < 0 || t >= T) {
-      if (t < 0) t = -t - 1;
-      if (t >= T) t = 2 * T - 1 - t;
-    }
-    return t;
-  };
-  for (int t = 0; t < T; ++t) {
-    double tmp = (double)xs[(int64_t)t * VM] * w[0];
-    for (int k = radius; k >= 1; --k)
-      tmp += ((double)xs[(int64_t)refl(t - k) * VM] + (double)xs[(int64_t)refl(t + k) * VM]) * w[k];
-    sm[(int64_t)t * nser + sidx] = (float)tmp;
-  }
   const int n = T - 1;                       // intervals
   const double h = 1.0 / (double)n, ih2 = 6.0 / (h * h);
   auto y = [&](int t) { return (double)sm[(int64_t)t * nser + sidx]; };
@@ -660,8 +803,16 @@ extern "C" int sar_vr_signal_f32(const float* x, int B, int T, int V, int M, con
   const size_t lds = sizeof(float) * 3 * FRAMES * ((V * M) | 1) + sizeof(int) * 2 * E;
   SAR_REQUIRE(lds <= 64 * 1024, "sar_vr_signal: V*M = %d too large for the LDS slab", V * M);
   dim3 grid((T + FRAMES - 1) / FRAMES, B);
-  hipLaunchKernelGGL(vr_signal_kernel<0>, grid, dim3(FRAMES), lds, as_stream(s), x, nullptr, T, T, V, M, e_src, e_dst, E,
-                     loc, wavelength, z_re, z_im);
+  const char* fe = getenv("SAR_VR_FAST_PLAIN");   // test switch (read per call): the up-sampled path's arithmetic on plain clips
+  const bool fast = fe && fe[0] == '1';
+  if (fast) {
+    const size_t lds1 = sizeof(float) * 3 * FRAMES * (V | 1) + sizeof(int) * 2 * E;
+    hipLaunchKernelGGL(vr_signal_fast_kernel<0>, grid, dim3(FRAMES), lds1, as_stream(s), x, nullptr, T, T, V, M, e_src, e_dst, E,
+                       loc, wavelength, z_re, z_im);
+  } else {
+    hipLaunchKernelGGL(vr_signal_kernel<0>, grid, dim3(FRAMES), lds, as_stream(s), x, nullptr, T, T, V, M, e_src, e_dst, E,
+                       loc, wavelength, z_re, z_im);
+  }
   SAR_LAUNCH_CHECK("sar_vr_signal_f32");
   return 0;
 }
@@ -686,8 +837,10 @@ extern "C" int sar_upsample_prepare_f64(const float* x, int B, int T, int V, int
   float* sm = (float*)workspace;
   double* m2 = (double*)((char*)workspace + (((nser * T * 4) + 7) / 8) * 8);
   double* cp = m2 + nser * T;
-  hipLaunchKernelGGL(upsample_prepare_kernel, dim3((unsigned)((nser + 63) / 64)), dim3(64), 0, as_stream(s), x, B, T, V * M,
-                     weights, radius, sm, m2, cp, coef);
+  hipLaunchKernelGGL(upsample_smooth_kernel, dim3((unsigned)((nser * T + 255) / 256)), dim3(256), 0, as_stream(s), x, B, T, V * M,
+                     weights, radius, sm);
+  hipLaunchKernelGGL(upsample_prepare_kernel, dim3((unsigned)((nser + 63) / 64)), dim3(64), 0, as_stream(s), B, T, V * M, sm, m2,
+                     cp, coef);
   SAR_LAUNCH_CHECK("sar_upsample_prepare_f64");
   return 0;
 }
@@ -702,8 +855,16 @@ extern "C" int sar_vr_signal_upsampled_f32(const double* coef, int B, int T, int
   SAR_REQUIRE(lds <= 64 * 1024, "sar_vr_signal_upsampled: V*M = %d too large for the LDS slab", V * M);
   const int Tup = T * P;
   dim3 grid((Tup + FRAMES - 1) / FRAMES, B);
-  hipLaunchKernelGGL(vr_signal_kernel<1>, grid, dim3(FRAMES), lds, as_stream(s), nullptr, coef, T, Tup, V, M, e_src, e_dst,
-                     E, loc, wavelength, z_re, z_im);
+  const char* fe = getenv("SAR_VR_FAST");   // A/B switch (read per call): 0 = the literal evaluation
+  const bool fast = !(fe && fe[0] == '0');
+  if (fast) {
+    const size_t lds1 = sizeof(float) * 3 * FRAMES * (V | 1) + sizeof(int) * 2 * E;   // one body at a time
+    hipLaunchKernelGGL(vr_signal_fast_kernel<1>, grid, dim3(FRAMES), lds1, as_stream(s), nullptr, coef, T, Tup, V, M, e_src, e_dst,
+                       E, loc, wavelength, z_re, z_im);
+  } else {
+    hipLaunchKernelGGL(vr_signal_kernel<1>, grid, dim3(FRAMES), lds, as_stream(s), nullptr, coef, T, Tup, V, M, e_src, e_dst,
+                       E, loc, wavelength, z_re, z_im);
+  }
   SAR_LAUNCH_CHECK("sar_vr_signal_upsampled_f32");
   return 0;
 }
