@@ -11,6 +11,10 @@
 constexpr int SAR_GRAPH2_NOT_APPLICABLE = -1000;
 __attribute__((visibility("hidden"))) int sar_graph2_cn8_dispatch(const sar_conv_desc& d, const void* wp, hipStream_t st, int* np);
 
+// conv_gemm_cn8_dma.hip: the 9-tap data gradients with LDS-DMA operand staging (experiment switch SAR_CN8_DMA=1)
+constexpr int SAR_CN8_DMA_NOT_APPLICABLE = -1001;
+__attribute__((visibility("hidden"))) int sar_cn8_dma_dispatch(int tr, const sar_conv_desc& d, const void* wp, hipStream_t st, int* np);
+
 namespace {
 
 constexpr int KC16 = 16;   // src channels per main-loop stage = one MFMA k-step = two CN8 planes

@@ -1043,6 +1043,10 @@ template <int TR, int TAPS>
 int launch_by_m8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) {
   // M > 64: 128 x 256 tiles (wave tile 64 x 128): per output element the weight image -- re-read from L2 by every tile and
   // stage -- is fetched half as often as with 128 x 128 tiles (measured: SAR_CN8_TN128=1 restores the small tile)
+  if constexpr (TAPS == 9 && (TR == 1 || TR == 3)) {
+    const int rc = sar_cn8_dma_dispatch(TR, d, wp, st, np);   // LDS-DMA operand staging (SAR_CN8_DMA=1)
+    if (rc != SAR_CN8_DMA_NOT_APPLICABLE) return rc;
+  }
   if constexpr (TAPS == 9 && (TR == 0 || TR == 1 || TR == 3))
     if (d.M > 32 && (TR != 0 || d.stride == 1) && tile_choice() == 2 && db_enabled() && d.V * 19 <= 512)
       return launch_db8<TR, 2, 2, 1, 4>(d, wp, st, np);

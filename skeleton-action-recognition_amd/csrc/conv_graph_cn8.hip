@@ -22,14 +22,16 @@
 
 namespace {
 
+constexpr bool SAR_GRAPH2_WG4_DEFAULT = true;
 constexpr int NVMAX = 16;   // virtual joints per frame the tables may ask for
 
 #ifndef SAR_G2_PF2
 #define SAR_G2_PF2 0      // operand prefetch distance 2 (two staging register sets); 0 = one stage ahead (A/B builds)
 #endif
-#ifndef SAR_G2_WG4
-#define SAR_G2_WG4 1      // four workgroups per CU (<= 128 VGPRs: one fragment set, aux half units loaded inside the epilogue); 0 = three
-#endif
+// SAR_G2_WG4 (template parameter; SAR_GRAPH2_WG4=0|1 at run time): four workgroups per CU (<= 128 VGPRs: one fragment set, aux
+// half units loaded inside the epilogue) or three (148-152 VGPRs: two fragment sets, aux half units requested before the last
+// MFMA phase).  Alone the four-workgroup kernel is 4 % faster; beside the weight-gradient stream the three-workgroup one leaves
+// room for the other stream's workgroups (profiles/r04_bf16_instep_ab.txt).
 #ifndef SAR_G2_WG4_PREAUX
 #define SAR_G2_WG4_PREAUX 0   // 1: the ADD epilogue's aux half units requested before the last MFMA phase (5 spilled registers at 128: measured 1-3 % slower)
 #endif
@@ -37,7 +39,7 @@ constexpr int NVMAX = 16;   // virtual joints per frame the tables may ask for
 #define SAR_G2_ABLATE 0   // diagnostic builds only (tools/ablate_g2.sh): 1 no MFMA, 2 global loads of stage 0 only, 4 no epilogue, 8 no mini-builder, 16 LDS stores of stage 0 only
 #endif
 
-template <int MS, int NS, int WM, int WN>
+template <int MS, int NS, int WM, int WN, int SAR_G2_WG4>
 __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kernel(const ConvK8 k, const int nv_asserted) {
   constexpr int BM = 32 * MS * WM, TN = 32 * NS * WN;
   constexpr int PL = 2;                      // CN8 planes per stage (16 source channels = one MFMA k-step)
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
   else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
 }
 
-template <int MS, int NS, int WM, int WN>
+template <int MS, int NS, int WM, int WN, int WG4>
 int launch_graph2_cfg(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* nparts_only, int nv) {
   ConvK8 k;
   fill_common(d, wp, k);
@@ -364,7 +366,7 @@ int launch_graph2_cfg(const sar_conv_desc& d, const uint4* wp, hipStream_t st, i
   k.ntiles = d.B * k.TPS;
   k.ny = (d.M + BM - 1) / BM;
   const int nwork = k.ntiles * k.ny;
-  hipLaunchKernelGGL((conv_graph2_cn8_kernel<MS, NS, WM, WN>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k, nv);
+  hipLaunchKernelGGL((conv_graph2_cn8_kernel<MS, NS, WM, WN, WG4>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, k, nv);
   return 0;
 }
 
@@ -382,7 +384,16 @@ int sar_graph2_cn8_dispatch(const sar_conv_desc& d, const void* wp_, hipStream_t
   const int nv = (d.g_flags >> SAR_GRAPH_FEW_DENSE_SHIFT) & 0xff;
   if (nv > NVMAX) return SAR_GRAPH2_NOT_APPLICABLE;
   const uint4* wp = (const uint4*)wp_;
-  if (d.M > 64) return launch_graph2_cfg<2, 2, 2, 2>(d, wp, st, np, nv);
-  if (d.M > 32) return launch_graph2_cfg<2, 2, 1, 4>(d, wp, st, np, nv);
-  return launch_graph2_cfg<1, 2, 1, 4>(d, wp, st, np, nv);
+  static const bool wg4 = [] {
+    const char* e = getenv("SAR_GRAPH2_WG4");
+    return e ? e[0] == '1' : SAR_GRAPH2_WG4_DEFAULT;
+  }();
+  if (wg4) {
+    if (d.M > 64) return launch_graph2_cfg<2, 2, 2, 2, 1>(d, wp, st, np, nv);
+    if (d.M > 32) return launch_graph2_cfg<2, 2, 1, 4, 1>(d, wp, st, np, nv);
+    return launch_graph2_cfg<1, 2, 1, 4, 1>(d, wp, st, np, nv);
+  }
+  if (d.M > 64) return launch_graph2_cfg<2, 2, 2, 2, 0>(d, wp, st, np, nv);
+  if (d.M > 32) return launch_graph2_cfg<2, 2, 1, 4, 0>(d, wp, st, np, nv);
+  return launch_graph2_cfg<1, 2, 1, 4, 0>(d, wp, st, np, nv);
 }

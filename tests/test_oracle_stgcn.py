@@ -82,3 +82,59 @@ def test_moving_statistics_update():
     assert set(new) == {"data_bn.moving_mean", "data_bn.moving_var", "l0.bn1.moving_mean", "l0.bn1.moving_var",
                         "l0.bn2.moving_mean", "l0.bn2.moving_var"}
     assert torch.all(new["l0.bn1.moving_var"] > 0.98)   # 0.99*1 + 0.01*var
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the oracle's primitives against an independent scipy / numpy implementation with published
+# semantics, on the reference's bundled NTU clips (fixture: tests/golden/stgcn_primitives.npz, generator next to it)
+
+def test_oracle_primitives_match_the_independent_scipy_numpy_fixture(golden_dir):
+    """oracle/stgcn.py (torch CPU ops) vs tests/golden/make_golden_stgcn_primitives.py (scipy.signal.correlate on explicitly
+    padded arrays, numpy BatchNormalization, per-slice matrix products): data_bn prologue, GraphConvTD, train-mode BN +
+    moving statistics (unbiased in the 4-D path, biased in data_bn), the 9x1 convolution with TF-SAME pads (4,4) / (3,4) and
+    the strided 1x1 residual convolution, in float64 on two bundled NTU clips.  What this CANNOT pin (no TensorFlow here)
+    is listed in oracle/stgcn.py's header."""
+    import os
+
+    import numpy as np
+    import torch
+    from oracle import stgcn as O
+    from oracle.graph import spatial_adjacency
+    g = np.load(os.path.join(golden_dir, "stgcn_primitives.npz"))
+    clips = torch.from_numpy(np.load(os.path.join(golden_dir, "ntu_clips_0_2.npy"))).double()
+    t = lambda k: torch.from_numpy(np.asarray(g[k], dtype=np.float64))
+    A = torch.from_numpy(spatial_adjacency().astype(np.float32)).double()
+    close = lambda a, b, tol=1e-10: float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)
+    # data_bn (models/stgcn.py:136-147): channel index v C + c, statistics over (N M, T), biased moving variance
+    p = {"data_bn.gamma": t("dbn_gamma"), "data_bn.beta": t("dbn_beta"), "data_bn.moving_mean": torch.zeros(75, dtype=torch.float64),
+         "data_bn.moving_var": torch.ones(75, dtype=torch.float64)}
+    ns = {}
+    x0 = O.data_bn(clips, p, True, ns)
+    assert close(x0, torch.from_numpy(g["x0"]).double(), 1e-6)          # fixture stored as float32
+    assert close(ns["data_bn.moving_mean"], t("dbn_mm")) and close(ns["data_bn.moving_var"], t("dbn_mv"))
+    # GraphConvTD (models/gcn.py:199-209)
+    gg = O.graph_conv_td(x0, t("kg"), t("bg"), A)
+    assert close(gg.sum(dim=(2, 3)), t("g_sum"), 2e-6)
+    assert close(gg[:, :, ::37, ::6], t("g_probe"), 2e-6)               # x0 re-derived here in float64, fixture's x0 identical to 1e-16
+    # BN train mode (axis 1 of a 4-D tensor: unbiased moving variance) + ReLU
+    ns = {}
+    F_ = g["bn_gamma"].shape[0]
+    h = O.batch_norm(gg, t("bn_gamma"), t("bn_beta"), torch.zeros(F_, dtype=torch.float64), torch.ones(F_, dtype=torch.float64),
+                     True, (0, 2, 3), True, ns, "bn")
+    h = torch.relu(h)
+    assert close(h[:, :, ::37, ::6], t("h_probe"), 1e-9)
+    assert close(ns["bn.moving_mean"], t("bn_mm"), 1e-9) and close(ns["bn.moving_var"], t("bn_mv"), 1e-9)
+    # 9x1 convolution, TF 'SAME': stride 1 pads (4,4); stride 2 pads (3,4) -- the first / last frames are where a wrong pad shows
+    u1 = O.temporal_conv(h, t("kt"), t("bt"), 1)
+    u2 = O.temporal_conv(h, t("kt"), t("bt"), 2)
+    assert u1.shape[2] == 300 and u2.shape[2] == 150
+    assert close(u1[:, :, ::37, ::6], t("u1_probe"), 1e-9) and close(u1[:, :, [0, 1, 2, 3, 296, 297, 298, 299]], t("u1_edges"), 1e-9)
+    assert close(u2[:, :, ::19, ::6], t("u2_probe"), 1e-9) and close(u2[:, :, [0, 1, 2, 147, 148, 149]], t("u2_edges"), 1e-9)
+    assert close(u1.sum(dim=(2, 3)), t("u1_sum"), 1e-9) and close(u2.sum(dim=(2, 3)), t("u2_sum"), 1e-9)
+    # a symmetric (4,4) pad at stride 2 -- the classic mistake -- is NOT what the fixture holds
+    import torch.nn.functional as F
+    wrong = F.conv2d(F.pad(h, (0, 0, 4, 4)), O.hwio_to_oihw(t("kt")), t("bt"), stride=(2, 1))[:, :, :150]
+    assert not close(wrong[:, :, [0, 1, 2, 147, 148, 149]], t("u2_edges"), 1e-3)
+    # strided 1x1 residual convolution (models/stgcn.py:47-54): samples t = 0, 2, 4, ...
+    r2 = O.temporal_conv(x0, t("kr"), t("br"), 2)
+    assert close(r2[:, :, ::19, ::6], t("r2_probe"), 1e-9) and close(r2.sum(dim=(2, 3)), t("r2_sum"), 1e-9)
