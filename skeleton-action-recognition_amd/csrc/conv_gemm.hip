@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
   store_lds(0, smem);
   __syncthreads();
   // accumulators start at the bias term: b[m] (temporal) or sum_k b_k[m] colsum(A_k)[v] (graph), 0 off-tile
+  SAR_LDS_SKEW();   // last read of the bias rows (overlaid on buffer 1's weight region)
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -300,12 +301,23 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
   // any wave gets there.  (Without this barrier a wave that the SIMD arbitration held back for a whole MFMA phase initialised
   // its accumulators from the next stage's weights: one wrong tile in ~1 of 1 000 launches, found by tools/trace_divergence.py
   // in round 3 -- the fp32 step was not repeatable in 1-4 % of its runs, in round 2 as well.)
+  // HAPPENS-BEFORE of the LDS regions of this kernel:
+  //  * bias rows (rowp, in buffer 1's W region when the tile is large): written before the barrier above, last read by the
+  //    accumulator initialisation, first overwritten by store_lds(KC, buffer 1) at the end of stage 0 -- ordered by THIS barrier;
+  //  * buffer it ^ 1 is rewritten at the end of stage s by a wave that has passed the closing barrier of stage s - 1, which every
+  //    wave joins after its MFMA phase of stage s - 1 = its last read of that buffer;
+  //  * rowp is rewritten with the MASK parameters in the epilogue by waves that passed the closing barrier of the LAST stage
+  //    (nobody reads buffer 1 / rowp between that barrier and the barrier behind the rewrite);
+  //  * the epilogue's transpose area (start of smem) is wave-private, written after the same closing barrier.
+#ifndef SAR_DEBUG_LDS_DROP_BIAS_BARRIER
   __syncthreads();
+#endif
   // one main-loop stage on LDS buffer IT (compile-time, so every LDS address is register + immediate)
   auto stage = [&](int c0, auto IT) {
     constexpr int it = decltype(IT)::value;
     const bool more = c0 + KC < d.Kc && !(SAR_ABLATE & 2);
     if (more && !(SAR_ABLATE & 16)) issue_loads(c0 + KC);   // 16: LDS stores of stale registers only
+    SAR_LDS_SKEW();   // this wave's reads of buffer IT start late: the other waves may only refill IT ^ 1 meanwhile
     const float* Wl = smem + it * TC::BUF;
     const float* S = Wl + TC::WPAD * WSTR;
 

@@ -205,6 +205,14 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
 
   issue_loads(0);
   __syncthreads();   // rowp
+  // HAPPENS-BEFORE of the LDS regions of this kernel (single image, two barriers per stage):
+  //  * image (W | S): written by store_lds(s) behind the closing barrier of stage s - 1, which every wave joins after its MFMA phase
+  //    of stage s - 1 (its last read of the image); read behind the opening barrier of stage s;
+  //  * rowp holds the bias rows until every wave has initialised its accumulators (below, before the opening barrier of stage 0)
+  //    and is rewritten with the MASK parameters behind the opening barrier of the LAST stage (>= 1 barrier later); the epilogue
+  //    reads them behind the closing barrier of the last stage;
+  //  * the epilogue's transpose area aliases the image and is wave-private; it is written behind that same closing barrier.
+  SAR_LDS_SKEW();   // last read of the bias rows
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -241,6 +249,7 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
 
   auto mma_phase = [&]() {
     constexpr int JSURE = PAR ? JT - 1 : JT;
+    SAR_LDS_SKEW();   // this wave reads the image late: nobody may restage it before the closing barrier
     if (!(SAR_ABLATE8 & 1)) {
 #ifdef SAR_CN8_SETPRIO
       __builtin_amdgcn_s_setprio(1);   // experiment: the multiplying wave wins issue arbitration against co-resident staging waves

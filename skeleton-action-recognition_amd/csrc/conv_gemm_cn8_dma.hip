@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 4 : 2) void conv_gemm_cn8_dma_kernel
   const uint4* Wa = Wl + (tp0 * 2 + hi) * BM + wm * MS * 32 + l31;
   auto mma_phase = [&](int bufo) {
     constexpr int JSURE = PAR ? JT - 1 : JT;
+    SAR_LDS_SKEW();   // this wave reads the image late: no DMA may land in it before the closing barrier
     auto frag_load = [&](int j, uint4 (&a)[MS], uint4 (&bq)[NS]) {
       const int tpw = PAR ? 2 * j : j;
 #pragma unroll

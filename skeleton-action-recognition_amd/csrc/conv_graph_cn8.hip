@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     }
   };
   auto mma_phase = [&](const uint4* buf) {
+    SAR_LDS_SKEW();   // this wave reads buffer s & 1 late: the others may only fill the OTHER buffer before the next barrier A
     const uint4* Wa = buf + hi * BM + wm * MS * 32 + l31;
     uint4 fa[2][MS], fb[2][NS];
     auto frag_load = [&](int tp, uint4 (&a)[MS], uint4 (&bq)[NS]) {

@@ -1,0 +1,42 @@
+"""LDS overlay / reuse checks of the conv kernels.
+
+Every LDS region of conv_gemm.hip, conv_gemm_cn8.hip, conv_gemm_cn8_dma.hip and conv_graph_cn8.hip is written, read and
+REWRITTEN; the happens-before chain of each rewrite is a comment at the rewrite.  A missing barrier there is a race that
+ordinary runs almost never lose -- round 3's bias-row race of the fp32 headline kernel lost 1 launch in 1 000.  The library is
+therefore also built with -DSAR_DEBUG_LDS (csrc/sar_common.h SAR_LDS_SKEW: ONE wave of every workgroup sleeps ~16 000 cycles
+in front of each of its last-read sites) as sar_amd/libsar_hip_ldsdebug.so: with every barrier in place the skew only costs
+time and the kernel parity tests below must still pass; libsar_hip_ldsbroken.so is the same build with round 3's bug PUT BACK
+(the barrier between the accumulator initialisation from the bias rows and the first refill of LDS buffer 1 removed): the
+instrument must turn that 1-in-1 000 race into a deterministic parity failure."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "skeleton-action-recognition_amd", "sar_amd")
+
+
+def _pytest_with_lib(lib, args, timeout=1500):
+    path = os.path.join(LIBDIR, lib)
+    assert os.path.exists(path), "%s missing: build it with `make -C skeleton-action-recognition_amd/csrc ldsdebug` (__graft_entry__.build() does)" % path
+    env = dict(os.environ, SAR_HIP_LIB=path)
+    return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT)
+
+
+def test_conv_kernels_pass_their_parity_tests_with_a_sleeping_wave_in_front_of_every_last_read():
+    r = _pytest_with_lib("libsar_hip_ldsdebug.so",
+                         ["tests/test_gpu_stgcn_kernels.py", "-k", "graph_conv or temporal_conv or residual_conv",
+                          "tests/test_gpu_cn8.py", "-k", "graph_conv or temporal or residual"])
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (tail, r.stderr[-1500:])
+
+
+def test_the_instrument_fires_on_the_round_3_bias_row_race():
+    """the fp32 temporal convolution with its bias rows overlaid on LDS buffer 1 and NO barrier in front of the first refill: the
+    sleeping wave initialises its accumulators from the next stage's weights -- every time, not once in 1 000 launches"""
+    r = _pytest_with_lib("libsar_hip_ldsbroken.so", ["tests/test_gpu_stgcn_kernels.py", "-k", "temporal_conv_forward"])
+    assert r.returncode != 0 and "failed" in r.stdout, r.stdout[-1500:]

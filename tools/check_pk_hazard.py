@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
-"""Counts, per HIP translation unit, the packed-fp32 instructions whose destination register pair is also a source pair
-AND whose high half reads the low register of that pair (op_sel_hi = 0): the pattern behind the intermittent ReLU-mask
-flips of conv_gemm_cn8's MASK epilogue on MI355X (csrc/Makefile).  Usage: tools/check_pk_hazard.py [file.hip ...]"""
+"""Counts, per HIP translation unit, the packed-fp32 instructions that read ONE VGPR pair through TWO source operands with
+DIFFERENT half selections (op_sel / op_sel_hi), e.g.
+    v_pk_fma_f32 v[68:69], v[108:109], v[104:105], v[104:105] op_sel:[0,0,1] op_sel_hi:[1,0,1]
+(hipcc's SLP vectoriser emits it for fma(aux, scale, shift) of two columns when (scale, shift) sit in one pair).
+On MI355X that form returns a wrong result in ~5e-5 (beside v_mfma_f32_32x32x16_bf16) to 5e-3 (beside
+v_mfma_f32_16x16x32_bf16) of its executions while ANOTHER wave of the same SIMD issues bf16 matrix instructions, and is
+exact otherwise (alone, beside fp32 MFMA, with distinct pairs, or without modifiers): tools/pk_hazard_forms.hip is the
+minimal reproducer, profiles/r04_pk_hazard_forms.txt its output.  (Round 2 had blamed the destination / source overlap of
+the same instruction; the overlap is irrelevant.)  Usage: tools/check_pk_hazard.py [file.hip ...]; a second column counts
+the round-2 pattern for comparison."""
 import os
 import re
 import subprocess
@@ -14,11 +21,16 @@ CSRC = os.path.join(ROOT, "skeleton-action-recognition_amd", "csrc")
 files = sys.argv[1:] or sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f != "conv2d.hip")
 pat = re.compile(r"\s*v_pk_(fma|mul|add)_f32 (v\[\d+:\d+\]), ([^,]+), ([^,\s]+)(?:, ([^,\s]+))?(.*)")
 for f in files:
-    extra = ["-fno-slp-vectorize"] if f == "conv_gemm_cn8.hip" else (["-ffp-contract=off"] if f == "radar.hip" else [])
+    noslp = os.environ.get("PK_NOSLP", "")      # comma list of TUs to scan as built with -fno-slp-vectorize ("Makefile" = as the Makefile builds them)
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    as_makefile = f.replace(".hip", ".o") in " ".join(l for l in mk.splitlines() if "-fno-slp-vectorize" in l)
+    extra = ["-fno-slp-vectorize"] if (f in noslp.split(",") or (noslp in ("", "Makefile") and as_makefile)) else []
+    if f == "radar.hip":
+        extra.append("-ffp-contract=off")
     with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
-        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + CSRC, *extra,
+        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), *extra,
                         os.path.join(CSRC, f), "-o", tmp.name], check=True, stderr=subprocess.DEVNULL)
-        total = hazard = 0
+        total = hazard = same_pair = same_pair_fma = 0
         for line in open(tmp.name):
             m = pat.match(line)
             if not m:
@@ -29,4 +41,15 @@ for f in files:
             sel_hi = [int(x) for x in oh.group(1).split(",")] if oh else [1, 1, 1]
             if any(sv == dst and i < len(sel_hi) and sel_hi[i] == 0 for i, sv in enumerate(srcs)):
                 hazard += 1
-        print("%-24s packed fp32 ops %5d, high half reads the low register of its own destination: %d" % (f, total, hazard))
+            ol = re.search(r"op_sel:\[([\d,]+)\]", rest)
+            sel_lo = [int(x) for x in ol.group(1).split(",")] if ol else [0, 0, 0]
+            sel_lo += [0] * (3 - len(sel_lo))
+            sel_hi += [1] * (3 - len(sel_hi))
+            n = 3 if m.group(1) == "fma" else 2
+            for i in range(n):
+                for j in range(i + 1, n):
+                    if srcs[i] and srcs[i] == srcs[j] and srcs[i].startswith("v[") and (sel_lo[i], sel_hi[i]) != (sel_lo[j], sel_hi[j]):
+                        same_pair += 1
+                        same_pair_fma += m.group(1) == "fma"
+        print("%-24s packed fp32 ops %5d | ONE pair through two operands with different half selects: %4d, of them v_pk_fma_f32 (the form "
+              "that fails beside bf16 MFMAs; the mul / add forms measured exact): %4d | (round-2 pattern: %d)" % (f, total, same_pair, same_pair_fma, hazard))
