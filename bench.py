@@ -32,7 +32,7 @@ EXECUTED_FLOP_PER_CLIP_TRAIN = (1939.7 + 16.8 + 6082.6 + 92.2) * 1e6 * 2 * 2 * 3
 PEAK_FP64_VALU_TFLOPS = 78.6       # MI355X: packed-free fp64 vector FMA, half the fp32 vector rate of MI355X_MICROARCH.md (157.3 TF)
 
 
-FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<"),
+FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<", "conv_gemm_cn8_dma_kernel<"),
                  "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",)}
 
 
@@ -522,7 +522,7 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
                 terms = frames * 24 * 2
                 per = sig["ms"] / sig["calls"]
                 out["radar_roofline"] = {
-                    "bound": "valu", "kernel": "vr_signal_kernel<SPLINE> (+ upsample_prepare_kernel)",
+                    "bound": "valu", "kernel": "vr_signal_fast_kernel<SPLINE> (+ upsample_smooth / upsample_prepare kernels)",
                     "avg_launch_ms": round(per, 4),
                     "prepare_avg_launch_ms": round(prep["ms"] / prep["calls"], 4) if prep and prep["calls"] else None,
                     "achieved": round(terms / (per * 1e-3) / 1e9, 2), "unit": "G (edge, body) terms/s",
@@ -530,8 +530,18 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
                     "peak_f64_valu_tflops": PEAK_FP64_VALU_TFLOPS,
                     "frac_of_f64_valu_peak": round(sig["flops"] / sig["calls"] / (per * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 4),
                     "share_of_step": round((per + (prep["ms"] / prep["calls"] if prep and prep["calls"] else 0.0)) / (dt / steps * 1e3), 4),
-                    "note": "the float64 spline evaluation uses a few per cent of the fp64 vector peak: the kernel is bound by its "
-                            "fp32 transcendental / IEEE-division VALU work, see profiles/r04_pathB_pad250_* (SQ_INSTS_VALU)"}
+                    "note": "the float64 spline evaluation uses a few per cent of the fp64 vector peak: the kernel is bound by the ISSUE of "
+                            "its fp32 vector instructions (IEEE square roots / divisions, the phase's sin / cos)"}
+                import glob
+                vf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pathB_pad250_valu.json")))
+                if vf:      # SQ_INSTS_VALU of the PROFILED build (its own rocprofv3 --pmc pass), not of this run
+                    vk = json.load(open(vf[-1]))["kernels"].get("vr_signal_fast_kernel<1>")
+                    if vk:
+                        out["radar_roofline"].update(
+                            peak="1 024 SIMDs x launch duration x 2.1 GHz / 4 cycles per wave64 vector instruction",
+                            valu_wave_instructions_per_launch=vk["valu_wave_instructions_per_launch"],
+                            frac=round(vk["valu_wave_instructions_per_launch"] / (1024 * per * 1e-3 * 2.1e9 / 4), 4),
+                            frac_source="SQ_INSTS_VALU from %s (profiled build) over THIS run's launch duration" % os.path.basename(vf[-1]))
     del trainer, model, batches
     return out
 

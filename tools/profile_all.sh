@@ -1,0 +1,16 @@
+#!/bin/bash
+# The round's four profile sets in one gpurun call: fp32 headline, bf16, Path B, Path B on the x250 up-sampled input.
+#   gpurun --timeout 2400 -- tools/profile_all.sh ;  then here: tools/profile_all.sh summarize r04
+cd "$(dirname "$0")/.."
+if [ "$1" = summarize ]; then
+  T=${2:-r04}
+  python3 tools/summarize_profiles.py ${T} prof fp32
+  python3 tools/summarize_profiles.py ${T}_bf16 prof_bf16 bf16
+  python3 tools/summarize_profiles.py ${T}_pathB prof_pathB pathB
+  python3 tools/summarize_profiles.py ${T}_pathB_pad250 prof_pathB_pad250 pathB --workload spectrogram --num-pad-frames 250
+else
+  tools/profile_round.sh prof
+  tools/profile_round.sh prof_bf16 --mfma bf16
+  tools/profile_round.sh prof_pathB --workload spectrogram
+  tools/profile_round.sh prof_pathB_pad250 --workload spectrogram --num-pad-frames 250
+fi

@@ -10,9 +10,9 @@ SUB=${1:-prof}
 O=$R/gpurun_out/$SUB
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 "$@" > $O/bench_under_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 "$@" > $O/bench_under_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 "$@" > $O/bench_under_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 --sustained-steps 0 "$@" > $O/bench_under_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 --sustained-steps 0 "$@" > $O/bench_under_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0 --sustained-steps 0 "$@" > $O/bench_under_write.log 2>&1
 cd $R && python3 bench.py --steps 10 --warmup 3 --no-secondary "$@" > $O/bench_plain.log 2>&1
 tail -1 $O/bench_plain.log | cut -c1-400
 ls $O/*/*/ | head -20

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 P = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "prof")
 MODE = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+EXTRA = (" " + " ".join(sys.argv[4:])) if len(sys.argv) > 4 else ""     # the extra bench.py arguments of the profiled command, if not the mode's default
 BF16 = MODE == "bf16"
 OUT = os.path.join(ROOT, "profiles")
 os.makedirs(OUT, exist_ok=True)
@@ -60,12 +61,15 @@ for k, (calls, avg_ns, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
                  "hbm_gbps": None if hbm is None else round(hbm / avg_ns, 1)})
 if BF16:   # conv_gemm_cn8_kernel<TR, TAPS = 9, ...> / the deep-prefetch variant (bf16 CN8 activations)
     fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_cn8_kernel<%d, 9" % tr) for tr in (0, 1, 2, 3))
-           or r["kernel"].startswith("conv_gemm_cn8_db_kernel<")]
+           or r["kernel"].startswith(("conv_gemm_cn8_db_kernel<", "conv_gemm_cn8_dma_kernel<"))]
 elif MODE == "pathB":
     fam = [r for r in rows if r["kernel"].startswith("conv2d_gemm_kernel")]
 else:
     fam = [r for r in rows if any(r["kernel"].startswith("conv_gemm_kernel<1, %d, 9" % tr) for tr in (0, 1, 2, 3))]
 calls = sum(r["calls"] for r in fam)
+# train steps the traced process ran: one optimizer launch per step (the fp32 headline leg appends its 100 sustained steps
+# unless --sustained-steps 0 is passed)
+nsteps = next((dur[k][0] for k in ("sgd_nesterov_kernel", "adam_kernel") if k in dur), 7)
 import subprocess
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
@@ -75,18 +79,19 @@ except Exception:
     commit = "unknown"
 summary = {
     "commit": commit,          # the tree the profiled build was made from (bench.py quotes it next to roofline.traffic)
-    "command": ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary%s ; "
+    "command": ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0%s ; "
                 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-                "--no-cpu-baseline --no-isolated-pass --no-secondary%s") % (({"bf16": " --mfma bf16", "pathB": " --workload spectrogram"}.get(MODE, ""),) * 2),
+                "--no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0%s") % ((EXTRA or {"bf16": " --mfma bf16", "pathB": " --workload spectrogram"}.get(MODE, ""),) * 2),
     "hbm_rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a coalesced stream; calibrated on "
                 "sgd_nesterov / bn_add_relu_fwd / affine2 whose byte counts are known)",
-    "dominant_family": {"bf16": "conv_gemm_cn8_kernel<9 taps>", "pathB": "conv2d_gemm_kernel (3x3 / 1x1)"}.get(
+    "dominant_family": {"bf16": "conv_gemm_cn8_kernel<9 taps> + conv_gemm_cn8_dma_kernel (9-tap data gradients with LDS-DMA staging)", "pathB": "conv2d_gemm_kernel (3x3 / 1x1)"}.get(
         MODE, "conv_gemm_kernel<TEMPORAL, 9 taps>") + " (forward + data-gradient instantiations)",
     "dominant_family_launches": calls,
     "dominant_family_avg_us": round(sum(r["avg_us"] * r["calls"] for r in fam) / calls, 2),
     "dominant_family_hbm_bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["calls"] for r in fam) / calls),
-    "total_kernel_ms_per_step": round(sum(r["avg_us"] * r["calls"] for r in rows) / 7e3, 3),
-    "total_hbm_bytes_per_step": int(sum((r["hbm_bytes_per_launch"] or 0) * r["calls"] for r in rows) / 7),
+    "steps_in_trace": nsteps,
+    "total_kernel_ms_per_step": round(sum(r["avg_us"] * r["calls"] for r in rows) / (1e3 * nsteps), 3),
+    "total_hbm_bytes_per_step": int(sum((r["hbm_bytes_per_launch"] or 0) * r["calls"] for r in rows) / nsteps),
     "kernels": rows,
 }
 json.dump(summary, open(os.path.join(OUT, "%s_kernel_summary.json" % tag), "w"), indent=1)
