@@ -579,6 +579,72 @@ __global__ __launch_bounds__(256) void upsample_smooth_kernel(const float* __res
   sm[(int64_t)t * nser + sidx] = (float)tmp;
 }
 
+// The spline solve with its per-series state in LDS (round 4; T <= PREP_TMAX).  upsample_prepare_kernel below keeps the second
+// derivatives and the sweep coefficients in global scratch: every step of its 300-step recurrences is a dependent global-memory
+// round trip, and 75 waves cannot hide it (0.31 ms at bs = 32 for 2e6 vector instructions: 1 % of the issue capacity).  Here the
+// right-hand sides r(i) are computed first (independent loads), the Thomas sweeps run on LDS ([T][64] float64, lanes = series:
+// conflict-free), and the sweep's coefficient sequence -- which does not depend on the data -- is kept once per workgroup.  Same
+// formulas in the same order: bit-identical pieces.
+constexpr int PREP_TMAX = 304;
+__global__ __launch_bounds__(64) void upsample_prepare_lds_kernel(int B, int T, int VM, const float* __restrict__ sm,
+                                                                  double* __restrict__ coef) {
+  __shared__ double m2s[PREP_TMAX * 64];
+  __shared__ double cps[PREP_TMAX];
+  const int nser = B * 3 * VM;
+  const int lane = threadIdx.x;
+  const int sidx = blockIdx.x * 64 + lane;
+  const bool live = sidx < nser;
+  const int sx = live ? sidx : nser - 1;     // idle lanes shadow the last series (no divergent barriers, nothing stored)
+  const int vm = sx % VM, c = (sx / VM) % 3, b = sx / (3 * VM);
+  const int n = T - 1;                       // intervals
+  const double h = 1.0 / (double)n, ih2 = 6.0 / (h * h);
+  auto y = [&](int t) { return (double)sm[(int64_t)t * nser + sx]; };
+  auto M2 = [&](int i) -> double& { return m2s[i * 64 + lane]; };
+  // r(i) = 6 / h^2 (y(i-1) - 2 y(i) + y(i+1)) for i = 1 .. n-1: independent loads, three values in flight
+  {
+    double ym = y(0), y0 = y(1);
+    for (int i = 1; i <= n - 1; ++i) {
+      const double yp = y(i + 1);
+      M2(i) = ih2 * (ym - 2.0 * y0 + yp);
+      ym = y0;
+      y0 = yp;
+    }
+  }
+  const double r1 = M2(1), rn1 = M2(n - 1);
+  M2(1) = r1 / 6.0;
+  M2(n - 1) = rn1 / 6.0;
+  if (n - 2 >= 2) {   // interior unknowns m[2..n-2]: m[i-1] + 4 m[i] + m[i+1] = r[i]
+    double cprev = 0.0, dprev = 0.0;
+    const double m1 = M2(1), mn1 = M2(n - 1);
+    for (int i = 2; i <= n - 2; ++i) {
+      double rhs = M2(i);
+      if (i == 2) rhs -= m1;
+      if (i == n - 2) rhs -= mn1;
+      const double lower = (i == 2) ? 0.0 : 1.0;
+      const double denom = 4.0 - lower * cprev;
+      cprev = ((i == n - 2) ? 0.0 : 1.0) / denom;
+      dprev = (rhs - lower * dprev) / denom;
+      if (lane == 0) cps[i] = cprev;     // the same sequence in every lane
+      M2(i) = dprev;
+    }
+    __syncthreads();                     // cps (one wave: the barrier is a wait for the LDS stores)
+    for (int i = n - 3; i >= 2; --i) M2(i) = M2(i) - cps[i] * M2(i + 1);
+  }
+  M2(0) = 2.0 * M2(1) - M2(2);
+  M2(n) = 2.0 * M2(n - 1) - M2(n - 2);
+  if (!live) return;
+  double yi = y(0);
+  for (int i = 0; i < n; ++i) {
+    const double mi = M2(i), mj = M2(i + 1), yj = y(i + 1);
+    double* q = coef + ((int64_t)b * n + i) * (3 * VM * 4) + (c * VM + vm) * 4;
+    q[0] = yi;
+    q[1] = (yj - yi) / h - h * (2.0 * mi + mj) / 6.0;
+    q[2] = mi / 2.0;
+    q[3] = (mj - mi) / (6.0 * h);
+    yi = yj;
+  }
+}
+
 __global__ __launch_bounds__(64) void upsample_prepare_kernel(int B, int T, int VM, const float* __restrict__ sm,
                                                               double* __restrict__ m2, double* __restrict__ cp,
                                                               double* __restrict__ coef) {
@@ -839,8 +905,12 @@ extern "C" int sar_upsample_prepare_f64(const float* x, int B, int T, int V, int
   double* cp = m2 + nser * T;
   hipLaunchKernelGGL(upsample_smooth_kernel, dim3((unsigned)((nser * T + 255) / 256)), dim3(256), 0, as_stream(s), x, B, T, V * M,
                      weights, radius, sm);
-  hipLaunchKernelGGL(upsample_prepare_kernel, dim3((unsigned)((nser + 63) / 64)), dim3(64), 0, as_stream(s), B, T, V * M, sm, m2,
-                     cp, coef);
+  const char* pe = getenv("SAR_UPSAMPLE_LDS");   // A/B switch (read per call): 0 = the global-scratch solve
+  if (T <= PREP_TMAX && !(pe && pe[0] == '0'))
+    hipLaunchKernelGGL(upsample_prepare_lds_kernel, dim3((unsigned)((nser + 63) / 64)), dim3(64), 0, as_stream(s), B, T, V * M, sm, coef);
+  else
+    hipLaunchKernelGGL(upsample_prepare_kernel, dim3((unsigned)((nser + 63) / 64)), dim3(64), 0, as_stream(s), B, T, V * M, sm, m2,
+                       cp, coef);
   SAR_LAUNCH_CHECK("sar_upsample_prepare_f64");
   return 0;
 }

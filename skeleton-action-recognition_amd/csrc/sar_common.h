@@ -123,7 +123,7 @@ static inline hipStream_t as_stream(sar_stream_t s) { return (hipStream_t)s; }
 // Every LDS region of the conv kernels is written, read and REWRITTEN (next stage, per-row parameters, the epilogue's
 // transpose area); each rewrite is ordered behind the last read by a barrier that the comments at the rewrite name.  A missing
 // barrier is a race that ordinary runs almost never lose (the round-3 bias-row race of conv_gemm.hip: 1 launch in 1 000).  In
-// a -DSAR_DEBUG_LDS build ONE wave of every workgroup (a different one from workgroup to workgroup) sleeps ~16 000 cycles in
+// a -DSAR_DEBUG_LDS build ONE wave of every workgroup (a different one from workgroup to workgroup) sleeps ~32 000 cycles in
 // front of each of its last-read sites: if no barrier holds the rewriting waves back they are several stages ahead by then and
 // the sleeper reads the wrong stage's operands -- a deterministic parity failure instead of a rare one.  The build with
 // -DSAR_DEBUG_LDS_DROP_BIAS_BARRIER (the round-3 bug put back) is kept to show that the instrument fires.
@@ -131,7 +131,7 @@ static inline hipStream_t as_stream(sar_stream_t s) { return (hipStream_t)s; }
 #define SAR_LDS_SKEW()                                                        \
   do {                                                                        \
     if (((threadIdx.x >> 6) & 3) == ((blockIdx.x + (blockIdx.x >> 3)) & 3)) { \
-      asm volatile("s_sleep 127\n\ts_sleep 127" ::: "memory"); /* no LDS read may move across */ \
+      asm volatile("s_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127" ::: "memory"); /* no LDS read may move across */ \
     }                                                                         \
   } while (0)
 #else

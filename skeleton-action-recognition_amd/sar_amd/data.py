@@ -223,8 +223,13 @@ class NpySkeletonData:
         jobs = [np.sort(np.asarray(idx)) for idx in shards]
         clip = self.data.shape[1:]
 
+        same_dtype = self.data.dtype == np.float32
+
         def build(idx, x, y):
-            np.take(self.data, idx, axis=0, out=x)
+            if same_dtype:
+                np.take(self.data, idx, axis=0, out=x)     # gather straight into the pinned float32 slot
+            else:                                          # a float64 / float16 .npy: np.take(out=) refuses the cast
+                np.copyto(x, self.data[idx], casting="unsafe")
             y[:] = self.labels[idx]
 
         return parallel_batches(jobs, build, lambda idx: (len(idx),) + tuple(clip), device,

@@ -149,3 +149,23 @@ def test_tfrecord_input_pipeline_keeps_up_with_the_gpu(tmp_path):
         rates[name] = max(got[1:])
     print("main_gnn.py --mfma bf16 clips/s:", rates)
     assert rates["tfrecord"] >= 0.95 * rates["synthetic"], rates
+
+
+def test_npy_loader_accepts_float64_and_float16_files(tmp_path):
+    """the loader threads gather each batch with np.take(..., out=<pinned float32 slot>), which refuses to cast; a
+    `*_data_joint.npy` saved as float64 (numpy's default) or float16 must still load, converted to float32."""
+    import pickle
+    from sar_amd.data import NpySkeletonData
+    rng = np.random.default_rng(1)
+    ref = np.clip(0.12 * rng.standard_normal((12, 3, 20, 25, 2)), -1.1, 0.75)
+    with open(str(tmp_path / "l.pkl"), "wb") as f:
+        pickle.dump((["s%d" % i for i in range(12)], list(range(12))), f)
+    dev = torch.device("cuda", 0)
+    for dt in (np.float64, np.float16, np.float32):
+        np.save(str(tmp_path / "d.npy"), ref.astype(dt))
+        data = NpySkeletonData(str(tmp_path / "d.npy"), str(tmp_path / "l.pkl"), num_classes=12)
+        got = list(data.batches(4, 0, 1, dev, shuffle=False))
+        assert len(got) == 3
+        x = torch.cat([b[0] for b in got]).cpu().numpy()
+        y = torch.cat([b[1] for b in got]).cpu().numpy()
+        assert x.dtype == np.float32 and np.array_equal(x, ref.astype(dt).astype(np.float32)) and np.array_equal(y, np.arange(12))
