@@ -81,7 +81,13 @@ int sar_context_destroy(sar_context* ctx);   /* waits for nothing: synchronise t
  * 2^28 floats (the kernels address rows with 32-bit byte offsets through buffer descriptors); V <= 64.
  * ------------------------------------------------------------------------------------------------ */
 enum { SAR_CONV_GRAPH = 0, SAR_CONV_TEMPORAL = 1 };
-enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3 };
+enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3,
+       /* bf16 (CN8) graph data gradient only, round 4: out = gate(acc + aux), where gate keeps channel c of column n iff bit (c & 7) of
+        * aux_mask[(c >> 3) * ld_aux2 + n] is set (the 1-byte-per-unit ReLU mask a block tail wrote), and the BatchNorm-backward sums
+        * of the tail that PRODUCED aux2 are reduced from the same accumulators: partials[m][part] = (sum out, sum out (aux2 - aux_mean)).
+        * It replaces, for the block below, the masked-gradient write of bn_add_relu_bwd_apply and the whole bn_add_relu_bwd_reduce
+        * pass (models/stgcn.py:37,62-63 backward). */
+       SAR_EPI_ADD_GATE = 4 };
 
 /* g_flags: the caller asserts that EVERY gather weight g_wt is exactly representable in bfloat16 (the NTU adjacency of
  * graph/ntu_rgb_d.py holds 0.25 / 0.5 / 1).  The bf16 (CN8) kernels then apply a dense adjacency slice on the matrix cores
@@ -119,7 +125,9 @@ typedef struct sar_conv_desc {
   const float* aux; int64_t ld_aux;                  /* epilogue operand [M][ld_aux] */
   const float* aux_scale; const float* aux_shift;    /* [M] (SAR_EPI_MASK) */
   const float* aux_mean;   /* [M] or NULL: centre of the second MASK reduction */
-  float* partials;         /* [M][nparts][2] (SAR_EPI_STATS / SAR_EPI_MASK) */
+  float* partials;         /* [M][nparts][2] (SAR_EPI_STATS / SAR_EPI_MASK / SAR_EPI_ADD_GATE) */
+  const void* aux2; int64_t ld_aux2;                 /* SAR_EPI_ADD_GATE: CN8 tensor [ceil(M/8)][ld_aux2] of the second reduction */
+  const unsigned char* aux_mask;                     /* SAR_EPI_ADD_GATE: [ceil(M/8)][ld_aux2] gate bytes */
 } sar_conv_desc;
 
 /* sizeof(sar_conv_desc) (which=0) / sizeof(sar_wgrad_desc) (1) / sizeof(sar_conv2d_desc) (2) as compiled: lets a binding verify its mirror */

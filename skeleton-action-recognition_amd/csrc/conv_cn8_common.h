@@ -87,6 +87,24 @@ struct Epi8Desc {
   int so_out, so_aux, g_w, rows_w;
 };
 
+// SAR_EPI_ADD_GATE: the second reduction operand (CN8, e.g. the tail's u) and the gate bytes, both [planes][ld_aux2], from plane g_w
+struct Gate8Desc {
+  __amdgpu_buffer_rsrc_t ru, rm;
+  int so_u, so_m;
+};
+__device__ __forceinline__ Gate8Desc gate8_desc(const ConvK8& k, int g_w) {
+  const sar_conv_desc& d = k.d;
+  Gate8Desc g;
+  const int64_t nu = (int64_t)(k.Go - g_w) * d.ld_aux2;
+  const int64_t bu = nu * 16, bm = nu;
+  g.ru = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.aux2 + (int64_t)g_w * d.ld_aux2 * 16), 0,
+                                           (unsigned)(bu <= 0 ? 0 : (bu > 0x7fffffffll ? 0x7fffffffll : bu)), 0x00020000);
+  g.rm = __builtin_amdgcn_make_buffer_rsrc((void*)(d.aux_mask + (int64_t)g_w * d.ld_aux2), 0,
+                                           (unsigned)(bm <= 0 ? 0 : (bm > 0x7fffffffll ? 0x7fffffffll : bm)), 0x00020000);
+  g.so_u = (int)(d.ld_aux2 * 16), g.so_m = (int)d.ld_aux2;
+  return g;
+}
+
 template <int MS>
 __device__ __forceinline__ Epi8Desc epi8_desc(const ConvK8& k, int wm, int m0, bool has_aux) {
   const sar_conv_desc& d = k.d;
@@ -116,8 +134,9 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
   const int part = tile * WN + wn;
   auto run = [&](auto EPI_) {
     constexpr int EPI = decltype(EPI_)::value;
-    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
-    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
+    constexpr bool gate = EPI == SAR_EPI_ADD_GATE;
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK || gate;
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD || gate;
     if (EPI == SAR_EPI_MASK && !PRE) {
       if (tid < BM) {
         const int row = m0 + tid;
@@ -136,6 +155,8 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
     const __amdgpu_buffer_rsrc_t ro = e8.ro, ra = e8.ra;
     // vo[ns]: byte offset of this lane's half unit inside a plane (0x80000000 = off-tile column: rejected)
     const int so_out = e8.so_out, so_aux = e8.so_aux;
+    Gate8Desc g8;
+    if constexpr (gate) g8 = gate8_desc(k, g_w);
     float* P = smem + wave * (16 * 65);
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
@@ -143,6 +164,22 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
       for (int rb = 0; rb < 2; ++rb) {
         // registers 8 rb .. 8 rb + 7 = two groups of 4 consecutive channels: planes 4 ms + 2 rb + {0, 1}
         float ax[NS][8];
+        float ux[NS][8];
+        unsigned gbits[NS][2];
+        if constexpr (gate) {   // the second reduction operand and the gate byte of the two planes of this half block
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const int pl = 4 * ms + 2 * rb + q2;
+              const u32x2 uu = __builtin_amdgcn_raw_buffer_load_b64(g8.ru, vo[ns], pl * g8.so_u, 0);
+              gbits[ns][q2] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(g8.rm, vo[ns] >> 4, pl * g8.so_m, 0);   // byte = column (vo = 16 col + 8 hi)
+              float f[4];
+              cn8_unpack4(make_uint2(uu[0], uu[1]), f);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ux[ns][4 * q2 + i] = f[i];
+            }
+        }
         if (has_aux) {
 #pragma unroll
           for (int q2 = 0; q2 < 2; ++q2)
@@ -162,7 +199,7 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
           const int r = rb * 8 + r8;
           float s1 = 0.f, s2 = 0.f;
           float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+          if (EPI == SAR_EPI_MASK || gate) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns) {
             float val = acc[ms][ns][r];
@@ -175,6 +212,14 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
               s2 = fmaf(val, ax[ns][r8] - ap.z, s2);
             } else if (EPI == SAR_EPI_ADD) {
               val += ax[ns][r8];
+            } else if (gate) {   // channel 4 hi + (r8 & 3) of the unit in plane (r8 >> 2) of this half block
+              val += ax[ns][r8];
+              val = ((gbits[ns][r8 >> 2] >> (4 * hi + (r8 & 3))) & 1u) ? val : 0.f;
+              // the sums run over the value as STORED (rounded to bfloat16): they replace a pass that read the stored tensor, and
+              // the apply pass of the block below centres exactly these values
+              const float vr = __uint_as_float(cn8_pack2(val, 0.f) << 16);
+              s1 += vr;
+              s2 = fmaf(vr, ux[ns][r8] - ap.z, s2);
             }
             acc[ms][ns][r] = val;
           }
@@ -217,6 +262,7 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
     case SAR_EPI_STATS: run(std::integral_constant<int, SAR_EPI_STATS>()); break;
     case SAR_EPI_MASK: run(std::integral_constant<int, SAR_EPI_MASK>()); break;
     case SAR_EPI_ADD: run(std::integral_constant<int, SAR_EPI_ADD>()); break;
+    case SAR_EPI_ADD_GATE: run(std::integral_constant<int, SAR_EPI_ADD_GATE>()); break;
     default: run(std::integral_constant<int, SAR_EPI_NONE>()); break;
   }
 }

@@ -1078,6 +1078,10 @@ int dispatch8(const sar_conv_desc& d, const uint4* wp, hipStream_t st, int* np) 
   if (d.mode == SAR_CONV_GRAPH) {
     const int rc2 = sar_graph2_cn8_dispatch(d, wp, st, np);   // gather at operand-read time (power-of-two gather weights)
     if (rc2 != SAR_GRAPH2_NOT_APPLICABLE) return rc2;
+    if (d.epi == SAR_EPI_ADD_GATE) {
+      sar_set_error("sar_conv_gemm_cn8: SAR_EPI_ADD_GATE needs the read-gather graph kernel (SAR_GRAPH_READ_GATHER=0 or an unsupported tile)");
+      return SAR_E_UNSUP;
+    }
     if (d.nz[0] == 1 && d.nz[1] == 1) return launch_graph_by_m8<1, 1, 4>(d, wp, st, np);
     if (d.nz[0] == 1 && d.nz[2] == 1) return launch_graph_by_m8<1, 4, 1>(d, wp, st, np);
     return launch_graph_by_m8<4, 4, 4>(d, wp, st, np);
@@ -1101,7 +1105,10 @@ int check8(const sar_conv_desc* d) {
     SAR_REQUIRE(d->taps == 9 || d->taps == 1, "sar_conv_gemm_cn8: temporal kernel size %d not built (1 and 9 are)", d->taps);
     SAR_REQUIRE(d->stride >= 1 && d->pad >= 0, "sar_conv_gemm_cn8: bad stride/pad");
   }
-  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm_cn8: bad epilogue %d", d->epi);
+  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD_GATE, "sar_conv_gemm_cn8: bad epilogue %d", d->epi);
+  if (d->epi == SAR_EPI_ADD_GATE)
+    SAR_REQUIRE(d->mode == SAR_CONV_GRAPH && (d->g_flags & SAR_GRAPH_FEW_DENSE),
+                "sar_conv_gemm_cn8: SAR_EPI_ADD_GATE is built for the graph data gradient with SAR_GRAPH_FEW_DENSE tables");
   return 0;
 }
 
@@ -1151,9 +1158,14 @@ extern "C" int sar_conv_gemm_cn8(const sar_conv_desc* d, const void* packed_w, s
   SAR_REQUIRE(d->ld_out < (1 << 26) && d->ld_aux < (1 << 26), "sar_conv_gemm_cn8: leading dimension too large (2^26 columns)");
   SAR_REQUIRE((int64_t)d->B * d->T_out * d->V < (1 << 27), "sar_conv_gemm_cn8: more than 2^27 output columns");
   SAR_REQUIRE((int64_t)d->taps * 2 * ((d->Kc + 15) / 16) * d->M * 16 < (1ll << 31), "sar_conv_gemm_cn8: weight tensor too large");
-  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm_cn8: partials required");
-  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
+  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD_GATE) SAR_REQUIRE(d->partials, "sar_conv_gemm_cn8: partials required");
+  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD || d->epi == SAR_EPI_ADD_GATE)
     SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm_cn8: aux required");
+  if (d->epi == SAR_EPI_ADD_GATE) {
+    SAR_REQUIRE(d->aux2 && d->aux_mask && d->aux_mean && d->partials && d->ld_aux2 >= (int64_t)d->B * d->T_out * d->V && d->ld_aux2 < (1 << 26),
+                "sar_conv_gemm_cn8: SAR_EPI_ADD_GATE needs aux2, aux_mask, aux_mean, partials and ld_aux2 >= B*T*V");
+    SAR_REQUIRE(((uintptr_t)d->aux2 & 15) == 0, "sar_conv_gemm_cn8: aux2 must be 16-byte aligned");
+  }
   if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->aux_scale && d->aux_shift, "sar_conv_gemm_cn8: aux affine required");
   int rc = dispatch8(*d, (const uint4*)packed_w, as_stream(s), nullptr);
   if (rc) return rc;

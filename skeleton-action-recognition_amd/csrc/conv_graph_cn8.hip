@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
   };
   // the ADD epilogue's aux half units (skip-path / residual gradient of the data gradient) are loaded before the last MFMA
   // phase, not inside the epilogue (conv_gemm_cn8_kernel)
-  const bool pre_aux = (!SAR_G2_WG4 || SAR_G2_WG4_PREAUX) && d.epi == SAR_EPI_ADD;
+  const bool epi_gate = d.epi == SAR_EPI_ADD_GATE;
+  const bool pre_aux = (!SAR_G2_WG4 || SAR_G2_WG4_PREAUX) && (d.epi == SAR_EPI_ADD || epi_gate);
   u32x2 axr[MS * 4 * NS];
   auto issue_aux = [&]() {
     const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
@@ -315,6 +316,11 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     const int sn = s + (SAR_G2_PF2 ? 2 : 1);
     if (!(SAR_G2_ABLATE & 2) && sn < nst) issue_loads(sn * KC16, wreg, xreg);   // uniform; in flight for TWO stages
     if (last && pre_aux) issue_aux();   // uniform (last stage: the aux half units land during the builder + MFMA phase)
+    if (last && epi_gate && tid < BM) {   // SAR_EPI_ADD_GATE: the centre of the second reduction replaces the bias rows (every wave
+      float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);   // is past its accumulator initialisation: >= 1 barrier ago)
+      if (m0 + tid < d.M && d.aux_mean) ap.z = d.aux_mean[m0 + tid];
+      rowp[tid] = ap;
+    }
     if (!(SAR_G2_ABLATE & 8)) build_virtual(buf);
     __syncthreads();         // B: virtual joints complete
     if (!(SAR_G2_ABLATE & 1)) mma_phase(buf);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAR_HIP_LIB") or os.path.join(_HERE, "libsar_hip.so")   # env override: diagnostic builds
 
 SAR_CONV_GRAPH, SAR_CONV_TEMPORAL = 0, 1
-SAR_EPI_NONE, SAR_EPI_STATS, SAR_EPI_MASK, SAR_EPI_ADD = 0, 1, 2, 3
+SAR_EPI_NONE, SAR_EPI_STATS, SAR_EPI_MASK, SAR_EPI_ADD, SAR_EPI_ADD_GATE = 0, 1, 2, 3, 4
 SAR_GRAPH_WT_BF16_EXACT = 1
 SAR_GRAPH_FEW_DENSE = 4
 SAR_GRAPH_FEW_DENSE_SHIFT = 8
@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("pro_scale", _fp), ("pro_shift", _fp),
         ("g_idx", _fp), ("g_wt", _fp), ("g_colsum", _fp),
         ("aux", _fp), ("ld_aux", C.c_int64), ("aux_scale", _fp), ("aux_shift", _fp), ("aux_mean", _fp),
-        ("partials", _fp),
+        ("partials", _fp), ("aux2", _fp), ("ld_aux2", C.c_int64), ("aux_mask", _fp),
     ]
 
 

@@ -48,9 +48,11 @@ def to_cn(x8, channels):
 
 
 def conv_gemm(mode, src, out, packed, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, transposed=False, bias=None,
-              pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None, aux_affine=None, aux_mean=None):
+              pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None, aux_affine=None, aux_mean=None, aux2=None,
+              aux_mask=None):
     """sar_conv_gemm_cn8: src / out / aux CN8, `packed` the bf16 weight image (ops.PackedWeights.image).  Returns
-    (partials, nparts) when the epilogue reduces."""
+    (partials, nparts) when the epilogue reduces.  SAR_EPI_ADD_GATE (graph data gradient): out = gate(acc + aux) with the gate
+    bytes `aux_mask`, partial sums (sum out, sum out (aux2 - aux_mean))."""
     lib = L.load()
     d = ConvDesc()
     d.mode, d.transposed, d.B, d.V = mode, int(transposed), B, V
@@ -74,8 +76,13 @@ def conv_gemm(mode, src, out, packed, *, B, V, T_src, T_out, Kc, M, taps, stride
     if aux_affine is not None:
         d.aux_scale, d.aux_shift = ptr(_f32(aux_affine[0])), ptr(_f32(aux_affine[1]))
     d.aux_mean = ptr(_f32(aux_mean))
+    if epi == L.SAR_EPI_ADD_GATE:
+        assert aux2 is not None and aux_mask is not None and aux_mean is not None and aux2.shape[0] == out.shape[0]
+        assert aux_mask.dtype == torch.uint8 and aux_mask.shape == (out.shape[0], aux2.shape[1]) and aux_mask.is_contiguous()
+        _cn8(aux2)
+        d.aux2, d.ld_aux2, d.aux_mask = ptr(aux2), aux2.shape[1], ptr(aux_mask)
     partials, nparts = None, 0
-    if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
+    if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK, L.SAR_EPI_ADD_GATE):
         nparts = lib.sar_conv_gemm_cn8_nparts(C.byref(d))
         if nparts <= 0:
             check(nparts or -1, "sar_conv_gemm_cn8_nparts")

@@ -13,6 +13,11 @@ from . import ops, ops8
 from .stgcn import BN_EPS, BN_MOMENTUM, KS, KT, same_pad  # noqa: F401
 
 RELU_MASK = __import__("os").environ.get("SAR_CN8_RELU_MASK", "1") == "1"
+# Round 4: the graph data gradient of block i gates its result (= the output gradient of block i - 1) with block i - 1's ReLU
+# mask and reduces block i - 1's BatchNorm-backward sums in its epilogue (SAR_EPI_ADD_GATE): block i - 1 then needs neither the
+# bn_add_relu_bwd_reduce pass nor the masked-gradient write of its apply pass.  Not for a block whose residual branch has its own
+# BatchNorm (a third sum over r) and not for the last block (its output gradient comes from the pooling).  SAR_CN8_FUSE_TAIL=0: off.
+FUSE_TAIL = __import__("os").environ.get("SAR_CN8_FUSE_TAIL", "1") == "1"
 
 
 def forward(eng, x, training=True, keep=None):
@@ -111,8 +116,11 @@ def backward(eng, dlogits, bucket_cb=None):
                eng.g["logits.kernel"].view(c_last, eng.num_classes), eng.g["logits.bias"], dfeat)
     dY = ops8.empty(c_last, sv["y_last_shape"][1], dev)
     ops8.pool_bwd(dfeat, c_last, B, sv["T_last"] * V, M, dY)
+    gated = None       # (partials, nparts) of this block's BatchNorm-backward sums when dY arrives gated from the block above
+    fuse = FUSE_TAIL and RELU_MASK and bool(eng.tab_bwd.g_flags & L.SAR_GRAPH_FEW_DENSE) and __import__("os").environ.get("SAR_GRAPH_READ_GATHER", "1") != "0"
     for i in reversed(range(len(eng.blocks))):
-        dY = _block_backward(eng, i, sv["blocks"][i], dY, B)
+        below = sv["blocks"][i - 1] if (fuse and i >= 1 and eng.kinds[i - 1] != "conv" and sv["blocks"][i - 1].get("ymask") is not None) else None
+        dY, gated = _block_backward(eng, i, sv["blocks"][i], dY, B, gated, below)
         if eng._deferred:
             eng._flush_deferred()
         eng._buckets_after_block(i, bucket_cb)
@@ -127,7 +135,10 @@ def backward(eng, dlogits, bucket_cb=None):
     eng._finish_backward(bucket_cb)
 
 
-def _block_backward(eng, i, sb, dY, B):
+def _block_backward(eng, i, sb, dY, B, gated=None, below=None):
+    """backward of block i.  gated: this block's BatchNorm-backward partial sums when dY already carries the ReLU gate (the
+    block above produced both in its graph data gradient); below: the saved tensors of block i - 1 when THIS block's graph data
+    gradient is to do the same for it.  Returns (dX, gated-for-the-block-below)."""
     V, dev = eng.V, dY.device
     pre = "l%d." % i
     X, g, u, r, y = sb["X"], sb["g"], sb["u"], sb["r"], sb["y"]
@@ -139,7 +150,11 @@ def _block_backward(eng, i, sb, dY, B):
     img = eng.packed.image
     # ---- tail: y = relu(bn2(u) + res)
     rk = (rbn.k1, rbn.k2, rbn.k3) if conv else None
-    if ops.BN_TAIL:          # the reduce kernel's last workgroup per plane finalises BN2 (and the residual BN): no launch between
+    if gated is not None:    # the sums came with dY: (sum dz, sum dz (u - mean)) per channel and partial
+        assert not conv
+        ops.bn_bwd_finalize(gated[0], gated[1], gated[1] * 2, 2, 0, 1, f, n_out, eng.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
+                            eng.g[pre + "bn2.gamma"], eng.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
+    elif ops.BN_TAIL:          # the reduce kernel's last workgroup per plane finalises BN2 (and the residual BN): no launch between
         tail = ops.make_bn_tail(dev, n_out, eng.p[pre + "bn2.gamma"], bn2, eng.g[pre + "bn2.gamma"], eng.g[pre + "bn2.beta"],
                                 *((eng.p[pre + "res_bn.gamma"], rbn, eng.g[pre + "res_bn.gamma"], eng.g[pre + "res_bn.beta"])
                                   if conv else ()))
@@ -154,7 +169,7 @@ def _block_backward(eng, i, sb, dY, B):
                                 eng.g[pre + "res_bn.gamma"], eng.g[pre + "res_bn.beta"], rbn.k1, rbn.k2, rbn.k3)
     du = ops8.empty(f, n_out, dev)
     dr = ops8.empty(f, n_out, dev) if conv else None
-    dz = dY if kind == "identity" else None      # in place: dY becomes the pre-ReLU gradient for the skip path
+    dz = dY if (kind == "identity" and gated is None) else None      # in place: dY becomes the pre-ReLU gradient for the skip path (already gated: nothing to write)
     ops8.bn_add_relu_bwd_apply(dY, y, u, r if conv else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz, f, mask=sb.get("ymask"))
     # ---- temporal conv: weight / bias gradient, then data gradient fused with the ReLU mask and the BN1 reductions
     flat_w = eng.grad[eng.offsets[pre + "tcn.kernel"]:eng.offsets[pre + "tcn.bias"] + f]
@@ -187,6 +202,13 @@ def _block_backward(eng, i, sb, dY, B):
     # ---- graph conv data gradient (+ skip-path gradient)
     dX = ops8.empty(cin, n_in, dev)
     aux = dY if kind == "identity" else dXres
+    if below is not None and aux is not None:
+        # dX = gate_{i-1}(W^T dg . A^T + skip gradient) and block i - 1's BatchNorm-backward sums in one epilogue
+        bn2b = eng.bn["l%d.bn2" % (i - 1)]
+        pm = ops8.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, img(pre + "gcn.b"), B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
+                            tables=eng.tab_bwd, epi=L.SAR_EPI_ADD_GATE, aux=aux, aux2=below["u"], aux_mask=below["ymask"],
+                            aux_mean=bn2b.mean)
+        return dX, pm
     ops8.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, img(pre + "gcn.b"), B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
                    tables=eng.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux)
-    return dX
+    return dX, None

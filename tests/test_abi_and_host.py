@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_descriptor_struct_layout_matches_header():
     """ctypes mirrors of sar_conv_desc / sar_wgrad_desc: field order and natural alignment."""
     from sar_amd import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 18 * 4 + 19 * 8
+    assert ctypes.sizeof(_lib.ConvDesc) == 18 * 4 + 22 * 8      # round 4: + aux2, ld_aux2, aux_mask (SAR_EPI_ADD_GATE)
     assert ctypes.sizeof(_lib.WgradDesc) == 16 * 4 + 14 * 8
     assert _lib.ConvDesc.src.offset == 72 and _lib.WgradDesc.src.offset == 64
     lib = _lib.load()                                   # the library reports the sizes it was compiled with

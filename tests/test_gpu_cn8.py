@@ -560,3 +560,78 @@ def test_graph_conv_read_gather_equals_the_unit_builder_bit_for_bit(dev):
         assert torch.equal(o1, o0), key
         assert torch.equal(p1, p0), key
         assert torch.equal(d1, d0), key
+
+
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (4, 256, 256, 75), (2, 40, 72, 9)])
+def test_graph_data_gradient_gated_epilogue(dev, B, cin, f, T):
+    """SAR_EPI_ADD_GATE (round 4): out = gate(W^T dg . A^T + aux) with the gate bytes a block tail wrote (bit j of byte (plane, n) =
+    channel 8 plane + j), and the BatchNorm-backward sums of that tail, (sum out, sum out (u - mean)), reduced from the same
+    accumulators.  Against the plain SAR_EPI_ADD launch: the gated output must equal the gated ADD output BIT FOR BIT, the sums the
+    float64 sums of it within 1e-4."""
+    from sar_amd import ops8, _lib as L
+    g = torch.Generator().manual_seed(11 * cin + f)
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    dout = torch.randn(B, f, T, 25, generator=g).bfloat16()
+    add = torch.randn(B, cin, T, 25, generator=g).bfloat16()
+    u = torch.randn(B, cin, T, 25, generator=g).bfloat16()
+    mean = torch.randn(cin, generator=g) * 0.2
+    keep = torch.rand(B, cin, T, 25, generator=g) > 0.4                      # the ReLU mask of the tail below
+    n = B * T * 25
+    planes = (cin + 7) // 8
+    kb = torch.zeros(planes * 8, n, dtype=torch.int32)
+    kb[:cin] = keep.permute(1, 0, 2, 3).reshape(cin, n).int()
+    mask = (kb.view(planes, 8, n) << torch.arange(8, dtype=torch.int32).view(1, 8, 1)).sum(dim=1).to(torch.uint8).contiguous().to(dev)
+    tabT = _tables(dev, True)
+    pw = _pack(dev, kernel, f, 1, 3 * f, 3, f, cin)
+    args = dict(B=B, V=25, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tabT)
+    plain, gated = ops8.empty(cin, n, dev), ops8.empty(cin, n, dev)
+    ops8.conv_gemm(L.SAR_CONV_GRAPH, _cn8(dout, dev), plain, pw, epi=L.SAR_EPI_ADD, aux=_cn8(add, dev), **args)
+    pm = ops8.conv_gemm(L.SAR_CONV_GRAPH, _cn8(dout, dev), gated, pw, epi=L.SAR_EPI_ADD_GATE, aux=_cn8(add, dev), aux2=_cn8(u, dev),
+                        aux_mask=mask, aux_mean=mean.to(dev), **args)
+    torch.cuda.synchronize()
+    want = torch.where(keep, _back(plain, cin, B, T), torch.zeros(()).double())
+    got = _back(gated, cin, B, T)
+    assert torch.equal(got, want)
+    part = pm[0].cpu().double().sum(dim=1)                                   # (cin, 2)
+    # the sums run over the STORED (bfloat16) values: float64 sums of the output, up to fp32 accumulation
+    s1 = want.sum(dim=(0, 2, 3))
+    s2 = (want * (u.double() - mean.double().view(1, -1, 1, 1))).sum(dim=(0, 2, 3))
+    scale1 = want.abs().sum(dim=(0, 2, 3)).max()
+    assert (part[:, 0] - s1).abs().max() <= 1e-5 * scale1 and (part[:, 1] - s2).abs().max() <= 2e-5 * scale1
+
+
+def test_fused_tail_reduction_matches_the_separate_passes(dev):
+    """SAR_CN8_FUSE_TAIL (default on): the graph data gradient of block i gates the output gradient of block i - 1 and reduces its
+    BatchNorm-backward sums; the unfused schedule (SAR_CN8_FUSE_TAIL=0: bn_add_relu_bwd_reduce pass + masked-gradient write) sums
+    the same stored values in another order.  A 1e-6 difference of a BatchNorm-backward constant moves a few of the next
+    bfloat16-STORED gradients by one ulp (2^-9), and ten blocks of heavily cancelling sums amplify that ~3x per block (measured:
+    7e-7 at l8.bn1 ... 8e-3 at l0): the top blocks must agree tightly, the bottom ones within what bf16 storage makes of any
+    re-ordering (two runs of ONE schedule agree bit for bit)."""
+    code = r'''
+import sys, pickle, torch
+sys.path.insert(0, "."); sys.path.insert(0, "skeleton-action-recognition_amd")
+from sar_amd.stgcn import STGCN
+from sar_amd.train import synthetic_clips
+dev = torch.device("cuda", 0)
+eng = STGCN(num_classes=60, device=dev, seed=0, mfma="bf16")
+x, y = synthetic_clips(4, dev, seed=3, T=60)
+logits, loss = eng.loss_and_grad(x, y)
+torch.cuda.synchronize()
+pickle.dump(dict(g={k: v.cpu().clone() for k, v in eng.g.items()}, logits=logits.cpu(), loss=loss.cpu()), open(sys.argv[1], "wb"))
+'''
+    on = _run_in_env(code, {"SAR_CN8_FUSE_TAIL": "1"})
+    on2 = _run_in_env(code, {"SAR_CN8_FUSE_TAIL": "1"})
+    off = _run_in_env(code, {"SAR_CN8_FUSE_TAIL": "0"})
+    assert torch.equal(on["logits"], off["logits"]) and torch.equal(on["loss"], off["loss"])
+    worst = {}
+    for k, v in on["g"].items():
+        assert torch.equal(v, on2["g"][k]), k                       # the fused schedule repeats bit for bit
+        if k.endswith(".bias") and ("tcn" in k or "res." in k or "gcn" in k):
+            continue                                                # a bias in front of a BatchNorm: its gradient is rounding noise around 0
+        rel = (v - off["g"][k]).abs().max().item() / max(off["g"][k].abs().max().item(), 1e-30)
+        blk = k.split(".")[0]
+        worst[blk] = max(worst.get(blk, 0.0), rel)
+    print("fused vs separate tail reduction, worst relative gradient difference per block:", {k: "%.1e" % v for k, v in worst.items()})
+    assert worst["l9"] == 0.0 and worst["logits"] == 0.0           # nothing above the first fused epilogue changes
+    assert worst["l8"] < 1e-3 and worst["l7"] < 2e-3
+    assert max(worst.values()) < 5e-2
