@@ -72,11 +72,20 @@ calls = sum(r["calls"] for r in fam)
 nsteps = next((dur[k][0] for k in ("sgd_nesterov_kernel", "adam_kernel") if k in dur), 7)
 import subprocess
 try:
+    if os.environ.get("SAR_PROFILE_COMMIT"):      # re-summarising an older trace: name the tree it was measured on
+        raise KeyError
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "skeleton-action-recognition_amd", "bench.py"], text=True).strip():
         commit += "+uncommitted"
+except KeyError:
+    commit = os.environ["SAR_PROFILE_COMMIT"]
 except Exception:
     commit = "unknown"
+# a kernel whose launch count is not a multiple of the step count belongs to the set-up (parameter initialisation copies, table
+# builds), not to the step: it stays in the list, flagged, and out of the per-step totals
+for r in rows:
+    r["per_step"] = (r["calls"] % nsteps == 0)
+step_rows = [r for r in rows if r["per_step"]]
 summary = {
     "commit": commit,          # the tree the profiled build was made from (bench.py quotes it next to roofline.traffic)
     "command": ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0%s ; "
@@ -90,8 +99,9 @@ summary = {
     "dominant_family_avg_us": round(sum(r["avg_us"] * r["calls"] for r in fam) / calls, 2),
     "dominant_family_hbm_bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["calls"] for r in fam) / calls),
     "steps_in_trace": nsteps,
-    "total_kernel_ms_per_step": round(sum(r["avg_us"] * r["calls"] for r in rows) / (1e3 * nsteps), 3),
-    "total_hbm_bytes_per_step": int(sum((r["hbm_bytes_per_launch"] or 0) * r["calls"] for r in rows) / nsteps),
+    "total_kernel_ms_per_step": round(sum(r["avg_us"] * r["calls"] for r in step_rows) / (1e3 * nsteps), 3),
+    "setup_kernel_ms_excluded": round(sum(r["avg_us"] * r["calls"] for r in rows if not r["per_step"]) / 1e3, 3),
+    "total_hbm_bytes_per_step": int(sum((r["hbm_bytes_per_launch"] or 0) * r["calls"] for r in step_rows) / nsteps),
     "kernels": rows,
 }
 json.dump(summary, open(os.path.join(OUT, "%s_kernel_summary.json" % tag), "w"), indent=1)
