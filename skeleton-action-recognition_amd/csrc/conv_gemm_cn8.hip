@@ -772,7 +772,14 @@ __global__ __launch_bounds__(256, (NZ0 + NZ1 + NZ2 > 6) ? 2 : 3) void conv_graph
   bf16x8 bfr[2];
   unsigned tr_addr = 0;
   int zst_unit = 0;
+  // A-operand keep mask: element e of this lane's fragment is joint 8 G + e.  The 32-joint read of a V-joint frame reaches into
+  // the NEXT frame's first 32 - V columns; their B rows are zero, but 0 x Inf = NaN, so those elements are cleared before the
+  // product (what the vector gather never touched must not reach the result either).
+  unsigned keep[4] = {0u, 0u, 0u, 0u};
   if (mg) {
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd)
+      keep[dd] = ((8 * gG + 2 * dd < V) ? 0xffffu : 0u) | ((8 * gG + 2 * dd + 1 < V) ? 0xffff0000u : 0u);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       float a[8];
@@ -819,7 +826,9 @@ __global__ __launch_bounds__(256, (NZ0 + NZ1 + NZ2 > 6) ? 2 : 3) void conv_graph
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)ra);
           const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(ra + 64));
           const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-          afr[i] = *reinterpret_cast<const bf16x8*>(&av);
+          uint4 am = *reinterpret_cast<const uint4*>(&av);
+          am.x &= keep[0], am.y &= keep[1], am.z &= keep[2], am.w &= keep[3];
+          afr[i] = *reinterpret_cast<const bf16x8*>(&am);
         }
         f32x4 z[3][2];
 #pragma unroll

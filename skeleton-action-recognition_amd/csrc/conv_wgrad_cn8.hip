@@ -445,6 +445,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
   const int gG = lane >> 4, gi = lane & 15;
   bf16x8 bfr[2];
   unsigned tr_addr = 0;
+  // A-operand keep mask of the matrix-core gather (element e of a lane's fragment = joint 8 G + e): joints >= V are the next
+  // frame's columns; their B rows are zero but 0 x Inf = NaN, so they are cleared before the product (conv_gemm_cn8.hip)
+  unsigned keep[4];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd)
+    keep[dd] = ((8 * gG + 2 * dd < WV) ? 0xffffu : 0u) | ((8 * gG + 2 * dd + 1 < WV) ? 0xffff0000u : 0u);
   int zst_unit = 0;
   if (mg) {
     constexpr int DS = DENSE >= 0 ? DENSE : 0;
@@ -539,7 +545,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)ra);
         const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(ra + 64));
         const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-        afr[f] = *reinterpret_cast<const bf16x8*>(&av);
+        uint4 am = *reinterpret_cast<const uint4*>(&av);
+        am.x &= keep[0], am.y &= keep[1], am.z &= keep[2], am.w &= keep[3];
+        afr[f] = *reinterpret_cast<const bf16x8*>(&am);
       }
       f32x4 z[FT][2];
 #pragma unroll

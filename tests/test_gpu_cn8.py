@@ -562,6 +562,49 @@ def test_graph_conv_read_gather_equals_the_unit_builder_bit_for_bit(dev):
         assert torch.equal(d1, d0), key
 
 
+_GRAPH_NONFINITE = r'''
+import sys, pickle, torch
+sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "skeleton-action-recognition_amd")
+import test_gpu_cn8 as T
+from sar_amd import ops8, _lib as L
+dev = torch.device("cuda", 0)
+res = {}
+for (B, cin, f, Tt, bad) in [(2, 64, 64, 11, 4), (1, 128, 256, 5, 1), (2, 40, 72, 9, 8)]:
+    g = torch.Generator().manual_seed(B * 1000 + cin)
+    x = torch.randn(B, cin, Tt, 25, generator=g).bfloat16()
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    tab = T._tables(dev)
+    outs = []
+    for poison in (False, True):
+        xx = x.clone()
+        xx[0, :, bad] = float("inf") if poison else 0.0
+        out = ops8.empty(f, B * Tt * 25, dev)
+        ops8.conv_gemm(L.SAR_CONV_GRAPH, T._cn8(xx, dev), out, T._pack(dev, kernel, f, 3 * f, 1, 3, cin, f), B=B, V=25, T_src=Tt,
+                       T_out=Tt, Kc=cin, M=f, taps=3, tables=tab)
+        torch.cuda.synchronize()
+        outs.append(T._back(out, f, B, Tt).cpu())
+    res[(B, cin, f, Tt, bad)] = (outs[0], outs[1], tab.g_flags)
+pickle.dump(res, open(sys.argv[1], "wb"))
+'''
+
+
+@pytest.mark.parametrize("read_gather", ["0", "1"])
+def test_graph_conv_keeps_non_finite_values_inside_their_frame(dev, read_gather):
+    """The matrix-core adjacency gather (conv_graph_cn8_kernel, SAR_GRAPH_READ_GATHER=0) reads 32 joints of a 25-joint frame:
+    the 7 extra columns belong to the NEXT frame and meet zero rows of A_k -- but 0 x Inf = NaN.  The operand fragment is
+    masked to joints < V, so a frame of Inf changes that frame's outputs only, as in the vector gather and in the
+    reference operator (models/stgcn.py:26-31: the contraction runs over the joints of ONE frame)."""
+    from sar_amd import _lib as L
+    got = _run_in_env(_GRAPH_NONFINITE, {"SAR_GRAPH_READ_GATHER": read_gather})
+    for (B, cin, f, Tt, bad), (clean, poisoned, fl) in got.items():
+        assert fl & L.SAR_GRAPH_WT_BF16_EXACT
+        keep = [t for t in range(Tt) if t != bad]
+        assert torch.isfinite(poisoned[0][:, keep]).all(), (B, cin, f, Tt)
+        assert torch.equal(poisoned[0][:, keep], clean[0][:, keep])
+        assert torch.equal(poisoned[1:], clean[1:])
+        assert not torch.isfinite(poisoned[0][:, bad]).any()
+
+
 @pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 11), (2, 64, 128, 6), (1, 128, 256, 5), (4, 256, 256, 75), (2, 40, 72, 9)])
 def test_graph_data_gradient_gated_epilogue(dev, B, cin, f, T):
     """SAR_EPI_ADD_GATE (round 4): out = gate(W^T dg . A^T + aux) with the gate bytes a block tail wrote (bit j of byte (plane, n) =
