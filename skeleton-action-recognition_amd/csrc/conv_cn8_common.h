@@ -158,42 +158,45 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
     Gate8Desc g8;
     if constexpr (gate) g8 = gate8_desc(k, g_w);
     float* P = smem + wave * (16 * 65);
+    // Operands the epilogue reads from memory -- the aux half units (unless the kernel requested them all beforehand: PRE) and, for
+    // SAR_EPI_ADD_GATE, the second reduction operand + the gate byte -- are requested ONE half block (two planes) ahead of their
+    // use and consumed as raw bf16 pairs: loaded where they were used, every half block paid its own memory round trip, four per
+    // 64-row wave tile (tools/g2_timeline.sh: 22 000 of a 64-channel data-gradient workgroup's 49 000 cycles)
+    constexpr bool piped = (has_aux && !PRE) || gate;
+    constexpr int HB = 2 * MS;
+    u32x2 araw[2][2][NS], uraw[2][2][NS];
+    unsigned graw[2][2][NS];
+    auto hb_loads = [&](int hb, u32x2 (&aa)[2][NS], u32x2 (&uu)[2][NS], unsigned (&gg)[2][NS]) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const int pl = 2 * hb + q2;
+          if constexpr (has_aux && !PRE) aa[q2][ns] = __builtin_amdgcn_raw_buffer_load_b64(ra, vo[ns], pl * so_aux, 0);
+          if constexpr (gate) {
+            uu[q2][ns] = __builtin_amdgcn_raw_buffer_load_b64(g8.ru, vo[ns], pl * g8.so_u, 0);
+            gg[q2][ns] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(g8.rm, vo[ns] >> 4, pl * g8.so_m, 0);   // byte = column (vo = 16 col + 8 hi)
+          }
+        }
+    };
+    auto bf_elem = [](const u32x2& w, int i) {   // element i (0..3) of a half unit, as cn8_unpack4
+      const unsigned dw = w[i >> 1];
+      return __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
+    };
+    if constexpr (piped) hb_loads(0, araw[0], uraw[0], graw[0]);
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         // registers 8 rb .. 8 rb + 7 = two groups of 4 consecutive channels: planes 4 ms + 2 rb + {0, 1}
-        float ax[NS][8];
-        float ux[NS][8];
-        unsigned gbits[NS][2];
-        if constexpr (gate) {   // the second reduction operand and the gate byte of the two planes of this half block
-#pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-              const int pl = 4 * ms + 2 * rb + q2;
-              const u32x2 uu = __builtin_amdgcn_raw_buffer_load_b64(g8.ru, vo[ns], pl * g8.so_u, 0);
-              gbits[ns][q2] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(g8.rm, vo[ns] >> 4, pl * g8.so_m, 0);   // byte = column (vo = 16 col + 8 hi)
-              float f[4];
-              cn8_unpack4(make_uint2(uu[0], uu[1]), f);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) ux[ns][4 * q2 + i] = f[i];
-            }
-        }
-        if (has_aux) {
-#pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-              u32x2 a;
-              if constexpr (PRE) a = axr[((ms * 2 + rb) * 2 + q2) * NS + ns];
-              else a = __builtin_amdgcn_raw_buffer_load_b64(ra, vo[ns], (4 * ms + 2 * rb + q2) * so_aux, 0);
-              float f[4];
-              cn8_unpack4(make_uint2(a[0], a[1]), f);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) ax[ns][4 * q2 + i] = f[i];
-            }
-        }
+        const int hb = 2 * ms + rb;
+        if constexpr (piped)
+          if (hb + 1 < HB) hb_loads(hb + 1, araw[(hb + 1) & 1], uraw[(hb + 1) & 1], graw[(hb + 1) & 1]);
+        auto ax = [&](int ns, int r8) {
+          if constexpr (PRE) return bf_elem(axr[(hb * 2 + (r8 >> 2)) * NS + ns], r8 & 3);
+          else return bf_elem(araw[hb & 1][r8 >> 2][ns], r8 & 3);
+        };
+        auto ux = [&](int ns, int r8) { return bf_elem(uraw[hb & 1][r8 >> 2][ns], r8 & 3); };
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) {
           const int r = rb * 8 + r8;
@@ -207,19 +210,20 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
               s1 += val;
               s2 = fmaf(val, val, s2);
             } else if (EPI == SAR_EPI_MASK) {
-              val = (fmaf(ax[ns][r8], ap.x, ap.y) > 0.f) ? val : 0.f;
+              const float a = ax(ns, r8);
+              val = (fmaf(a, ap.x, ap.y) > 0.f) ? val : 0.f;
               s1 += val;
-              s2 = fmaf(val, ax[ns][r8] - ap.z, s2);
+              s2 = fmaf(val, a - ap.z, s2);
             } else if (EPI == SAR_EPI_ADD) {
-              val += ax[ns][r8];
+              val += ax(ns, r8);
             } else if (gate) {   // channel 4 hi + (r8 & 3) of the unit in plane (r8 >> 2) of this half block
-              val += ax[ns][r8];
-              val = ((gbits[ns][r8 >> 2] >> (4 * hi + (r8 & 3))) & 1u) ? val : 0.f;
+              val += ax(ns, r8);
+              val = ((graw[hb & 1][r8 >> 2][ns] >> (4 * hi + (r8 & 3))) & 1u) ? val : 0.f;
               // the sums run over the value as STORED (rounded to bfloat16): they replace a pass that read the stored tensor, and
               // the apply pass of the block below centres exactly these values
               const float vr = __uint_as_float(cn8_pack2(val, 0.f) << 16);
               s1 += vr;
-              s2 = fmaf(vr, ux[ns][r8] - ap.z, s2);
+              s2 = fmaf(vr, ux(ns, r8) - ap.z, s2);
             }
             acc[ms][ns][r] = val;
           }

@@ -35,8 +35,28 @@ constexpr int NVMAX = 16;   // virtual joints per frame the tables may ask for
 #ifndef SAR_G2_WG4_PREAUX
 #define SAR_G2_WG4_PREAUX 0   // 1: the ADD epilogue's aux half units requested before the last MFMA phase (5 spilled registers at 128: measured 1-3 % slower)
 #endif
+#ifndef SAR_G2_BIAS_CHUNK
+#define SAR_G2_BIAS_CHUNK 4
+#endif
 #ifndef SAR_G2_ABLATE
 #define SAR_G2_ABLATE 0   // diagnostic builds only (tools/ablate_g2.sh): 1 no MFMA, 2 global loads of stage 0 only, 4 no epilogue, 8 no mini-builder, 16 LDS stores of stage 0 only
+#endif
+
+// Diagnostic build -DSAR_G2_TIMELINE (tools/g2_timeline.sh): wave 0 of every workgroup writes one row -- start / end in 100 MHz
+// ticks (s_memrealtime), HW_ID, XCC_ID, shader-clock cycles of the prologue (up to its barrier / the wait there / the geometry + accumulator
+// initialisation behind it) / the stages / the epilogue -- so that the
+// launch's timeline (workgroups resident per CU, lifetimes, dispatch rate) can be read back.
+#ifdef SAR_G2_TIMELINE
+constexpr int G2_TL_WG = 16384;
+__device__ unsigned g_g2_tl[G2_TL_WG][12];
+#define G2_TL(i)                                                  \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    tl_acc[i] = (unsigned)(t_ - tl_last);                         \
+    tl_last = t_;                                                 \
+  } while (0)
+#else
+#define G2_TL(i)
 #endif
 
 template <int MS, int NS, int WM, int WN, int SAR_G2_WG4>
@@ -70,6 +90,11 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
   const int ny = k.ny;
   const int w = xcd_work(k.ntiles * ny);
   if (w < 0) return;
+#ifdef SAR_G2_TIMELINE
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl_last = __builtin_amdgcn_s_memtime();
+  unsigned tl_acc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#endif
   const int tile = w / ny;
   const int b = tile / k.TPS;
   const int t0 = (tile - b * k.TPS) * k.FT;
@@ -122,43 +147,10 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
   issue_loads(0, wregA, xregA);
   if (SAR_G2_PF2 && KC16 < d.Kc) issue_loads(KC16, wregB, xregB);
 
-  // classify the 3 V gather lists (wave 0; 64 lists per pass): a list with ONE entry of weight 1 is the raw column of that
-  // joint, an empty list the zero unit, everything else a virtual joint (ranked in (slice, joint) order)
-  if (wave == 0) {
-    int base = 0;
-    for (int p0 = 0; p0 < 3 * V; p0 += 64) {
-      const int p = p0 + lane;
-      const bool in = p < 3 * V;
-      const int tp = in ? p / V : 0;
-      const int nzl = d.nz[tp];
-      int cnt = 0, first = 0;
-      float wfirst = 0.f;
-      int ei[4];
-      float ew[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ei[j] = 0, ew[j] = 0.f;
-        if (in && j < nzl) {
-          ei[j] = d.g_idx[p * 4 + j];
-          ew[j] = d.g_wt[p * 4 + j];
-          if (ew[j] != 0.f) {
-            if (cnt == 0) first = ei[j], wfirst = ew[j];
-            ++cnt;
-          }
-        }
-      }
-      const bool virt = in && (cnt > 1 || (cnt == 1 && wfirst != 1.0f));
-      const unsigned long long bal = __ballot(virt);
-      const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
-      if (in) vmap[p] = virt ? (rank < nv_asserted ? V + rank : -1) : (cnt == 1 ? first : -1);
-      if (virt && rank < nv_asserted && rank < NVMAX) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vl_idx[rank][j] = ei[j], vl_wt[rank][j] = ew[j];
-      }
-      base += __popcll(bal);
-    }
-    if (lane == 0) nv_s = base < nv_asserted ? base : nv_asserted;
-  }
+  // Every table the prologue needs is REQUESTED before the first of them is used (vmcnt retires in order, so the first use waits
+  // for the stage-0 operands anyway: one round trip for everything; with the classification below reading its lists pass by
+  // pass, then the column sums, then the bias, wave 0 spent four dependent round trips -- 8 500-10 400 cycles -- before the
+  // workgroup's first barrier: tools/g2_timeline.sh)
   float gcs[3][NS];   // column sums of A_k at this lane's joints (bias term; masked by colok at the use)
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
@@ -173,10 +165,61 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     bias_row.y = d.bias[d.M + m0 + tid];
     bias_row.z = d.bias[2 * d.M + m0 + tid];
   }
-  if (tid < BM) rowp[tid] = bias_row;
+  // classify the 3 V gather lists (wave 0; list p = lane + 64 pass, V <= 64: at most three passes): a list with ONE entry of
+  // weight 1 is the raw column of that joint, an empty list the zero unit, everything else a virtual joint (ranked in (slice,
+  // joint) order)
+  if (wave == 0) {
+    constexpr int NPASS = 3;
+    int ei[NPASS][4];
+    float ew[NPASS][4];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int p = ps * 64 + lane;
+      const int pc = p < 3 * V ? p : 0;   // clamped: the loads are unconditional, the pass is masked below
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ei[ps][j] = d.g_idx[pc * 4 + j], ew[ps][j] = d.g_wt[pc * 4 + j];
+    }
+    int base = 0;
+    const int nz0 = d.nz[0], nz1 = d.nz[1], nz2 = d.nz[2];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int p = ps * 64 + lane;
+      const bool in = p < 3 * V;
+      const int tp = in ? p / V : 0;
+      const int nzl = tp == 0 ? nz0 : (tp == 1 ? nz1 : nz2);   // (d.nz[tp] with a per-lane tp is a LOAD from the kernel arguments: one more round trip per pass)
+      int cnt = 0, first = 0;
+      float wfirst = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = in && j < nzl;
+        if (!live) ei[ps][j] = 0, ew[ps][j] = 0.f;
+        if (live && ew[ps][j] != 0.f) {
+          if (cnt == 0) first = ei[ps][j], wfirst = ew[ps][j];
+          ++cnt;
+        }
+      }
+      const bool virt = in && (cnt > 1 || (cnt == 1 && wfirst != 1.0f));
+      const unsigned long long bal = __ballot(virt);
+      const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (in) vmap[p] = virt ? (rank < nv_asserted ? V + rank : -1) : (cnt == 1 ? first : -1);
+      if (virt && rank < nv_asserted && rank < NVMAX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vl_idx[rank][j] = ei[ps][j], vl_wt[rank][j] = ew[ps][j];
+      }
+      base += __popcll(bal);
+    }
+    if (lane == 0) nv_s = base < nv_asserted ? base : nv_asserted;
+  }
+  asm volatile("" ::: "memory");   // the bias rows' wait + LDS store stay BEHIND the classification's loads (hoisted above them, the store's
+  if (tid < BM) rowp[tid] = bias_row;   // wait for the bias separated two round trips that now are one)
   if (tid < 2 * PL) smem_u[(tid >> 1) * BUF + WUNITS + (tid & 1) * XS + ZUNIT] = make_uint4(0u, 0u, 0u, 0u);   // the zero units
+  G2_TL(0);
   __syncthreads();   // rowp, vmap, nv_s
+  G2_TL(1);
 
+  bool colok[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) colok[ns] = (wn * NS + ns) * 32 + l31 < ncols;
   const int NV = nv_s;
   const int FS = V + NV;   // units per frame of the raw tile
   int xdst[XJ];
@@ -187,13 +230,11 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     const int f = xc / V, v = xc - f * V;
     xdst[j] = xc < k.FT * V ? WUNITS + xh * XS + f * FS + v : -1;   // columns beyond the tile's frames are not stored
   }
-  bool colok[NS];
   unsigned vo[NS];
   int boff[3][NS];   // unit (inside a buffer) of this lane's B fragment of slice tp for column block ns
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const int p = (wn * NS + ns) * 32 + l31;
-    colok[ns] = p < ncols;
     const int pv = colok[ns] ? p : 0;
     vo[ns] = colok[ns] ? (unsigned)((((int64_t)b * d.T_out + t0) * V + pv) * 16 + 8 * hi) : 0x80000000u;
     const int fo = pv / V, v = pv - fo * V;
@@ -202,14 +243,37 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
       const int vm = vmap[tp * V + v];
       boff[tp][ns] = WUNITS + hi * XS + ((colok[ns] && vm >= 0) ? fo * FS + vm : ZUNIT);
     }
-    // bias term sum_k b_k[m] colsum(A_k)[w]
+  }
+  // bias term sum_k b_k[m] colsum(A_k)[w] (forward only: a data gradient has none and starts from zero).  The bias rows are read
+  // BC at a time, unconditionally, BEFORE the arithmetic: written as `colok ? f(rowp[..]) : 0` per accumulator the compiler emitted
+  // 64 branches, each with its own LDS read and wait -- 64 dependent LDS round trips, about half of a 64-channel workgroup's
+  // prologue (tools/g2_timeline.sh)
+  if (d.bias) {   // uniform
+    constexpr int BC = SAR_G2_BIAS_CHUNK;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float4 bp = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
-        acc[ms][ns][r] = colok[ns] ? fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns])) : 0.f;
+      for (int r0 = 0; r0 < 16; r0 += BC) {
+        float4 bp[BC];
+#pragma unroll
+        for (int r = 0; r < BC; ++r) bp[r] = rowp[(wm * MS + ms) * 32 + mfma_row(r0 + r, hi)];
+#pragma unroll
+        for (int r = 0; r < BC; ++r) asm volatile("" : "+v"(bp[r].x), "+v"(bp[r].y), "+v"(bp[r].z));   // the reads stay where they are
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int r = 0; r < BC; ++r) {
+            const float v = fmaf(bp[r].z, gcs[2][ns], fmaf(bp[r].y, gcs[1][ns], bp[r].x * gcs[0][ns]));
+            acc[ms][ns][r0 + r] = colok[ns] ? v : 0.f;
+          }
       }
+  } else {
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
   }
   // mini-builder geometry: item = (plane, frame, virtual joint), at most ONE per thread (PL * FT * NV <= 256 is checked by the host)
   const int nitems = PL * k.FT * NV;
@@ -325,6 +389,7 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     __syncthreads();         // B: virtual joints complete
     if (!(SAR_G2_ABLATE & 1)) mma_phase(buf);
   };
+  G2_TL(2);
   int s_ = 0;
   if (SAR_G2_PF2) {
     for (; s_ + 2 < nst; s_ += 2) {
@@ -342,6 +407,7 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     stage(s_, wregA, xregA, true);
   }
   __syncthreads();           // the epilogue's transpose area aliases the image
+  G2_TL(3);
   if (SAR_G2_ABLATE & 4) {   // every accumulator stays live
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
@@ -352,7 +418,18 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     return;
   }
   if (pre_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
-  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
+  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);   // four workgroups per CU: aux read one half block ahead inside the epilogue
+#ifdef SAR_G2_TIMELINE
+  G2_TL(4);
+  if (tid == 0 && blockIdx.x < G2_TL_WG) {
+    unsigned* row = g_g2_tl[blockIdx.x];
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    row[0] = (unsigned)tl_rt0, row[1] = (unsigned)rt1;
+    row[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+    row[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    row[4] = tl_acc[0], row[5] = tl_acc[1], row[6] = tl_acc[2], row[7] = tl_acc[3], row[8] = tl_acc[4], row[9] = (unsigned)w;
+  }
+#endif
 }
 
 template <int MS, int NS, int WM, int WN, int WG4>
@@ -378,6 +455,18 @@ int launch_graph2_cfg(const sar_conv_desc& d, const uint4* wp, hipStream_t st, i
 }
 
 }  // namespace
+
+#ifdef SAR_G2_TIMELINE
+extern "C" int sar_debug_g2_timeline(unsigned* out, int nwg, int reset) {   // out: [nwg][12]
+  if (nwg > G2_TL_WG) nwg = G2_TL_WG;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g2_tl), (size_t)nwg * 12 * sizeof(unsigned)) != hipSuccess) return -1;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_g2_tl)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * 12 * G2_TL_WG) != hipSuccess) return -1;
+  }
+  return nwg;
+}
+#endif
 
 // Called by sar_conv_gemm_cn8 / sar_conv_gemm_cn8_nparts (conv_gemm_cn8.hip) for SAR_CONV_GRAPH descriptors.  Returns
 // SAR_GRAPH2_NOT_APPLICABLE when the caller has not asserted SAR_GRAPH_FEW_DENSE or the tile cannot hold the virtual joints

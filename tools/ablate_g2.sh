@@ -9,7 +9,7 @@ if [ "$1" = build ]; then
   mkdir -p tools/bin
   for m in ${MODES:-1 2 4 8 18 19 23}; do
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DSAR_G2_ABLATE=$m -c $C/conv_graph_cn8.hip -o tools/bin/g2_a$m.o
-    OTHERS=$(ls $C/*.o | grep -v "/conv_graph_cn8.o")
+    OTHERS=$(ls $C/*.o | grep -v "/conv_graph_cn8.o\|\.lds")
     hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libsar_g$m.so tools/bin/g2_a$m.o $OTHERS
   done
 else
