@@ -123,10 +123,35 @@ __device__ __forceinline__ Epi8Desc epi8_desc(const ConvK8& k, int wm, int m0, b
   return e;
 }
 
+// The operands one half block (two CN8 planes) of the epilogue reads from memory: aux half units (AUX) and, for
+// SAR_EPI_ADD_GATE (GATE), the second reduction operand + the gate byte.  [q2][ns] = plane 2 hb + q2, column block ns.
+template <int NS>
+struct Epi8Half {
+  u32x2 a[2][NS], u[2][NS];
+  unsigned g[2][NS];
+};
+template <int NS, bool AUX, bool GATE>
+__device__ __forceinline__ void epi8_half_loads(const Epi8Desc& e8, const Gate8Desc& g8, const unsigned (&vo)[NS], int hb,
+                                                Epi8Half<NS>& h) {
+#pragma unroll
+  for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int pl = 2 * hb + q2;
+      if constexpr (AUX) h.a[q2][ns] = __builtin_amdgcn_raw_buffer_load_b64(e8.ra, vo[ns], pl * e8.so_aux, 0);
+      if constexpr (GATE) {
+        h.u[q2][ns] = __builtin_amdgcn_raw_buffer_load_b64(g8.ru, vo[ns], pl * g8.so_u, 0);
+        h.g[q2][ns] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(g8.rm, vo[ns] >> 4, pl * g8.so_m, 0);   // byte = column (vo = 16 col + 8 hi)
+      }
+    }
+}
+
+// PRE: every aux half unit was requested by the kernel (axr).  pre0 (only without PRE): half block 0's operands were requested
+// by the kernel before its last MFMA phase (epi8_half_loads with the same descriptors) -- the epilogue's only exposed round trip.
 template <int MS, int NS, int WN, int BM, bool PRE = false>
 __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int wn, int m0, const unsigned (&vo)[NS],
                                           f32x16 (&acc)[MS][NS], float4* rowp, float* smem,
-                                          const u32x2* axr = nullptr) {
+                                          const u32x2* axr = nullptr, const Epi8Half<NS>* pre0 = nullptr) {
   const sar_conv_desc& d = k.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,39 +189,36 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
     // 64-row wave tile (tools/g2_timeline.sh: 22 000 of a 64-channel data-gradient workgroup's 49 000 cycles)
     constexpr bool piped = (has_aux && !PRE) || gate;
     constexpr int HB = 2 * MS;
-    u32x2 araw[2][2][NS], uraw[2][2][NS];
-    unsigned graw[2][2][NS];
-    auto hb_loads = [&](int hb, u32x2 (&aa)[2][NS], u32x2 (&uu)[2][NS], unsigned (&gg)[2][NS]) {
-#pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) {
-          const int pl = 2 * hb + q2;
-          if constexpr (has_aux && !PRE) aa[q2][ns] = __builtin_amdgcn_raw_buffer_load_b64(ra, vo[ns], pl * so_aux, 0);
-          if constexpr (gate) {
-            uu[q2][ns] = __builtin_amdgcn_raw_buffer_load_b64(g8.ru, vo[ns], pl * g8.so_u, 0);
-            gg[q2][ns] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(g8.rm, vo[ns] >> 4, pl * g8.so_m, 0);   // byte = column (vo = 16 col + 8 hi)
-          }
-        }
-    };
+    // without the gate a half block is ~40 vector instructions -- nothing to hide the next one's round trip behind: then ALL half
+    // blocks are requested up front (aux only: 8 NS registers per wave tile row block)
+    constexpr bool all_ahead = piped && !gate;
+    Epi8Half<NS> hbuf[all_ahead ? HB : 2];
     auto bf_elem = [](const u32x2& w, int i) {   // element i (0..3) of a half unit, as cn8_unpack4
       const unsigned dw = w[i >> 1];
       return __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
     };
-    if constexpr (piped) hb_loads(0, araw[0], uraw[0], graw[0]);
+    if constexpr (piped) {
+      if (pre0) hbuf[0] = *pre0;   // uniform
+      else epi8_half_loads<NS, has_aux && !PRE, gate>(e8, g8, vo, 0, hbuf[0]);
+      if constexpr (all_ahead) {
+#pragma unroll
+        for (int h = 1; h < HB; ++h) epi8_half_loads<NS, true, false>(e8, g8, vo, h, hbuf[h]);
+      }
+    }
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         // registers 8 rb .. 8 rb + 7 = two groups of 4 consecutive channels: planes 4 ms + 2 rb + {0, 1}
         const int hb = 2 * ms + rb;
-        if constexpr (piped)
-          if (hb + 1 < HB) hb_loads(hb + 1, araw[(hb + 1) & 1], uraw[(hb + 1) & 1], graw[(hb + 1) & 1]);
+        constexpr int HM = all_ahead ? 0xff : 1;   // buffer of half block hb: hbuf[hb & HM]
+        if constexpr (piped && !all_ahead)
+          if (hb + 1 < HB) epi8_half_loads<NS, has_aux && !PRE, gate>(e8, g8, vo, hb + 1, hbuf[(hb + 1) & 1]);
         auto ax = [&](int ns, int r8) {
           if constexpr (PRE) return bf_elem(axr[(hb * 2 + (r8 >> 2)) * NS + ns], r8 & 3);
-          else return bf_elem(araw[hb & 1][r8 >> 2][ns], r8 & 3);
+          else return bf_elem(hbuf[hb & HM].a[r8 >> 2][ns], r8 & 3);
         };
-        auto ux = [&](int ns, int r8) { return bf_elem(uraw[hb & 1][r8 >> 2][ns], r8 & 3); };
+        auto ux = [&](int ns, int r8) { return bf_elem(hbuf[hb & HM].u[r8 >> 2][ns], r8 & 3); };
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) {
           const int r = rb * 8 + r8;
@@ -218,7 +240,7 @@ __device__ __forceinline__ void epilogue8(const ConvK8& k, int tile, int wm, int
               val += ax(ns, r8);
             } else if (gate) {   // channel 4 hi + (r8 & 3) of the unit in plane (r8 >> 2) of this half block
               val += ax(ns, r8);
-              val = ((graw[hb & 1][r8 >> 2][ns] >> (4 * hi + (r8 & 3))) & 1u) ? val : 0.f;
+              val = ((hbuf[hb & HM].g[r8 >> 2][ns] >> (4 * hi + (r8 & 3))) & 1u) ? val : 0.f;
               // the sums run over the value as STORED (rounded to bfloat16): they replace a pass that read the stored tensor, and
               // the apply pass of the block below centres exactly these values
               const float vr = __uint_as_float(cn8_pack2(val, 0.f) << 16);

@@ -35,11 +35,14 @@ constexpr int NVMAX = 16;   // virtual joints per frame the tables may ask for
 #ifndef SAR_G2_WG4_PREAUX
 #define SAR_G2_WG4_PREAUX 0   // 1: the ADD epilogue's aux half units requested before the last MFMA phase (5 spilled registers at 128: measured 1-3 % slower)
 #endif
+#ifndef SAR_G2_PRE_HALF
+#define SAR_G2_PRE_HALF 0   // 1: half block 0 of the epilogue requested before the last MFMA phase -- measured: no effect (0.94 vs 0.95 ms per step), the epilogue is VALU work
+#endif
 #ifndef SAR_G2_BIAS_CHUNK
 #define SAR_G2_BIAS_CHUNK 4
 #endif
 #ifndef SAR_G2_ABLATE
-#define SAR_G2_ABLATE 0   // diagnostic builds only (tools/ablate_g2.sh): 1 no MFMA, 2 global loads of stage 0 only, 4 no epilogue, 8 no mini-builder, 16 LDS stores of stage 0 only
+#define SAR_G2_ABLATE 0   // diagnostic builds only (tools/ablate_g2.sh): 1 no MFMA, 2 global loads of stage 0 only, 4 no epilogue, 8 no mini-builder, 16 LDS stores of stage 0 only, 32 no classification of the gather lists
 #endif
 
 // Diagnostic build -DSAR_G2_TIMELINE (tools/g2_timeline.sh): wave 0 of every workgroup writes one row -- start / end in 100 MHz
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
   // classify the 3 V gather lists (wave 0; list p = lane + 64 pass, V <= 64: at most three passes): a list with ONE entry of
   // weight 1 is the raw column of that joint, an empty list the zero unit, everything else a virtual joint (ranked in (slice,
   // joint) order)
-  if (wave == 0) {
+  if (SAR_G2_ABLATE & 32) {   // diagnostic: no classification (every list reads its own joint, no virtual joints: WRONG results)
+    if (tid < 3 * V) vmap[tid] = tid % V;
+    if (tid == 0) nv_s = 0;
+  } else if (wave == 0) {
     constexpr int NPASS = 3;
     int ei[NPASS][4];
     float ew[NPASS][4];
@@ -354,6 +360,10 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
   // phase, not inside the epilogue (conv_gemm_cn8_kernel)
   const bool epi_gate = d.epi == SAR_EPI_ADD_GATE;
   const bool pre_aux = (!SAR_G2_WG4 || SAR_G2_WG4_PREAUX) && (d.epi == SAR_EPI_ADD || epi_gate);
+  // four workgroups per CU: no room for every aux half unit during the MFMA phase -- the epilogue reads its operands one half
+  // block ahead, and the first half block is requested here, before the last MFMA phase
+  const bool pre_half = SAR_G2_PRE_HALF && !pre_aux && (d.epi == SAR_EPI_ADD || epi_gate);
+  Epi8Half<NS> pre0;
   u32x2 axr[MS * 4 * NS];
   auto issue_aux = [&]() {
     const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
@@ -387,6 +397,11 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     }
     if (!(SAR_G2_ABLATE & 8)) build_virtual(buf);
     __syncthreads();         // B: virtual joints complete
+    if (last && pre_half) {  // uniform: the epilogue's first half block lands during the last MFMA phase (the staging registers are free)
+      const Epi8Desc e8 = epi8_desc<MS>(k, wm, m0, true);
+      if (epi_gate) epi8_half_loads<NS, true, true>(e8, gate8_desc(k, e8.g_w), vo, 0, pre0);
+      else epi8_half_loads<NS, true, false>(e8, Gate8Desc(), vo, 0, pre0);
+    }
     if (!(SAR_G2_ABLATE & 1)) mma_phase(buf);
   };
   G2_TL(2);
@@ -418,7 +433,8 @@ __global__ __launch_bounds__(256, SAR_G2_WG4 ? 4 : 3) void conv_graph2_cn8_kerne
     return;
   }
   if (pre_aux) epilogue8<MS, NS, WN, BM, true>(k, tile, wm, wn, m0, vo, acc, rowp, smem, axr);
-  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);   // four workgroups per CU: aux read one half block ahead inside the epilogue
+  else if (pre_half) epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem, nullptr, &pre0);
+  else epilogue8<MS, NS, WN, BM, false>(k, tile, wm, wn, m0, vo, acc, rowp, smem);
 #ifdef SAR_G2_TIMELINE
   G2_TL(4);
   if (tid == 0 && blockIdx.x < G2_TL_WG) {

@@ -26,7 +26,11 @@ for (cin, f, T) in [(64, 64, 300), (128, 128, 150), (256, 256, 75)]:
     Wg = torch.randn((cin, 3 * f), generator=g, device=dev) * 0.1
     pw_gb, pw_gf = pack(Wg, f, 1, 3 * f, 3, f, cin), pack(Wg, f, 3 * f, 1, 3, cin, f)
     g_, dx = ops8.empty(f, n, dev), ops8.empty(cin, n, dev)
+    X2 = rnd(cin, n, 5)
+    gmask = torch.randint(0, 256, ((cin + 7) // 8, X2.shape[1]), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+    gmean = 0.1 * torch.randn(cin, generator=g, device=dev)
     K = {"g_fwd": lambda: ops8.conv_gemm(L.SAR_CONV_GRAPH, X, g_, pw_gf, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=3, tables=tab, epi=L.SAR_EPI_STATS),
+         "g_dgate": lambda: ops8.conv_gemm(L.SAR_CONV_GRAPH, dG, dx, pw_gb, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tabT, epi=L.SAR_EPI_ADD_GATE, aux=X, aux2=X2, aux_mask=gmask, aux_mean=gmean),
          "g_dgrad": lambda: ops8.conv_gemm(L.SAR_CONV_GRAPH, dG, dx, pw_gb, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tabT, epi=L.SAR_EPI_ADD, aux=X)}
     for name, fn in K.items():
         for _ in range(3): fn()
