@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float t = wave_sum(bsum[q][e]);
+        const float t = wave_sum_dpp(bsum[q][e]);
         if (lane == 0) bred[wave][q * 8 + e] = t;
       }
     __syncthreads();
@@ -397,6 +397,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
   const int l31 = lane & 31, hi = lane >> 5;
   int split, by, bz;
   if (!xcd_split(d.nsplit, k.gy, k.gz, split, by, bz)) return;
+#ifdef SAR_CN8_STAMPS   // graph kernel: [0] store_raw (waits for the loads), [1] barrier, [2] build_z + barrier, [3] k-steps + closing barrier, [4] prologue, [5] epilogue
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0;
+#endif
   const int m0 = by * 64, c0 = bz * 64;
   const int wmb = wave & 1, wc = wave >> 1;
 
@@ -600,12 +605,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
   const unsigned b_base = (unsigned)(uintptr_t)Dimg + tr_lane_bytes(lane, PS, 4 * wmb);
 
   if (tile_lo < tile_hi) issue_loads(tile_lo);
+  WSTAMP8(4);
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     store_raw();
+    WSTAMP8(0);
     __syncthreads();
+    WSTAMP8(1);
     if (tile + 1 < tile_hi) issue_loads(tile + 1);
     build_z();
     __syncthreads();
+    WSTAMP8(2);
     // k-steps, software-pipelined by hand over two fragment sets (see wgrad_cn8_kernel): the eight transposed reads of
     // k-step ks + 1 are issued before the three MFMAs of k-step ks
     bf16x8 fb[2], fa[2][3];
@@ -641,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
       frag_mma(fb[0], fa[0]);
     }
     __syncthreads();
+    WSTAMP8(3);
   }
 
   float* slab = d.slab + (int64_t)split * (d.wsize + d.bsize);
@@ -659,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float s = wave_sum(bsum[q][t][e]);
+          const float s = wave_sum_dpp(bsum[q][t][e]);
           if (lane == 0) bred[wave][(q * 3 + t) * 8 + e] = s;
         }
     __syncthreads();
@@ -669,6 +679,338 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph_cn8_kernel(const WgradK8 k
       if (m0 + mm < d.M) slab[d.wsize + (int64_t)t * d.M + m0 + mm] = bred[pl & 3][((pl >> 2) * 3 + t) * 8 + e];
     }
   }
+#ifdef SAR_CN8_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  WSTAMP8(5);
+  if (tid == 0 && blockIdx.x < WSTAMP_WG) {
+    unsigned* row = g_wstamps8[blockIdx.x];
+    for (int i2 = 0; i2 < 6; ++i2) row[i2] = (unsigned)st_acc[i2];
+    row[6] = 1u;
+    row[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    row[8] = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0);
+    row[9] = (unsigned)(tile_hi > tile_lo ? tile_hi - tile_lo : 0);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ graph, read-gather
+// The same weight / bias gradient without the z images (SAR_GRAPH_FEW_DENSE tables, conv_graph_cn8.hip): nearly every gather list
+// of the NTU adjacency is {one joint, weight 1} or empty, so z_k is a PERMUTATION of the raw tile's columns -- and the transposed
+// LDS read takes its column from the lane's address (lane 4q+p of a 16-lane group supplies column q): the A fragment of slice k
+// is read straight from the raw image at the listed joints.  The few other lists are built per frame as virtual joints behind
+// the raw columns (fp32 chain of the unit builder, rounded once).  In wgrad_graph_cn8_kernel the z builder was 3 700-4 200 of
+// a tile's ~6 400 cycles (tools/stamps8.sh) and its images half of the LDS.  With the images gone there is room for TWO tiles:
+// the units are staged by LDS-DMA into the buffer that is not being multiplied (no staging registers, no store phase, two
+// barriers per tile).
+//   X plane: [0, 125) raw units of the tile's 5 frames | [125, 128) zero | [128 + 4 f + r] virtual joint r of frame f
+//   per lane: the unit of every (slice, k-step, half) it supplies, one byte each (4 registers per gathered slice)
+constexpr int NVW = 4;   // virtual joints per frame this kernel has room for (NTU forward tables: 2)
+template <bool ID0>
+__global__ __launch_bounds__(256, 2) void wgrad_graph2_cn8_kernel(const WgradK8 k, const int nv_asserted) {
+  constexpr int FT = 5, NLIVE = FT * WV, NPOS = 128, KSTEPS = NPOS / 16;
+  constexpr int PSD = pad_stride(NPOS);              // 132
+  constexpr int VBASE = NPOS, ZU = NLIVE;             // first virtual unit; a unit that is always zero
+  constexpr int PSX = pad_stride(VBASE + FT * NVW);   // 148
+  constexpr int XJ = (NLIVE + 63) / 64;
+  constexpr int T0 = ID0 ? 1 : 0, NG = 3 - T0;        // gathered slices T0 .. 2
+  static_assert(KSTEPS == 8 && PSX < 256, "one byte per (k-step, half)");
+  constexpr int BUF = 8 * PSX + 8 * PSD;            // one tile: raw src planes (+ virtual joints) and dout planes
+  __shared__ uint4 lds[2 * BUF];
+  __shared__ float bred[4][48];
+  __shared__ int vmap[3 * WV];
+  __shared__ int vl_idx[NVW][4];
+  __shared__ float vl_wt[NVW][4];
+  __shared__ int nv_s;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const sar_wgrad_desc& d = k.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  int split, by, bz;
+  if (!xcd_split(d.nsplit, k.gy, k.gz, split, by, bz)) return;
+#ifdef SAR_CN8_STAMPS   // [0] store_raw (waits for the loads), [1] barrier, [2] virtual joints + barrier, [3] k-steps + closing barrier, [4] prologue, [5] epilogue
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0;
+#endif
+  const int m0 = by * 64, c0 = bz * 64;
+  const int wmb = wave & 1, wc = wave >> 1;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum[2][3][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum[q][t][e] = 0.f;
+  // everything behind the raw columns starts as zero: [125, 128) and the dout tail stay so, the virtual joints are rewritten per tile
+  for (int i = tid; i < 2 * 8 * (PSX - NLIVE); i += 256) {
+    const int bf = i / (8 * (PSX - NLIVE)), r = i - bf * 8 * (PSX - NLIVE);
+    lds[bf * BUF + (r / (PSX - NLIVE)) * PSX + NLIVE + r % (PSX - NLIVE)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  for (int i = tid; i < 2 * 8 * (PSD - NLIVE); i += 256) {
+    const int bf = i / (8 * (PSD - NLIVE)), r = i - bf * 8 * (PSD - NLIVE);
+    lds[bf * BUF + 8 * PSX + (r / (PSD - NLIVE)) * PSD + NLIVE + r % (PSD - NLIVE)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  const int tps = (k.ntiles + d.nsplit - 1) / d.nsplit;
+  const int tile_lo = split * tps;
+  const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
+  const int seq = d.T_src * WV;
+  const bool do_bias = d.bsize > 0 && bz == 0;
+
+  // colsum(A_k)[w] of the dout units this lane stages (bias gradient)
+  float cs[XJ][3];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int i = lane + 64 * j;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) cs[j][t] = (i < NLIVE && d.g_colsum) ? d.g_colsum[t * WV + i % WV] : 0.f;
+  }
+  // classify the 3 V gather lists (wave 0; conv_graph2_cn8_kernel): {one entry, weight 1} -> that raw joint, empty -> the zero unit,
+  // anything else -> a virtual joint, ranked in (slice, joint) order
+  if (wave == 0) {
+    constexpr int NPASS = (3 * WV + 63) / 64;
+    int ei[NPASS][4];
+    float ew[NPASS][4];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int p = ps * 64 + lane;
+      const int pc = p < 3 * WV ? p : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ei[ps][j] = d.g_idx[pc * 4 + j], ew[ps][j] = d.g_wt[pc * 4 + j];
+    }
+    const int nz0 = d.nz[0], nz1 = d.nz[1], nz2 = d.nz[2];
+    int base = 0;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int p = ps * 64 + lane;
+      const bool in = p < 3 * WV;
+      const int tp = in ? p / WV : 0;
+      const int nzl = tp == 0 ? nz0 : (tp == 1 ? nz1 : nz2);
+      int cnt = 0, first = 0;
+      float wfirst = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = in && j < nzl;
+        if (!live) ei[ps][j] = 0, ew[ps][j] = 0.f;
+        if (live && ew[ps][j] != 0.f) {
+          if (cnt == 0) first = ei[ps][j], wfirst = ew[ps][j];
+          ++cnt;
+        }
+      }
+      const bool virt = in && (cnt > 1 || (cnt == 1 && wfirst != 1.0f));
+      const unsigned long long bal = __ballot(virt);
+      const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (in) vmap[p] = virt ? ((rank < nv_asserted && rank < NVW) ? WV + rank : -1) : (cnt == 1 ? first : -1);
+      if (virt && rank < nv_asserted && rank < NVW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vl_idx[rank][j] = ei[ps][j], vl_wt[rank][j] = ew[ps][j];
+      }
+      base += __popcll(bal);
+    }
+    if (lane == 0) nv_s = base < nv_asserted ? (base < NVW ? base : NVW) : (nv_asserted < NVW ? nv_asserted : NVW);
+  }
+  __syncthreads();   // vmap, virtual lists, zero fill
+  const int NV = nv_s;
+
+  // the units this lane supplies to the transposed reads: position p = 16 ks + 8 (G >> 1) + q (+ 4 for the second read)
+  const int G = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  unsigned goffs[NG][KSTEPS / 2];
+#pragma unroll
+  for (int t = T0; t < 3; ++t)
+#pragma unroll
+    for (int kp = 0; kp < KSTEPS / 2; ++kp) {
+      unsigned w = 0;
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) {
+        const int ks = 2 * kp + (b4 >> 1), h2 = b4 & 1;
+        const int p = 16 * ks + 8 * (G >> 1) + q4 + 4 * h2;
+        int u = ZU;
+        if (p < NLIVE) {
+          const int f = p / WV, v = p - f * WV;
+          const int vm = vmap[t * WV + v];
+          u = vm < 0 ? ZU : (vm < WV ? f * WV + vm : VBASE + f * NVW + (vm - WV));
+        }
+        w |= (unsigned)u << (8 * b4);
+      }
+      goffs[t - T0][kp] = w;
+    }
+  // mini-builder: item = (plane, frame, virtual joint), one per thread (8 * 5 * NVW <= 256)
+  int vb_dst = -1, vb_src[4] = {0, 0, 0, 0};
+  float vb_wt[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tid < 8 * FT * NV) {
+    const int pl = tid / (FT * NV), rem = tid - pl * (FT * NV);
+    const int f = rem / NV, r = rem - f * NV;
+    vb_dst = pl * PSX + VBASE + f * NVW + r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vb_src[j] = pl * PSX + f * WV + vl_idx[r][j];
+      vb_wt[j] = vl_wt[r][j];
+    }
+  }
+
+  // Staging is LDS-DMA (buffer_load ... lds, conv_gemm_cn8_dma.hip): a CN8 unit needs no arithmetic between HBM and LDS, so the
+  // tile's 16 planes go straight into the OTHER buffer while this one is multiplied -- no staging registers, no store phase.
+  // Wave w requests planes w and w + 4 of src and dout, two 64-unit pieces each; lanes beyond the tile's 125 columns (and columns
+  // beyond the sequence) are rejected by the range check and write zeros: units [125, 128) stay zero.
+  int tb = 0, tt0 = 0;   // sequence / first frame of the tile about to be requested
+  auto seek = [&](int tile) { tb = tile / k.TPS, tt0 = (tile - tb * k.TPS) * FT; };
+  auto issue_dma = [&](int bufo) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ip = wave + 4 * q;
+      const int g = c0 / 8 + ip, gd = m0 / 8 + ip;
+      const bool live = g < k.Gs, dlive = gd < k.Gd;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)d.src + ((int64_t)(live ? g : 0) * d.ld_src + (int64_t)tb * seq) * 16), 0,
+          live ? (unsigned)seq * 16u : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)d.dout + ((int64_t)(dlive ? gd : 0) * d.ld_dout + (int64_t)tb * seq) * 16), 0,
+          dlive ? (unsigned)seq * 16u : 0u, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = lane + 64 * j;
+        const unsigned vo = i < NLIVE ? (unsigned)((tt0 * WV + i) * 16) : 0x7fffffffu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds + bufo + ip * PSX + 64 * j), 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(lds + bufo + 8 * PSX + ip * PSD + 64 * j), 16, vo, 0, 0, 0);
+      }
+    }
+    tt0 += FT;               // the next tile of this split
+    if (tt0 >= d.T_out) tt0 = 0, ++tb;
+  };
+  auto bias_sums = [&](const uint4* Dimg) {   // this lane's dout units: planes wave, wave + 4, columns lane + 64 j
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ip = wave + 4 * q;
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        float f[8];
+        cn8_unpack(Dimg[ip * PSD + lane + 64 * j], f);   // (columns 125 .. 127: zero units, cs = 0)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[q][t][e] = fmaf(f[e], cs[j][t], bsum[q][t][e]);
+      }
+    }
+  };
+  auto build_virtual = [&](uint4* Ximg) {
+    if (vb_dst >= 0) {
+      float z[8], x[8];
+      cn8_unpack(Ximg[vb_src[0]], x);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) z[c] = vb_wt[0] * x[c];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        cn8_unpack(Ximg[vb_src[j]], x);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) z[c] = vb_wt[j] != 0.f ? fmaf(vb_wt[j], x[c], z[c]) : z[c];
+      }
+      Ximg[vb_dst] = cn8_pack(z);
+    }
+  };
+
+  // lane constants of the transposed reads (relative to a buffer): plane + channel-quad part (gathered reads add the unit), and the plain ones
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  const unsigned xg_rel = (unsigned)((((4 * wc + 2 * (G & 1) + (pp >> 1)) * PSX) * 16) + 8 * (pp & 1));
+  const unsigned x_rel = tr_lane_bytes(lane, PSX, 4 * wc);
+  const unsigned b_rel = (unsigned)(8 * PSX * 16) + tr_lane_bytes(lane, PSD, 4 * wmb);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  auto gfrag = [&](unsigned xg_base, unsigned w, int b4) {   // bytes b4, b4 + 1 of w: the units of the two reads of one k-step
+    const unsigned u0 = (w >> (8 * b4)) & 0xffu, u1 = (w >> (8 * b4 + 8)) & 0xffu;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(xg_base + (u0 << 4)));
+    const s16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(xg_base + (u1 << 4)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
+    return *reinterpret_cast<const bf16x8*>(&v);
+  };
+
+  // Happens-before of the two buffers: the DMA of tile i + 1 into buffer (i + 1) & 1 is issued behind barrier A of tile i; that
+  // buffer was last read (bias sums, mini-builder, k-steps) for tile i - 1, which every wave finished before it joined barrier A
+  // of tile i.  The DMA of tile i is complete (vmcnt) in every wave before that wave joins barrier A of tile i.
+  if (tile_lo < tile_hi) {
+    seek(tile_lo);
+    issue_dma((tile_lo & 1) * BUF);
+  }
+  WSTAMP8(4);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int bufo = (tile & 1) * BUF;
+    WSTAMP8(0);
+    __syncthreads();         // A: this tile's units are in LDS (vmcnt(0) in front of the barrier)
+    WSTAMP8(1);
+    if (tile + 1 < tile_hi) issue_dma(((tile + 1) & 1) * BUF);
+    if (do_bias) bias_sums(lds + bufo + 8 * PSX);
+    if (NV > 0) {   // uniform
+      build_virtual(lds + bufo);
+      __syncthreads();       // B: virtual joints complete
+    }
+    WSTAMP8(2);
+    // k-steps, fully unrolled (the gather units are register bytes), software-pipelined over two fragment sets
+    const unsigned xg_base = lds0 + bufo * 16 + xg_rel, x_base = lds0 + bufo * 16 + x_rel, b_base = lds0 + bufo * 16 + b_rel;
+    bf16x8 fb[2], fa[2][3];
+    auto frag_load = [&](int ks, bf16x8& bv, bf16x8 (&av)[3]) {
+      bv = tr_frag(b_base + ks * 256);
+      if (ID0) av[0] = tr_frag(x_base + ks * 256);
+#pragma unroll
+      for (int t = T0; t < 3; ++t) av[t] = gfrag(xg_base, goffs[t - T0][ks >> 1], 2 * (ks & 1));
+    };
+    auto frag_mma = [&](const bf16x8& bv, const bf16x8 (&av)[3]) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t], bv, acc[t], 0, 0, 0);
+    };
+    frag_load(0, fb[0], fa[0]);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + 1 < KSTEPS) frag_load(ks + 1, fb[(ks + 1) & 1], fa[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(fb[ks & 1], fa[ks & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    WSTAMP8(3);
+  }
+
+  float* slab = d.slab + (int64_t)split * (d.wsize + d.bsize);
+  const int m = m0 + wmb * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + wc * 32 + mfma_row(r, hi);
+      if (c < d.Kc && m < d.M) slab[(int64_t)t * d.w_stride_tap + (int64_t)c * d.w_stride_c + m] = acc[t][r];
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float s = wave_sum_dpp(bsum[q][t][e]);
+          if (lane == 0) bred[wave][(q * 3 + t) * 8 + e] = s;
+        }
+    __syncthreads();
+    if (tid < 192) {   // (slice t, channel m0 + mm): dout plane mm / 8 = wave' + 4 q
+      const int t = tid >> 6, mm = tid & 63;
+      const int pl = mm >> 3, e = mm & 7;
+      if (m0 + mm < d.M) slab[d.wsize + (int64_t)t * d.M + m0 + mm] = bred[pl & 3][((pl >> 2) * 3 + t) * 8 + e];
+    }
+  }
+#ifdef SAR_CN8_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  WSTAMP8(5);
+  if (tid == 0 && blockIdx.x < WSTAMP_WG) {
+    unsigned* row = g_wstamps8[blockIdx.x];
+    for (int i2 = 0; i2 < 6; ++i2) row[i2] = (unsigned)st_acc[i2];
+    row[6] = 1u;
+    row[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    row[8] = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0);
+    row[9] = (unsigned)(tile_hi > tile_lo ? tile_hi - tile_lo : 0);
+  }
+#endif
 }
 
 template <int TAPS, int STRIDE, bool WIDE = false>
@@ -737,6 +1079,14 @@ extern "C" int sar_conv_wgrad_cn8(const sar_wgrad_desc* d, int slice0_identity, 
       SAR_REQUIRE(d->nz[i] >= 1 && d->nz[i] <= 4, "sar_conv_wgrad_cn8: adjacency slice %d needs %d gather entries (max 4)", i, d->nz[i]);
     SAR_REQUIRE(!slice0_identity || d->nz[0] == 1, "sar_conv_wgrad_cn8: an identity slice has one gather entry");
     k.gz = (d->Kc + 63) / 64;
+    // read-gather kernel: SAR_GRAPH_FEW_DENSE tables with at most NVW virtual joints (SAR_WGRAD_READ_GATHER=0: the z-image kernel)
+    static const bool rg = [] { const char* e = getenv("SAR_WGRAD_READ_GATHER"); return !(e && e[0] == '0'); }();
+    const int nvd = (d->g_flags >> SAR_GRAPH_FEW_DENSE_SHIFT) & 0xff;
+    if (rg && (d->g_flags & SAR_GRAPH_FEW_DENSE) && nvd <= NVW) {
+      const int nwork = k.d.nsplit * k.gy * k.gz;
+      if (slice0_identity) hipLaunchKernelGGL((wgrad_graph2_cn8_kernel<true>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, as_stream(s), k, nvd);
+      else hipLaunchKernelGGL((wgrad_graph2_cn8_kernel<false>), dim3(((nwork + 7) / 8) * 8), dim3(256), 0, as_stream(s), k, nvd);
+    } else
     if (d->nz[0] == 1 && d->nz[1] == 1) launch_g<1, 1, 4>(k, slice0_identity != 0, as_stream(s));
     else if (d->nz[0] == 1 && d->nz[2] == 1) launch_g<1, 4, 1>(k, slice0_identity != 0, as_stream(s));
     else launch_g<4, 4, 4>(k, false, as_stream(s));

@@ -60,6 +60,24 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+// The same total in EVERY lane without the LDS crossbar: __shfl_xor is ds_bpermute_b32 (a dependent LDS round trip per step, six
+// per sum: the 48 bias sums of a graph weight-gradient workgroup took ~23 000 cycles, tools/stamps8.sh); the butterfly inside a
+// row of 16 lanes is four DPP adds, the four row totals are read with v_readlane.  Summation order differs from wave_sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_lanes(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  x += dpp_lanes<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+  x += dpp_lanes<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+  x += dpp_lanes<0x141>(x);   // row_half_mirror: lane i <-> 7 - i of each 8
+  x += dpp_lanes<0x140>(x);   // row_mirror: lane i <-> 15 - i of each 16
+  const int xi = __float_as_int(x);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(xi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ double wave_sum_d(double x) {
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
   return x;

@@ -56,7 +56,7 @@ for (cin, f, s, T, cnt) in [(64, 64, 1, 300, 3), (64, 128, 2, 300, 1), (128, 128
         tot[name] = tot.get(name, 0.0) + us * cnt
         line += "  %s %6.1f us" % (name, us)
         lib = L.load()
-        if hasattr(lib, "sar_debug_wgrad8_stamps") and name == "t_wgrad":
+        if hasattr(lib, "sar_debug_wgrad8_stamps") and name in ("t_wgrad", "g_wgrad"):
             import ctypes
             buf = (ctypes.c_ulonglong * 10)()
             torch.cuda.synchronize(); lib.sar_debug_wgrad8_stamps(buf, 1)
