@@ -119,12 +119,10 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
     off0[ns] += hi * SCOLS;   // this lane's k half
   }
 
-  if (tid < BM) {
-    const int row = m0 + tid;
-    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.bias && row < d.M) bp.x = d.bias[row];
-    rowp[tid] = bp;
-  }
+  // the bias row is REQUESTED here and stored to LDS behind the stage-0 loads: stored here, its wait (a memory round trip) stood in
+  // front of the issue of the stage's operands (tools/g2_timeline.sh found the same pattern in the graph kernel)
+  float bias_v = 0.f;
+  if (tid < BM && d.bias && m0 + tid < d.M) bias_v = d.bias[m0 + tid];
   if (tid < 2) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
   f32x16 acc[MS][NS];
 
@@ -204,6 +202,8 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
   };
 
   issue_loads(0);
+  asm volatile("" ::: "memory");
+  if (tid < BM) rowp[tid] = make_float4(bias_v, 0.f, 0.f, 0.f);
   __syncthreads();   // rowp
   // HAPPENS-BEFORE of the LDS regions of this kernel (single image, two barriers per stage):
   //  * image (W | S): written by store_lds(s) behind the closing barrier of stage s - 1, which every wave joins after its MFMA phase
@@ -439,12 +439,10 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_cn8_db_kernel(const ConvK8 k
 
   const bool epi_mask = d.epi == SAR_EPI_MASK;
   const bool has_aux = epi_mask || d.epi == SAR_EPI_ADD;
-  if (tid < BM) {
-    const int row = m0 + tid;
-    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.bias && row < d.M) bp.x = d.bias[row];
-    rowp[tid] = bp;
-  }
+  // the bias row is REQUESTED here and stored to LDS behind the stage-0 loads: stored here, its wait (a memory round trip) stood in
+  // front of the issue of the stage's operands (tools/g2_timeline.sh found the same pattern in the graph kernel)
+  float bias_v = 0.f;
+  if (tid < BM && d.bias && m0 + tid < d.M) bias_v = d.bias[m0 + tid];
   if (tid < 2) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
   f32x16 acc[MS][NS];
 
@@ -555,6 +553,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_cn8_db_kernel(const ConvK8 k
   issue_w(0);
   issue_s(0, sregA);
   if (KC16 < d.Kc) issue_s(KC16, sregB);
+  asm volatile("" ::: "memory");
+  if (tid < BM) rowp[tid] = make_float4(bias_v, 0.f, 0.f, 0.f);
   __syncthreads();   // rowp / zero column
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)

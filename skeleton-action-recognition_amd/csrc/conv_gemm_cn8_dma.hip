@@ -95,12 +95,8 @@ __global__ __launch_bounds__(256, NB == 1 ? 4 : 2) void conv_gemm_cn8_dma_kernel
 
   const bool epi_mask = d.epi == SAR_EPI_MASK;
   const bool has_aux = epi_mask || d.epi == SAR_EPI_ADD;
-  if (tid < BM) {
-    const int row = m0 + tid;
-    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.bias && row < d.M) bp.x = d.bias[row];
-    rowp[tid] = bp;
-  }
+  float bias_v = 0.f;   // requested here, stored behind the stage-0 requests (conv_gemm_cn8_kernel)
+  if (tid < BM && d.bias && m0 + tid < d.M) bias_v = d.bias[m0 + tid];
   if (tid < 2 * NB) Sl[(tid >> 1) * BUFU + (tid & 1) * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
   f32x16 acc[MS][NS];
 
@@ -137,6 +133,8 @@ __global__ __launch_bounds__(256, NB == 1 ? 4 : 2) void conv_gemm_cn8_dma_kernel
   };
 
   issue_dma(0, 0);
+  asm volatile("" ::: "memory");
+  if (tid < BM) rowp[tid] = make_float4(bias_v, 0.f, 0.f, 0.f);
   __syncthreads();   // rowp / zero column (and, by the compiler's vmcnt(0) in front of the barrier, stage 0)
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
