@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
   constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area (floats / 4), aliases the operand image
   constexpr int IMG_U = TC::UNITS > PAREA_U ? TC::UNITS : PAREA_U;
   __shared__ uint4 smem_u[IMG_U + BM];       // image | per-row parameters (float4 per row)
+  // Folded BatchNorm scale / shift of ALL src channels, staged once: fetched per stage in the store phase (cn8_params8) they were
+  // vector loads with a wait each -- scale, wait, shift, wait, per plane: four dependent L2 round trips in EVERY stage, most of
+  // the 2 700-3 500 cycles the phase stamps attributed to "store" (found in the ISA after tools/g2_timeline.sh)
+  constexpr int PMAX = 512;
+  __shared__ float pro_l[2 * PMAX];
   uint4* Wl = smem_u;
   uint4* Sl = smem_u + TC::WUNITS;
   float* smem = reinterpret_cast<float*>(smem_u);
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
   const bool has_pro = d.pro_scale != nullptr;
   const bool pro_relu = d.pro_relu != 0;
+  const bool pro_lds = has_pro && d.Kc <= PMAX;   // uniform
   const int ncj = (k.RW + 255) >> 8;   // live 256-column chunks of the staged window (wave-uniform, <= CJ)
   uint4 wreg[WIT];
   uint4 sreg[2][CJ];
@@ -188,8 +194,16 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
     for (int h = 0; h < 2; ++h) {
       if (has_pro) {   // uniform: BatchNorm + ReLU of the producer folded into the operand (models/stgcn.py:27-28)
         float psc[8], psh[8];
-        cn8_params8(d.pro_scale, c0 + 8 * h, d.Kc, psc);
-        cn8_params8(d.pro_shift, c0 + 8 * h, d.Kc, psh);
+        if (pro_lds) {   // uniform: four broadcast LDS reads (channels beyond Kc: zeros, as cn8_params8)
+          const float4* ps = reinterpret_cast<const float4*>(pro_l + c0 + 8 * h);
+          const float4* pt = reinterpret_cast<const float4*>(pro_l + PMAX + c0 + 8 * h);
+          const float4 a = ps[0], bq = ps[1], c = pt[0], e = pt[1];
+          psc[0] = a.x, psc[1] = a.y, psc[2] = a.z, psc[3] = a.w, psc[4] = bq.x, psc[5] = bq.y, psc[6] = bq.z, psc[7] = bq.w;
+          psh[0] = c.x, psh[1] = c.y, psh[2] = c.z, psh[3] = c.w, psh[4] = e.x, psh[5] = e.y, psh[6] = e.z, psh[7] = e.w;
+        } else {
+          cn8_params8(d.pro_scale, c0 + 8 * h, d.Kc, psc);
+          cn8_params8(d.pro_shift, c0 + 8 * h, d.Kc, psh);
+        }
 #pragma unroll
         for (int j = 0; j < CJ; ++j)
           if (j < ncj)   // padding / columns outside the sequence stay exactly 0 (keep mask)
@@ -202,9 +216,20 @@ __global__ __launch_bounds__(256, MS * NS > 4 ? 2 : 3) void conv_gemm_cn8_kernel
   };
 
   issue_loads(0);
+  if (pro_lds) {   // uniform; requested behind the stage-0 operands, visible behind the barrier below
+    float pv[2][2 * PMAX / 256];
+#pragma unroll
+    for (int i = 0; i < PMAX / 256; ++i) {
+      const int c = tid + 256 * i;
+      pv[0][i] = c < d.Kc ? d.pro_scale[c] : 0.f;
+      pv[1][i] = c < d.Kc ? d.pro_shift[c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PMAX / 256; ++i) pro_l[tid + 256 * i] = pv[0][i], pro_l[PMAX + tid + 256 * i] = pv[1][i];
+  }
   asm volatile("" ::: "memory");
   if (tid < BM) rowp[tid] = make_float4(bias_v, 0.f, 0.f, 0.f);
-  __syncthreads();   // rowp
+  __syncthreads();   // rowp, pro_l
   // HAPPENS-BEFORE of the LDS regions of this kernel (single image, two barriers per stage):
   //  * image (W | S): written by store_lds(s) behind the closing barrier of stage s - 1, which every wave joins after its MFMA phase
   //    of stage s - 1 (its last read of the image); read behind the opening barrier of stage s;

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
   constexpr int FT = C::FT, PS_S = C::PS_S, PS_D = C::PS_D, SJ = C::SJ, DJ = C::DJ, SU = C::SU, NACC = C::NACC;
   __shared__ uint4 lds[C::LDS_UNITS];
   __shared__ float bred[4][16];
+  __shared__ __attribute__((aligned(16))) float pro_w[128];   // folded BN scale [0, 64) / shift [64, 128) of this workgroup's src channels
   constexpr int NSP = C::NSP, SQ = NSP / 4;   // src image planes; planes staged per wave (wave w: planes w, w + 4)
   uint4* Himg = lds;                 // src image planes (SPLIT: E planes 0-3, O planes 4-7)
   uint4* Dimg = lds + NSP * PS_S;    // 8 dout planes
@@ -166,6 +167,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
   const bool has_pro = d.pro_scale != nullptr;
   const bool pro_relu = d.pro_relu != 0;
   const bool do_bias = d.bsize > 0 && bz == 0;
+  if (tid < 128) {
+    const int c = c0 + (tid & 63);
+    const float* pp = tid < 64 ? d.pro_scale : d.pro_shift;
+    pro_w[tid] = (has_pro && c < d.Kc) ? pp[c] : 0.f;
+  }
+  __syncthreads();   // pro_w
 
   // ---- stager geometry.  Wave w stages src image planes w, w+4 and dout planes w, w+4; lane -> units lane + 64 j.
   // src unit i of an image plane = frame i / V of the image, joint i % V; its column offset inside the sequence is
@@ -224,10 +231,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_cn8_kernel(const WgradK8 k) {
       const int ip = wave + 4 * q;
      if (q < SQ) {
       if (has_pro) {   // uniform: BatchNorm + ReLU of the producer folded into the operand (models/stgcn.py:27-28)
-        const int cb = c0 + 8 * (C::SPLIT ? (ip & 3) : ip);
-        float psc[8], psh[8];
-        cn8_params8(d.pro_scale, cb, d.Kc, psc);
-        cn8_params8(d.pro_shift, cb, d.Kc, psh);
+        // the plane's scale / shift from the workgroup's LDS copy (fetched here with cn8_params8 they were two dependent L2 round
+        // trips per plane in EVERY tile's store phase: conv_gemm_cn8.hip)
+        const int cr = 8 * (C::SPLIT ? (ip & 3) : ip);
+        const float4* ps = reinterpret_cast<const float4*>(pro_w + cr);
+        const float4* pt = reinterpret_cast<const float4*>(pro_w + 64 + cr);
+        const float4 pa = ps[0], pb = ps[1], pc = pt[0], pe = pt[1];
+        const float psc[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+        const float psh[8] = {pc.x, pc.y, pc.z, pc.w, pe.x, pe.y, pe.z, pe.w};
 #pragma unroll
         for (int j = 0; j < SJ; ++j)   // padding / columns outside the sequence stay exactly 0 (keep mask)
           sreg[q][j] = cn8_bn_relu_unit(sreg[q][j], psc, psh, pro_relu, ((sin[q] >> j) & 1u) ? 0xffffffffu : 0u);

@@ -399,5 +399,7 @@ class ResNet18:
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         """torch.optim.Adam(lr) (main_spectrogram.py:106) over the flat buffers."""
         self.step_dev += 1.0
-        self.lr_dev.fill_(float(lr))
+        if getattr(self, "_lr_host", None) != float(lr):      # one launch less per step while the schedule holds the rate
+            self.lr_dev.fill_(float(lr))
+            self._lr_host = float(lr)
         ops.adam(self.flat, self.adam_m, self.adam_v, self.grad, self.lr_dev, self.step_dev, betas[0], betas[1], eps)

@@ -629,7 +629,9 @@ class STGCN:
 
     def sgd_step(self, lr, momentum=0.9):
         """tf.keras SGD(momentum, nesterov=True) over the flat buffers (main_gnn.py:312-314)."""
-        self.lr_dev.fill_(float(lr))
+        if getattr(self, "_lr_host", None) != float(lr):      # one launch less per step while the schedule holds the rate
+            self.lr_dev.fill_(float(lr))
+            self._lr_host = float(lr)
         ops.sgd_nesterov(self.flat, self.velocity, self.grad, self.lr_dev, momentum)
 
     def predict(self, x):
