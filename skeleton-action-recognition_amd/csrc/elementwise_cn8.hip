@@ -11,8 +11,11 @@ namespace {
 
 constexpr int TPB = 256;
 
-inline int unit_blocks(int64_t n) {
-  int64_t b = (n + TPB - 1) / TPB;
+// Streaming kernels process EW_U units per thread and iteration, all loads first: with one unit per thread a 960 000-column plane
+// was 3 750 workgroups of ONE 16-byte unit per thread, each paying its 24-48 parameter loads for 12 KB of traffic.
+constexpr int EW_U = 4;
+inline int unit_blocks(int64_t n, int per_thread = 1) {
+  int64_t b = (n + (int64_t)TPB * per_thread - 1) / ((int64_t)TPB * per_thread);
   if (b < 1) b = 1;
   if (b > 65535) b = 65535;
   return (int)b;
@@ -43,19 +46,31 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_cn8_kernel(const uint4* _
   cn8_params(res_kind == 2 ? rsc : nullptr, g, C, 1.f, ra);
   cn8_params(res_kind == 2 ? rsh : nullptr, g, C, 0.f, rb);
   const int64_t base = (int64_t)g * ld;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    float uv[8], rv[8], o[8];
-    cn8_unpack(u[base + i], uv);
-    if (res_kind) cn8_unpack(r[base + i], rv);
+  for (int64_t i0 = (int64_t)blockIdx.x * (TPB * EW_U) + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * (TPB * EW_U)) {
+    uint4 xu[EW_U], xr[EW_U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float z = fmaf(uv[j], a[j], b[j]);
-      if (res_kind) z += fmaf(rv[j], ra[j], rb[j]);
-      o[j] = fmaxf(z, 0.f);
+    for (int q = 0; q < EW_U; ++q) {
+      const int64_t i = i0 + q * TPB, ic = i < n ? i : n - 1;
+      xu[q] = u[base + ic];
+      if (res_kind) xr[q] = r[base + ic];
     }
-    const uint4 p = cn8_pack(o);
-    y[base + i] = p;
-    if (mask) mask[base + i] = (unsigned char)cn8_positive_bits(p);   // uniform
+#pragma unroll
+    for (int q = 0; q < EW_U; ++q) {
+      const int64_t i = i0 + q * TPB;
+      if (i >= n) break;
+      float uv[8], rv[8], o[8];
+      cn8_unpack(xu[q], uv);
+      if (res_kind) cn8_unpack(xr[q], rv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float z = fmaf(uv[j], a[j], b[j]);
+        if (res_kind) z += fmaf(rv[j], ra[j], rb[j]);
+        o[j] = fmaxf(z, 0.f);
+      }
+      const uint4 p = cn8_pack(o);
+      y[base + i] = p;
+      if (mask) mask[base + i] = (unsigned char)cn8_positive_bits(p);   // uniform
+    }
   }
 }
 
@@ -149,24 +164,38 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_cn8_kernel(
   cn8_params(dr ? rk2 : nullptr, g, C, 0.f, b2);
   cn8_params(dr ? rk3 : nullptr, g, C, 0.f, b3);
   const int64_t base = (int64_t)g * ld;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    float gv[8], uv[8], rv[8], o1[8], o2[8], o3[8];
-    cn8_unpack(dy[base + i], gv);
-    unsigned mb;
-    if (mask) mb = mask[base + i];   // uniform
-    else mb = cn8_positive_bits(y[base + i]);
-    cn8_unpack(u[base + i], uv);
-    if (dr) cn8_unpack(r[base + i], rv);
+  for (int64_t i0 = (int64_t)blockIdx.x * (TPB * EW_U) + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * (TPB * EW_U)) {
+    uint4 xg[EW_U], xu[EW_U], xr[EW_U];
+    unsigned xm[EW_U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float dz = ((mb >> j) & 1u) ? gv[j] : 0.f;
-      o3[j] = dz;
-      o1[j] = fmaf(a1[j], dz, fmaf(a2[j], uv[j], a3[j]));
-      if (dr) o2[j] = fmaf(b1[j], dz, fmaf(b2[j], rv[j], b3[j]));
+    for (int q = 0; q < EW_U; ++q) {   // (dz_out may be dy: a thread stores only the units it has already read)
+      const int64_t i = i0 + q * TPB, ic = i < n ? i : n - 1;
+      xg[q] = dy[base + ic];
+      if (mask) xm[q] = mask[base + ic];   // uniform
+      else xm[q] = cn8_positive_bits(y[base + ic]);
+      xu[q] = u[base + ic];
+      if (dr) xr[q] = r[base + ic];
     }
-    du[base + i] = cn8_pack(o1);
-    if (dr) dr[base + i] = cn8_pack(o2);
-    if (dz_out) dz_out[base + i] = cn8_pack(o3);
+#pragma unroll
+    for (int q = 0; q < EW_U; ++q) {
+      const int64_t i = i0 + q * TPB;
+      if (i >= n) break;
+      float gv[8], uv[8], rv[8], o1[8], o2[8], o3[8];
+      cn8_unpack(xg[q], gv);
+      const unsigned mb = xm[q];
+      cn8_unpack(xu[q], uv);
+      if (dr) cn8_unpack(xr[q], rv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dz = ((mb >> j) & 1u) ? gv[j] : 0.f;
+        o3[j] = dz;
+        o1[j] = fmaf(a1[j], dz, fmaf(a2[j], uv[j], a3[j]));
+        if (dr) o2[j] = fmaf(b1[j], dz, fmaf(b2[j], rv[j], b3[j]));
+      }
+      du[base + i] = cn8_pack(o1);
+      if (dr) dr[base + i] = cn8_pack(o2);
+      if (dz_out) dz_out[base + i] = cn8_pack(o3);
+    }
   }
 }
 
@@ -179,13 +208,25 @@ __global__ __launch_bounds__(TPB) void affine2_cn8_kernel(const uint4* __restric
   cn8_params(k2, g, C, 0.f, a2);
   cn8_params(k3, g, C, 0.f, a3);
   const int64_t base = (int64_t)g * ld;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    float av[8], bv[8], o[8];
-    cn8_unpack(a[base + i], av);
-    cn8_unpack(b[base + i], bv);
+  for (int64_t i0 = (int64_t)blockIdx.x * (TPB * EW_U) + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * (TPB * EW_U)) {
+    uint4 xa[EW_U], xb[EW_U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = fmaf(a1[j], av[j], fmaf(a2[j], bv[j], a3[j]));
-    out[base + i] = cn8_pack(o);
+    for (int q = 0; q < EW_U; ++q) {   // (out may be a: a thread stores only the units it has already read)
+      const int64_t i = i0 + q * TPB, ic = i < n ? i : n - 1;
+      xa[q] = a[base + ic];
+      xb[q] = b[base + ic];
+    }
+#pragma unroll
+    for (int q = 0; q < EW_U; ++q) {
+      const int64_t i = i0 + q * TPB;
+      if (i >= n) break;
+      float av[8], bv[8], o[8];
+      cn8_unpack(xa[q], av);
+      cn8_unpack(xb[q], bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaf(a1[j], av[j], fmaf(a2[j], bv[j], a3[j]));
+      out[base + i] = cn8_pack(o);
+    }
   }
 }
 
@@ -285,7 +326,7 @@ extern "C" int sar_bn_add_relu_fwd_cn8(const void* u, const float* sc, const flo
   SAR_REQUIRE(res_kind >= 0 && res_kind <= 2 && (res_kind == 0 || r) && (res_kind != 2 || (rsc && rsh)),
               "sar_bn_add_relu_fwd_cn8: residual arguments");
   SAR_REQUIRE(al16({u, r, y}), "sar_bn_add_relu_fwd_cn8: CN8 tensors must be 16-byte aligned");
-  hipLaunchKernelGGL(bn_add_relu_fwd_cn8_kernel, dim3(unit_blocks(n), CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)u, sc,
+  hipLaunchKernelGGL(bn_add_relu_fwd_cn8_kernel, dim3(unit_blocks(n, EW_U), CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)u, sc,
                      sh, res_kind, (const uint4*)r, rsc, rsh, (uint4*)y, C, n, ld);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_fwd_cn8");
   return 0;
@@ -298,7 +339,7 @@ extern "C" int sar_bn_add_relu_fwd_mask_cn8(const void* u, const float* sc, cons
   SAR_REQUIRE(res_kind >= 0 && res_kind <= 2 && (res_kind == 0 || r) && (res_kind != 2 || (rsc && rsh)),
               "sar_bn_add_relu_fwd_mask_cn8: residual arguments");
   SAR_REQUIRE(al16({u, r, y}), "sar_bn_add_relu_fwd_mask_cn8: CN8 tensors must be 16-byte aligned");
-  hipLaunchKernelGGL(bn_add_relu_fwd_cn8_kernel, dim3(unit_blocks(n), CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)u, sc,
+  hipLaunchKernelGGL(bn_add_relu_fwd_cn8_kernel, dim3(unit_blocks(n, EW_U), CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)u, sc,
                      sh, res_kind, (const uint4*)r, rsc, rsh, (uint4*)y, C, n, ld, (unsigned char*)mask);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_fwd_mask_cn8");
   return 0;
@@ -351,7 +392,7 @@ extern "C" int sar_bn_add_relu_bwd_apply_cn8(const void* dy, const void* y, cons
   SAR_REQUIRE(dy && y && u && k1 && k2 && k3 && du && C > 0 && n > 0 && ld >= n, "sar_bn_add_relu_bwd_apply_cn8: bad arguments");
   SAR_REQUIRE(!dr || (r && rk1 && rk2 && rk3), "sar_bn_add_relu_bwd_apply_cn8: residual-branch arguments");
   SAR_REQUIRE(al16({dy, y, u, r, du, dr, dz_out}), "sar_bn_add_relu_bwd_apply_cn8: CN8 tensors must be 16-byte aligned");
-  hipLaunchKernelGGL(bn_add_relu_bwd_apply_cn8_kernel, dim3(unit_blocks(n), CN8_G(C)), dim3(TPB), 0, as_stream(s),
+  hipLaunchKernelGGL(bn_add_relu_bwd_apply_cn8_kernel, dim3(unit_blocks(n, EW_U), CN8_G(C)), dim3(TPB), 0, as_stream(s),
                      (const uint4*)dy, (const uint4*)y, (const uint4*)u, (const uint4*)r, k1, k2, k3, rk1, rk2, rk3, (uint4*)du,
                      (uint4*)dr, (uint4*)dz_out, C, n, ld);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_cn8");
@@ -365,7 +406,7 @@ extern "C" int sar_bn_add_relu_bwd_apply_mask_cn8(const void* dy, const void* ma
   SAR_REQUIRE(dy && mask && u && k1 && k2 && k3 && du && C > 0 && n > 0 && ld >= n, "sar_bn_add_relu_bwd_apply_mask_cn8: bad arguments");
   SAR_REQUIRE(!dr || (r && rk1 && rk2 && rk3), "sar_bn_add_relu_bwd_apply_mask_cn8: residual-branch arguments");
   SAR_REQUIRE(al16({dy, u, r, du, dr, dz_out}), "sar_bn_add_relu_bwd_apply_mask_cn8: CN8 tensors must be 16-byte aligned");
-  hipLaunchKernelGGL(bn_add_relu_bwd_apply_cn8_kernel, dim3(unit_blocks(n), CN8_G(C)), dim3(TPB), 0, as_stream(s),
+  hipLaunchKernelGGL(bn_add_relu_bwd_apply_cn8_kernel, dim3(unit_blocks(n, EW_U), CN8_G(C)), dim3(TPB), 0, as_stream(s),
                      (const uint4*)dy, (const uint4*)nullptr, (const uint4*)u, (const uint4*)r, k1, k2, k3, rk1, rk2, rk3, (uint4*)du,
                      (uint4*)dr, (uint4*)dz_out, C, n, ld, (const unsigned char*)mask);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_mask_cn8");
@@ -376,7 +417,7 @@ extern "C" int sar_affine2_cn8(const void* a, const void* b, const float* k1, co
                                int64_t n, int64_t ld, sar_stream_t s) {
   SAR_REQUIRE(a && b && k1 && k2 && k3 && out && C > 0 && n > 0 && ld >= n, "sar_affine2_cn8: bad arguments");
   SAR_REQUIRE(al16({a, b, out}), "sar_affine2_cn8: CN8 tensors must be 16-byte aligned");
-  hipLaunchKernelGGL(affine2_cn8_kernel, dim3(unit_blocks(n), CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)a,
+  hipLaunchKernelGGL(affine2_cn8_kernel, dim3(unit_blocks(n, EW_U), CN8_G(C)), dim3(TPB), 0, as_stream(s), (const uint4*)a,
                      (const uint4*)b, k1, k2, k3, (uint4*)out, C, n, ld);
   SAR_LAUNCH_CHECK("sar_affine2_cn8");
   return 0;
