@@ -961,6 +961,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_graph2_cn8_kernel(const WgradK8 
     }
     WSTAMP8(2);
     // k-steps, fully unrolled (the gather units are register bytes), software-pipelined over two fragment sets
+    SAR_LDS_SKEW();   // this wave reads buffer tile & 1 late: the others may only request tile + 2 into it behind barrier A of tile + 1
     const unsigned xg_base = lds0 + bufo * 16 + xg_rel, x_base = lds0 + bufo * 16 + x_rel, b_base = lds0 + bufo * 16 + b_rel;
     bf16x8 fb[2], fa[2][3];
     auto frag_load = [&](int ks, bf16x8& bv, bf16x8 (&av)[3]) {
