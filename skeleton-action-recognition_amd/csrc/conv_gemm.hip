@@ -456,18 +456,21 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
   const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK;
   auto fast_epilogue = [&](auto EPI_) {
     constexpr int EPI = decltype(EPI_)::value;
-    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
+    constexpr bool gate = EPI == SAR_EPI_ADD_GATE;   // out = gate(acc + aux), sums of the gated values (include/sar_hip.h)
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK || gate;
     // Fast path.  A lane's 16 accumulator rows of one 32-row block are rows (r&3) + 8 (r>>2) + 4 hi: with
     // M % 8 == 0 validity is uniform per group of 4 registers (scalar branch), the row part of every address is
     // a scalar offset and the column part one per-lane byte offset: buffer loads / stores, no address VALU.
-    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
-    if (EPI == SAR_EPI_MASK) {   // per-row affine of the mask -> LDS (all waves are past the main loop)
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD || gate;
+    if (EPI == SAR_EPI_MASK || gate) {   // per-row affine of the mask / centre of the second sum -> LDS (all waves are past the main loop)
       if (tid < BM) {
         const int row = m0 + tid;
         float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < d.M) {
-          ap.x = d.aux_scale[row];
-          ap.y = d.aux_shift[row];
+          if (EPI == SAR_EPI_MASK) {
+            ap.x = d.aux_scale[row];
+            ap.y = d.aux_shift[row];
+          }
           if (d.aux_mean) ap.z = d.aux_mean[row];
         }
         rowp[tid] = ap;
@@ -492,12 +495,29 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
       vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
     }
     const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);   // bytes per row
+    // SAR_EPI_ADD_GATE: aux2 [M][ld_aux2] fp32 and its gate bytes [M][ld_aux2 / 4] (bit j of byte i = column 4 i + j, the layout
+    // sar_bn_add_relu_fwd_mask_f32 writes)
+    const float* u2 = reinterpret_cast<const float*>(d.aux2);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gate ? u2 + (int64_t)rows_w * d.ld_aux2 : d.out), 0, gate ? rows_bytes(d.ld_aux2) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gate ? d.aux_mask + (int64_t)rows_w * (d.ld_aux2 >> 2) : (const unsigned char*)d.out), 0,
+        gate ? rows_bytes(d.ld_aux2) >> 4 : 0u, 0x00020000);
+    unsigned vo_u[NS], vo_m[NS], cbit[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      vo_u[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux2) * 4) : 0x80000000u;
+      vo_m[ns] = colok[ns] ? (unsigned)((coln[ns] >> 2) + hi * d.ld_aux2) : 0x80000000u;
+      cbit[ns] = (unsigned)(coln[ns] & 3);
+    }
+    const int so_u = (int)(d.ld_aux2 * 4), so_m = (int)(d.ld_aux2 >> 2);
     float* P = smem + wave * (16 * 65);   // wave-private transpose area for the sums (16 sums x 64 lanes, stride 65)
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {   // 8 registers = 16 sums per transpose round
-        float ax[NS][16];
+        float ax[NS][16], ux[NS][16];
+        unsigned gm[NS][16];
         if (has_aux) {   // the aux loads of this half row block are issued before the first use
 #pragma unroll
           for (int r8 = 0; r8 < 8; ++r8)
@@ -506,6 +526,12 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
               const int r = rb * 8 + r8;
               ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                   ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+              if (gate) {
+                ux[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    ru, vo_u[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_u, 0));
+                gm[ns][r] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(
+                    rm, vo_m[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_m, 0);
+              }
             }
         }
 #pragma unroll
@@ -514,7 +540,7 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
           const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;   // wave-uniform
           float s1 = 0.f, s2 = 0.f;
           float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+          if (EPI == SAR_EPI_MASK || gate) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns) {
             float val = acc[ms][ns][r];
@@ -527,6 +553,11 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
               s2 = fmaf(val, ax[ns][r] - ap.z, s2);
             } else if (EPI == SAR_EPI_ADD) {
               val += ax[ns][r];
+            } else if (gate) {   // replaces, for the block below, bn_add_relu_bwd_reduce and the masked-gradient write of the apply pass
+              val += ax[ns][r];
+              val = ((gm[ns][r] >> cbit[ns]) & 1u) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ux[ns][r] - ap.z, s2);
             }
             if (grp_ok)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
@@ -560,6 +591,7 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
       case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
       case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
       case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
+      case SAR_EPI_ADD_GATE: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD_GATE>()); break;
       default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
     }
     return;
@@ -679,10 +711,16 @@ int validate(const sar_conv_desc* d) {
   SAR_REQUIRE(d->ld_out < (1 << 22) && d->ld_aux < (1 << 22), "sar_conv_gemm: leading dimension too large (2^22 columns)");
   SAR_REQUIRE(((int64_t)(d->taps - 1) * d->w_stride_tap + (int64_t)4 * d->w_stride_c + d->M) < (1 << 28),
               "sar_conv_gemm: weight tensor too large for 32-bit offsets");
-  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm: bad epilogue %d", d->epi);
-  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm: partials required");
-  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
+  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD_GATE, "sar_conv_gemm: bad epilogue %d", d->epi);
+  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD_GATE)
+    SAR_REQUIRE(d->partials, "sar_conv_gemm: partials required");
+  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD || d->epi == SAR_EPI_ADD_GATE)
     SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm: aux required");
+  if (d->epi == SAR_EPI_ADD_GATE) {   // fp32: aux2 is [M][ld_aux2] floats, aux_mask [M][ld_aux2 / 4] bytes (one bit per column)
+    SAR_REQUIRE(d->mode == SAR_CONV_GRAPH && (d->M & 7) == 0, "sar_conv_gemm: SAR_EPI_ADD_GATE is built for the graph data gradient with M %% 8 == 0");
+    SAR_REQUIRE(d->aux2 && d->aux_mask && d->ld_aux2 >= (int64_t)d->B * d->T_out * d->V && (d->ld_aux2 & 3) == 0 && d->ld_aux2 < (1 << 22),
+                "sar_conv_gemm: SAR_EPI_ADD_GATE needs aux2, aux_mask and ld_aux2 %% 4 == 0");
+  }
   if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->aux_scale && d->aux_shift, "sar_conv_gemm: aux affine required");
   if (d->mode == SAR_CONV_GRAPH) {
     SAR_REQUIRE(d->taps == 3, "sar_conv_gemm: graph mode needs 3 adjacency slices (got %d)", d->taps);

@@ -85,7 +85,7 @@ class PackedWeights:
 
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
-              aux_affine=None, aux_mean=None, bf16=False, packed=None, partials_out=None):
+              aux_affine=None, aux_mean=None, bf16=False, packed=None, partials_out=None, aux2=None, aux_mask=None):
     """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (M % 8 == 0, Kc >= 16: bf16
     MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel).  Returns (partials, nparts) when the
     epilogue reduces, else None."""
@@ -112,9 +112,13 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     if aux_affine is not None:
         d.aux_scale, d.aux_shift = ptr(_f32(aux_affine[0])), ptr(_f32(aux_affine[1]))
     d.aux_mean = ptr(_f32(aux_mean))
+    if epi == L.SAR_EPI_ADD_GATE:      # fp32 kernel only: aux2 [M][ld] floats, aux_mask [M][ld / 4] bytes (relu_mask layout)
+        assert not bf16 and aux2 is not None and aux_mask is not None and aux_mask.dtype == torch.uint8
+        assert aux2.stride(0) % 4 == 0 and aux_mask.shape == (M, aux2.stride(0) // 4) and aux_mask.is_contiguous()
+        d.aux2, d.ld_aux2, d.aux_mask = ptr(_f32(aux2)), aux2.stride(0), ptr(aux_mask)
     partials = None
     nparts = 0
-    if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
+    if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK, L.SAR_EPI_ADD_GATE):
         nparts = lib.sar_conv_gemm_nparts(C.byref(d))
         if nparts <= 0:
             check(nparts or -1, "sar_conv_gemm_nparts")

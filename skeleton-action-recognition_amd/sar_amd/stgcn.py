@@ -27,6 +27,7 @@ KS, KT = 3, 9        # kernel_size=[3, 9], models/stgcn.py:14
 # beside the NEXT block's element-wise BatchNorm passes instead of beside this block's data-gradient GEMMs.  Three interleaved
 # rounds: fp32 59.22 -> 58.99 ms per step; bf16 13.26 -> 13.55 (slower: there the order stays as it was).  SAR_WGRAD_DEFER=0/1 forces it.
 _WGRAD_DEFER_ENV = __import__("os").environ.get("SAR_WGRAD_DEFER")
+_FUSE_TAIL_F32 = __import__("os").environ.get("SAR_F32_FUSE_TAIL", "1") == "1"   # SAR_EPI_ADD_GATE in the fp32 graph data gradient
 # (filters, stride, residual) -- models/stgcn.py:113-123
 BLOCKS = [(64, 1, False), (64, 1, True), (64, 1, True), (64, 1, True), (128, 2, True), (128, 1, True), (128, 1, True),
           (256, 2, True), (256, 1, True), (256, 1, True)]
@@ -479,8 +480,20 @@ class STGCN:
         ops.pool_bwd(dfeat, B, sv["T_last"] * V, M, dY)
         if self.dense_A:
             self._dA_layers = torch.zeros((len(self.blocks), KS * V * V), dtype=torch.float32, device=dev)
+        # fp32 engine, gather tables: the graph data gradient of block i gates the output gradient of block i - 1 with that block's
+        # ReLU mask and reduces its BatchNorm-backward sums in the same epilogue (SAR_EPI_ADD_GATE; sar_amd/stgcn8.py does the same
+        # for the bf16 engine) -- the bn_add_relu_bwd_reduce pass and the masked-gradient write of the apply pass are gone for
+        # every block whose successor's skip path is not a convolution
+        fuse = self._fuse_tail_f32()
+        gated = None
         for i in reversed(range(len(self.blocks))):
-            dY = self._block_backward(i, sv["blocks"][i], dY, B)
+            if fuse:
+                sbb = sv["blocks"][i - 1] if i >= 1 else None
+                below = sbb if (sbb is not None and self.kinds[i - 1] != "conv" and sbb.get("ymask") is not None
+                                and sv["blocks"][i]["kind"] != "none" and sv["blocks"][i]["cin"] % 8 == 0) else None
+                dY, gated = self._block_backward(i, sv["blocks"][i], dY, B, gated, below)
+            else:
+                dY = self._block_backward(i, sv["blocks"][i], dY, B)
             if self._deferred:
                 self._flush_deferred()
             self._buckets_after_block(i, bucket_cb)
@@ -499,7 +512,17 @@ class STGCN:
                             self.g["data_bn.gamma"], self.g["data_bn.beta"])
         self._finish_backward(bucket_cb)
 
-    def _block_backward(self, i, sb, dY, B):
+    def _fuse_tail_f32(self):
+        """SAR_EPI_ADD_GATE in the fp32 graph data gradient (SAR_F32_FUSE_TAIL=0 turns it off): plain ST-GCN engine, fp32 MFMA
+        operands, gather tables, ReLU masks written by the forward tails"""
+        return (_FUSE_TAIL_F32 and type(self)._block_backward is STGCN._block_backward and not self.bf16 and not self.dense_A
+                and not getattr(self, "cn8", False) and ops.RELU_MASK and not ops.BN_TAIL)
+
+    def _block_backward(self, i, sb, dY, B, gated=None, below=None):
+        """gated: this block's BatchNorm-backward partial sums when dY already carries the ReLU gate (produced by the graph data
+        gradient of the block above); below: the saved tensors of block i - 1 when THIS block's graph data gradient is to do the
+        same for it.  With the fused tail on (backward()) the return value is (dX, sums-for-the-block-below), else dX."""
+        fused_call = self._fuse_tail_f32()
         V, dev = self.V, dY.device
         pre = "l%d." % i
         X, g, u, r, y = sb["X"], sb["g"], sb["u"], sb["r"], sb["y"]
@@ -509,7 +532,11 @@ class STGCN:
         rbn = self.bn.get(pre + "res_bn")
         # ---- tail: y = relu(bn2(u) + res)   (models/stgcn.py:37,62-63)
         rk = (rbn.k1, rbn.k2, rbn.k3) if kind == "conv" else None
-        if ops.BN_TAIL:      # the reduce kernel's last workgroup per channel finalises BN2 (and the residual BN): no launch between
+        if gated is not None:    # the sums came with dY: (sum dz, sum dz (u - mean)) per channel and partial
+            assert kind != "conv"
+            ops.bn_bwd_finalize(gated[0], gated[1], gated[1] * 2, 2, 0, 1, f, n_out, self.p[pre + "bn2.gamma"], bn2.mean, bn2.rstd,
+                                self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"], bn2.k1, bn2.k2, bn2.k3)
+        elif ops.BN_TAIL:      # the reduce kernel's last workgroup per channel finalises BN2 (and the residual BN): no launch between
             tail = ops.make_bn_tail(dev, n_out, self.p[pre + "bn2.gamma"], bn2, self.g[pre + "bn2.gamma"], self.g[pre + "bn2.beta"],
                                     *((self.p[pre + "res_bn.gamma"], rbn, self.g[pre + "res_bn.gamma"], self.g[pre + "res_bn.beta"])
                                       if kind == "conv" else ()))
@@ -526,7 +553,7 @@ class STGCN:
                                     rbn.k3)
         du = torch.empty_like(u)
         dr = torch.empty_like(r) if kind == "conv" else None
-        dz = dY if kind == "identity" else None  # in place: dY becomes the pre-ReLU gradient for the skip path
+        dz = dY if (kind == "identity" and gated is None) else None  # in place: dY becomes the pre-ReLU gradient for the skip path (already gated: nothing to write)
         ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz,
                                   mask=sb.get("ymask"))
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
@@ -565,10 +592,17 @@ class STGCN:
             gT = self._wT[o:o + KS * f * cin]                             # [k][f][c]
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
+        if below is not None and aux is not None:
+            # dX = gate_{i-1}(W^T dg . A^T + skip gradient) and block i - 1's BatchNorm-backward sums in one epilogue
+            bn2b = self.bn["l%d.bn2" % (i - 1)]
+            pm = ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
+                               tables=self.tab_bwd, epi=L.SAR_EPI_ADD_GATE, aux=aux, aux2=below["u"], aux_mask=below["ymask"],
+                               aux_mean=bn2b.mean)
+            return dX, pm
         ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
                       tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux, bf16=self.bf16,
                       packed=gimg)
-        return dX
+        return (dX, None) if fused_call else dX
 
     def _residual_backward(self, i, sb, dr, B):
         """weight gradient and data gradient of the strided 1x1 residual convolution (blocks 5 and 8); None otherwise"""

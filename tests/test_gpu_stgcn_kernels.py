@@ -137,6 +137,38 @@ def test_graph_conv_gradients(dev, B, cin, f, T):
     assert rel_err(flat[cin * 3 * f:].cpu(), gb) < TOL
 
 
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 64, 12), (2, 64, 128, 8), (1, 128, 256, 4), (4, 256, 256, 76), (2, 40, 72, 8)])
+def test_graph_data_gradient_gated_epilogue_f32(dev, B, cin, f, T):
+    """SAR_EPI_ADD_GATE of sar_conv_gemm_f32 (include/sar_hip.h): out = gate(W^T dg . A^T + aux) with the ReLU-mask bytes of the
+    block below (one bit per column, sar_bn_add_relu_fwd_mask_f32's layout), partials = (sum out, sum out (aux2 - mean)): the
+    stored tensor equals the SAR_EPI_ADD result gated afterwards bit for bit, the sums equal fp64 sums of it to 1e-6."""
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(11 * cin + f)
+    n = B * T * 25
+    assert n % 4 == 0
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    dout = torch.randn(f, n, generator=g).to(dev)
+    add = torch.randn(cin, n, generator=g).to(dev)
+    u = torch.randn(cin, n, generator=g).to(dev)
+    mean = (0.1 * torch.randn(cin, generator=g)).to(dev)
+    keep = (torch.rand(cin, n, generator=g) > 0.4).to(dev)
+    mask = (keep.view(cin, n // 4, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], device=dev, dtype=torch.int32)).sum(dim=2).to(torch.uint8).contiguous()
+    gT = torch.empty((3 * f, cin), device=dev)
+    ops.transpose(kernel.to(dev).contiguous(), gT, 1, cin, 3 * f)
+    args = dict(B=B, V=25, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=_tables(dev, True))
+    plain, gated = torch.empty((cin, n), device=dev), torch.empty((cin, n), device=dev)
+    ops.conv_gemm(L.SAR_CONV_GRAPH, dout, plain, gT, f * cin, cin, epi=L.SAR_EPI_ADD, aux=add, **args)
+    pm = ops.conv_gemm(L.SAR_CONV_GRAPH, dout, gated, gT, f * cin, cin, epi=L.SAR_EPI_ADD_GATE, aux=add, aux2=u, aux_mask=mask,
+                       aux_mean=mean, **args)
+    torch.cuda.synchronize()
+    want = torch.where(keep, plain, torch.zeros_like(plain))
+    assert torch.equal(gated, want)
+    part = pm[0].double().sum(dim=1).cpu()
+    s1 = want.double().sum(dim=1).cpu()
+    s2 = (want.double() * (u.double() - mean.double().view(-1, 1))).sum(dim=1).cpu()
+    assert rel_err(part[:, 0], s1) < 1e-6 and rel_err(part[:, 1], s2) < 1e-6
+
+
 @pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2), (4, 256, 75, 1), (3, 128, 150, 2),
                                      (2, 72, 11, 1), (1, 200, 9, 2), (2, 44, 12, 2)])
 def test_temporal_conv_gradients(dev, B, f, T, s):
