@@ -82,8 +82,9 @@ int sar_context_destroy(sar_context* ctx);   /* waits for nothing: synchronise t
  * ------------------------------------------------------------------------------------------------ */
 enum { SAR_CONV_GRAPH = 0, SAR_CONV_TEMPORAL = 1 };
 enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3,
-       /* bf16 (CN8) graph data gradient only, round 4: out = gate(acc + aux), where gate keeps channel c of column n iff bit (c & 7) of
-        * aux_mask[(c >> 3) * ld_aux2 + n] is set (the 1-byte-per-unit ReLU mask a block tail wrote), and the BatchNorm-backward sums
+       /* graph data gradient only, round 4: out = gate(acc + aux), where gate keeps channel c of column n iff -- sar_conv_gemm_cn8 (bf16):
+        * bit (c & 7) of aux_mask[(c >> 3) * ld_aux2 + n]; sar_conv_gemm_f32: bit (n & 3) of aux_mask[c * (ld_aux2 / 4) + (n >> 2)],
+        * aux2 = [M][ld_aux2] floats, ld_aux2 % 4 == 0, M % 8 == 0 -- is set (the ReLU mask a block tail wrote), and the BatchNorm-backward sums
         * of the tail that PRODUCED aux2 are reduced from the same accumulators: partials[m][part] = (sum out, sum out (aux2 - aux_mean)).
         * It replaces, for the block below, the masked-gradient write of bn_add_relu_bwd_apply and the whole bn_add_relu_bwd_reduce
         * pass (models/stgcn.py:37,62-63 backward). */
@@ -126,8 +127,8 @@ typedef struct sar_conv_desc {
   const float* aux_scale; const float* aux_shift;    /* [M] (SAR_EPI_MASK) */
   const float* aux_mean;   /* [M] or NULL: centre of the second MASK reduction */
   float* partials;         /* [M][nparts][2] (SAR_EPI_STATS / SAR_EPI_MASK / SAR_EPI_ADD_GATE) */
-  const void* aux2; int64_t ld_aux2;                 /* SAR_EPI_ADD_GATE: CN8 tensor [ceil(M/8)][ld_aux2] of the second reduction */
-  const unsigned char* aux_mask;                     /* SAR_EPI_ADD_GATE: [ceil(M/8)][ld_aux2] gate bytes */
+  const void* aux2; int64_t ld_aux2;                 /* SAR_EPI_ADD_GATE: tensor of the second reduction: CN8 [ceil(M/8)][ld_aux2] units / fp32 [M][ld_aux2] */
+  const unsigned char* aux_mask;                     /* SAR_EPI_ADD_GATE: gate bytes: CN8 [ceil(M/8)][ld_aux2] / fp32 [M][ld_aux2 / 4] */
 } sar_conv_desc;
 
 /* sizeof(sar_conv_desc) (which=0) / sizeof(sar_wgrad_desc) (1) / sizeof(sar_conv2d_desc) (2) as compiled: lets a binding verify its mirror */
