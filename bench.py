@@ -23,6 +23,7 @@ for _p in (ROOT, os.path.join(ROOT, "skeleton-action-recognition_amd")):
         sys.path.insert(0, _p)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (v_mfma_f32_32x32x16_bf16)
 FLOP_PER_CLIP_TRAIN = 102.56e9     # 3 x 34.19 GFLOP
 BYTES_PER_CLIP_TRAIN_BF16 = 427.3e6   # block-fused algorithmic HBM traffic per clip and train step, bf16 storage
 # What the build EXECUTES per clip and train step: SURVEY's 102.56 GFLOP prices the dense 'nkctv,kvw->nctw' einsum (432
@@ -403,16 +404,23 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
                 "tflops": round(ifl / (ims * 1e-3) / 1e12, 2) if ims > 0 else None,
                 "gbps": round(iby / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
                 "avg_launch_ms": round(ims / max(icalls, 1), 4),
-                "frac_of_fp32_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if (ims > 0 and not bf16) else None}
+                "frac_of_fp32_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if (ims > 0 and not bf16) else None,
+                "frac_of_bf16_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if (ims > 0 and bf16) else None}
             out["kernel_ms_per_step_isolated"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(iso.items())}
             out["wgrad_side_stream"] = True
-        if bf16:   # the bf16 kernels are bound by moving activations, not by the matrix pipe (2.5 PFLOP/s dense bf16)
+        if bf16:   # which roof binds the family: the larger of (algorithmic FLOPs / 2.5 PFLOP/s dense bf16) and (algorithmic bytes / 8 TB/s)
             by = sum(summ[k]["bytes"] for k in fam)
+            fl_ = sum(summ[k]["flops"] for k in fam)
             gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             step_bytes = BYTES_PER_CLIP_TRAIN_BF16 if mfma == "bf16" else 2 * BYTES_PER_CLIP_TRAIN_BF16
             isolated = out["roofline"].get("isolated")
-            out["roofline"] = {"bound": "hbm", "kernel": "9-tap temporal conv GEMMs on CN8 activations (fwd + data-grad launches); " + in_step,
-                               "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+            mfma_bound = fl_ / (PEAK_BF16_MFMA_TFLOPS * 1e12) >= by / 8.0e12      # 9-tap family: 62 us at the matrix roof, 34 us at the HBM roof per launch
+            out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm",
+                               "kernel": "9-tap temporal conv GEMMs on CN8 activations (fwd + data-grad launches); " + in_step,
+                               "achieved": round(achieved, 1) if mfma_bound else round(gbs, 1),
+                               "peak": PEAK_BF16_MFMA_TFLOPS if mfma_bound else 8000.0, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                               "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4) if mfma_bound else round(gbs / 8000.0, 4),
+                               "hbm_gbps": round(gbs, 1), "hbm_frac": round(gbs / 8000.0, 4),
                                "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch, PMC passes of the PROFILED build (%s), not of this run" % traffic_src
                                                if traffic else None,
