@@ -154,6 +154,24 @@ typedef struct sar_pack_item {
 int sar_pack_weights_bf16_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units, void* out,
                                 sar_stream_t s);
 
+/* fp32-ACCURATE results on the bf16 matrix pipe ("split" arithmetic, csrc/conv_gemm_split.hip): every fp32 operand is a sum of
+ * bfloat16 terms (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 24 significant bits, remainders exact), the products of
+ * the terms are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and the cross products with i + j <= 2 (dropped ones
+ * <= 3 * 2^-27 |a b|) replace one fp32 MFMA at 6/16 of its cost.  Same operator, descriptor, epilogues, fp32 storage and
+ * partial-sum contract as sar_conv_gemm_f32 -- models/stgcn.py:29-36 and its data gradient under the fp32 parity tolerances.
+ * arith: SAR_SPLIT_BF16X6 is the product mode; X1 (plain bf16 operands), X3 (two terms, three products), X9 (all nine products)
+ * and F16X3 (two fp16 terms, static scales: NO range management) are measured data points (tools/split_probe.py).
+ * Built for the 9-tap TEMPORAL operator at V = 25, stride 1 / 2, 8 <= Kc <= 256, M % 8 == 0; anything else returns SAR_E_UNSUP
+ * (sar_conv_gemm_split_nparts too): the caller keeps sar_conv_gemm_f32 for it.  `packed` = the weight term images written by
+ * sar_pack_weights_split_batch (same items as sar_pack_weights_bf16_batch, but G = ceil(Kc / 8), and an item occupies
+ * sar_conv_gemm_split_workspace_bytes / 16 units = terms * taps * G * M).  Partial sums: [M][sar_conv_gemm_split_nparts][2]. */
+enum { SAR_SPLIT_BF16X1 = 1, SAR_SPLIT_BF16X3 = 3, SAR_SPLIT_BF16X6 = 6, SAR_SPLIT_BF16X9 = 9, SAR_SPLIT_F16X3 = 103, SAR_SPLIT_F16X3S = 104 };
+int64_t sar_conv_gemm_split_workspace_bytes(const sar_conv_desc* d, int arith);
+int sar_conv_gemm_split_nparts(const sar_conv_desc* d);
+int sar_pack_weights_split_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units, int arith,
+                                 void* out, sar_stream_t s);
+int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void* packed, sar_stream_t s);
+
 /* Weight gradient of the same operator (reduction over all positions n):
  *   dW[tap][c][m] = sum_n dout[m, n] * OP_tap(pro(src))[c, n]        (tf.GradientTape of the conv,
  *   dbias                                                             main_gnn.py:233)

@@ -1,0 +1,120 @@
+// conv_epi_f32.h -- the fp32-storage epilogue shared by the bf16-operand kernels (conv_gemm_bf16.hip) and the split-arithmetic
+// kernels (conv_gemm_split.hip): mask / add, buffer stores, BatchNorm partial sums through a wave-private LDS transpose
+// (include/sar_hip.h: SAR_EPI_NONE / STATS / MASK / ADD; partials [M][nparts][2]).  Include inside the unit's anonymous namespace.
+#pragma once
+// (the including unit has <type_traits> and sar_common.h in scope)
+
+// ---- epilogue (as conv_gemm.hip): mask / add, store, BatchNorm partial sums.  Every wave is past its last MFMA phase
+// and the closing barrier: the transpose area aliases the operand image.
+template <int MS, int NS, int WN, int BM>
+__device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, int tile, int wm, int wn, int m0,
+                                           const bool (&colok)[NS], const int64_t (&coln)[NS], f32x16 (&acc)[MS][NS],
+                                           float4* rowp, float* smem) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int part = tile * WN + wn;
+  const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK;
+  auto fast_epilogue = [&](auto EPI_) {
+    constexpr int EPI = decltype(EPI_)::value;
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
+    if (EPI == SAR_EPI_MASK) {
+      if (tid < BM) {
+        const int row = m0 + tid;
+        float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < d.M) {
+          ap.x = d.aux_scale[row];
+          ap.y = d.aux_shift[row];
+          if (d.aux_mean) ap.z = d.aux_mean[row];
+        }
+        rowp[tid] = ap;
+      }
+      __syncthreads();
+    }
+    const int rows_w = m0 + wm * MS * 32;
+    auto rows_bytes = [&](int64_t ld) {
+      const int64_t n = (int64_t)(d.M - rows_w) * ld * 4;
+      return (unsigned)(n <= 0 ? 0 : (n > 0x80000000ll ? 0x80000000ll : n));
+    };
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + (int64_t)rows_w * d.ld_out), 0, rows_bytes(d.ld_out), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_aux ? d.aux + (int64_t)rows_w * d.ld_aux : d.out), 0, has_aux ? rows_bytes(d.ld_aux) : 0u, 0x00020000);
+    unsigned vo_out[NS], vo_aux[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
+      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+    }
+    const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
+    float* P = smem + wave * (16 * 65);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float ax[NS][16];
+        if (has_aux) {
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const int r = rb * 8 + r8;
+              ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+            }
+        }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = rb * 8 + r8;
+          const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;
+          float s1 = 0.f, s2 = 0.f;
+          float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            float val = acc[ms][ns][r];
+            if (EPI == SAR_EPI_STATS) {
+              s1 += val;
+              s2 = fmaf(val, val, s2);
+            } else if (EPI == SAR_EPI_MASK) {
+              val = (fmaf(ax[ns][r], ap.x, ap.y) > 0.f) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ax[ns][r] - ap.z, s2);
+            } else if (EPI == SAR_EPI_ADD) {
+              val += ax[ns][r];
+            }
+            if (grp_ok)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
+                                                    (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_out, 0);
+          }
+          if (stats) {
+            P[(2 * r8) * 65 + lane] = s1;
+            P[(2 * r8 + 1) * 65 + lane] = s2;
+          }
+        }
+        if (stats) {
+          __builtin_amdgcn_wave_barrier();
+          const int q = lane & 15, sub = (lane >> 4) & 1;
+          const float* pr = P + q * 65 + hi * 32 + sub * 16;
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t += pr[i];
+          t += __shfl_xor(t, 16);
+          __builtin_amdgcn_wave_barrier();
+          const int r = rb * 8 + (q >> 1);
+          const int row = rows_w + ms * 32 + mfma_row(r, hi);
+          if (sub == 0 && row < d.M) d.partials[((int64_t)row * nparts + part) * 2 + (q & 1)] = t;
+        }
+      }
+    }
+  };
+  (void)stats;
+  switch (d.epi) {   // M % 8 == 0 is a precondition of this kernel (checked by the host)
+    case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
+    case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
+    case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
+    default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
+  }
+}
+

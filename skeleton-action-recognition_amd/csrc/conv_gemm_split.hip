@@ -1,0 +1,522 @@
+// conv_gemm_split.hip -- the 9-tap temporal convolution and its data gradients with fp32 results on the bf16 matrix pipe
+// ("split" arithmetic, gfx950).
+//
+//   out[m, n] = sum_tap sum_c W[tap][c][m] * pro(src)[c, n + shift(tap)] (+ bias) ; epilogue          (models/stgcn.py:29-36)
+//
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate on this chip.  Here every fp32 operand is written as a sum
+// of bfloat16 TERMS,  a = a0 + a1 + a2  with  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)  (round to nearest; the
+// remainders are exact in fp32, 8 + 8 + 8 significant bits: |a - a0 - a1 - a2| <= 2^-27 |a|), and the product a b is the sum of
+// the cross products a_i b_j with i + j <= 2 -- each EXACT in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; the dropped
+// products are <= 3 * 2^-27 |a b| -- issued smallest terms first into ONE fp32 accumulator ("x6").  Activations, weights,
+// BatchNorm sums, bias and epilogue stay fp32: the kernel is a drop-in for conv_gemm_kernel<TEMPORAL, 9> (conv_gemm.hip) under
+// the same parity tolerances.  Other arithmetics of the same kernel, kept as measured data points: x1 (one term = plain bf16
+// operands), x3 (two terms, three products, ~2^-17), x9 (all nine products), and h3 (two fp16 terms, the second scaled by
+// 2^11, three products into two accumulators, static operand scales: no range management -- a probe, not a product mode).
+//
+// Design (MI355X):
+//  * tile 64 (m) x 256 (columns = 10 frames x 25 joints), 4 waves side by side, wave tile 64 x 64 (2 x 2 MFMA blocks).
+//  * stage = 8 source channels.  The 16 k of one MFMA are 8 channels x 2 TAPS: lanes 0-31 hold tap 2q, lanes 32-63 tap 2q + 1
+//    (a tap is a shift of the column by V units, so the half's tap is part of the lane's LDS address).  Nine taps = five k-steps,
+//    the last one half empty (its second half reads a zero weight slot): 10 % idle matrix work buys an operand image of 53 KB
+//    -- three workgroups per CU -- instead of 99 KB with 16 channels per stage.
+//  * LDS image: NT weight terms [term][tap][64 rows] + one zero slot, NT source terms [term][column] + one zero column; units of
+//    16 bytes = 8 channels of one row / column, the k-innermost operand of the bf16 MFMA: every fragment is one ds_read_b128.
+//  * weights are split ONCE per step into their term images by the pack kernel; a stage's weight pieces reach LDS by LDS-DMA
+//    (buffer_load_dwordx4 ... lds: no registers, no VALU).  The source is split in the stager behind the folded BatchNorm +
+//    ReLU: a lane owns a column, loads it from 8 channel rows (coalesced row segments), and writes NT ds_write_b128.
+//  * single image; the W DMA of stage s + 1 is issued behind the closing barrier of stage s, the source loads of stage s + 1 are
+//    in flight (registers) during the MFMA phase of stage s.  Happens-before chain: see the main loop.
+#include "sar_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#include "conv_epi_f32.h"
+
+constexpr int KC8 = 8;    // source channels per stage
+constexpr int VJ = 25;   // joints per frame: compile-time (tap shifts are immediates); other V stay on the fp32 kernel
+constexpr int AR_B1 = SAR_SPLIT_BF16X1, AR_B3 = SAR_SPLIT_BF16X3, AR_B6 = SAR_SPLIT_BF16X6, AR_B9 = SAR_SPLIT_BF16X9,
+              AR_H3 = SAR_SPLIT_F16X3, AR_H3S = SAR_SPLIT_F16X3S;
+constexpr float H3_SW = 256.f, H3_LO = 2048.f;   // fp16 probes: static weight scale; the source scale is 2^desc.reserved0
+
+constexpr bool ar_f16(int ar) { return ar == AR_H3 || ar == AR_H3S; }
+constexpr bool ar_two_acc(int ar) { return ar == AR_H3; }
+constexpr int ar_nt(int ar) { return ar == AR_B1 ? 1 : ((ar == AR_B3 || ar_f16(ar)) ? 2 : 3); }
+constexpr int ar_nprod(int ar) { return ar == AR_B1 ? 1 : (ar == AR_B3 || ar_f16(ar)) ? 3 : (ar == AR_B6 ? 6 : 9); }
+// product p of an arithmetic: (W term, src term), smallest magnitude first
+constexpr int ar_pi(int ar, int p) {
+  constexpr int i9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+  return ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 1 ? 1 : 0) : i9[p + 9 - ar_nprod(ar)];
+}
+constexpr int ar_pj(int ar, int p) {
+  constexpr int j9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+  return ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 0 ? 1 : 0) : j9[p + 9 - ar_nprod(ar)];
+}
+
+__device__ __forceinline__ unsigned pk_bf16(float x, float y) {
+  bf16x2 p;
+  p[0] = (__bf16)x;
+  p[1] = (__bf16)y;
+  return *reinterpret_cast<unsigned*>(&p);
+}
+__device__ __forceinline__ unsigned pk_f16(float x, float y) {
+  f16x2 p;
+  p[0] = (_Float16)x;
+  p[1] = (_Float16)y;
+  return *reinterpret_cast<unsigned*>(&p);
+}
+
+// 8 consecutive-channel values of one row / column -> the NT term units (k-innermost: element j of a unit = channel j)
+template <int AR>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&u)[ar_nt(AR)], float scale) {
+  constexpr int NT = ar_nt(AR);
+  unsigned w[NT][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float x = v[2 * p], y = v[2 * p + 1];
+    if constexpr (ar_f16(AR)) {
+      x = __builtin_fminf(__builtin_fmaxf(x * scale, -65504.f), 65504.f);
+      y = __builtin_fminf(__builtin_fmaxf(y * scale, -65504.f), 65504.f);
+      f16x2 h;
+      h[0] = (_Float16)x;
+      h[1] = (_Float16)y;
+      w[0][p] = *reinterpret_cast<unsigned*>(&h);
+      const float lo = ar_two_acc(AR) ? H3_LO : 1.f;   // two accumulators: the remainder carries 2^11
+      w[1][p] = pk_f16((x - (float)h[0]) * lo, (y - (float)h[1]) * lo);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const unsigned b = pk_bf16(x, y);
+        w[t][p] = b;
+        if (t + 1 < NT) {   // the remainder is exact in fp32
+          x -= __uint_as_float(b << 16);
+          y -= __uint_as_float(b & 0xffff0000u);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) u[t] = make_uint4(w[t][0], w[t][1], w[t][2], w[t][3]);
+}
+
+// fp32 weights (element (tap, c, m) at src_off + tap*st + c*sc + m*sm) -> term images [term][tap][g][m], 16-byte units of 8
+// channels, zero beyond Kc.  blockIdx.y = item (sar_pack_item; G = ceil(Kc / 8)).
+template <int AR>
+__global__ void pack_split_kernel(const float* __restrict__ base, const sar_pack_item* __restrict__ items, uint4* __restrict__ out) {
+  constexpr int NT = ar_nt(AR);
+  const sar_pack_item it = items[blockIdx.y];
+  const int64_t n = (int64_t)it.taps * it.G * it.M;
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const int m = (int)(u % it.M);
+  const int g = (int)((u / it.M) % it.G);
+  const int tp = (int)(u / ((int64_t)it.M * it.G));
+  const float* W = base + it.src_off + tp * it.st + m * it.sm;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 8 * g + j;
+    v[j] = c < it.Kc ? W[c * it.sc] : 0.f;
+  }
+  uint4 t[NT];
+  split8<AR>(v, t, H3_SW);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) out[it.dst_unit + i * n + u] = t[i];
+}
+
+struct ConvKS {
+  sar_conv_desc d;
+  const uint4* wp;   // term images [term][tap][G][M]
+  int G;             // channel groups of 8
+  int FT, TPS, RW, nparts, ntiles, ny;
+};
+
+// TR: 0 forward; 1 data gradient, stride 1; 3 data gradient, stride 2, parity-split column map (conv_gemm.hip).  WIDE: the
+// staged window of a stride-2 forward tile (27 frames) instead of 18.
+template <int TR, int AR, int WIDE>
+__global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_gemm_split_kernel(const ConvKS k) {
+  constexpr int NT = ar_nt(AR), NPROD = ar_nprod(AR), NACC = ar_two_acc(AR) ? 2 : 1;
+  constexpr bool SCALED = ar_f16(AR);   // the accumulators carry the operand scales: bias joins at the end
+  constexpr int TAPS = 9, BM = 64, MS = 2, NS = 2, WN = 4, V = VJ;
+  constexpr int PAR = (TR == 3);
+  constexpr int ZCOL = WIDE ? 27 * V : 18 * V, SCOLS = ZCOL + 1;
+  constexpr int CJ = (ZCOL + 255) / 256;
+  constexpr int WPIECES = NT * TAPS, ZSLOT = WPIECES * 64;   // weight pieces of 64 units, then the zero slot
+  constexpr int WU = ZSLOT + 64, SU = NT * SCOLS;
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area aliases the image
+  constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
+  constexpr int PPW = (WPIECES + 3) / 4;      // weight pieces per wave
+  constexpr int KCMAX = 256;
+  __shared__ uint4 smem_u[IMG_U + BM + KCMAX / 2];   // image | per-row parameters (float4) | folded BN (scale, shift) per src channel
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + WU;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  float2* bnp = reinterpret_cast<float2*>(smem_u + IMG_U + BM);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave;
+  // workgroup -> (tile, row block), XCD-aware (conv_gemm.hip): the row blocks of a tile sit on one XCD
+  const int ny = k.ny, nwork = k.ntiles * ny;
+  int w = blockIdx.x;
+  {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;
+  }
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+
+  // ---- per-lane column geometry.  Tap index i of this wave (TR 0 / 1: the tap; TR 3: the i-th tap of the wave's parity)
+  // reads column  off0 + i * ostep;  k-step q multiplies tap indices 2q (lanes 0-31) and 2q + 1 (lanes 32-63).
+  bool colok[NS];
+  int64_t coln[NS];
+  int boff[NS], bstep[NS];
+  int t_lo;
+  if (TR == 0) t_lo = t0 * d.stride - d.pad;
+  else if (TR == 1) t_lo = t0 + d.pad - (TAPS - 1);
+  else t_lo = floordiv(t0 + d.pad - (TAPS - 1), 2);
+  constexpr int HALFC = 128;
+  const int par = PAR ? (wn >= 2 ? 1 : 0) : 0;
+  const int tp0 = PAR ? ((par + d.pad) & 1) : 0;
+  const int ntap_w = PAR ? (TAPS - tp0 + 1) / 2 : TAPS;
+  const int nq = (ntap_w + 1) >> 1;          // k-steps of this wave (wave-uniform)
+  const bool last_half = (ntap_w & 1) != 0;  // the last k-step's second half is empty
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    int fo, v;
+    if (PAR) {
+      const int pp = p - par * HALFC;
+      const int fh = pp / V;
+      v = pp - fh * V;
+      fo = 2 * fh + par;
+    } else {
+      fo = p / V;
+      v = p - fo * V;
+    }
+    colok[ns] = (fo < k.FT) && (t0 + fo < d.T_out);
+    if (!colok[ns]) fo = par;
+    coln[ns] = ((int64_t)b * d.T_out + (t0 + fo)) * V + v;
+    int off0, ostep;
+    if (TR == 0) {
+      off0 = fo * d.stride * V + v;
+      ostep = V;
+    } else if (TR == 1) {
+      off0 = (fo + TAPS - 1) * V + v;
+      ostep = -V;
+    } else {
+      off0 = (((t0 + fo + d.pad - tp0) >> 1) - t_lo) * V + v;
+      ostep = -V;
+    }
+    boff[ns] = colok[ns] ? off0 + hi * ostep : ZCOL;   // a dead column multiplies the zero column in every k-step
+    bstep[ns] = colok[ns] ? 2 * ostep : 0;
+  }
+  // weight slot of tap index i: TR 0 / 1 tap i; TR 3 tap tp0 + 2 i
+  const int abase = (PAR ? (tp0 + 2 * hi) : hi) * 64 + l31;
+  constexpr int ASTEP = (PAR ? 4 : 2) * 64;
+
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) bp.x = d.bias[row];
+    rowp[tid] = bp;
+  }
+  if (tid < KCMAX) {
+    float2 p = make_float2(1.f, 0.f);
+    if (d.pro_scale && tid < d.Kc) p = make_float2(d.pro_scale[tid], d.pro_shift[tid]);
+    bnp[tid] = p;
+  }
+  if (tid < NT) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid >= 64 && tid < 128) Wl[ZSLOT + tid - 64] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16 acc[NACC][MS][NS];
+
+  const int seq_len = d.T_src * V;
+  const float* src_b = d.src + (int64_t)b * seq_len;
+
+  // ---- source staging: per-lane offsets and masks once
+  int svo[CJ];
+  bool sok[CJ];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int col = tid + 256 * j;
+    const int rabs = t_lo * V + col;
+    sok[j] = col < k.RW && (unsigned)rabs < (unsigned)seq_len;
+    svo[j] = sok[j] ? rabs * 4 : 0;
+  }
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  const float h3_sa = __builtin_ldexpf(1.f, d.reserved0);
+  float sreg[CJ][8];
+  auto issue_s_loads = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + q;
+      const int cg = c < d.Kc ? c : 0;   // wave-uniform
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq_len * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) sreg[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo[j], 0, 0));
+    }
+  };
+  float psc[8], psh[8];
+  auto load_bnp = [&](int c0) {   // the folded BatchNorm of the stage's 8 channels (broadcast reads), AHEAD of the stage's W DMA:
+#pragma unroll                    // an LDS read behind an LDS-DMA makes the compiler wait for the DMA
+    for (int q2 = 0; q2 < 4; ++q2) {
+      const float4 p2 = *reinterpret_cast<const float4*>(&bnp[c0 + 2 * q2]);
+      psc[2 * q2] = p2.x, psh[2 * q2] = p2.y, psc[2 * q2 + 1] = p2.z, psh[2 * q2 + 1] = p2.w;
+    }
+  };
+  auto store_s = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float val = fmaxf(fmaf(sreg[j][q], psc[q], psh[q]), relu_lo);
+        v[q] = (sok[j] && c0 + q < d.Kc) ? val : 0.f;   // TF-SAME padding stays exactly 0 behind the folded BatchNorm
+      }
+      uint4 u[NT];
+      split8<AR>(v, u, h3_sa);
+      if ((j + 1) * 256 <= ZCOL || tid + 256 * j < ZCOL) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) Sl[t * SCOLS + tid + 256 * j] = u[t];
+      }
+    }
+  };
+  // ---- weight pieces by LDS-DMA: piece p = term * 9 + tap = 64 rows of one (term, tap) of channel group g
+  const unsigned wbytes = (unsigned)((int64_t)NT * TAPS * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;   // rows beyond M: rejected -> 0
+  auto issue_w_dma = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + 4 * i;   // wave-uniform
+      if (p < WPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + p * 64), 16, wvo, (p * k.G + g) * d.M * 16, 0, 0);
+    }
+  };
+
+  issue_s_loads(0);
+  __syncthreads();   // rowp, bnp, zero column / slot
+  load_bnp(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  issue_w_dma(0);
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[ms * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        if (!SCALED) acc[0][ms][ns][r] = colok[ns] ? bp.x : 0.f;
+        else acc[0][ms][ns][r] = 0.f, acc[NACC - 1][ms][ns][r] = 0.f;
+      }
+    }
+
+  auto kstep = [&](int q, bool last) {
+    uint4 a[NT][MS], bq[NT][NS];
+    int ao = abase + q * ASTEP;
+    const bool dead = last && last_half && hi;   // this lane's half of the k-step has no tap
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[dead ? ZSLOT + l31 + ms * 32 : t * (TAPS * 64) + ao + ms * 32];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int bo = dead ? ZCOL : boff[ns] + q * bstep[ns];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bq[t][ns] = Sl[t * SCOLS + bo];
+    }
+#pragma unroll
+    for (int p = 0; p < NPROD; ++p) {
+      const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+      const int ai = (NACC == 2 && i + j > 0) ? 1 : 0;   // h3: the cross terms carry 2^11 and have their own accumulator
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          if (ar_f16(AR))
+            acc[ai][ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8*>(&a[i][ms]),
+                                                                     *reinterpret_cast<f16x8*>(&bq[j][ns]), acc[ai][ms][ns], 0, 0, 0);
+          else
+            acc[ai][ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[i][ms]),
+                                                                      *reinterpret_cast<bf16x8*>(&bq[j][ns]), acc[ai][ms][ns], 0, 0, 0);
+        }
+    }
+  };
+
+  // Happens-before of the single image.  store_s(s) and the W DMA of stage s write the image behind the CLOSING barrier of
+  // stage s - 1 (every wave has read its last fragment of stage s - 1); the OPENING barrier of stage s follows every wave's
+  // ds_writes and its vmcnt(0) (its own DMA pieces have landed): behind it the whole image of stage s is in LDS.
+  const int nst = (d.Kc + KC8 - 1) / KC8;
+  for (int s_ = 0; s_ < nst; ++s_) {
+    store_s(s_ * KC8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // opening
+    if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC8);   // registers; in flight during the MFMA phase
+    SAR_LDS_SKEW();
+    if (PAR) {
+#pragma unroll
+      for (int q = 0; q < (TAPS + 1) / 4 + 1; ++q)
+        if (q < nq) kstep(q, q == nq - 1);
+    } else {
+#pragma unroll
+      for (int q = 0; q < (TAPS + 1) / 2; ++q) kstep(q, q == (TAPS + 1) / 2 - 1);
+    }
+    __syncthreads();   // closing: the image may be overwritten (next stage / the epilogue's transpose area)
+    if (s_ + 1 < nst) {
+      load_bnp((s_ + 1) * KC8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_w_dma(s_ + 1);
+    }
+  }
+
+  if (SCALED) {   // fp16 terms: undo the operand scales, join the cross terms, add the bias
+    const float c0 = 1.f / (h3_sa * H3_SW), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 bp = rowp[ms * 32 + mfma_row(r, hi)];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const float v = fmaf(acc[NACC - 1][ms][ns][r], c1, acc[0][ms][ns][r] * c0) + bp.x;
+          acc[0][ms][ns][r] = colok[ns] ? v : 0.f;
+        }
+      }
+    __syncthreads();   // every wave has read its bias rows: the MASK epilogue rewrites rowp
+  }
+  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc[0], rowp, smem);
+}
+
+int geometry_s(const sar_conv_desc& d, int tr, ConvKS& k) {
+  const int TAPS = 9;
+  k.FT = 10;                                 // 256 / 25, parity split: 2 * (128 / 25)
+  if (tr == 3) {
+    const int t_even = d.T_out + (d.T_out & 1);
+    if (k.FT > t_even) k.FT = t_even;
+  } else if (k.FT > d.T_out) k.FT = d.T_out;
+  k.TPS = (d.T_out + k.FT - 1) / k.FT;
+  int nf;
+  if (tr == 0) nf = (k.FT - 1) * d.stride + TAPS;
+  else if (tr == 1) nf = k.FT + TAPS - 1;
+  else nf = (k.FT - 1 + TAPS - 1) / 2 + 2;
+  k.RW = nf * d.V;
+  k.nparts = d.B * k.TPS * 4;
+  k.ntiles = d.B * k.TPS;
+  k.ny = (d.M + 63) / 64;
+  k.G = (d.Kc + 7) / 8;
+  return 0;
+}
+
+// which kernel a descriptor takes: 0 / 1 / 3 (TR), or -1 = not built (the caller keeps sar_conv_gemm_f32)
+int split_tr(const sar_conv_desc& d) {
+  if (d.mode != SAR_CONV_TEMPORAL || d.taps != 9 || d.V != VJ) return -1;
+  if (d.Kc < 8 || d.Kc > 256 || (d.M & 7)) return -1;
+  if (!d.transposed) return (d.stride == 1 || d.stride == 2) ? 0 : -1;
+  if (d.stride == 1) return 1;
+  if (d.stride == 2) return 3;
+  return -1;
+}
+
+template <int AR>
+int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, hipStream_t st) {
+  ConvKS k;
+  k.d = d;
+  k.wp = wp;
+  geometry_s(d, tr, k);
+  const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
+  if (tr == 0 && d.stride == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 0>), grid, block, 0, st, k);
+  else if (tr == 0) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 1>), grid, block, 0, st, k);
+  else if (tr == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<1, AR, 0>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((conv_gemm_split_kernel<3, AR, 0>), grid, block, 0, st, k);
+  return 0;
+}
+
+bool ar_known(int ar) { return ar == AR_B1 || ar == AR_B3 || ar == AR_B6 || ar == AR_B9 || ar == AR_H3 || ar == AR_H3S; }
+
+}  // namespace
+
+extern "C" int64_t sar_conv_gemm_split_workspace_bytes(const sar_conv_desc* d, int arith) {
+  if (!d || d->Kc <= 0 || d->M <= 0 || d->taps <= 0 || !ar_known(arith)) return SAR_E_ARG;
+  return (int64_t)ar_nt(arith) * d->taps * ((d->Kc + 7) / 8) * d->M * 16;
+}
+
+extern "C" int sar_conv_gemm_split_nparts(const sar_conv_desc* d) {
+  if (!d || d->V <= 0 || d->T_out <= 0 || d->B <= 0 || d->M <= 0) return SAR_E_ARG;
+  const int tr = split_tr(*d);
+  if (tr < 0) return SAR_E_UNSUP;
+  ConvKS k;
+  geometry_s(*d, tr, k);
+  return k.nparts;
+}
+
+extern "C" int sar_pack_weights_split_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units,
+                                            int arith, void* out, sar_stream_t s) {
+  SAR_REQUIRE(base && items && out && nitems > 0 && max_units > 0, "sar_pack_weights_split_batch: bad arguments");
+  SAR_REQUIRE(((uintptr_t)out & 15) == 0, "sar_pack_weights_split_batch: out must be 16-byte aligned");
+  SAR_REQUIRE(nitems <= 65535 && (max_units + 255) / 256 < (1ll << 31), "sar_pack_weights_split_batch: too many items / units");
+  SAR_REQUIRE(ar_known(arith), "sar_pack_weights_split_batch: unknown arithmetic %d", arith);
+  const dim3 grid((unsigned)((max_units + 255) / 256), nitems), block(256);
+  switch (arith) {
+    case AR_B1: hipLaunchKernelGGL(pack_split_kernel<AR_B1>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
+    case AR_B3: hipLaunchKernelGGL(pack_split_kernel<AR_B3>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
+    case AR_B6: hipLaunchKernelGGL(pack_split_kernel<AR_B6>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
+    case AR_B9: hipLaunchKernelGGL(pack_split_kernel<AR_B9>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
+    case AR_H3S: hipLaunchKernelGGL(pack_split_kernel<AR_H3S>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
+    default: hipLaunchKernelGGL(pack_split_kernel<AR_H3>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
+  }
+  SAR_LAUNCH_CHECK("sar_pack_weights_split_batch");
+  return 0;
+}
+
+extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void* packed, sar_stream_t s) {
+  SAR_REQUIRE(d != nullptr && packed != nullptr, "sar_conv_gemm_split: null descriptor / weight image");
+  SAR_REQUIRE(((uintptr_t)packed & 15) == 0, "sar_conv_gemm_split: the weight image must be 16-byte aligned");
+  SAR_REQUIRE(ar_known(arith), "sar_conv_gemm_split: unknown arithmetic %d", arith);
+  SAR_REQUIRE(d->B > 0 && d->V > 0 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0, "sar_conv_gemm_split: bad sizes");
+  const int tr = split_tr(*d);
+  if (tr < 0) {
+    sar_set_error("sar_conv_gemm_split: built for the 9-tap temporal convolution at V = 25, stride 1 / 2, 8 <= Kc <= 256, M %% 8 == 0 "
+                  "(mode %d, taps %d, V %d, stride %d, Kc %d, M %d): use sar_conv_gemm_f32",
+                  d->mode, d->taps, d->V, d->stride, d->Kc, d->M);
+    return SAR_E_UNSUP;
+  }
+  SAR_REQUIRE(d->stride >= 1 && d->pad >= 0 && d->pad <= 8, "sar_conv_gemm_split: bad stride/pad");
+  SAR_REQUIRE(d->src && d->out, "sar_conv_gemm_split: null src/out");
+  SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_out >= (int64_t)d->B * d->T_out * d->V,
+              "sar_conv_gemm_split: leading dimension smaller than B*T*V");
+  SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_gemm_split: pro_scale/pro_shift mismatch");
+  SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 28), "sar_conv_gemm_split: sequence row too long");
+  SAR_REQUIRE(d->ld_out < (1 << 22) && d->ld_aux < (1 << 22), "sar_conv_gemm_split: leading dimension too large (2^22 columns)");
+  SAR_REQUIRE(sar_conv_gemm_split_workspace_bytes(d, arith) < (1ll << 31), "sar_conv_gemm_split: weight tensor too large");
+  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm_split: bad epilogue %d", d->epi);
+  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm_split: partials required");
+  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
+    SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm_split: aux required");
+  if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->aux_scale && d->aux_shift, "sar_conv_gemm_split: aux affine required");
+  const uint4* wp = (const uint4*)packed;
+  hipStream_t st = as_stream(s);
+  switch (arith) {
+    case AR_B1: launch_split<AR_B1>(*d, tr, wp, st); break;
+    case AR_B3: launch_split<AR_B3>(*d, tr, wp, st); break;
+    case AR_B6: launch_split<AR_B6>(*d, tr, wp, st); break;
+    case AR_B9: launch_split<AR_B9>(*d, tr, wp, st); break;
+    case AR_H3S: launch_split<AR_H3S>(*d, tr, wp, st); break;
+    default: launch_split<AR_H3>(*d, tr, wp, st); break;
+  }
+  SAR_LAUNCH_CHECK("sar_conv_gemm_split");
+  return 0;
+}

@@ -15,6 +15,7 @@ SAR_GRAPH_WT_BF16_EXACT = 1
 SAR_GRAPH_FEW_DENSE = 4
 SAR_GRAPH_FEW_DENSE_SHIFT = 8
 SAR_C2D_AUX_EVEN_PIXELS = 1
+SAR_SPLIT = {"bf16x1": 1, "bf16x3": 3, "bf16x6": 6, "bf16x9": 9, "f16x3": 103, "f16x3s": 104}   # include/sar_hip.h SAR_SPLIT_*
 
 _fp = C.c_void_p  # every device pointer crosses the ABI as void*
 
@@ -82,6 +83,10 @@ SIGNATURES = {
     "sar_conv_gemm_bf16_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_bf16": (_i, [C.POINTER(ConvDesc), _fp, _fp]),
     "sar_pack_weights_bf16_batch": (_i, [_fp, _fp, _i, _i64, _fp, _fp]),
+    "sar_conv_gemm_split_workspace_bytes": (_i64, [C.POINTER(ConvDesc), _i]),
+    "sar_conv_gemm_split_nparts": (_i, [C.POINTER(ConvDesc)]),
+    "sar_pack_weights_split_batch": (_i, [_fp, _fp, _i, _i64, _i, _fp, _fp]),
+    "sar_conv_gemm_split": (_i, [C.POINTER(ConvDesc), _i, _fp, _fp]),
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_conv_wgrad_bf16": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),

@@ -83,13 +83,55 @@ class PackedWeights:
         return self.buf[off * 16:(off + n) * 16]
 
 
+class PackedSplitWeights(PackedWeights):
+    """Term images of many weight tensors for the split-arithmetic kernels (sar_conv_gemm_split, include/sar_hip.h): the same
+    items as PackedWeights with channel groups of 8 and `terms` images per item, refreshed by ONE launch per step."""
+
+    TERMS = {"bf16x1": 1, "bf16x3": 2, "bf16x6": 3, "bf16x9": 3, "f16x3": 2, "f16x3s": 2}
+
+    def __init__(self, arith):
+        super().__init__()
+        self.arith, self.terms = arith, self.TERMS[arith]
+
+    def add(self, key, src_off, st, sc, sm, taps, Kc, M):
+        G = (Kc + 7) // 8
+        n = self.terms * taps * G * M
+        self.index[key] = (self.units, n)
+        self.items.append((src_off, st, sc, sm, self.units, taps, Kc, M, G))
+        self.units += n
+
+    def refresh(self, flat):
+        check(L.load().sar_pack_weights_split_batch(ptr(flat), ptr(self.table), len(self.items), self.max_units,
+                                                    L.SAR_SPLIT[self.arith], ptr(self.buf), stream_ptr()),
+              "sar_pack_weights_split_batch")
+
+
+def split_applicable(mode, V, Kc, M, taps, stride):
+    """shapes csrc/conv_gemm_split.hip is built for (the others stay on the fp32 kernels)"""
+    return mode == L.SAR_CONV_TEMPORAL and taps == 9 and V == 25 and 8 <= Kc <= 256 and M % 8 == 0 and stride in (1, 2)
+
+
+def _pack_split_single(W, w_stride_tap, w_stride_c, taps, Kc, M, arith):
+    """one tensor, packed on the spot (kernel tests / probes; the engines keep a PackedSplitWeights)"""
+    pk = PackedSplitWeights(arith)
+    pk.add("w", 0, w_stride_tap, w_stride_c, 1, taps, Kc, M)
+    pk.finalize(W.device)
+    pk.refresh(W)
+    return pk.image("w")
+
+
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
-              aux_affine=None, aux_mean=None, bf16=False, packed=None, partials_out=None, aux2=None, aux_mask=None):
+              aux_affine=None, aux_mean=None, bf16=False, packed=None, partials_out=None, aux2=None, aux_mask=None,
+              split=None):
     """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (M % 8 == 0, Kc >= 16: bf16
-    MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel).  Returns (partials, nparts) when the
-    epilogue reduces, else None."""
+    MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel); or, with split="bf16x6", the fp32-accurate
+    split arithmetic on the bf16 matrix pipe (sar_conv_gemm_split; `packed` = the PackedSplitWeights image or None = pack
+    here).  Returns (partials, nparts) when the epilogue reduces, else None."""
     lib = L.load()
+    split = split if (split and split_applicable(mode, V, Kc, M, taps, stride) and epi != L.SAR_EPI_ADD_GATE) else None
+    if split:
+        bf16 = False
     d = ConvDesc()
     d.mode, d.transposed, d.B, d.V = mode, int(transposed), B, V
     d.T_src, d.T_out, d.Kc, d.M = T_src, T_out, Kc, M
@@ -98,7 +140,10 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     d.src, d.ld_src = ptr(src), src.stride(0)
     d.out, d.ld_out = ptr(out), out.stride(0)
     bf16 = bf16 and M % 8 == 0 and Kc >= 16
-    use_packed = bf16 and packed is not None      # packed: the operand image from PackedWeights (W is then not read)
+    use_packed = (bf16 or split) and packed is not None      # packed: the operand image from PackedWeights (W is then not read)
+    if split and packed is None:
+        packed = _pack_split_single(W, w_stride_tap, w_stride_c, taps, Kc, M, split)
+        use_packed = True
     d.W, d.w_stride_tap, d.w_stride_c = (None if use_packed else ptr(W)), w_stride_tap, w_stride_c
     d.bias = ptr(_f32(bias))
     if pro is not None:
@@ -119,7 +164,7 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     partials = None
     nparts = 0
     if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK, L.SAR_EPI_ADD_GATE):
-        nparts = lib.sar_conv_gemm_nparts(C.byref(d))
+        nparts = lib.sar_conv_gemm_split_nparts(C.byref(d)) if split else lib.sar_conv_gemm_nparts(C.byref(d))
         if nparts <= 0:
             check(nparts or -1, "sar_conv_gemm_nparts")
         if partials_out is not None:      # caller-owned rows of a stacked partials tensor (sar_amd/stgin.py)
@@ -132,7 +177,15 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     n_conv = B * (T_src if transposed else T_out) * V
     flops = 2.0 * M * Kc * taps * n_conv
     tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else "")))
-    if bf16:
+    if split:
+        if split.startswith("f16"):      # probe arithmetics: the source scale 2^e from the tensor's amax (host sync: not a product path)
+            import math
+            amax = float(src.abs().max()) * (max(1.0, float((pro[0].abs() * 1.0).max())) if pro is not None else 1.0) + (
+                float(pro[1].abs().max()) if pro is not None else 0.0)
+            d.reserved0 = 14 - int(math.ceil(math.log2(max(amax, 1e-30))))
+        with profiler.region(tag + "_split", flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
+            check(lib.sar_conv_gemm_split(C.byref(d), L.SAR_SPLIT[split], ptr(packed), stream_ptr()), "sar_conv_gemm_split")
+    elif bf16:
         ws = packed if use_packed else torch.empty(lib.sar_conv_gemm_bf16_workspace_bytes(C.byref(d)), dtype=torch.uint8,
                                                    device=src.device)
         with profiler.region(tag + "_bf16", flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
