@@ -34,7 +34,8 @@ PEAK_FP64_VALU_TFLOPS = 78.6       # MI355X: packed-free fp64 vector FMA, half t
 
 
 FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<", "conv_gemm_cn8_dma_kernel<"),
-                 "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",)}
+                 "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",),
+                 "f32_split": ("conv_gemm_split_kernel<",), "f32_split_bf16x6": ("conv_gemm_split_kernel<",)}
 
 
 def measured_traffic(mode="fp32"):
@@ -45,6 +46,7 @@ def measured_traffic(mode="fp32"):
     are not this mode's kernel family is refused (None)."""
     import glob
     pat = {"pathB": "r[0-9][0-9]_pathB_kernel_summary.json", "bf16": "r[0-9][0-9]_bf16_kernel_summary.json",
+           "f32_split": "r[0-9][0-9]_f32split_kernel_summary.json", "f32_split_bf16x6": "r[0-9][0-9]_f32split_bf16x6_kernel_summary.json",
            "bf16_operands": "r[0-9][0-9]_bf16_operands_kernel_summary.json"}.get(mode, "r[0-9][0-9]_kernel_summary.json")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
@@ -357,8 +359,12 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
         traffic, traffic_src = measured_traffic(mfma)
         kern_ms = {k: round(v["ms"] / ksteps, 3) for k, v in sorted(summ.items())}
         kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
-        bf16 = mfma != "fp32"
+        bf16 = mfma in ("bf16", "bf16_operands")
         desc = {"fp32": "fp32",
+                "f32_split": "fp32 (fp32 storage and results; GEMM contractions as 3 products of 2 fp16 terms per operand on the fp16 "
+                             "matrix pipe, fp32 accumulation: csrc/conv_gemm_split.hip f16x3s)",
+                "f32_split_bf16x6": "fp32 (fp32 storage and results; GEMM contractions as 6 products of 3 bf16 terms per operand on the "
+                                    "bf16 matrix pipe, fp32 accumulation: csrc/conv_gemm_split.hip bf16x6)",
                 "bf16": "bf16 (bf16 CN8 activations in HBM, bf16 MFMA operands; fp32 accumulation, BatchNorm statistics, master "
                         "weights, optimizer)",
                 "bf16_operands": "bf16-MFMA-operand (fp32 activations in HBM)"}[mfma]
@@ -570,7 +576,7 @@ def main():
                     help="stgcn = BASELINE.json's headline (configs[1]); spectrogram = Path B (configs[3] shape per GPU)")
     ap.add_argument("--num-pad-frames", type=int, default=0,
                     help="spectrogram workload: GPU-side frame up-sampling factor (the reference's loader default is 250)")
-    ap.add_argument("--mfma", default="fp32", choices=["fp32", "bf16", "bf16_operands"],
+    ap.add_argument("--mfma", default="fp32", choices=["fp32", "bf16", "bf16_operands", "f32_split", "f32_split_bf16x6"],
                     help="fp32 = BASELINE.json configs[1] (default, the headline); bf16 = configs[2]: bf16 activations in HBM (CN8 "
                          "layout) + bf16 MFMA operands, fp32 accumulation / BatchNorm statistics / master weights; bf16_operands = "
                          "the round-1 intermediate (bf16 MFMA operands, fp32 activations in HBM)")

@@ -154,23 +154,41 @@ typedef struct sar_pack_item {
 int sar_pack_weights_bf16_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units, void* out,
                                 sar_stream_t s);
 
-/* fp32-ACCURATE results on the bf16 matrix pipe ("split" arithmetic, csrc/conv_gemm_split.hip): every fp32 operand is a sum of
- * bfloat16 terms (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 24 significant bits, remainders exact), the products of
- * the terms are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and the cross products with i + j <= 2 (dropped ones
- * <= 3 * 2^-27 |a b|) replace one fp32 MFMA at 6/16 of its cost.  Same operator, descriptor, epilogues, fp32 storage and
- * partial-sum contract as sar_conv_gemm_f32 -- models/stgcn.py:29-36 and its data gradient under the fp32 parity tolerances.
- * arith: SAR_SPLIT_BF16X6 is the product mode; X1 (plain bf16 operands), X3 (two terms, three products), X9 (all nine products)
- * and F16X3 (two fp16 terms, static scales: NO range management) are measured data points (tools/split_probe.py).
+/* fp32-ACCURATE results on the bf16 / fp16 matrix pipe ("split" arithmetic, csrc/conv_gemm_split.hip; fp32 MFMA runs at 1/16 of
+ * that pipe's rate).  Same operator, descriptor, epilogues, fp32 storage and partial-sum contract as sar_conv_gemm_f32 --
+ * models/stgcn.py:29-36 and its data gradient, under the fp32 parity tolerances.  `arith`:
+ *   SAR_SPLIT_BF16X6  every fp32 operand = three bfloat16 terms (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 24
+ *                     significant bits, remainders exact), the six cross products with i + j <= 2, each exact in the fp32
+ *                     accumulator of v_mfma_f32_32x32x16_bf16 (dropped products <= 3 * 2^-27 |a b|).  No range limits.
+ *   SAR_SPLIT_F16X3S  two fp16 terms of the operand scaled by a power of two (h0 = fp16(s a), h1 = fp16(s a - h0)), three
+ *                     products (dropped: h1 g1 <= 2^-24 |a b|): half the matrix work.  The scale of each operand comes from an
+ *                     UPPER BOUND of its magnitudes that the caller keeps in device memory (`src_bound` for pro(src), `w_bound`
+ *                     for W: the BITS of a non-negative float; sar_amax_f32 / sar_bn_bound_f32 / sar_affine_bound_f32 /
+ *                     sar_pack_weights_split_batch produce them without a host sync): s = 2^(14 - floor(log2(bound))).  Values
+ *                     beyond the bound saturate at the fp16 maximum (a stale bound gives a wrong, finite result).
+ *   X1 / X3 / X9 / F16X3 are measured data points (tools/split_probe.py, profiles/r05_split_probe_*).
  * Built for the 9-tap TEMPORAL operator at V = 25, stride 1 / 2, 8 <= Kc <= 256, M % 8 == 0; anything else returns SAR_E_UNSUP
  * (sar_conv_gemm_split_nparts too): the caller keeps sar_conv_gemm_f32 for it.  `packed` = the weight term images written by
  * sar_pack_weights_split_batch (same items as sar_pack_weights_bf16_batch, but G = ceil(Kc / 8), and an item occupies
- * sar_conv_gemm_split_workspace_bytes / 16 units = terms * taps * G * M).  Partial sums: [M][sar_conv_gemm_split_nparts][2]. */
+ * sar_conv_gemm_split_workspace_bytes / 16 units = terms * taps * G * M); item_amax[nitems] receives each item's amax bits (fp16
+ * arithmetics; = the item's w_bound).  Partial sums: [M][sar_conv_gemm_split_nparts][2]. */
 enum { SAR_SPLIT_BF16X1 = 1, SAR_SPLIT_BF16X3 = 3, SAR_SPLIT_BF16X6 = 6, SAR_SPLIT_BF16X9 = 9, SAR_SPLIT_F16X3 = 103, SAR_SPLIT_F16X3S = 104 };
 int64_t sar_conv_gemm_split_workspace_bytes(const sar_conv_desc* d, int arith);
 int sar_conv_gemm_split_nparts(const sar_conv_desc* d);
 int sar_pack_weights_split_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units, int arith,
-                                 void* out, sar_stream_t s);
-int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void* packed, sar_stream_t s);
+                                 void* out, uint32_t* item_amax, sar_stream_t s);
+int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void* packed, const uint32_t* src_bound, const uint32_t* w_bound,
+                        sar_stream_t s);
+/* Operand bounds for the fp16 arithmetics.  A cell is one uint32 in device memory holding the bits of a non-negative float;
+ * every function below RAISES it (atomic max: order-independent, deterministic), the caller zeroes it first.
+ *   sar_amax_f32:          cell = max(cell, max |x|) over a [C][n] matrix with row stride ld
+ *   sar_bn_bound_f32:      cell = max(cell, max_c |gamma_c| sqrt(count - 1) + |beta_c|): bounds |gamma (x - mean) rstd + beta| for
+ *                          ANY data normalised by its own batch statistics over `count` samples (Samuelson's inequality) -- the
+ *                          train-mode BatchNormalization + ReLU of models/stgcn.py:27-28 folded into an operand load
+ *   sar_affine_bound_f32:  cell = max(cell, max_c |scale_c| * src_cell + max_c |shift_c|): any folded affine (eval-mode BN) */
+int sar_amax_f32(const float* x, int C, int64_t n, int64_t ld, uint32_t* cell, sar_stream_t s);
+int sar_bn_bound_f32(const float* gamma, const float* beta, int C, double count, uint32_t* cell, sar_stream_t s);
+int sar_affine_bound_f32(const float* scale, const float* shift, int C, const uint32_t* src_cell, uint32_t* cell, sar_stream_t s);
 
 /* Weight gradient of the same operator (reduction over all positions n):
  *   dW[tap][c][m] = sum_n dout[m, n] * OP_tap(pro(src))[c, n]        (tf.GradientTape of the conv,

@@ -9,9 +9,20 @@
 // the cross products a_i b_j with i + j <= 2 -- each EXACT in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; the dropped
 // products are <= 3 * 2^-27 |a b| -- issued smallest terms first into ONE fp32 accumulator ("x6").  Activations, weights,
 // BatchNorm sums, bias and epilogue stay fp32: the kernel is a drop-in for conv_gemm_kernel<TEMPORAL, 9> (conv_gemm.hip) under
-// the same parity tolerances.  Other arithmetics of the same kernel, kept as measured data points: x1 (one term = plain bf16
-// operands), x3 (two terms, three products, ~2^-17), x9 (all nine products), and h3 (two fp16 terms, the second scaled by
-// 2^11, three products into two accumulators, static operand scales: no range management -- a probe, not a product mode).
+// the same parity tolerances.
+//
+// The product arithmetic is the fp16 form of the same idea, "f16x3s": a = h0 + h1 with h0 = fp16(s a), h1 = fp16(s a - h0) (11 + 11
+// significant bits), products h0 g0 + h0 g1 + h1 g0 (the dropped h1 g1 <= 2^-24 |a b|) into one fp32 accumulator: HALF the matrix
+// work of x6 and 4 instead of 6 bytes of LDS per operand element; measured error 0.6-0.9x the fp32 MFMA kernel's, 2.6-3.0x its
+// speed (profiles/r05_split_probe_temporal_*.txt).  fp16 has 5 exponent bits, so each operand tensor is scaled by a power of two
+// s = 2^e taken from an UPPER BOUND of its largest magnitude that the caller provides in device memory (no host sync):
+// e = 14 - floor(log2(bound)) puts the bound in [2^14, 2^15).  Elements within 2^-18 of the bound keep 22 bits; smaller ones are
+// represented to 2^-40 of the bound (fp16 subnormals) -- norm-wise below the fp32 accumulation error of any sum they enter.  The
+// bound of a weight tensor is its amax (sar_pack_weights_split_batch), of a BatchNorm-ed source the Samuelson bound
+// |gamma| sqrt(n - 1) + |beta| (sar_bn_bound_f32: no pass over the data) or scale * amax + shift (sar_affine_bound_f32), of a
+// gradient tensor its amax (sar_amax_f32).  Values are clamped to +-65504 behind the scale: a stale bound saturates, it does not
+// produce infinities.  The other arithmetics stay as measured data points: x1 (one bf16 term), x3, x9, and f16x3 with the second
+// term scaled by 2^11 into its own accumulator (error 0.5x fp32, 128 accumulator registers).
 //
 // Design (MI355X):
 //  * tile 64 (m) x 256 (columns = 10 frames x 25 joints), 4 waves side by side, wave tile 64 x 64 (2 x 2 MFMA blocks).
@@ -43,7 +54,7 @@ constexpr int KC8 = 8;    // source channels per stage
 constexpr int VJ = 25;   // joints per frame: compile-time (tap shifts are immediates); other V stay on the fp32 kernel
 constexpr int AR_B1 = SAR_SPLIT_BF16X1, AR_B3 = SAR_SPLIT_BF16X3, AR_B6 = SAR_SPLIT_BF16X6, AR_B9 = SAR_SPLIT_BF16X9,
               AR_H3 = SAR_SPLIT_F16X3, AR_H3S = SAR_SPLIT_F16X3S;
-constexpr float H3_SW = 256.f, H3_LO = 2048.f;   // fp16 probes: static weight scale; the source scale is 2^desc.reserved0
+constexpr float H3_LO = 2048.f;   // f16x3 (two accumulators): the second term carries 2^11
 
 constexpr bool ar_f16(int ar) { return ar == AR_H3 || ar == AR_H3S; }
 constexpr bool ar_two_acc(int ar) { return ar == AR_H3; }
@@ -57,6 +68,96 @@ constexpr int ar_pi(int ar, int p) {
 constexpr int ar_pj(int ar, int p) {
   constexpr int j9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
   return ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 0 ? 1 : 0) : j9[p + 9 - ar_nprod(ar)];
+}
+
+// power-of-two scale exponent of an operand from (the bits of) an upper bound of its magnitudes: bound * 2^e in [2^14, 2^15)
+__host__ __device__ __forceinline__ int scale_exp(unsigned bound_bits) {
+  const int fl = (int)((bound_bits >> 23) & 0xffu) - 127;
+  const int e = 14 - fl;
+  return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+
+// cell = max(cell, |x|) over a [C][n] matrix (row stride ld): bits of non-negative floats order like unsigned integers, and a
+// maximum does not depend on the order of its operands: deterministic with atomics.  grid (chunks, C).
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, int64_t ld, unsigned* __restrict__ cell) {
+  const float* row = x + (int64_t)blockIdx.y * ld;
+  unsigned m = 0;
+  const bool vec = ((n | ld) & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const uint4 v = reinterpret_cast<const uint4*>(row)[i];
+      const unsigned a = (v.x & 0x7fffffffu) > (v.y & 0x7fffffffu) ? (v.x & 0x7fffffffu) : (v.y & 0x7fffffffu);
+      const unsigned b = (v.z & 0x7fffffffu) > (v.w & 0x7fffffffu) ? (v.z & 0x7fffffffu) : (v.w & 0x7fffffffu);
+      const unsigned c = a > b ? a : b;
+      m = c > m ? c : m;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const unsigned c = __float_as_uint(row[i]) & 0x7fffffffu;
+      m = c > m ? c : m;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  __shared__ unsigned wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = wm[0] > wm[1] ? wm[0] : wm[1], b = wm[2] > wm[3] ? wm[2] : wm[3];
+    a = a > b ? a : b;
+    if (a > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, a);
+  }
+}
+
+// mode 0 (Samuelson): cell = max_c |gamma_c| sqrt(count - 1) + |beta_c|  -- an upper bound of |gamma (x - mean) rstd + beta| for ANY
+//   data whose mean / biased variance over `count` samples are the ones rstd was formed from (train-mode BatchNorm)
+// mode 1 (affine): cell = max_c |scale_c| * bound(src) + max_c |shift_c|   (eval-mode BatchNorm, any folded affine)
+// one workgroup; a 2^-10 margin covers the fp32 roundings of the folded evaluation
+__global__ __launch_bounds__(256) void bound_kernel(const float* __restrict__ a, const float* __restrict__ b, int C, float root,
+                                                    const unsigned* __restrict__ src_cell, int mode, unsigned* __restrict__ cell) {
+  float m0 = 0.f, m1 = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float av = fabsf(a[c]), bv = fabsf(b[c]);
+    if (mode == 0) m0 = fmaxf(m0, fmaf(av, root, bv));
+    else m0 = fmaxf(m0, av), m1 = fmaxf(m1, bv);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m0 = fmaxf(m0, __shfl_xor(m0, o)), m1 = fmaxf(m1, __shfl_xor(m1, o));
+  __shared__ float w0[4], w1[4];
+  if ((threadIdx.x & 63) == 0) w0[threadIdx.x >> 6] = m0, w1[threadIdx.x >> 6] = m1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m0 = fmaxf(fmaxf(w0[0], w0[1]), fmaxf(w0[2], w0[3]));
+    m1 = fmaxf(fmaxf(w1[0], w1[1]), fmaxf(w1[2], w1[3]));
+    float v = mode == 0 ? m0 : fmaf(m0, __uint_as_float(*src_cell), m1);
+    v *= 1.0009765625f;
+    atomicMax(cell, __float_as_uint(v));
+  }
+}
+
+// per-item amax of the weight tensors of a pack batch (blockIdx.y = item)
+__global__ __launch_bounds__(256) void pack_amax_kernel(const float* __restrict__ base, const sar_pack_item* __restrict__ items,
+                                                        unsigned* __restrict__ item_amax) {
+  const sar_pack_item it = items[blockIdx.y];
+  const int64_t n = (int64_t)it.taps * it.Kc * it.M;
+  unsigned m = 0;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n; u += (int64_t)gridDim.x * 256) {
+    const int mm = (int)(u % it.M);
+    const int c = (int)((u / it.M) % it.Kc);
+    const int tp = (int)(u / ((int64_t)it.M * it.Kc));
+    const unsigned v = __float_as_uint(base[it.src_off + tp * it.st + c * it.sc + mm * it.sm]) & 0x7fffffffu;
+    m = v > m ? v : m;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(item_amax + blockIdx.y, m);
 }
 
 __device__ __forceinline__ unsigned pk_bf16(float x, float y) {
@@ -81,8 +182,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&u)[ar_nt(AR)
   for (int p = 0; p < 4; ++p) {
     float x = v[2 * p], y = v[2 * p + 1];
     if constexpr (ar_f16(AR)) {
-      x = __builtin_fminf(__builtin_fmaxf(x * scale, -65504.f), 65504.f);
-      y = __builtin_fminf(__builtin_fmaxf(y * scale, -65504.f), 65504.f);
+      x = __builtin_amdgcn_fmed3f(x * scale, -65504.f, 65504.f);   // scale == 1 where the caller folded it into the prologue
+      y = __builtin_amdgcn_fmed3f(y * scale, -65504.f, 65504.f);
       f16x2 h;
       h[0] = (_Float16)x;
       h[1] = (_Float16)y;
@@ -108,9 +209,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&u)[ar_nt(AR)
 // fp32 weights (element (tap, c, m) at src_off + tap*st + c*sc + m*sm) -> term images [term][tap][g][m], 16-byte units of 8
 // channels, zero beyond Kc.  blockIdx.y = item (sar_pack_item; G = ceil(Kc / 8)).
 template <int AR>
-__global__ void pack_split_kernel(const float* __restrict__ base, const sar_pack_item* __restrict__ items, uint4* __restrict__ out) {
+__global__ void pack_split_kernel(const float* __restrict__ base, const sar_pack_item* __restrict__ items,
+                                  const unsigned* __restrict__ item_amax, uint4* __restrict__ out) {
   constexpr int NT = ar_nt(AR);
   const sar_pack_item it = items[blockIdx.y];
+  const float wscale = ar_f16(AR) ? __builtin_ldexpf(1.f, scale_exp(item_amax[blockIdx.y])) : 1.f;
   const int64_t n = (int64_t)it.taps * it.G * it.M;
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
@@ -125,7 +228,7 @@ __global__ void pack_split_kernel(const float* __restrict__ base, const sar_pack
     v[j] = c < it.Kc ? W[c * it.sc] : 0.f;
   }
   uint4 t[NT];
-  split8<AR>(v, t, H3_SW);
+  split8<AR>(v, t, wscale);
 #pragma unroll
   for (int i = 0; i < NT; ++i) out[it.dst_unit + i * n + u] = t[i];
 }
@@ -135,6 +238,8 @@ struct ConvKS {
   const uint4* wp;   // term images [term][tap][G][M]
   int G;             // channel groups of 8
   int FT, TPS, RW, nparts, ntiles, ny;
+  const unsigned* src_bound;   // fp16 arithmetics: bits of an upper bound of |pro(src)| / of |W| (device memory)
+  const unsigned* w_bound;
 };
 
 // TR: 0 forward; 1 data gradient, stride 1; 3 data gradient, stride 2, parity-split column map (conv_gemm.hip).  WIDE: the
@@ -234,9 +339,15 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     if (d.bias && row < d.M) bp.x = d.bias[row];
     rowp[tid] = bp;
   }
-  if (tid < KCMAX) {
-    float2 p = make_float2(1.f, 0.f);
-    if (d.pro_scale && tid < d.Kc) p = make_float2(d.pro_scale[tid], d.pro_shift[tid]);
+  int ea = 0, ew = 0;   // fp16 arithmetics: operand scale exponents (wave-uniform)
+  if (SCALED) {
+    ea = scale_exp(*k.src_bound);
+    ew = scale_exp(*k.w_bound);
+  }
+  const float h3_sa = __builtin_ldexpf(1.f, ea);
+  if (tid < KCMAX) {   // the folded prologue, with the source scale folded in (a power of two: exact)
+    float2 p = make_float2(h3_sa, 0.f);
+    if (d.pro_scale && tid < d.Kc) p = make_float2(d.pro_scale[tid] * h3_sa, d.pro_shift[tid] * h3_sa);
     bnp[tid] = p;
   }
   if (tid < NT) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
@@ -257,7 +368,6 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     svo[j] = sok[j] ? rabs * 4 : 0;
   }
   const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
-  const float h3_sa = __builtin_ldexpf(1.f, d.reserved0);
   float sreg[CJ][8];
   auto issue_s_loads = [&](int c0) {
 #pragma unroll
@@ -288,7 +398,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
         v[q] = (sok[j] && c0 + q < d.Kc) ? val : 0.f;   // TF-SAME padding stays exactly 0 behind the folded BatchNorm
       }
       uint4 u[NT];
-      split8<AR>(v, u, h3_sa);
+      split8<AR>(v, u, 1.f);
       if ((j + 1) * 256 <= ZCOL || tid + 256 * j < ZCOL) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) Sl[t * SCOLS + tid + 256 * j] = u[t];
@@ -384,7 +494,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
   }
 
   if (SCALED) {   // fp16 terms: undo the operand scales, join the cross terms, add the bias
-    const float c0 = 1.f / (h3_sa * H3_SW), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
+    const float c0 = __builtin_ldexpf(1.f, -(ea + ew)), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -432,10 +542,12 @@ int split_tr(const sar_conv_desc& d) {
 }
 
 template <int AR>
-int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, hipStream_t st) {
+int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned* src_bound, const unsigned* w_bound, hipStream_t st) {
   ConvKS k;
   k.d = d;
   k.wp = wp;
+  k.src_bound = src_bound;
+  k.w_bound = w_bound;
   geometry_s(d, tr, k);
   const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
   if (tr == 0 && d.stride == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 0>), grid, block, 0, st, k);
@@ -463,29 +575,62 @@ extern "C" int sar_conv_gemm_split_nparts(const sar_conv_desc* d) {
   return k.nparts;
 }
 
+extern "C" int sar_amax_f32(const float* x, int C, int64_t n, int64_t ld, uint32_t* cell, sar_stream_t s) {
+  SAR_REQUIRE(x && cell && C > 0 && C <= 65535 && n > 0 && ld >= n, "sar_amax_f32: bad arguments");
+  int64_t chunks = (n + 8191) / 8192;
+  if (chunks > 256) chunks = 256;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)chunks, C), dim3(256), 0, as_stream(s), x, n, ld, cell);
+  SAR_LAUNCH_CHECK("sar_amax_f32");
+  return 0;
+}
+
+extern "C" int sar_bn_bound_f32(const float* gamma, const float* beta, int C, double count, uint32_t* cell, sar_stream_t s) {
+  SAR_REQUIRE(gamma && beta && cell && C > 0 && count >= 2, "sar_bn_bound_f32: bad arguments");
+  hipLaunchKernelGGL(bound_kernel, dim3(1), dim3(256), 0, as_stream(s), gamma, beta, C, (float)sqrt(count - 1.0) * 1.000001f,
+                     (const unsigned*)nullptr, 0, cell);
+  SAR_LAUNCH_CHECK("sar_bn_bound_f32");
+  return 0;
+}
+
+extern "C" int sar_affine_bound_f32(const float* scale, const float* shift, int C, const uint32_t* src_cell, uint32_t* cell,
+                                    sar_stream_t s) {
+  SAR_REQUIRE(scale && shift && src_cell && cell && C > 0, "sar_affine_bound_f32: bad arguments");
+  hipLaunchKernelGGL(bound_kernel, dim3(1), dim3(256), 0, as_stream(s), scale, shift, C, 0.f, src_cell, 1, cell);
+  SAR_LAUNCH_CHECK("sar_affine_bound_f32");
+  return 0;
+}
+
 extern "C" int sar_pack_weights_split_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units,
-                                            int arith, void* out, sar_stream_t s) {
+                                            int arith, void* out, uint32_t* item_amax, sar_stream_t s) {
   SAR_REQUIRE(base && items && out && nitems > 0 && max_units > 0, "sar_pack_weights_split_batch: bad arguments");
   SAR_REQUIRE(((uintptr_t)out & 15) == 0, "sar_pack_weights_split_batch: out must be 16-byte aligned");
   SAR_REQUIRE(nitems <= 65535 && (max_units + 255) / 256 < (1ll << 31), "sar_pack_weights_split_batch: too many items / units");
   SAR_REQUIRE(ar_known(arith), "sar_pack_weights_split_batch: unknown arithmetic %d", arith);
+  if (ar_f16(arith)) {   // the scale of every item from its amax, on the device
+    SAR_REQUIRE(item_amax != nullptr, "sar_pack_weights_split_batch: fp16 arithmetics need item_amax[nitems]");
+    hipError_t e = hipMemsetAsync(item_amax, 0, sizeof(uint32_t) * nitems, as_stream(s));
+    if (e != hipSuccess) { sar_set_error("sar_pack_weights_split_batch: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(pack_amax_kernel, dim3(16, nitems), dim3(256), 0, as_stream(s), base, items, item_amax);
+  }
   const dim3 grid((unsigned)((max_units + 255) / 256), nitems), block(256);
   switch (arith) {
-    case AR_B1: hipLaunchKernelGGL(pack_split_kernel<AR_B1>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
-    case AR_B3: hipLaunchKernelGGL(pack_split_kernel<AR_B3>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
-    case AR_B6: hipLaunchKernelGGL(pack_split_kernel<AR_B6>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
-    case AR_B9: hipLaunchKernelGGL(pack_split_kernel<AR_B9>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
-    case AR_H3S: hipLaunchKernelGGL(pack_split_kernel<AR_H3S>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
-    default: hipLaunchKernelGGL(pack_split_kernel<AR_H3>, grid, block, 0, as_stream(s), base, items, (uint4*)out); break;
+    case AR_B1: hipLaunchKernelGGL(pack_split_kernel<AR_B1>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
+    case AR_B3: hipLaunchKernelGGL(pack_split_kernel<AR_B3>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
+    case AR_B6: hipLaunchKernelGGL(pack_split_kernel<AR_B6>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
+    case AR_B9: hipLaunchKernelGGL(pack_split_kernel<AR_B9>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
+    case AR_H3S: hipLaunchKernelGGL(pack_split_kernel<AR_H3S>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
+    default: hipLaunchKernelGGL(pack_split_kernel<AR_H3>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
   }
   SAR_LAUNCH_CHECK("sar_pack_weights_split_batch");
   return 0;
 }
 
-extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void* packed, sar_stream_t s) {
+extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void* packed, const uint32_t* src_bound,
+                                   const uint32_t* w_bound, sar_stream_t s) {
   SAR_REQUIRE(d != nullptr && packed != nullptr, "sar_conv_gemm_split: null descriptor / weight image");
   SAR_REQUIRE(((uintptr_t)packed & 15) == 0, "sar_conv_gemm_split: the weight image must be 16-byte aligned");
   SAR_REQUIRE(ar_known(arith), "sar_conv_gemm_split: unknown arithmetic %d", arith);
+  SAR_REQUIRE(!ar_f16(arith) || (src_bound && w_bound), "sar_conv_gemm_split: fp16 arithmetics need the operand bounds");
   SAR_REQUIRE(d->B > 0 && d->V > 0 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0, "sar_conv_gemm_split: bad sizes");
   const int tr = split_tr(*d);
   if (tr < 0) {
@@ -510,12 +655,12 @@ extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void
   const uint4* wp = (const uint4*)packed;
   hipStream_t st = as_stream(s);
   switch (arith) {
-    case AR_B1: launch_split<AR_B1>(*d, tr, wp, st); break;
-    case AR_B3: launch_split<AR_B3>(*d, tr, wp, st); break;
-    case AR_B6: launch_split<AR_B6>(*d, tr, wp, st); break;
-    case AR_B9: launch_split<AR_B9>(*d, tr, wp, st); break;
-    case AR_H3S: launch_split<AR_H3S>(*d, tr, wp, st); break;
-    default: launch_split<AR_H3>(*d, tr, wp, st); break;
+    case AR_B1: launch_split<AR_B1>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_B3: launch_split<AR_B3>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_B6: launch_split<AR_B6>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_B9: launch_split<AR_B9>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_H3S: launch_split<AR_H3S>(*d, tr, wp, src_bound, w_bound, st); break;
+    default: launch_split<AR_H3>(*d, tr, wp, src_bound, w_bound, st); break;
   }
   SAR_LAUNCH_CHECK("sar_conv_gemm_split");
   return 0;

@@ -85,8 +85,11 @@ SIGNATURES = {
     "sar_pack_weights_bf16_batch": (_i, [_fp, _fp, _i, _i64, _fp, _fp]),
     "sar_conv_gemm_split_workspace_bytes": (_i64, [C.POINTER(ConvDesc), _i]),
     "sar_conv_gemm_split_nparts": (_i, [C.POINTER(ConvDesc)]),
-    "sar_pack_weights_split_batch": (_i, [_fp, _fp, _i, _i64, _i, _fp, _fp]),
-    "sar_conv_gemm_split": (_i, [C.POINTER(ConvDesc), _i, _fp, _fp]),
+    "sar_pack_weights_split_batch": (_i, [_fp, _fp, _i, _i64, _i, _fp, _fp, _fp]),
+    "sar_conv_gemm_split": (_i, [C.POINTER(ConvDesc), _i, _fp, _fp, _fp, _fp]),
+    "sar_amax_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),
+    "sar_bn_bound_f32": (_i, [_fp, _fp, _i, _d, _fp, _fp]),
+    "sar_affine_bound_f32": (_i, [_fp, _fp, _i, _fp, _fp, _fp]),
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_conv_wgrad_bf16": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),

@@ -85,25 +85,56 @@ class PackedWeights:
 
 class PackedSplitWeights(PackedWeights):
     """Term images of many weight tensors for the split-arithmetic kernels (sar_conv_gemm_split, include/sar_hip.h): the same
-    items as PackedWeights with channel groups of 8 and `terms` images per item, refreshed by ONE launch per step."""
+    items as PackedWeights with channel groups of 8 and `terms` images per item, refreshed by ONE call per step; the fp16
+    arithmetics also get every item's amax (the bits of a float, device memory) = its `w_bound`."""
 
     TERMS = {"bf16x1": 1, "bf16x3": 2, "bf16x6": 3, "bf16x9": 3, "f16x3": 2, "f16x3s": 2}
 
     def __init__(self, arith):
         super().__init__()
-        self.arith, self.terms = arith, self.TERMS[arith]
+        self.arith, self.terms, self.item_of = arith, self.TERMS[arith], {}
 
     def add(self, key, src_off, st, sc, sm, taps, Kc, M):
         G = (Kc + 7) // 8
         n = self.terms * taps * G * M
         self.index[key] = (self.units, n)
+        self.item_of[key] = len(self.items)
         self.items.append((src_off, st, sc, sm, self.units, taps, Kc, M, G))
         self.units += n
 
+    def finalize(self, device):
+        super().finalize(device)
+        self.amax = torch.zeros(len(self.items), dtype=torch.int32, device=device)
+
     def refresh(self, flat):
         check(L.load().sar_pack_weights_split_batch(ptr(flat), ptr(self.table), len(self.items), self.max_units,
-                                                    L.SAR_SPLIT[self.arith], ptr(self.buf), stream_ptr()),
+                                                    L.SAR_SPLIT[self.arith], ptr(self.buf), ptr(self.amax), stream_ptr()),
               "sar_pack_weights_split_batch")
+
+    def bound(self, key):
+        i = self.item_of[key]
+        return self.amax[i:i + 1]
+
+
+def amax(x, cell):
+    """cell (1-element int32 view, zeroed by the caller) = max(cell, bits of max |x|) -- sar_amax_f32, no host sync"""
+    check(L.load().sar_amax_f32(ptr(_f32(x)), x.shape[0], x.shape[1], x.stride(0), ptr(cell), stream_ptr()), "sar_amax_f32")
+
+
+def bn_bound(gamma, beta, count, cell):
+    """Samuelson bound of a train-mode BatchNorm output (sar_bn_bound_f32)"""
+    check(L.load().sar_bn_bound_f32(ptr(_f32(gamma)), ptr(_f32(beta)), gamma.numel(), float(count), ptr(cell), stream_ptr()),
+          "sar_bn_bound_f32")
+
+
+def affine_bound(scale, shift, src_cell, cell):
+    check(L.load().sar_affine_bound_f32(ptr(_f32(scale)), ptr(_f32(shift)), scale.numel(), ptr(src_cell), ptr(cell), stream_ptr()),
+          "sar_affine_bound_f32")
+
+
+# the arithmetic a conv_gemm / conv_wgrad call WITHOUT an explicit `split` argument takes (None = the fp32 kernels): the kernel
+# parity suites run once per value (tests/conftest.py)
+DEFAULT_SPLIT = None
 
 
 def split_applicable(mode, V, Kc, M, taps, stride):
@@ -112,23 +143,36 @@ def split_applicable(mode, V, Kc, M, taps, stride):
 
 
 def _pack_split_single(W, w_stride_tap, w_stride_c, taps, Kc, M, arith):
-    """one tensor, packed on the spot (kernel tests / probes; the engines keep a PackedSplitWeights)"""
+    """one tensor, packed on the spot (kernel tests / probes; the engines keep a PackedSplitWeights): (image, w_bound)"""
     pk = PackedSplitWeights(arith)
     pk.add("w", 0, w_stride_tap, w_stride_c, 1, taps, Kc, M)
     pk.finalize(W.device)
     pk.refresh(W)
-    return pk.image("w")
+    return pk.image("w"), pk.bound("w")
+
+
+def _src_bound_single(src, pro):
+    """the bound of pro(src) for a stand-alone call: amax of the tensor, through the folded affine when there is one"""
+    cells = torch.zeros(2, dtype=torch.int32, device=src.device)
+    amax(src, cells[0:1])
+    if pro is None:
+        return cells[0:1]
+    affine_bound(pro[0], pro[1], cells[0:1], cells[1:2])
+    return cells[1:2]
 
 
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
               aux_affine=None, aux_mean=None, bf16=False, packed=None, partials_out=None, aux2=None, aux_mask=None,
-              split=None):
+              split="default", bounds=None):
     """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (M % 8 == 0, Kc >= 16: bf16
     MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel); or, with split="bf16x6", the fp32-accurate
-    split arithmetic on the bf16 matrix pipe (sar_conv_gemm_split; `packed` = the PackedSplitWeights image or None = pack
-    here).  Returns (partials, nparts) when the epilogue reduces, else None."""
+    split arithmetic on the bf16 / fp16 matrix pipe (sar_conv_gemm_split; `packed` = the PackedSplitWeights image or None = pack
+    here; bounds = (src_bound, w_bound) cells for the fp16 arithmetics, None = computed here by device kernels).  Returns
+    (partials, nparts) when the epilogue reduces, else None."""
     lib = L.load()
+    if split == "default":
+        split = DEFAULT_SPLIT
     split = split if (split and split_applicable(mode, V, Kc, M, taps, stride) and epi != L.SAR_EPI_ADD_GATE) else None
     if split:
         bf16 = False
@@ -141,8 +185,9 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     d.out, d.ld_out = ptr(out), out.stride(0)
     bf16 = bf16 and M % 8 == 0 and Kc >= 16
     use_packed = (bf16 or split) and packed is not None      # packed: the operand image from PackedWeights (W is then not read)
+    w_bound = bounds[1] if bounds is not None else None
     if split and packed is None:
-        packed = _pack_split_single(W, w_stride_tap, w_stride_c, taps, Kc, M, split)
+        packed, w_bound = _pack_split_single(W, w_stride_tap, w_stride_c, taps, Kc, M, split)
         use_packed = True
     d.W, d.w_stride_tap, d.w_stride_c = (None if use_packed else ptr(W)), w_stride_tap, w_stride_c
     d.bias = ptr(_f32(bias))
@@ -178,13 +223,12 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     flops = 2.0 * M * Kc * taps * n_conv
     tag = ("gemm_graph" if mode == L.SAR_CONV_GRAPH else ("gemm_temporal%d%s" % (taps, "_dgrad" if transposed else "")))
     if split:
-        if split.startswith("f16"):      # probe arithmetics: the source scale 2^e from the tensor's amax (host sync: not a product path)
-            import math
-            amax = float(src.abs().max()) * (max(1.0, float((pro[0].abs() * 1.0).max())) if pro is not None else 1.0) + (
-                float(pro[1].abs().max()) if pro is not None else 0.0)
-            d.reserved0 = 14 - int(math.ceil(math.log2(max(amax, 1e-30))))
+        src_bound = bounds[0] if bounds is not None else None
+        if split.startswith("f16") and src_bound is None:
+            src_bound = _src_bound_single(src, pro)
         with profiler.region(tag + "_split", flops, 4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
-            check(lib.sar_conv_gemm_split(C.byref(d), L.SAR_SPLIT[split], ptr(packed), stream_ptr()), "sar_conv_gemm_split")
+            check(lib.sar_conv_gemm_split(C.byref(d), L.SAR_SPLIT[split], ptr(packed), ptr(src_bound), ptr(w_bound), stream_ptr()),
+                  "sar_conv_gemm_split")
     elif bf16:
         ws = packed if use_packed else torch.empty(lib.sar_conv_gemm_bf16_workspace_bytes(C.byref(d)), dtype=torch.uint8,
                                                    device=src.device)

@@ -28,6 +28,9 @@ KS, KT = 3, 9        # kernel_size=[3, 9], models/stgcn.py:14
 # rounds: fp32 59.22 -> 58.99 ms per step; bf16 13.26 -> 13.55 (slower: there the order stays as it was).  SAR_WGRAD_DEFER=0/1 forces it.
 _WGRAD_DEFER_ENV = __import__("os").environ.get("SAR_WGRAD_DEFER")
 _FUSE_TAIL_F32 = __import__("os").environ.get("SAR_F32_FUSE_TAIL", "1") == "1"   # SAR_EPI_ADD_GATE in the fp32 graph data gradient
+# the arithmetic an STGCN built without an explicit `mfma` uses (the parity suites run once per value: tests/conftest.py)
+DEFAULT_MFMA = __import__("os").environ.get("SAR_MFMA", "fp32")
+SPLIT_ARITH = {"f32_split": "f16x3s", "f32_split_bf16x6": "bf16x6"}      # engine mode -> arithmetic of csrc/conv_gemm_split.hip
 # (filters, stride, residual) -- models/stgcn.py:113-123
 BLOCKS = [(64, 1, False), (64, 1, True), (64, 1, True), (64, 1, True), (128, 2, True), (128, 1, True), (128, 1, True),
           (256, 2, True), (256, 1, True), (256, 1, True)]
@@ -58,7 +61,7 @@ class _BN:
 
 class STGCN:
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
-                 blocks=None, motion=False, mfma="fp32", trainable_adjacency=False):
+                 blocks=None, motion=False, mfma=None, trainable_adjacency=False):
         L.load()  # fail loudly if the HIP library is missing
         # mfma="fp32" (default) is the reference's arithmetic.
         # mfma="bf16" is SURVEY.md 8d config 3: activations and activation gradients are stored in HBM as bfloat16 (CN8
@@ -66,9 +69,17 @@ class STGCN:
         # accumulation (sar_conv_gemm_cn8, sar_conv_wgrad_cn8); BatchNorm statistics, master weights, gradients and the
         # optimizer stay fp32 (sar_amd/stgcn8.py holds the step).
         # mfma="bf16_operands" is the round-1 intermediate kept for A/B runs: bf16 MFMA operands, fp32 activations in HBM.
-        assert mfma in ("fp32", "bf16", "bf16_operands")
+        # mfma="f32_split": fp32 RESULTS on the fp16 matrix pipe -- storage, BatchNorm statistics, epilogues and parameters are the
+        # fp32 engine's, the contraction of the GEMM-shaped kernels multiplies two fp16 terms per operand (three products, fp32
+        # accumulation: csrc/conv_gemm_split.hip; same parity tolerances as "fp32").  "f32_split_bf16x6": three bfloat16 terms,
+        # six products (no operand scaling).  Kernels without a split form, and inference, stay on the fp32 kernels.
+        if mfma is None:
+            mfma = DEFAULT_MFMA if (type(self) is STGCN and not trainable_adjacency) else "fp32"
+        assert mfma in ("fp32", "bf16", "bf16_operands", "f32_split", "f32_split_bf16x6")
+        self.mfma = mfma
         self.cn8 = mfma == "bf16"
         self.bf16 = mfma == "bf16_operands"
+        self.split = SPLIT_ARITH.get(mfma)
         # trainable_adjacency: the stacked adjacency becomes the trainable variable `adjacency_matrix`
         # (models/gcn.py:212-238 AdjGraphConv) shared by all blocks; the graph convolution then keeps the reference's
         # order -- 1x1 convolution to 3F channels, dense contraction with A (csrc/graph_dense.hip) -- and the backward pass
@@ -177,6 +188,20 @@ class STGCN:
             if pk.items:
                 pk.finalize(dev)
                 self.packed = pk
+        self.spacked, self._cells = None, None
+        if self.split:     # term images of the conv weights the split kernels take, both orientations, one refresh per step
+            pk = ops.PackedSplitWeights(self.split)
+            for i, (f, s_, res) in enumerate(self.blocks):
+                pre = "l%d." % i
+                ot = self.offsets[pre + "tcn.kernel"]
+                if ops.split_applicable(L.SAR_CONV_TEMPORAL, num_node, f, f, KT, s_):
+                    pk.add(pre + "tcn.f", ot, f * f, f, 1, KT, f, f)             # (tap, c, m) = kernel[tap][c][m]
+                    pk.add(pre + "tcn.b", ot, f * f, 1, f, KT, f, f)             # (tap, c', m') = kernel[tap][m'][c']
+            if pk.items:
+                pk.finalize(dev)
+                self.spacked = pk
+            # operand bounds of the fp16 arithmetic (include/sar_hip.h: cells), zeroed at the start of every training step
+            self._cells = torch.zeros(8 * len(self.blocks), dtype=torch.int32, device=dev)
         # fp32 operands of the data-gradient GEMMs ((tap, f, c) / (k*F + f, c) / (f, c) transposes of the kernels): ONE
         # re-layout launch at the start of backward() instead of one small dependent launch in front of every data gradient
         # (22 per step, each on the critical chain)
@@ -334,6 +359,9 @@ class STGCN:
         saved = {"x": x, "N": N, "M": M, "T": T, "blocks": [], "training": training}
         if self.packed is not None:
             self.packed.refresh(self.flat)       # the parameters may have changed since the last step
+        if self.spacked is not None and training:
+            self.spacked.refresh(self.flat)
+            self._cells.zero_()
         # ---- data_bn (models/stgcn.py:142-147)
         nch = V * Cin
         if training:
@@ -388,9 +416,13 @@ class STGCN:
         bn1 = self.bn[pre + "bn1"]
         # tgcn: BN -> ReLU folded into the operand load, Conv2D [9,1] stride s SAME (models/stgcn.py:26-36)
         u = torch.empty((f, n_out), dtype=torch.float32, device=dev)
+        simg = self._simg(pre + "tcn.f") if training else None        # inference keeps the fp32 kernels (no batch statistics to bound with)
+        if simg is not None and self._f16:
+            ops.bn_bound(self.p[pre + "bn1.gamma"], self.p[pre + "bn1.beta"], n_in, self._cell(i, 0))
         r2 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, g, u, self.p[pre + "tcn.kernel"], f * f, f, B=B, V=V, T_src=T, T_out=To,
                            Kc=f, M=f, taps=KT, stride=s, pad=pad, bias=self.p[pre + "tcn.bias"],
-                           pro=(bn1.scale, bn1.shift), pro_relu=True, epi=epi, bf16=self.bf16, packed=self._img(pre + "tcn.f"))
+                           pro=(bn1.scale, bn1.shift), pro_relu=True, epi=epi,
+                           **self._split_args(simg, self._cell(i, 0), self._img(pre + "tcn.f")))
         if training:
             self._bn_forward_stats(pre + "bn2", r2[0], r2[1], n_out, True, True)
         else:
@@ -422,6 +454,27 @@ class STGCN:
     def _img(self, key):
         """packed bf16 operand image of a conv weight (bf16 mode), else None"""
         return self.packed.image(key) if self.packed is not None and key in self.packed.index else None
+
+    # ---- split arithmetic (mfma="f32_split*")
+    @property
+    def _f16(self):
+        return bool(self.split) and self.split.startswith("f16")
+
+    def _simg(self, key):
+        """(term images, w_bound cell) of a conv weight in split mode, else None"""
+        pk = self.spacked
+        return (pk.image(key), pk.bound(key)) if pk is not None and key in pk.index else None
+
+    def _cell(self, i, j):
+        """operand-bound cell j of block i: 0 relu(bn1(g)), 1 du, 2 dg, 3 X, 4 dr"""
+        return self._cells[8 * i + j:8 * i + j + 1] if self._cells is not None else None
+
+    def _split_args(self, simg, src_cell, packed=None):
+        """the arithmetic keyword arguments of ops.conv_gemm: a launch on the split kernels (simg from _simg), else the fp32 /
+        bf16-operand kernel with its `packed` image"""
+        if simg is None:
+            return dict(split=None, bf16=self.bf16, packed=packed)
+        return dict(split=self.split, packed=simg[0], bounds=(src_cell, simg[1]))
 
     # ------------------------------------------------------------------ backward
     def _off_critical_path(self, fn, *tensors):
@@ -564,6 +617,9 @@ class STGCN:
             pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
             bf16=self.bf16), g, du)
         wimg = self._img(pre + "tcn.b")
+        simg = self._simg(pre + "tcn.b")
+        if simg is not None and self._f16:
+            ops.amax(du, self._cell(i, 1))
         wT = None
         if wimg is None:
             o = self._wT_off[pre + "tcn"]
@@ -571,7 +627,8 @@ class STGCN:
         dz1 = torch.empty((f, n_in), dtype=torch.float32, device=dev)
         pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, du, dz1, wT, f * f, f, B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=KT,
                            stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g,
-                           aux_affine=(bn1.scale, bn1.shift), aux_mean=bn1.mean, bf16=self.bf16, packed=wimg)
+                           aux_affine=(bn1.scale, bn1.shift), aux_mean=bn1.mean,
+                           **self._split_args(simg, self._cell(i, 1), wimg))
         ops.bn_bwd_finalize(pm[0], pm[1], pm[1] * 2, 2, 0, 1, f, n_in, self.p[pre + "bn1.gamma"], bn1.mean, bn1.rstd,
                             self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
         dg = dz1

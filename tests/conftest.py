@@ -18,3 +18,30 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- the fp32 parity suites run once per ARITHMETIC of the fp32-storage engine: "fp32" = the fp32 MFMA kernels,
+# "f32_split" = fp32 results on the fp16 matrix pipe (csrc/conv_gemm_split.hip), SAME tolerances.  The mode is the default of every
+# ops.conv_gemm / conv_wgrad call and of every STGCN built without an explicit `mfma` in these modules.
+SPLIT_SUITES = {"test_gpu_stgcn_kernels.py", "test_gpu_stgcn_model.py", "test_gpu_batch64.py"}
+ARITH_MODES = ["fp32", "f32_split"]
+
+
+def pytest_generate_tests(metafunc):
+    if os.path.basename(getattr(metafunc.module, "__file__", "")) in SPLIT_SUITES and "arith_mode" in metafunc.fixturenames:
+        metafunc.parametrize("arith_mode", ARITH_MODES, indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def arith_mode(request):
+    mode = getattr(request, "param", "fp32")
+    if mode == "fp32":
+        yield mode
+        return
+    from sar_amd import ops, stgcn
+    old = (ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA)
+    ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA = stgcn.SPLIT_ARITH[mode], mode
+    try:
+        yield mode
+    finally:
+        ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA = old
