@@ -222,6 +222,15 @@ int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s);
 int sar_conv_wgrad_bf16(const sar_wgrad_desc* d, sar_stream_t s);
 /* out[i] = sum_s slab[s*slab_stride + i] (i < n), summed in split order. */
 int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out, sar_stream_t s);
+/* The weight / bias gradient of the same operator in the split arithmetics SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3S
+ * (csrc/conv_wgrad_split.hip): same descriptor and slab contract as sar_conv_wgrad_f32 (slabs reduced by sar_slab_reduce_f32),
+ * src_bound / dout_bound = bound cells of pro(src) / dout for the fp16 arithmetic.  Built for the 9-tap TEMPORAL operator at
+ * V = 25, stride 1, 8 <= Kc <= 256; other shapes: SAR_E_UNSUP (keep sar_conv_wgrad_f32).  nsplit must be a multiple of the wk
+ * that sar_conv_wgrad_split_blocks reports (at M <= 64 two wave pairs of a workgroup split a tile's k-steps and write two slabs);
+ * that query returns the weight blocks per slab group (or SAR_E_UNSUP) and the positions per tile: a launch has
+ * (nsplit / wk) * blocks workgroups, two resident per CU. */
+int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, int* wk, int* tile_positions);
+int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const uint32_t* src_bound, const uint32_t* dout_bound, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Batch-norm plumbing (Keras BatchNormalization(axis=1), models/stgcn.py:27,37,56,111).

@@ -1,0 +1,379 @@
+// conv_wgrad_split.hip -- weight / bias gradient of the 9-tap temporal convolution (stride 1) with fp32 results on the fp16 /
+// bf16 matrix pipe (the "split" arithmetic of conv_gemm_split.hip; gfx950).
+//
+//   dW[tap][c][m] = sum_n pro(src)[c, n + (tap - pad) V] * dout[m, n]        (tf.GradientTape of the Conv2D [9,1],
+//   dbias[m]      = sum_n dout[m, n]   (fp32 sums of the fp32 values)         main_gnn.py:233, models/stgcn.py:29-36)
+//
+// Same slab contract as sar_conv_wgrad_f32 (include/sar_hip.h): slab[s][wsize + bsize], summed by sar_slab_reduce_f32 in slab
+// order (deterministic, no atomics).  Every fp32 operand element enters the matrix pipe as two fp16 terms of its scaled value
+// (f16x3s: three products per fp32 product) or three bfloat16 terms (bf16x6: six products); products are exact, accumulation fp32.
+//
+// Design (MI355X):
+//  * the contraction runs over positions n = (t, v) of one sequence, the contiguous axis of both operands in the CN layout: a
+//    lane's MFMA fragment is 8 consecutive positions of one row.  A temporal tap shifts the src window by tap * V positions,
+//    whatever the tile's alignment to frames: a tile is KT consecutive positions (a multiple of 16, not of V), its src window
+//    KT + 8 V positions.
+//  * workgroup = 32 src channels x 128 (M >= 128) or 64 (M = 64) dout channels x all nine taps: each wave owns a 32 x 32 block
+//    of every tap (9 accumulators = 144 registers); at M = 64 the two wave pairs split the tile's k-steps and write two slabs.
+//  * only the src window goes through LDS ([term][32 rows][window] 2-byte elements, split behind the folded BatchNorm + ReLU by
+//    the stager): V = 25 makes odd taps start on an odd element, so a window is read as aligned dwords and funnel-shifted by two
+//    bytes (v_alignbyte_b32) for odd taps.  Row stride / 2 is odd: the 32 rows of a fragment read hit distinct banks.
+//  * the dout fragment of a k-step is the same for all nine taps: each wave loads its 32 rows x 16 positions straight from
+//    global memory into registers one k-step ahead (two 16-byte loads per lane), sums them for the bias gradient, splits them
+//    in registers.  No LDS for dout: the image of a 240-position tile stays at 57 KB -- two workgroups per CU.
+//  * per k-step and wave: 27 MFMAs (f16x3s), ~80 vector instructions (split of dout, funnel shifts, bias sums), 81 dword LDS
+//    reads.
+#include "sar_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int VJ = 25, TAPS = 9, CB = 32;
+constexpr int AR_B6 = SAR_SPLIT_BF16X6, AR_H3S = SAR_SPLIT_F16X3S;
+constexpr bool ar_f16(int ar) { return ar == AR_H3S; }
+constexpr int ar_nt(int ar) { return ar == AR_H3S ? 2 : 3; }
+constexpr int ar_nprod(int ar) { return ar == AR_H3S ? 3 : 6; }
+// product p: (src term, dout term), smallest magnitude first (conv_gemm_split.hip)
+constexpr int ar_pi(int ar, int p) {
+  constexpr int i6[6] = {0, 2, 1, 0, 1, 0};
+  return ar == AR_H3S ? (p == 1 ? 1 : 0) : i6[p];
+}
+constexpr int ar_pj(int ar, int p) {
+  constexpr int j6[6] = {2, 0, 1, 1, 0, 0};
+  return ar == AR_H3S ? (p == 0 ? 1 : 0) : j6[p];
+}
+template <int AR> struct Cfg {
+  static constexpr int NT = ar_nt(AR);
+  static constexpr int KT = NT == 2 ? 240 : 112;        // positions per tile (multiple of 16)
+  static constexpr int KS = KT / 16;
+  static constexpr int WIN = KT + (TAPS - 1) * VJ;       // src window
+  static constexpr int RS = ((WIN + 2 + 1) / 2 * 2) + ((((WIN + 2 + 1) / 2) & 1) ? 0 : 2);   // row stride (elements): >= WIN + 2, RS / 2 odd
+  static constexpr int NCH = (WIN + 127) / 128;          // stager chunks of 128 positions (a lane owns two adjacent positions)
+  static_assert((RS / 2) % 2 == 1 && RS >= WIN + 2, "row stride");
+};
+
+__host__ __device__ __forceinline__ int scale_exp(unsigned bound_bits) {   // conv_gemm_split.hip
+  const int fl = (int)((bound_bits >> 23) & 0xffu) - 127;
+  const int e = 14 - fl;
+  return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+
+__device__ __forceinline__ unsigned pk_bf16(float x, float y) {
+  bf16x2 p;
+  p[0] = (__bf16)x;
+  p[1] = (__bf16)y;
+  return *reinterpret_cast<unsigned*>(&p);
+}
+__device__ __forceinline__ unsigned pk_f16(float x, float y) {
+  f16x2 p;
+  p[0] = (_Float16)x;
+  p[1] = (_Float16)y;
+  return *reinterpret_cast<unsigned*>(&p);
+}
+// two adjacent (already scaled) values -> one dword per term
+template <int AR>
+__device__ __forceinline__ void split2(float x, float y, unsigned (&w)[ar_nt(AR)]) {
+  constexpr int NT = ar_nt(AR);
+  if constexpr (ar_f16(AR)) {
+    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+    f16x2 h;
+    h[0] = (_Float16)x;
+    h[1] = (_Float16)y;
+    w[0] = *reinterpret_cast<unsigned*>(&h);
+    w[1] = pk_f16(x - (float)h[0], y - (float)h[1]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const unsigned b = pk_bf16(x, y);
+      w[t] = b;
+      if (t + 1 < NT) {
+        x -= __uint_as_float(b << 16);
+        y -= __uint_as_float(b & 0xffff0000u);
+      }
+    }
+  }
+}
+
+struct WgradKS {
+  sar_wgrad_desc d;
+  int TPS, ntiles, gy, gz;
+  const unsigned* src_bound;
+  const unsigned* dout_bound;
+};
+
+// WK = 1: four waves side by side along m (128 dout channels); WK = 2: two along m, the pairs split the k-steps (M <= 64)
+template <int AR, int WK>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS k) {
+  using C = Cfg<AR>;
+  constexpr int NT = C::NT, NPROD = ar_nprod(AR), KT = C::KT, KS = C::KS, WIN = C::WIN, RS = C::RS, NCH = C::NCH, V = VJ;
+  constexpr int WMM = 4 / WK, MBLK = 32 * WMM;
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[NT * CB * RS];
+  __shared__ float2 bnp[256];
+  const sar_wgrad_desc& d = k.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wmm = wave % WMM, kh = wave / WMM;
+
+  // workgroup -> (split group, m block, c block); the blocks of one split are adjacent slots of one XCD (L2 reuse of the tiles)
+  int sg, by, bz;
+  {
+    const int nyz = k.gy * k.gz, ngrp = d.nsplit / WK, nwork = ngrp * nyz;
+    const int per = (nwork + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int w = xcd * per + slot;
+    if (slot >= per || w >= nwork) return;
+    sg = w / nyz;
+    const int yz = w - sg * nyz;
+    bz = yz / k.gy;
+    by = yz - bz * k.gy;
+  }
+  const int m0 = by * MBLK + wmm * 32, c0 = bz * CB;
+  const int ngrp = d.nsplit / WK;
+
+  int ea = 0, eb = 0;
+  if (ar_f16(AR)) {
+    ea = scale_exp(*k.src_bound);
+    eb = scale_exp(*k.dout_bound);
+  }
+  const float sa = __builtin_ldexpf(1.f, ea), sb = __builtin_ldexpf(1.f, eb);
+  {   // the folded prologue of this block's 32 channels, the src scale folded in (power of two: exact)
+    float2 p = make_float2(sa, 0.f);
+    if (tid < CB && d.pro_scale && c0 + tid < d.Kc) p = make_float2(d.pro_scale[c0 + tid] * sa, d.pro_shift[c0 + tid] * sa);
+    if (tid < CB) bnp[tid] = p;
+  }
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = d.bsize > 0 && bz == 0;   // uniform
+
+  const int tps = (k.ntiles + ngrp - 1) / ngrp;
+  const int tile_lo = sg * tps;
+  const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  const int seq = d.T_src * V;   // stride 1: T_src == T_out
+
+  // LDS read base of this lane: row l31, element 8 * hi
+  const unsigned a_base = (unsigned)(uintptr_t)Hs + (unsigned)((l31 * RS + 8 * hi) * 2);
+  typedef const unsigned __attribute__((address_space(3))) * lds_u32;
+  // dout rows of this wave: one descriptor over the whole tensor, per-lane offsets
+  const bool mrow_ok = (m0 + l31) < d.M;
+  constexpr unsigned REJECT = 0xf0000000u;   // beyond num_records, and + 16 does not wrap
+  const int64_t dbytes = (int64_t)d.M * d.ld_dout * 4;
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.dout, 0, (unsigned)(dbytes < (int64_t)REJECT ? dbytes : (int64_t)REJECT), 0x00020000);
+  const unsigned drow = (unsigned)(((int64_t)(mrow_ok ? m0 + l31 : 0) * d.ld_dout) * 4);
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int b = tile / k.TPS;
+    const int n0 = (tile - b * k.TPS) * KT;
+    __syncthreads();   // closing: every wave has read its last fragment of the previous tile (and bnp is written)
+    // ---- stage the src window [n0 - pad V, n0 - pad V + WIN) of rows c0 .. c0 + 31: wave w takes rows w, w + 4, ..
+    {
+      const float* src_b = d.src + (int64_t)b * seq;
+      const int p_lo = n0 - d.pad * V;
+#pragma unroll 1
+      for (int rh = 0; rh < 2; ++rh) {
+        float x[4][NCH][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = wave + 4 * (rh * 4 + q);
+          const int c = c0 + row;
+          const int cg = c < d.Kc ? c : 0;
+          const __amdgpu_buffer_rsrc_t rs =
+              __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq * 4, 0x00020000);
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) {
+            const int pa = p_lo + 2 * lane + 128 * j;   // negative / past-the-end offsets: rejected by the range check -> 0
+            x[q][j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, pa * 4, 0, 0));
+            x[q][j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (pa + 1) * 4, 0, 0));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = wave + 4 * (rh * 4 + q);
+          const bool rok = c0 + row < d.Kc;
+          const float2 ps = bnp[row];
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) {
+            const int col = 2 * lane + 128 * j;
+            const int pa = p_lo + col;
+            const bool ok0 = rok && col < WIN && (unsigned)pa < (unsigned)seq;
+            const bool ok1 = rok && col + 1 < WIN && (unsigned)(pa + 1) < (unsigned)seq;
+            const float v0 = ok0 ? fmaxf(fmaf(x[q][j][0], ps.x, ps.y), relu_lo) : 0.f;   // TF-SAME padding stays exactly 0
+            const float v1 = ok1 ? fmaxf(fmaf(x[q][j][1], ps.x, ps.y), relu_lo) : 0.f;
+            unsigned w[NT];
+            split2<AR>(v0, v1, w);
+            if (col < RS) {
+#pragma unroll
+              for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // opening: the window is complete
+
+    // ---- k-steps of this wave (WK = 2: the second wave pair takes the odd ones)
+    const bool ragged = n0 + KT > seq;   // the tile reaches past the end of the sequence: mask dout per element
+    auto load_dout = [&](int ks, u32x4 (&raw)[2]) {
+      const int pos = n0 + 16 * ks + 8 * hi;
+      const unsigned vo = (mrow_ok && pos < seq) ? drow + (unsigned)(((int64_t)b * seq + pos) * 4) : REJECT;   // rejected -> 0
+      raw[0] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 0, 0);
+      raw[1] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 16, 0);
+    };
+    u32x4 raw[2][2];
+    load_dout(kh, raw[0]);
+#pragma unroll 1
+    for (int ks = kh; ks < KS; ks += 2 * WK) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {   // two k-steps per iteration: static double buffer
+        const int kc = ks + half * WK;
+        if (kc < KS) {
+          if (kc + WK < KS) load_dout(kc + WK, raw[half ^ 1]);
+          // split the dout fragment (8 consecutive positions of row m0 + l31)
+          float dv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dv[j] = __uint_as_float(raw[half][j >> 2][j & 3]);
+          if (ragged) {
+            const int nv = seq - (n0 + 16 * kc + 8 * hi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dv[j] = j < nv ? dv[j] : 0.f;
+          }
+          if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += dv[j];
+          }
+          unsigned bw[NT][4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            unsigned w[NT];
+            split2<AR>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bw[t][p] = w[t];
+          }
+          const unsigned a_ks = a_base + kc * 32;
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            const int e = t * V;   // window start in elements; V odd: parity of t
+            u32x4 aq[NT];
+#pragma unroll
+            for (int tm = 0; tm < NT; ++tm) {
+              if ((e & 1) == 0) {
+                lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (CB * RS * 2) + e * 2);
+                aq[tm] = u32x4{p[0], p[1], p[2], p[3]};
+              } else {
+                lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (CB * RS * 2) + (e - 1) * 2);
+                const unsigned w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
+                aq[tm] = u32x4{__builtin_amdgcn_alignbyte(w1, w0, 2), __builtin_amdgcn_alignbyte(w2, w1, 2),
+                               __builtin_amdgcn_alignbyte(w3, w2, 2), __builtin_amdgcn_alignbyte(w4, w3, 2)};
+              }
+            }
+#pragma unroll
+            for (int p = 0; p < NPROD; ++p) {
+              const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+              const u32x4 bq = u32x4{bw[j][0], bw[j][1], bw[j][2], bw[j][3]};
+              if (ar_f16(AR))
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&aq[i]),
+                                                                *reinterpret_cast<const f16x8*>(&bq), acc[t], 0, 0, 0);
+              else
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&aq[i]),
+                                                                 *reinterpret_cast<const bf16x8*>(&bq), acc[t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- this wave's slab: rows c (registers), columns m (lanes: contiguous)
+  float* slab = d.slab + (int64_t)(sg * WK + kh) * (d.wsize + d.bsize);
+  const float unscale = __builtin_ldexpf(1.f, -(ea + eb));
+  const int m = m0 + l31;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + mfma_row(r, hi);
+      if (c < d.Kc && m < d.M) slab[(int64_t)t * d.w_stride_tap + (int64_t)c * d.w_stride_c + m] = acc[t][r] * unscale;
+    }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32);
+    if (hi == 0 && m < d.M) slab[d.wsize + m] = bsum;
+  }
+}
+
+// which kernel: WK (1 or 2), or 0 = not built (the caller keeps sar_conv_wgrad_f32)
+int wgrad_split_wk(const sar_wgrad_desc& d, int arith) {
+  if (arith != AR_B6 && arith != AR_H3S) return 0;
+  if (d.mode != SAR_CONV_TEMPORAL || d.taps != TAPS || d.V != VJ || d.stride != 1 || d.T_src != d.T_out) return 0;
+  if (d.Kc < 8 || d.Kc > 256 || d.pad < 0 || d.pad > 8) return 0;
+  return d.M > 64 ? 1 : 2;
+}
+
+template <int AR>
+int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, const unsigned* db, hipStream_t st) {
+  WgradKS k;
+  k.d = d;
+  k.src_bound = sb;
+  k.dout_bound = db;
+  const int seq = d.T_out * d.V;
+  k.TPS = (seq + Cfg<AR>::KT - 1) / Cfg<AR>::KT;
+  k.ntiles = d.B * k.TPS;
+  k.gy = (d.M + 128 / wk - 1) / (128 / wk);
+  k.gz = (d.Kc + CB - 1) / CB;
+  const int nwork = (d.nsplit / wk) * k.gy * k.gz;
+  const dim3 grid(((nwork + 7) / 8) * 8), block(256);
+  if (wk == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 1>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 2>), grid, block, 0, st, k);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, int* wk_out, int* tile_positions) {
+  if (!d) return SAR_E_ARG;
+  const int wk = wgrad_split_wk(*d, arith);
+  if (!wk) return SAR_E_UNSUP;
+  if (wk_out) *wk_out = wk;
+  if (tile_positions) *tile_positions = arith == AR_H3S ? Cfg<AR_H3S>::KT : Cfg<AR_B6>::KT;
+  return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
+}
+
+extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const uint32_t* src_bound, const uint32_t* dout_bound,
+                                    sar_stream_t s) {
+  SAR_REQUIRE(d != nullptr, "sar_conv_wgrad_split: null descriptor");
+  const int wk = wgrad_split_wk(*d, arith);
+  if (!wk) {
+    sar_set_error("sar_conv_wgrad_split: built for the 9-tap temporal convolution at V = 25, stride 1, 8 <= Kc <= 256 in the "
+                  "arithmetics bf16x6 / f16x3s (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
+                  d->mode, d->taps, d->V, d->stride, d->Kc, arith);
+    return SAR_E_UNSUP;
+  }
+  SAR_REQUIRE(d->B > 0 && d->T_out > 0 && d->M > 0, "sar_conv_wgrad_split: bad sizes");
+  SAR_REQUIRE(d->src && d->dout && d->slab, "sar_conv_wgrad_split: null src/dout/slab");
+  SAR_REQUIRE(d->nsplit >= wk && d->nsplit % wk == 0 && d->nsplit <= 65535,
+              "sar_conv_wgrad_split: nsplit %d must be a positive multiple of %d", d->nsplit, wk);
+  SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_dout >= (int64_t)d->B * d->T_out * d->V,
+              "sar_conv_wgrad_split: leading dimension smaller than B*T*V");
+  SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 28), "sar_conv_wgrad_split: sequence row too long");
+  SAR_REQUIRE((int64_t)d->M * d->ld_dout * 4 < 0xf0000000ll, "sar_conv_wgrad_split: dout larger than 3.75 GiB");
+  SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_wgrad_split: pro_scale/pro_shift mismatch");
+  SAR_REQUIRE(d->wsize > 0 && (d->bsize == 0 || d->bsize == d->M), "sar_conv_wgrad_split: bad slab sizes");
+  SAR_REQUIRE(arith != AR_H3S || (src_bound && dout_bound), "sar_conv_wgrad_split: the fp16 arithmetic needs the operand bounds");
+  if (arith == AR_H3S) launch_wgrad_split<AR_H3S>(*d, wk, src_bound, dout_bound, as_stream(s));
+  else launch_wgrad_split<AR_B6>(*d, wk, src_bound, dout_bound, as_stream(s));
+  SAR_LAUNCH_CHECK("sar_conv_wgrad_split");
+  return 0;
+}

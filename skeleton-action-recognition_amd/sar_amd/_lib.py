@@ -87,6 +87,8 @@ SIGNATURES = {
     "sar_conv_gemm_split_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_pack_weights_split_batch": (_i, [_fp, _fp, _i, _i64, _i, _fp, _fp, _fp]),
     "sar_conv_gemm_split": (_i, [C.POINTER(ConvDesc), _i, _fp, _fp, _fp, _fp]),
+    "sar_conv_wgrad_split_blocks": (_i, [C.POINTER(WgradDesc), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sar_conv_wgrad_split": (_i, [C.POINTER(WgradDesc), _i, _fp, _fp, _fp]),
     "sar_amax_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),
     "sar_bn_bound_f32": (_i, [_fp, _fp, _i, _d, _fp, _fp]),
     "sar_affine_bound_f32": (_i, [_fp, _fp, _i, _fp, _fp, _fp]),

@@ -246,7 +246,7 @@ _WGRADG_SLOTS = int(__import__("os").environ.get("SAR_WGRADG_SLOTS", "512"))    
 
 
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
-               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, bf16=False):
+               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, bf16=False, split="default", bounds=None):
     """dW (and dbias, stored right behind it) -> dW_out[0 : wsize+bsize] (flat float32 view).  bf16=True routes the
     9-tap temporal operator (V = 25; stride 1, or stride 2 with the even-T SAME padding 3) to sar_conv_wgrad_bf16 (bf16 MFMA operands, fp32 accumulation and bias
     sums); every other shape stays on the fp32 kernel."""
@@ -254,6 +254,20 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     d = WgradDesc()
     d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
     d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
+    # split="bf16x6" / "f16x3s": the split arithmetic of csrc/conv_wgrad_split.hip where it is built (bounds = (src_bound,
+    # dout_bound) cells for the fp16 arithmetic, None = computed here by device kernels); other shapes stay on the fp32 kernel
+    if split == "default":
+        split = DEFAULT_SPLIT
+    sp_blocks = 0
+    if split in ("bf16x6", "f16x3s"):
+        wk, kt = C.c_int(0), C.c_int(0)
+        sp_blocks = lib.sar_conv_wgrad_split_blocks(C.byref(d), L.SAR_SPLIT[split], C.byref(wk), C.byref(kt))
+        if sp_blocks > 0:
+            bf16 = False
+            if nsplit is None:      # one round of the 512 resident workgroups (two per CU)
+                ntiles = B * ((T_out * V + kt.value - 1) // kt.value)
+                nsplit = max(1, min(ntiles, 512 // sp_blocks)) * wk.value
+    split = split if sp_blocks > 0 else None
     ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
     # (a bf16 graph weight gradient was built and measured: with the adjacency gather in its stager it ran 1.7x SLOWER
     # than the fp32 kernel -- 9.0 vs 5.4 ms per step -- so the graph weight gradient stays on the fp32 kernel)
@@ -290,9 +304,17 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
     d.slab = ptr(slab)
     tag = "wgrad_graph" if mode == L.SAR_CONV_GRAPH else "wgrad_temporal%d" % taps
-    with profiler.region(tag + ("_bf16" if bf16 else ""), 2.0 * M * Kc * taps * B * T_out * V,
+    if split:
+        src_bound, dout_bound = bounds if bounds is not None else (None, None)
+        if split.startswith("f16") and bounds is None:
+            src_bound = _src_bound_single(src, pro)
+            dout_bound = _src_bound_single(dout, None)
+    with profiler.region(tag + ("_split" if split else "_bf16" if bf16 else ""), 2.0 * M * Kc * taps * B * T_out * V,
                          4.0 * (Kc * B * T_src * V + M * B * T_out * V)):
-        if bf16:
+        if split:
+            check(lib.sar_conv_wgrad_split(C.byref(d), L.SAR_SPLIT[split], ptr(src_bound), ptr(dout_bound), stream_ptr()),
+                  "sar_conv_wgrad_split")
+        elif bf16:
             check(lib.sar_conv_wgrad_bf16(C.byref(d), stream_ptr()), "sar_conv_wgrad_bf16")
         else:
             check(lib.sar_conv_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv_wgrad_f32")

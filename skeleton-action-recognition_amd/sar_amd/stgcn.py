@@ -612,14 +612,15 @@ class STGCN:
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
         wt = self.g[pre + "tcn.kernel"]
         flat_w = self.grad[self.offsets[pre + "tcn.kernel"]:self.offsets[pre + "tcn.bias"] + f]
+        simg = self._simg(pre + "tcn.b")
+        if simg is not None and self._f16:
+            ops.amax(du, self._cell(i, 1))       # the bound of du: data gradient (src) and weight gradient (dout)
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
             pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
-            bf16=self.bf16), g, du)
+            bf16=self.bf16, split=self.split if simg is not None else None,
+            bounds=(self._cell(i, 0), self._cell(i, 1)) if self._f16 else None), g, du)
         wimg = self._img(pre + "tcn.b")
-        simg = self._simg(pre + "tcn.b")
-        if simg is not None and self._f16:
-            ops.amax(du, self._cell(i, 1))
         wT = None
         if wimg is None:
             o = self._wT_off[pre + "tcn"]
