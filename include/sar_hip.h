@@ -160,19 +160,24 @@ int sar_pack_weights_bf16_batch(const float* base, const sar_pack_item* items, i
  *   SAR_SPLIT_BF16X6  every fp32 operand = three bfloat16 terms (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 24
  *                     significant bits, remainders exact), the six cross products with i + j <= 2, each exact in the fp32
  *                     accumulator of v_mfma_f32_32x32x16_bf16 (dropped products <= 3 * 2^-27 |a b|).  No range limits.
- *   SAR_SPLIT_F16X3S  two fp16 terms of the operand scaled by a power of two (h0 = fp16(s a), h1 = fp16(s a - h0)), three
- *                     products (dropped: h1 g1 <= 2^-24 |a b|): half the matrix work.  The scale of each operand comes from an
+ *   SAR_SPLIT_F16X3A  (the product arithmetic of the f32_split engine) fp16 terms of the operands scaled by powers of two, three
+ *                     products, half the matrix work of X6: the well-conditioned operand (W; in the weight gradient the
+ *                     BatchNorm-ed src) as w0 = fp16(s w), w1 = fp16(s w - w0) and w0 2^-11, the wide-range operand (activations,
+ *                     gradients) as x0 = fp16(t x) and x1' = fp16((t x - x0) 2^11); acc += w0 x0 + w1 x0 + (w0 2^-11) x1'
+ *                     (dropped: w1 x1 <= 2^-24 |w x|).  x keeps 22 significant bits over 2^29 of dynamic range below its
+ *                     bound.  The scale of each operand comes from an
  *                     UPPER BOUND of its magnitudes that the caller keeps in device memory (`src_bound` for pro(src), `w_bound`
  *                     for W: the BITS of a non-negative float; sar_amax_f32 / sar_bn_bound_f32 / sar_affine_bound_f32 /
  *                     sar_pack_weights_split_batch produce them without a host sync): s = 2^(14 - floor(log2(bound))).  Values
  *                     beyond the bound saturate at the fp16 maximum (a stale bound gives a wrong, finite result).
- *   X1 / X3 / X9 / F16X3 are measured data points (tools/split_probe.py, profiles/r05_split_probe_*).
+ *   X1 / X3 / X9 / F16X3 / F16X3S (two symmetric fp16 terms: loses the low term of elements 2^18 below the bound -- not enough
+ *   for gradient tensors) are measured data points (tools/split_probe.py, profiles/r05_split_probe_*; 9-tap temporal only).
  * Built for the 9-tap TEMPORAL operator at V = 25, stride 1 / 2, 8 <= Kc <= 256, M % 8 == 0; anything else returns SAR_E_UNSUP
  * (sar_conv_gemm_split_nparts too): the caller keeps sar_conv_gemm_f32 for it.  `packed` = the weight term images written by
  * sar_pack_weights_split_batch (same items as sar_pack_weights_bf16_batch, but G = ceil(Kc / 8), and an item occupies
  * sar_conv_gemm_split_workspace_bytes / 16 units = terms * taps * G * M); item_amax[nitems] receives each item's amax bits (fp16
  * arithmetics; = the item's w_bound).  Partial sums: [M][sar_conv_gemm_split_nparts][2]. */
-enum { SAR_SPLIT_BF16X1 = 1, SAR_SPLIT_BF16X3 = 3, SAR_SPLIT_BF16X6 = 6, SAR_SPLIT_BF16X9 = 9, SAR_SPLIT_F16X3 = 103, SAR_SPLIT_F16X3S = 104 };
+enum { SAR_SPLIT_BF16X1 = 1, SAR_SPLIT_BF16X3 = 3, SAR_SPLIT_BF16X6 = 6, SAR_SPLIT_BF16X9 = 9, SAR_SPLIT_F16X3 = 103, SAR_SPLIT_F16X3S = 104, SAR_SPLIT_F16X3A = 105 };
 int64_t sar_conv_gemm_split_workspace_bytes(const sar_conv_desc* d, int arith);
 int sar_conv_gemm_split_nparts(const sar_conv_desc* d);
 int sar_pack_weights_split_batch(const float* base, const sar_pack_item* items, int nitems, int64_t max_units, int arith,
@@ -222,8 +227,8 @@ int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s);
 int sar_conv_wgrad_bf16(const sar_wgrad_desc* d, sar_stream_t s);
 /* out[i] = sum_s slab[s*slab_stride + i] (i < n), summed in split order. */
 int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out, sar_stream_t s);
-/* The weight / bias gradient of the same operator in the split arithmetics SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3S
- * (csrc/conv_wgrad_split.hip): same descriptor and slab contract as sar_conv_wgrad_f32 (slabs reduced by sar_slab_reduce_f32),
+/* The weight / bias gradient of the same operator in the split arithmetics SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A
+ * (csrc/conv_wgrad_split.hip; SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A): same descriptor and slab contract as sar_conv_wgrad_f32 (slabs reduced by sar_slab_reduce_f32),
  * src_bound / dout_bound = bound cells of pro(src) / dout for the fp16 arithmetic.  Built for the 9-tap TEMPORAL operator at
  * V = 25, stride 1, 8 <= Kc <= 256; other shapes: SAR_E_UNSUP (keep sar_conv_wgrad_f32).  nsplit must be a multiple of the wk
  * that sar_conv_wgrad_split_blocks reports (at M <= 64 two wave pairs of a workgroup split a tile's k-steps and write two slabs);

@@ -14,18 +14,21 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;
   const int part = tile * WN + wn;
-  const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK;
+  const bool stats = d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK || d.epi == SAR_EPI_ADD_GATE;
   auto fast_epilogue = [&](auto EPI_) {
     constexpr int EPI = decltype(EPI_)::value;
-    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK;
-    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD;
-    if (EPI == SAR_EPI_MASK) {
+    constexpr bool gate = EPI == SAR_EPI_ADD_GATE;   // out = gate(acc + aux), sums of the gated values (include/sar_hip.h; conv_gemm.hip)
+    constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK || gate;
+    constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD || gate;
+    if (EPI == SAR_EPI_MASK || gate) {
       if (tid < BM) {
         const int row = m0 + tid;
         float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < d.M) {
-          ap.x = d.aux_scale[row];
-          ap.y = d.aux_shift[row];
+          if (EPI == SAR_EPI_MASK) {
+            ap.x = d.aux_scale[row];
+            ap.y = d.aux_shift[row];
+          }
           if (d.aux_mean) ap.z = d.aux_mean[row];
         }
         rowp[tid] = ap;
@@ -48,12 +51,28 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
       vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
     }
     const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
+    // SAR_EPI_ADD_GATE: aux2 [M][ld_aux2] fp32 and its gate bytes [M][ld_aux2 / 4] (bit j of byte i = column 4 i + j)
+    const float* u2 = reinterpret_cast<const float*>(d.aux2);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gate ? u2 + (int64_t)rows_w * d.ld_aux2 : d.out), 0, gate ? rows_bytes(d.ld_aux2) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gate ? d.aux_mask + (int64_t)rows_w * (d.ld_aux2 >> 2) : (const unsigned char*)d.out), 0,
+        gate ? rows_bytes(d.ld_aux2) >> 4 : 0u, 0x00020000);
+    unsigned vo_u[NS], vo_m[NS], cbit[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      vo_u[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux2) * 4) : 0x80000000u;
+      vo_m[ns] = colok[ns] ? (unsigned)((coln[ns] >> 2) + hi * d.ld_aux2) : 0x80000000u;
+      cbit[ns] = (unsigned)(coln[ns] & 3);
+    }
+    const int so_u = (int)(d.ld_aux2 * 4), so_m = (int)(d.ld_aux2 >> 2);
     float* P = smem + wave * (16 * 65);
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
-        float ax[NS][16];
+        float ax[NS][16], ux[NS][16];
+        unsigned gm[NS][16];
         if (has_aux) {
 #pragma unroll
           for (int r8 = 0; r8 < 8; ++r8)
@@ -62,6 +81,12 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
               const int r = rb * 8 + r8;
               ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                   ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+              if (gate) {
+                ux[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    ru, vo_u[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_u, 0));
+                gm[ns][r] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(
+                    rm, vo_m[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_m, 0);
+              }
             }
         }
 #pragma unroll
@@ -70,7 +95,7 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
           const bool grp_ok = rows_w + ms * 32 + 8 * (r >> 2) < d.M;
           float s1 = 0.f, s2 = 0.f;
           float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (EPI == SAR_EPI_MASK) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
+          if (EPI == SAR_EPI_MASK || gate) ap = rowp[(wm * MS + ms) * 32 + mfma_row(r, hi)];
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns) {
             float val = acc[ms][ns][r];
@@ -83,6 +108,11 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
               s2 = fmaf(val, ax[ns][r] - ap.z, s2);
             } else if (EPI == SAR_EPI_ADD) {
               val += ax[ns][r];
+            } else if (gate) {   // replaces, for the block below, bn_add_relu_bwd_reduce and the masked-gradient write of the apply pass
+              val += ax[ns][r];
+              val = ((gm[ns][r] >> cbit[ns]) & 1u) ? val : 0.f;
+              s1 += val;
+              s2 = fmaf(val, ux[ns][r] - ap.z, s2);
             }
             if (grp_ok)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
@@ -114,6 +144,7 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
     case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
     case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;
     case SAR_EPI_ADD: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD>()); break;
+    case SAR_EPI_ADD_GATE: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD_GATE>()); break;
     default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
   }
 }

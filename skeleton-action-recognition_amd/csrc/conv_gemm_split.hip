@@ -53,21 +53,28 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int KC8 = 8;    // source channels per stage
 constexpr int VJ = 25;   // joints per frame: compile-time (tap shifts are immediates); other V stay on the fp32 kernel
 constexpr int AR_B1 = SAR_SPLIT_BF16X1, AR_B3 = SAR_SPLIT_BF16X3, AR_B6 = SAR_SPLIT_BF16X6, AR_B9 = SAR_SPLIT_BF16X9,
-              AR_H3 = SAR_SPLIT_F16X3, AR_H3S = SAR_SPLIT_F16X3S;
+              AR_H3 = SAR_SPLIT_F16X3, AR_H3S = SAR_SPLIT_F16X3S, AR_H3A = SAR_SPLIT_F16X3A;
 constexpr float H3_LO = 2048.f;   // f16x3 (two accumulators): the second term carries 2^11
 
-constexpr bool ar_f16(int ar) { return ar == AR_H3 || ar == AR_H3S; }
+constexpr bool ar_f16(int ar) { return ar == AR_H3 || ar == AR_H3S || ar == AR_H3A; }
 constexpr bool ar_two_acc(int ar) { return ar == AR_H3; }
-constexpr int ar_nt(int ar) { return ar == AR_B1 ? 1 : ((ar == AR_B3 || ar_f16(ar)) ? 2 : 3); }
+// terms of the W-side operand / of the source-side operand.  f16x3a (the product arithmetic) is ASYMMETRIC: the well-conditioned
+// operand (the weights: max / typical magnitude ~ 4) carries THREE images -- w0 = fp16(s w), w1 = fp16(s w - w0), w0 2^-11 -- and
+// the wide-range operand (activations, gradients) two -- x0 = fp16(s x), x1' = fp16((s x - x0) 2^11) -- so that the products
+// w0 x0 + w1 x0 + (w0 2^-11)(x1' 2^11 ...) = w0 x0 + w1 x0 + w0 x1 meet in ONE accumulator and the low term of the wide operand is
+// never an fp16 subnormal: 22 significant bits for every source element within 2^-29 of the tensor's bound (f16x3s: 2^-18 --
+// a gradient tensor with a few outliers lost its second term on most elements: 1e-4 errors in the whole-model parity test).
+constexpr int ar_nta(int ar) { return ar == AR_B1 ? 1 : ((ar == AR_B3 || ar == AR_H3 || ar == AR_H3S) ? 2 : 3); }
+constexpr int ar_ntb(int ar) { return ar == AR_B1 ? 1 : ((ar == AR_B3 || ar_f16(ar)) ? 2 : 3); }
 constexpr int ar_nprod(int ar) { return ar == AR_B1 ? 1 : (ar == AR_B3 || ar_f16(ar)) ? 3 : (ar == AR_B6 ? 6 : 9); }
 // product p of an arithmetic: (W term, src term), smallest magnitude first
 constexpr int ar_pi(int ar, int p) {
   constexpr int i9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
-  return ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 1 ? 1 : 0) : i9[p + 9 - ar_nprod(ar)];
+  return ar == AR_H3A ? 2 - p : ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 1 ? 1 : 0) : i9[p + 9 - ar_nprod(ar)];
 }
 constexpr int ar_pj(int ar, int p) {
   constexpr int j9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
-  return ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 0 ? 1 : 0) : j9[p + 9 - ar_nprod(ar)];
+  return ar == AR_H3A ? (p == 0 ? 1 : 0) : ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 0 ? 1 : 0) : j9[p + 9 - ar_nprod(ar)];
 }
 
 // power-of-two scale exponent of an operand from (the bits of) an upper bound of its magnitudes: bound * 2^e in [2^14, 2^15)
@@ -173,10 +180,11 @@ __device__ __forceinline__ unsigned pk_f16(float x, float y) {
   return *reinterpret_cast<unsigned*>(&p);
 }
 
-// 8 consecutive-channel values of one row / column -> the NT term units (k-innermost: element j of a unit = channel j)
-template <int AR>
-__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&u)[ar_nt(AR)], float scale) {
-  constexpr int NT = ar_nt(AR);
+// 8 consecutive-channel values of one row / column -> the term units (k-innermost: element j of a unit = channel j).  WSIDE: the
+// W-side (well-conditioned) operand's images, else the source side's.
+template <int AR, bool WSIDE>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&u)[WSIDE ? ar_nta(AR) : ar_ntb(AR)], float scale) {
+  constexpr int NT = WSIDE ? ar_nta(AR) : ar_ntb(AR);
   unsigned w[NT][4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -188,8 +196,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&u)[ar_nt(AR)
       h[0] = (_Float16)x;
       h[1] = (_Float16)y;
       w[0][p] = *reinterpret_cast<unsigned*>(&h);
-      const float lo = ar_two_acc(AR) ? H3_LO : 1.f;   // two accumulators: the remainder carries 2^11
+      // the remainder: up-scaled by 2^11 on the source side of f16x3a and in f16x3 (two accumulators)
+      const float lo = (ar_two_acc(AR) || (AR == AR_H3A && !WSIDE)) ? H3_LO : 1.f;
       w[1][p] = pk_f16((x - (float)h[0]) * lo, (y - (float)h[1]) * lo);
+      if constexpr (AR == AR_H3A && WSIDE) w[2][p] = pk_f16((float)h[0] * (1.f / H3_LO), (float)h[1] * (1.f / H3_LO));
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -211,7 +221,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&u)[ar_nt(AR)
 template <int AR>
 __global__ void pack_split_kernel(const float* __restrict__ base, const sar_pack_item* __restrict__ items,
                                   const unsigned* __restrict__ item_amax, uint4* __restrict__ out) {
-  constexpr int NT = ar_nt(AR);
+  constexpr int NT = ar_nta(AR);
   const sar_pack_item it = items[blockIdx.y];
   const float wscale = ar_f16(AR) ? __builtin_ldexpf(1.f, scale_exp(item_amax[blockIdx.y])) : 1.f;
   const int64_t n = (int64_t)it.taps * it.G * it.M;
@@ -228,7 +238,7 @@ __global__ void pack_split_kernel(const float* __restrict__ base, const sar_pack
     v[j] = c < it.Kc ? W[c * it.sc] : 0.f;
   }
   uint4 t[NT];
-  split8<AR>(v, t, wscale);
+  split8<AR, true>(v, t, wscale);
 #pragma unroll
   for (int i = 0; i < NT; ++i) out[it.dst_unit + i * n + u] = t[i];
 }
@@ -246,14 +256,14 @@ struct ConvKS {
 // staged window of a stride-2 forward tile (27 frames) instead of 18.
 template <int TR, int AR, int WIDE>
 __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_gemm_split_kernel(const ConvKS k) {
-  constexpr int NT = ar_nt(AR), NPROD = ar_nprod(AR), NACC = ar_two_acc(AR) ? 2 : 1;
+  constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), NACC = ar_two_acc(AR) ? 2 : 1;
   constexpr bool SCALED = ar_f16(AR);   // the accumulators carry the operand scales: bias joins at the end
   constexpr int TAPS = 9, BM = 64, MS = 2, NS = 2, WN = 4, V = VJ;
   constexpr int PAR = (TR == 3);
   constexpr int ZCOL = WIDE ? 27 * V : 18 * V, SCOLS = ZCOL + 1;
   constexpr int CJ = (ZCOL + 255) / 256;
-  constexpr int WPIECES = NT * TAPS, ZSLOT = WPIECES * 64;   // weight pieces of 64 units, then the zero slot
-  constexpr int WU = ZSLOT + 64, SU = NT * SCOLS;
+  constexpr int WPIECES = NTA * TAPS, ZSLOT = WPIECES * 64;   // weight pieces of 64 units, then the zero slot
+  constexpr int WU = ZSLOT + 64, SU = NTB * SCOLS;
   constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area aliases the image
   constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
   constexpr int PPW = (WPIECES + 3) / 4;      // weight pieces per wave
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     if (d.pro_scale && tid < d.Kc) p = make_float2(d.pro_scale[tid] * h3_sa, d.pro_shift[tid] * h3_sa);
     bnp[tid] = p;
   }
-  if (tid < NT) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < NTB) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
   if (tid >= 64 && tid < 128) Wl[ZSLOT + tid - 64] = make_uint4(0u, 0u, 0u, 0u);
   f32x16 acc[NACC][MS][NS];
 
@@ -397,16 +407,16 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
         const float val = fmaxf(fmaf(sreg[j][q], psc[q], psh[q]), relu_lo);
         v[q] = (sok[j] && c0 + q < d.Kc) ? val : 0.f;   // TF-SAME padding stays exactly 0 behind the folded BatchNorm
       }
-      uint4 u[NT];
-      split8<AR>(v, u, 1.f);
+      uint4 u[NTB];
+      split8<AR, false>(v, u, 1.f);
       if ((j + 1) * 256 <= ZCOL || tid + 256 * j < ZCOL) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) Sl[t * SCOLS + tid + 256 * j] = u[t];
+        for (int t = 0; t < NTB; ++t) Sl[t * SCOLS + tid + 256 * j] = u[t];
       }
     }
   };
   // ---- weight pieces by LDS-DMA: piece p = term * 9 + tap = 64 rows of one (term, tap) of channel group g
-  const unsigned wbytes = (unsigned)((int64_t)NT * TAPS * k.G * d.M * 16);
+  const unsigned wbytes = (unsigned)((int64_t)NTA * TAPS * k.G * d.M * 16);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
   const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;   // rows beyond M: rejected -> 0
   auto issue_w_dma = [&](int g) {
@@ -436,18 +446,18 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     }
 
   auto kstep = [&](int q, bool last) {
-    uint4 a[NT][MS], bq[NT][NS];
+    uint4 a[NTA][MS], bq[NTB][NS];
     int ao = abase + q * ASTEP;
     const bool dead = last && last_half && hi;   // this lane's half of the k-step has no tap
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTA; ++t)
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[dead ? ZSLOT + l31 + ms * 32 : t * (TAPS * 64) + ao + ms * 32];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       const int bo = dead ? ZCOL : boff[ns] + q * bstep[ns];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bq[t][ns] = Sl[t * SCOLS + bo];
+      for (int t = 0; t < NTB; ++t) bq[t][ns] = Sl[t * SCOLS + bo];
     }
 #pragma unroll
     for (int p = 0; p < NPROD; ++p) {
@@ -511,6 +521,303 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
   epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc[0], rowp, smem);
 }
 
+// ---- GraphConvTD (models/gcn.py:199-209) and its data gradient in the split arithmetics:
+//   out[m, (t,w)] = sum_k sum_c W_k[c][m] z_k[c, (t,w)] + sum_k b_k[m] colsum(A_k)[w],   z_k[c, (t,w)] = sum_v x[c, (t,v)] A_k[v, w]
+// The adjacency is applied when the operand is READ (the bf16 engine's conv_graph_cn8.hip, round 4): of the 3 V gather lists of the
+// NTU graph most are {one entry of weight 1} -- the B fragment of slice k for column (t, w) is then the unit of the RAW tile at joint
+// idx_k(w) -- or empty (the always-zero unit); the few others (2 forward, 8 transposed) become VIRTUAL joints behind the raw
+// columns: z formed in fp32 (the fp32 kernel's fma chain) from <= 4 gathered columns, then split like any other column.  So only
+// ONE image per term is staged, whatever the slice.  Stage = 16 src channels (lanes 0-31 multiply channels 0-7, lanes 32-63
+// channels 8-15 of the stage), three k-steps = the three slices.  The caller asserts the list structure (SAR_GRAPH_FEW_DENSE with
+// <= 16 such lists); no folded prologue (the engines have none in front of a graph convolution).
+template <int AR>
+__global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k) {
+  constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), NACC = ar_two_acc(AR) ? 2 : 1;
+  constexpr bool SCALED = ar_f16(AR);
+  constexpr int BM = 64, MS = 2, NS = 2, WN = 4, V = VJ, FTG = 10, NVMAX = 16, KC16 = 16;
+  constexpr int VCOL0 = 256, ZCOL = VCOL0 + NVMAX * FTG, SC = ZCOL + 1;
+  constexpr int WPIECES = NTA * 6, WU = WPIECES * 64, SU = NTB * 2 * SC;   // weight pieces [term][slice][half][64 rows]; source [term][half][column]
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;
+  constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
+  constexpr int PPW = (WPIECES + 3) / 4;
+  __shared__ uint4 smem_u[IMG_U + BM];
+  __shared__ int vmap[3 * V + 1];          // list (k, w) -> raw joint | V + virtual joint | -1 (empty)
+  __shared__ int vl_idx[NVMAX * 4];        // the virtual joints' gather entries
+  __shared__ float vl_wt[NVMAX * 4];
+  __shared__ int nd_s[2];
+  __shared__ float gs_s[2];                // largest sum of |weights| of a gather list (per classifying wave)
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + WU;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave;
+  const int ny = k.ny, nwork = k.ntiles * ny;
+  int w = blockIdx.x;
+  {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;
+  }
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+  const int nfr = (t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0;   // live frames of this tile
+  const int ncols = nfr * V;
+
+  // ---- classify the 3 V gather lists (threads 0 .. 3 V - 1, two waves)
+  int l_idx[4] = {0, 0, 0, 0};
+  float l_wt[4] = {0.f, 0.f, 0.f, 0.f};
+  int cnt = 0, first = 0;
+  bool dense = false;
+  if (tid < 3 * V) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      l_idx[j] = d.g_idx[tid * 4 + j];
+      l_wt[j] = d.g_wt[tid * 4 + j];
+    }
+#pragma unroll
+    for (int j = 3; j >= 0; --j)
+      if (l_wt[j] != 0.f) {
+        ++cnt;
+        first = j;
+      }
+    dense = cnt > 1 || (cnt == 1 && l_wt[first] != 1.f);
+  }
+  const unsigned long long dmask = __ballot(dense);
+  const int rank_w = __popcll(dmask & ((1ull << lane) - 1ull));
+  float lsum = fabsf(l_wt[0]) + fabsf(l_wt[1]) + fabsf(l_wt[2]) + fabsf(l_wt[3]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) lsum = fmaxf(lsum, __shfl_xor(lsum, o));
+  if (lane == 0 && wave < 2) {
+    nd_s[wave] = __popcll(dmask);
+    gs_s[wave] = lsum;
+  }
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) {
+      bp.x = d.bias[row];
+      bp.y = d.bias[d.M + row];
+      bp.z = d.bias[2 * d.M + row];
+    }
+    rowp[tid] = bp;
+  }
+  if (tid < 2 * NTB) Sl[tid * SC + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const int nd_raw = nd_s[0] + nd_s[1];
+  const int nd = nd_raw < NVMAX ? nd_raw : NVMAX;   // (the host refuses tables with more)
+  if (tid < 3 * V) {
+    const int rank = (wave == 1 ? nd_s[0] : 0) + rank_w;
+    int code = -1;
+    if (dense && rank < NVMAX) {
+      code = V + rank;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vl_idx[rank * 4 + j] = l_idx[j];
+        vl_wt[rank * 4 + j] = l_wt[j];
+      }
+    } else if (cnt == 1) code = l_idx[first];
+    vmap[tid] = code;
+  }
+  __syncthreads();
+
+  // ---- per-lane column geometry and the three slices' operand columns
+  bool colok[NS];
+  int64_t coln[NS];
+  float gcs[3][NS];
+  int baddr[3][NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    colok[ns] = p < ncols;
+    const int pv = colok[ns] ? p : 0;
+    coln[ns] = ((int64_t)b * d.T_out + t0) * V + pv;
+    const int fo = pv / V, v = pv - fo * V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      gcs[tp][ns] = (d.g_colsum && colok[ns]) ? d.g_colsum[tp * V + v] : 0.f;
+      const int code = vmap[tp * V + v];
+      int col = ZCOL;
+      if (colok[ns] && code >= 0) col = code < V ? fo * V + code : VCOL0 + fo * nd + (code - V);
+      baddr[tp][ns] = col + hi * SC;
+    }
+  }
+
+  int ea = 0, ew = 0;
+  if (SCALED) {   // a virtual joint is a weighted SUM of <= 4 source values: the bound of what is staged is bound(src) x max sum |weights|
+    const float gmax = fmaxf(fmaxf(gs_s[0], gs_s[1]), 1.f);
+    ea = scale_exp(__float_as_uint(__uint_as_float(*k.src_bound) * gmax));
+    ew = scale_exp(*k.w_bound);
+  }
+  const float sa = __builtin_ldexpf(1.f, ea);
+  f32x16 acc[NACC][MS][NS];
+
+  // ---- source staging.  Raw columns: thread = column, both channel halves.  Virtual joints: thread = (virtual column, half).
+  const int seq_len = d.T_src * V;
+  const float* src_t = d.src + ((int64_t)b * d.T_src + t0) * V;
+  const unsigned tile_bytes = (unsigned)(seq_len - t0 * V) * 4;
+  const int svo = tid < ncols ? tid * 4 : 0x7fffffff;   // rejected -> 0
+  const int vt = tid >> 1, vh = tid & 1;
+  const bool vact = vt < nfr * nd;
+  int vvo[4];
+  float vwt[4];
+  {
+    const int tf = nd > 0 ? vt / (nd > 0 ? nd : 1) : 0;
+    const int l = vt - tf * nd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vwt[j] = vact ? vl_wt[l * 4 + j] : 0.f;
+      vvo[j] = (vact && vwt[j] != 0.f) ? (tf * V + vl_idx[l * 4 + j]) * 4 : 0x7fffffff;
+    }
+  }
+  float sreg[2][8], vreg[4][8];
+  auto issue_s_loads = [&](int c0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + 8 * h + q;
+        const int cg = c < d.Kc ? c : 0;   // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_t + (int64_t)cg * d.ld_src), 0, tile_bytes, 0x00020000);
+        sreg[h][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo, 0, 0));
+      }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {   // (per-lane channel: the descriptor is per lane -> plain pointers through one whole-tile descriptor)
+      const int c = c0 + 8 * vh + q;
+      const int cg = c < d.Kc ? c : 0;
+      const float* row = src_t + (int64_t)cg * d.ld_src;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vreg[j][q] = (vvo[j] != 0x7fffffff) ? row[vvo[j] >> 2] : 0.f;
+    }
+  };
+  auto store_s = [&](int c0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float x = SCALED ? sreg[h][q] * sa : sreg[h][q];
+        v[q] = (tid < ncols && c0 + 8 * h + q < d.Kc) ? x : 0.f;
+      }
+      uint4 u[NTB];
+      split8<AR, false>(v, u, 1.f);
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) Sl[(t * 2 + h) * SC + tid] = u[t];
+    }
+    if (vact) {   // z = sum_j wt_j x_j: the fp32 kernel's chain (conv_gemm.hip), then the split
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float z = vwt[0] * vreg[0][q];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) z = fmaf(vwt[j], vreg[j][q], z);
+        z = SCALED ? z * sa : z;
+        v[q] = (c0 + 8 * vh + q < d.Kc) ? z : 0.f;
+      }
+      uint4 u[NTB];
+      split8<AR, false>(v, u, 1.f);
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) Sl[(t * 2 + vh) * SC + VCOL0 + vt] = u[t];
+    }
+  };
+  // weight pieces by LDS-DMA: piece p = (term * 3 + slice) * 2 + half = 64 rows of channel group g0 + half
+  const unsigned wbytes = (unsigned)((int64_t)NTA * 3 * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;
+  auto issue_w_dma = [&](int g0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + 4 * i;   // wave-uniform
+      if (p < WPIECES) {
+        const int ts = p >> 1, h = p & 1;   // ts = term * 3 + slice
+        const int g = g0 + h;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + p * 64), 16, g < k.G ? wvo : 0x80000000u, (ts * k.G + g) * d.M * 16, 0, 0);
+      }
+    }
+  };
+
+  issue_s_loads(0);
+  issue_w_dma(0);
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 bp = rowp[ms * 32 + mfma_row(r, hi)];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        if (!SCALED) acc[0][ms][ns][r] = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
+        else acc[0][ms][ns][r] = 0.f, acc[NACC - 1][ms][ns][r] = 0.f;
+      }
+    }
+
+  const int abase = hi * 64 + l31;
+  // Happens-before of the single image: as conv_gemm_split_kernel (store_s / DMA behind the closing barrier, the opening barrier
+  // behind every wave's ds_writes and vmcnt(0))
+  const int nst = (d.Kc + KC16 - 1) / KC16;
+  for (int s_ = 0; s_ < nst; ++s_) {
+    store_s(s_ * KC16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // opening
+    if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC16);
+    SAR_LDS_SKEW();
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      uint4 a[NTA][MS], bq[NTB][NS];
+#pragma unroll
+      for (int t = 0; t < NTA; ++t)
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[(t * 3 + tp) * 128 + abase + ms * 32];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) bq[t][ns] = Sl[t * 2 * SC + baddr[tp][ns]];
+#pragma unroll
+      for (int p = 0; p < NPROD; ++p) {
+        const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+        const int ai = (NACC == 2 && i + j > 0) ? 1 : 0;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            if (ar_f16(AR))
+              acc[ai][ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8*>(&a[i][ms]),
+                                                                       *reinterpret_cast<f16x8*>(&bq[j][ns]), acc[ai][ms][ns], 0, 0, 0);
+            else
+              acc[ai][ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[i][ms]),
+                                                                        *reinterpret_cast<bf16x8*>(&bq[j][ns]), acc[ai][ms][ns], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();   // closing
+    if (s_ + 1 < nst) issue_w_dma(2 * (s_ + 1));
+  }
+
+  if (SCALED) {
+    const float c0 = __builtin_ldexpf(1.f, -(ea + ew)), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 bp = rowp[ms * 32 + mfma_row(r, hi)];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const float bias = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
+          const float v = fmaf(acc[NACC - 1][ms][ns][r], c1, acc[0][ms][ns][r] * c0) + bias;
+          acc[0][ms][ns][r] = colok[ns] ? v : 0.f;
+        }
+      }
+    __syncthreads();   // every wave has read its bias rows: the gated epilogue rewrites rowp
+  }
+  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc[0], rowp, smem);
+}
+
 int geometry_s(const sar_conv_desc& d, int tr, ConvKS& k) {
   const int TAPS = 9;
   k.FT = 10;                                 // 256 / 25, parity split: 2 * (128 / 25)
@@ -520,7 +827,8 @@ int geometry_s(const sar_conv_desc& d, int tr, ConvKS& k) {
   } else if (k.FT > d.T_out) k.FT = d.T_out;
   k.TPS = (d.T_out + k.FT - 1) / k.FT;
   int nf;
-  if (tr == 0) nf = (k.FT - 1) * d.stride + TAPS;
+  if (tr == 4) nf = k.FT;
+  else if (tr == 0) nf = (k.FT - 1) * d.stride + TAPS;
   else if (tr == 1) nf = k.FT + TAPS - 1;
   else nf = (k.FT - 1 + TAPS - 1) / 2 + 2;
   k.RW = nf * d.V;
@@ -531,8 +839,15 @@ int geometry_s(const sar_conv_desc& d, int tr, ConvKS& k) {
   return 0;
 }
 
-// which kernel a descriptor takes: 0 / 1 / 3 (TR), or -1 = not built (the caller keeps sar_conv_gemm_f32)
+// which kernel a descriptor takes: 0 / 1 / 3 (TR), 4 = graph, or -1 = not built (the caller keeps sar_conv_gemm_f32)
 int split_tr(const sar_conv_desc& d) {
+  if (d.mode == SAR_CONV_GRAPH) {
+    const int ndense = (d.g_flags >> SAR_GRAPH_FEW_DENSE_SHIFT) & 0xff;
+    if (d.taps != 3 || d.V != VJ || d.T_src != d.T_out || d.pro_scale) return -1;
+    if (!(d.g_flags & SAR_GRAPH_FEW_DENSE) || ndense > 16) return -1;
+    if (d.Kc < 16 || d.Kc > 256 || (d.Kc & 15) || (d.M & 7)) return -1;
+    return 4;
+  }
   if (d.mode != SAR_CONV_TEMPORAL || d.taps != 9 || d.V != VJ) return -1;
   if (d.Kc < 8 || d.Kc > 256 || (d.M & 7)) return -1;
   if (!d.transposed) return (d.stride == 1 || d.stride == 2) ? 0 : -1;
@@ -550,20 +865,23 @@ int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned
   k.w_bound = w_bound;
   geometry_s(d, tr, k);
   const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
-  if (tr == 0 && d.stride == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 0>), grid, block, 0, st, k);
+  if (tr == 4) {
+    if constexpr (AR == AR_B6 || AR == AR_H3A) hipLaunchKernelGGL((conv_graph_split_kernel<AR>), grid, block, 0, st, k);
+    else return SAR_E_UNSUP;
+  } else if (tr == 0 && d.stride == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 0>), grid, block, 0, st, k);
   else if (tr == 0) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 1>), grid, block, 0, st, k);
   else if (tr == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<1, AR, 0>), grid, block, 0, st, k);
   else hipLaunchKernelGGL((conv_gemm_split_kernel<3, AR, 0>), grid, block, 0, st, k);
   return 0;
 }
 
-bool ar_known(int ar) { return ar == AR_B1 || ar == AR_B3 || ar == AR_B6 || ar == AR_B9 || ar == AR_H3 || ar == AR_H3S; }
+bool ar_known(int ar) { return ar == AR_B1 || ar == AR_B3 || ar == AR_B6 || ar == AR_B9 || ar == AR_H3 || ar == AR_H3S || ar == AR_H3A; }
 
 }  // namespace
 
 extern "C" int64_t sar_conv_gemm_split_workspace_bytes(const sar_conv_desc* d, int arith) {
   if (!d || d->Kc <= 0 || d->M <= 0 || d->taps <= 0 || !ar_known(arith)) return SAR_E_ARG;
-  return (int64_t)ar_nt(arith) * d->taps * ((d->Kc + 7) / 8) * d->M * 16;
+  return (int64_t)ar_nta(arith) * d->taps * ((d->Kc + 7) / 8) * d->M * 16;
 }
 
 extern "C" int sar_conv_gemm_split_nparts(const sar_conv_desc* d) {
@@ -619,6 +937,7 @@ extern "C" int sar_pack_weights_split_batch(const float* base, const sar_pack_it
     case AR_B6: hipLaunchKernelGGL(pack_split_kernel<AR_B6>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
     case AR_B9: hipLaunchKernelGGL(pack_split_kernel<AR_B9>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
     case AR_H3S: hipLaunchKernelGGL(pack_split_kernel<AR_H3S>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
+    case AR_H3A: hipLaunchKernelGGL(pack_split_kernel<AR_H3A>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
     default: hipLaunchKernelGGL(pack_split_kernel<AR_H3>, grid, block, 0, as_stream(s), base, items, item_amax, (uint4*)out); break;
   }
   SAR_LAUNCH_CHECK("sar_pack_weights_split_batch");
@@ -639,7 +958,13 @@ extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void
                   d->mode, d->taps, d->V, d->stride, d->Kc, d->M);
     return SAR_E_UNSUP;
   }
-  SAR_REQUIRE(d->stride >= 1 && d->pad >= 0 && d->pad <= 8, "sar_conv_gemm_split: bad stride/pad");
+  if (tr == 4) {
+    SAR_REQUIRE(d->g_idx && d->g_wt, "sar_conv_gemm_split: graph gather tables required");
+    SAR_REQUIRE(!d->bias || d->g_colsum, "sar_conv_gemm_split: graph bias needs g_colsum");
+    SAR_REQUIRE(arith == AR_B6 || arith == AR_H3A, "sar_conv_gemm_split: the graph kernel is built for bf16x6 / f16x3a");
+  } else {
+    SAR_REQUIRE(d->stride >= 1 && d->pad >= 0 && d->pad <= 8, "sar_conv_gemm_split: bad stride/pad");
+  }
   SAR_REQUIRE(d->src && d->out, "sar_conv_gemm_split: null src/out");
   SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_out >= (int64_t)d->B * d->T_out * d->V,
               "sar_conv_gemm_split: leading dimension smaller than B*T*V");
@@ -647,21 +972,28 @@ extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void
   SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 28), "sar_conv_gemm_split: sequence row too long");
   SAR_REQUIRE(d->ld_out < (1 << 22) && d->ld_aux < (1 << 22), "sar_conv_gemm_split: leading dimension too large (2^22 columns)");
   SAR_REQUIRE(sar_conv_gemm_split_workspace_bytes(d, arith) < (1ll << 31), "sar_conv_gemm_split: weight tensor too large");
-  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv_gemm_split: bad epilogue %d", d->epi);
-  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv_gemm_split: partials required");
-  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
+  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD_GATE, "sar_conv_gemm_split: bad epilogue %d", d->epi);
+  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD_GATE)
+    SAR_REQUIRE(d->partials, "sar_conv_gemm_split: partials required");
+  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD || d->epi == SAR_EPI_ADD_GATE)
     SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm_split: aux required");
+  if (d->epi == SAR_EPI_ADD_GATE)
+    SAR_REQUIRE(tr == 4 && d->aux2 && d->aux_mask && (d->ld_aux2 & 3) == 0 && d->ld_aux2 >= (int64_t)d->B * d->T_out * d->V &&
+                d->ld_aux2 < (1 << 22), "sar_conv_gemm_split: SAR_EPI_ADD_GATE is the graph data gradient's, with aux2 / aux_mask, ld_aux2 %% 4 == 0");
   if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->aux_scale && d->aux_shift, "sar_conv_gemm_split: aux affine required");
   const uint4* wp = (const uint4*)packed;
   hipStream_t st = as_stream(s);
+  int rc = 0;
   switch (arith) {
-    case AR_B1: launch_split<AR_B1>(*d, tr, wp, src_bound, w_bound, st); break;
-    case AR_B3: launch_split<AR_B3>(*d, tr, wp, src_bound, w_bound, st); break;
-    case AR_B6: launch_split<AR_B6>(*d, tr, wp, src_bound, w_bound, st); break;
-    case AR_B9: launch_split<AR_B9>(*d, tr, wp, src_bound, w_bound, st); break;
-    case AR_H3S: launch_split<AR_H3S>(*d, tr, wp, src_bound, w_bound, st); break;
-    default: launch_split<AR_H3>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_B1: rc = launch_split<AR_B1>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_B3: rc = launch_split<AR_B3>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_B6: rc = launch_split<AR_B6>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_B9: rc = launch_split<AR_B9>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_H3S: rc = launch_split<AR_H3S>(*d, tr, wp, src_bound, w_bound, st); break;
+    case AR_H3A: rc = launch_split<AR_H3A>(*d, tr, wp, src_bound, w_bound, st); break;
+    default: rc = launch_split<AR_H3>(*d, tr, wp, src_bound, w_bound, st); break;
   }
+  if (rc) return rc;
   SAR_LAUNCH_CHECK("sar_conv_gemm_split");
   return 0;
 }

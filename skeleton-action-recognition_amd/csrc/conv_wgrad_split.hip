@@ -6,7 +6,7 @@
 //
 // Same slab contract as sar_conv_wgrad_f32 (include/sar_hip.h): slab[s][wsize + bsize], summed by sar_slab_reduce_f32 in slab
 // order (deterministic, no atomics).  Every fp32 operand element enters the matrix pipe as two fp16 terms of its scaled value
-// (f16x3s: three products per fp32 product) or three bfloat16 terms (bf16x6: six products); products are exact, accumulation fp32.
+// (f16x3a: three products per fp32 product, conv_gemm_split.hip) or three bfloat16 terms (bf16x6: six products); products are exact, accumulation fp32.
 //
 // Design (MI355X):
 //  * the contraction runs over positions n = (t, v) of one sequence, the contiguous axis of both operands in the CN layout: a
@@ -20,8 +20,8 @@
 //    bytes (v_alignbyte_b32) for odd taps.  Row stride / 2 is odd: the 32 rows of a fragment read hit distinct banks.
 //  * the dout fragment of a k-step is the same for all nine taps: each wave loads its 32 rows x 16 positions straight from
 //    global memory into registers one k-step ahead (two 16-byte loads per lane), sums them for the bias gradient, splits them
-//    in registers.  No LDS for dout: the image of a 240-position tile stays at 57 KB -- two workgroups per CU.
-//  * per k-step and wave: 27 MFMAs (f16x3s), ~80 vector instructions (split of dout, funnel shifts, bias sums), 81 dword LDS
+//    in registers.  No LDS for dout: the three src images of a 192-position tile take 76 KB -- two workgroups per CU.
+//  * per k-step and wave: 27 MFMAs (f16x3a), ~80 vector instructions (split of dout, funnel shifts, bias sums), 81 dword LDS
 //    reads.
 #include "sar_common.h"
 #include <type_traits>
@@ -35,22 +35,26 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int VJ = 25, TAPS = 9, CB = 32;
-constexpr int AR_B6 = SAR_SPLIT_BF16X6, AR_H3S = SAR_SPLIT_F16X3S;
-constexpr bool ar_f16(int ar) { return ar == AR_H3S; }
-constexpr int ar_nt(int ar) { return ar == AR_H3S ? 2 : 3; }
-constexpr int ar_nprod(int ar) { return ar == AR_H3S ? 3 : 6; }
+constexpr int AR_B6 = SAR_SPLIT_BF16X6, AR_H3A = SAR_SPLIT_F16X3A;
+constexpr float H3_LO = 2048.f;
+constexpr bool ar_f16(int ar) { return ar == AR_H3A; }
+// f16x3a (conv_gemm_split.hip): the well-conditioned operand -- here the src activation behind its BatchNorm + ReLU, scaled from
+// the Samuelson bound -- carries three images (a0, a1, a0 2^-11), the wide-range operand -- dout, a gradient -- two (d0, d1 2^11)
+constexpr int ar_nta(int ar) { return 3; }
+constexpr int ar_ntb(int ar) { return ar == AR_H3A ? 2 : 3; }
+constexpr int ar_nprod(int ar) { return ar == AR_H3A ? 3 : 6; }
 // product p: (src term, dout term), smallest magnitude first (conv_gemm_split.hip)
 constexpr int ar_pi(int ar, int p) {
   constexpr int i6[6] = {0, 2, 1, 0, 1, 0};
-  return ar == AR_H3S ? (p == 1 ? 1 : 0) : i6[p];
+  return ar == AR_H3A ? 2 - p : i6[p];
 }
 constexpr int ar_pj(int ar, int p) {
   constexpr int j6[6] = {2, 0, 1, 1, 0, 0};
-  return ar == AR_H3S ? (p == 0 ? 1 : 0) : j6[p];
+  return ar == AR_H3A ? (p == 0 ? 1 : 0) : j6[p];
 }
 template <int AR> struct Cfg {
-  static constexpr int NT = ar_nt(AR);
-  static constexpr int KT = NT == 2 ? 240 : 112;        // positions per tile (multiple of 16)
+  static constexpr int NT = ar_nta(AR);                 // src images in LDS
+  static constexpr int KT = 192;                         // positions per tile (multiple of 16): 3 x 32 x 394 x 2 B = 75.6 KB
   static constexpr int KS = KT / 16;
   static constexpr int WIN = KT + (TAPS - 1) * VJ;       // src window
   static constexpr int RS = ((WIN + 2 + 1) / 2 * 2) + ((((WIN + 2 + 1) / 2) & 1) ? 0 : 2);   // row stride (elements): >= WIN + 2, RS / 2 odd
@@ -76,10 +80,10 @@ __device__ __forceinline__ unsigned pk_f16(float x, float y) {
   p[1] = (_Float16)y;
   return *reinterpret_cast<unsigned*>(&p);
 }
-// two adjacent (already scaled) values -> one dword per term
-template <int AR>
-__device__ __forceinline__ void split2(float x, float y, unsigned (&w)[ar_nt(AR)]) {
-  constexpr int NT = ar_nt(AR);
+// two adjacent (already scaled) values -> one dword per term.  WSIDE: the conditioned operand's images (src), else dout's
+template <int AR, bool WSIDE>
+__device__ __forceinline__ void split2(float x, float y, unsigned (&w)[WSIDE ? ar_nta(AR) : ar_ntb(AR)]) {
+  constexpr int NT = WSIDE ? ar_nta(AR) : ar_ntb(AR);
   if constexpr (ar_f16(AR)) {
     x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
     y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
@@ -87,7 +91,12 @@ __device__ __forceinline__ void split2(float x, float y, unsigned (&w)[ar_nt(AR)
     h[0] = (_Float16)x;
     h[1] = (_Float16)y;
     w[0] = *reinterpret_cast<unsigned*>(&h);
-    w[1] = pk_f16(x - (float)h[0], y - (float)h[1]);
+    if constexpr (WSIDE) {
+      w[1] = pk_f16(x - (float)h[0], y - (float)h[1]);
+      w[2] = pk_f16((float)h[0] * (1.f / H3_LO), (float)h[1] * (1.f / H3_LO));
+    } else {
+      w[1] = pk_f16((x - (float)h[0]) * H3_LO, (y - (float)h[1]) * H3_LO);
+    }
   } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -112,7 +121,7 @@ struct WgradKS {
 template <int AR, int WK>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS k) {
   using C = Cfg<AR>;
-  constexpr int NT = C::NT, NPROD = ar_nprod(AR), KT = C::KT, KS = C::KS, WIN = C::WIN, RS = C::RS, NCH = C::NCH, V = VJ;
+  constexpr int NT = C::NT, NTB = ar_ntb(AR), NPROD = ar_nprod(AR), KT = C::KT, KS = C::KS, WIN = C::WIN, RS = C::RS, NCH = C::NCH, V = VJ;
   constexpr int WMM = 4 / WK, MBLK = 32 * WMM;
   __shared__ __attribute__((aligned(16))) unsigned short Hs[NT * CB * RS];
   __shared__ float2 bnp[256];
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
             const float v0 = ok0 ? fmaxf(fmaf(x[q][j][0], ps.x, ps.y), relu_lo) : 0.f;   // TF-SAME padding stays exactly 0
             const float v1 = ok1 ? fmaxf(fmaf(x[q][j][1], ps.x, ps.y), relu_lo) : 0.f;
             unsigned w[NT];
-            split2<AR>(v0, v1, w);
+            split2<AR, true>(v0, v1, w);
             if (col < RS) {
 #pragma unroll
               for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
@@ -255,13 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
 #pragma unroll
             for (int j = 0; j < 8; ++j) bsum += dv[j];
           }
-          unsigned bw[NT][4];
+          unsigned bw[NTB][4];
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
-            unsigned w[NT];
-            split2<AR>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
+            unsigned w[NTB];
+            split2<AR, false>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bw[t][p] = w[t];
+            for (int t = 0; t < NTB; ++t) bw[t][p] = w[t];
           }
           const unsigned a_ks = a_base + kc * 32;
 #pragma unroll
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
 
 // which kernel: WK (1 or 2), or 0 = not built (the caller keeps sar_conv_wgrad_f32)
 int wgrad_split_wk(const sar_wgrad_desc& d, int arith) {
-  if (arith != AR_B6 && arith != AR_H3S) return 0;
+  if (arith != AR_B6 && arith != AR_H3A) return 0;
   if (d.mode != SAR_CONV_TEMPORAL || d.taps != TAPS || d.V != VJ || d.stride != 1 || d.T_src != d.T_out) return 0;
   if (d.Kc < 8 || d.Kc > 256 || d.pad < 0 || d.pad > 8) return 0;
   return d.M > 64 ? 1 : 2;
@@ -347,7 +356,7 @@ extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, i
   const int wk = wgrad_split_wk(*d, arith);
   if (!wk) return SAR_E_UNSUP;
   if (wk_out) *wk_out = wk;
-  if (tile_positions) *tile_positions = arith == AR_H3S ? Cfg<AR_H3S>::KT : Cfg<AR_B6>::KT;
+  if (tile_positions) *tile_positions = arith == AR_H3A ? Cfg<AR_H3A>::KT : Cfg<AR_B6>::KT;
   return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
 }
 
@@ -357,7 +366,7 @@ extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const ui
   const int wk = wgrad_split_wk(*d, arith);
   if (!wk) {
     sar_set_error("sar_conv_wgrad_split: built for the 9-tap temporal convolution at V = 25, stride 1, 8 <= Kc <= 256 in the "
-                  "arithmetics bf16x6 / f16x3s (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
+                  "arithmetics bf16x6 / f16x3a (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
                   d->mode, d->taps, d->V, d->stride, d->Kc, arith);
     return SAR_E_UNSUP;
   }
@@ -371,8 +380,8 @@ extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const ui
   SAR_REQUIRE((int64_t)d->M * d->ld_dout * 4 < 0xf0000000ll, "sar_conv_wgrad_split: dout larger than 3.75 GiB");
   SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_wgrad_split: pro_scale/pro_shift mismatch");
   SAR_REQUIRE(d->wsize > 0 && (d->bsize == 0 || d->bsize == d->M), "sar_conv_wgrad_split: bad slab sizes");
-  SAR_REQUIRE(arith != AR_H3S || (src_bound && dout_bound), "sar_conv_wgrad_split: the fp16 arithmetic needs the operand bounds");
-  if (arith == AR_H3S) launch_wgrad_split<AR_H3S>(*d, wk, src_bound, dout_bound, as_stream(s));
+  SAR_REQUIRE(arith != AR_H3A || (src_bound && dout_bound), "sar_conv_wgrad_split: the fp16 arithmetic needs the operand bounds");
+  if (arith == AR_H3A) launch_wgrad_split<AR_H3A>(*d, wk, src_bound, dout_bound, as_stream(s));
   else launch_wgrad_split<AR_B6>(*d, wk, src_bound, dout_bound, as_stream(s));
   SAR_LAUNCH_CHECK("sar_conv_wgrad_split");
   return 0;

@@ -88,7 +88,7 @@ class PackedSplitWeights(PackedWeights):
     items as PackedWeights with channel groups of 8 and `terms` images per item, refreshed by ONE call per step; the fp16
     arithmetics also get every item's amax (the bits of a float, device memory) = its `w_bound`."""
 
-    TERMS = {"bf16x1": 1, "bf16x3": 2, "bf16x6": 3, "bf16x9": 3, "f16x3": 2, "f16x3s": 2}
+    TERMS = {"bf16x1": 1, "bf16x3": 2, "bf16x6": 3, "bf16x9": 3, "f16x3": 2, "f16x3s": 2, "f16x3a": 3}
 
     def __init__(self, arith):
         super().__init__()
@@ -137,8 +137,11 @@ def affine_bound(scale, shift, src_cell, cell):
 DEFAULT_SPLIT = None
 
 
-def split_applicable(mode, V, Kc, M, taps, stride):
+def split_applicable(mode, V, Kc, M, taps, stride, tables=None, pro=None):
     """shapes csrc/conv_gemm_split.hip is built for (the others stay on the fp32 kernels)"""
+    if mode == L.SAR_CONV_GRAPH:       # read-gather graph kernel: few non-trivial gather lists, no folded prologue, 16-channel stages
+        return (taps == 3 and V == 25 and 16 <= Kc <= 256 and Kc % 16 == 0 and M % 8 == 0 and pro is None and tables is not None
+                and bool(tables.g_flags & L.SAR_GRAPH_FEW_DENSE) and tables.n_dense_lists <= 16)
     return mode == L.SAR_CONV_TEMPORAL and taps == 9 and V == 25 and 8 <= Kc <= 256 and M % 8 == 0 and stride in (1, 2)
 
 
@@ -173,7 +176,10 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     lib = L.load()
     if split == "default":
         split = DEFAULT_SPLIT
-    split = split if (split and split_applicable(mode, V, Kc, M, taps, stride) and epi != L.SAR_EPI_ADD_GATE) else None
+    split = split if (split and split_applicable(mode, V, Kc, M, taps, stride, tables, pro)
+                      and (epi != L.SAR_EPI_ADD_GATE or mode == L.SAR_CONV_GRAPH)) else None
+    if split and mode == L.SAR_CONV_GRAPH and split not in ("bf16x6", "f16x3a"):
+        split = None
     if split:
         bf16 = False
     d = ConvDesc()
@@ -197,6 +203,7 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
         d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
         for i in range(3):
             d.nz[i] = tables.nz[i]
+        d.g_flags = tables.g_flags
     if aux is not None:
         d.aux, d.ld_aux = ptr(_f32(aux)), aux.stride(0)
     if aux_affine is not None:
@@ -254,12 +261,12 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     d = WgradDesc()
     d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
     d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
-    # split="bf16x6" / "f16x3s": the split arithmetic of csrc/conv_wgrad_split.hip where it is built (bounds = (src_bound,
+    # split="bf16x6" / "f16x3a": the split arithmetic of csrc/conv_wgrad_split.hip where it is built (bounds = (src_bound,
     # dout_bound) cells for the fp16 arithmetic, None = computed here by device kernels); other shapes stay on the fp32 kernel
     if split == "default":
         split = DEFAULT_SPLIT
     sp_blocks = 0
-    if split in ("bf16x6", "f16x3s"):
+    if split in ("bf16x6", "f16x3a"):
         wk, kt = C.c_int(0), C.c_int(0)
         sp_blocks = lib.sar_conv_wgrad_split_blocks(C.byref(d), L.SAR_SPLIT[split], C.byref(wk), C.byref(kt))
         if sp_blocks > 0:

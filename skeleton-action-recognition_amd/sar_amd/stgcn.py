@@ -30,7 +30,9 @@ _WGRAD_DEFER_ENV = __import__("os").environ.get("SAR_WGRAD_DEFER")
 _FUSE_TAIL_F32 = __import__("os").environ.get("SAR_F32_FUSE_TAIL", "1") == "1"   # SAR_EPI_ADD_GATE in the fp32 graph data gradient
 # the arithmetic an STGCN built without an explicit `mfma` uses (the parity suites run once per value: tests/conftest.py)
 DEFAULT_MFMA = __import__("os").environ.get("SAR_MFMA", "fp32")
-SPLIT_ARITH = {"f32_split": "f16x3s", "f32_split_bf16x6": "bf16x6"}      # engine mode -> arithmetic of csrc/conv_gemm_split.hip
+SPLIT_ARITH = {"f32_split": "f16x3a", "f32_split_bf16x6": "bf16x6"}      # engine mode -> arithmetic of csrc/conv_gemm_split.hip
+# A/B switch: which kernel families of a split engine take the split kernels (default all that are built)
+_SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS", "tfwd,tdgrad,twgrad,gfwd,gdgrad,gwgrad").split(","))
 # (filters, stride, residual) -- models/stgcn.py:113-123
 BLOCKS = [(64, 1, False), (64, 1, True), (64, 1, True), (64, 1, True), (128, 2, True), (128, 1, True), (128, 1, True),
           (256, 2, True), (256, 1, True), (256, 1, True)]
@@ -191,9 +193,15 @@ class STGCN:
         self.spacked, self._cells = None, None
         if self.split:     # term images of the conv weights the split kernels take, both orientations, one refresh per step
             pk = ops.PackedSplitWeights(self.split)
+            cin = in_channels
             for i, (f, s_, res) in enumerate(self.blocks):
                 pre = "l%d." % i
-                ot = self.offsets[pre + "tcn.kernel"]
+                og, ot = self.offsets[pre + "gcn.kernel"], self.offsets[pre + "tcn.kernel"]
+                if ops.split_applicable(L.SAR_CONV_GRAPH, num_node, cin, f, KS, 1, self.tab_fwd):
+                    pk.add(pre + "gcn.f", og, f, KS * f, 1, KS, cin, f)          # (k, c, m) = kernel[c][k*F + m]
+                if ops.split_applicable(L.SAR_CONV_GRAPH, num_node, f, cin, KS, 1, self.tab_bwd):
+                    pk.add(pre + "gcn.b", og, f, 1, KS * f, KS, f, cin)          # (k, c', m') = kernel[m'][k*F + c']
+                cin = f
                 if ops.split_applicable(L.SAR_CONV_TEMPORAL, num_node, f, f, KT, s_):
                     pk.add(pre + "tcn.f", ot, f * f, f, 1, KT, f, f)             # (tap, c, m) = kernel[tap][c][m]
                     pk.add(pre + "tcn.b", ot, f * f, 1, f, KT, f, f)             # (tap, c', m') = kernel[tap][m'][c']
@@ -406,9 +414,12 @@ class STGCN:
                           M=KS * f, taps=1, stride=1, pad=0, bias=self.p[pre + "gcn.bias"])
             r1 = ops.graph_dense_fwd(y3, self.A, g, KS, f, V, B * T, stats=training)
         else:
+            gimg = self._simg(pre + "gcn.f") if training else None
+            if gimg is not None and self._f16:
+                ops.amax(X, self._cell(i, 3))       # the bound of the block input: graph convolution (src) and its weight gradient
             r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
-                               Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi, bf16=self.bf16,
-                               packed=self._img(pre + "gcn.f"))
+                               Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi,
+                               **self._split_args(gimg, self._cell(i, 3), self._img(pre + "gcn.f")))
         if training:
             self._bn_forward_stats(pre + "bn1", r1[0], r1[1], n_in, True, True)
         else:
@@ -463,6 +474,9 @@ class STGCN:
     def _simg(self, key):
         """(term images, w_bound cell) of a conv weight in split mode, else None"""
         pk = self.spacked
+        kind = {"tcn.f": "tfwd", "tcn.b": "tdgrad", "gcn.f": "gfwd", "gcn.b": "gdgrad"}[key.split(".", 1)[1]]
+        if kind not in _SPLIT_KINDS:
+            return None
         return (pk.image(key), pk.bound(key)) if pk is not None and key in pk.index else None
 
     def _cell(self, i, j):
@@ -618,7 +632,7 @@ class STGCN:
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
             pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
-            bf16=self.bf16, split=self.split if simg is not None else None,
+            bf16=self.bf16, split=self.split if (simg is not None and "twgrad" in _SPLIT_KINDS) else None,
             bounds=(self._cell(i, 0), self._cell(i, 1)) if self._f16 else None), g, du)
         wimg = self._img(pre + "tcn.b")
         wT = None
@@ -650,16 +664,19 @@ class STGCN:
             gT = self._wT[o:o + KS * f * cin]                             # [k][f][c]
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
+        sgimg = self._simg(pre + "gcn.b")
+        if sgimg is not None and self._f16:
+            ops.amax(dg, self._cell(i, 2))         # the bound of dg: graph data gradient (src) and weight gradient (dout)
         if below is not None and aux is not None:
             # dX = gate_{i-1}(W^T dg . A^T + skip gradient) and block i - 1's BatchNorm-backward sums in one epilogue
             bn2b = self.bn["l%d.bn2" % (i - 1)]
             pm = ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
                                tables=self.tab_bwd, epi=L.SAR_EPI_ADD_GATE, aux=aux, aux2=below["u"], aux_mask=below["ymask"],
-                               aux_mean=bn2b.mean)
+                               aux_mean=bn2b.mean, **self._split_args(sgimg, self._cell(i, 2), None))
             return dX, pm
         ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
-                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux, bf16=self.bf16,
-                      packed=gimg)
+                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux,
+                      **self._split_args(sgimg, self._cell(i, 2), gimg))
         return (dX, None) if fused_call else dX
 
     def _residual_backward(self, i, sb, dr, B):

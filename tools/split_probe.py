@@ -16,7 +16,7 @@ import torch  # noqa: E402
 from sar_amd import _lib as L, ops  # noqa: E402
 from sar_amd.stgcn import same_pad  # noqa: E402
 
-MODES = [None, "bf16x1", "bf16x3", "bf16x6", "bf16x9", "f16x3", "f16x3s"]
+MODES = [None, "bf16x1", "bf16x3", "bf16x6", "bf16x9", "f16x3", "f16x3s", "f16x3a"]
 
 
 def timeit(fn, reps):
