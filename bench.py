@@ -414,6 +414,36 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
                 "frac_of_bf16_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if (ims > 0 and bf16) else None}
             out["kernel_ms_per_step_isolated"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(iso.items())}
             out["wgrad_side_stream"] = True
+        if mfma in ("f32_split", "f32_split_bf16x6"):
+            # fp32 results on the fp16 / bf16 matrix pipe: the roof is that pipe's (2.5 PFLOP/s dense), priced on the MFMA FLOPs the
+            # kernels EXECUTE -- products per fp32 product (3 for f16x3a, 6 for bf16x6) x the 10 tap slots per 9 taps of the
+            # 9-tap kernels' k-steps -- never against the fp32 MFMA peak (a fraction > 1 there would read as work skipped)
+            nprod = 3 if mfma == "f32_split" else 6
+            exe = achieved * nprod * 10.0 / 9.0
+            isolated = out["roofline"].get("isolated")
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_split_kernel (9-tap temporal fwd + data-grad launches, %s); %s"
+                                                          % ("f16x3a" if nprod == 3 else "bf16x6", in_step),
+                               "achieved": round(exe, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
+                               "executed_over_algorithmic_flops": round(nprod * 10.0 / 9.0, 3),
+                               "fp32_equivalent_tflops": round(achieved, 2),
+                               "fp32_mfma_peak_for_reference": PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch, PMC passes of the PROFILED build (%s), not of this run" % traffic_src
+                                               if traffic else None,
+                               "algorithmic_bytes_per_launch": int(sum(summ[k]["bytes"] for k in fam) / max(calls, 1)),
+                               "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
+                               "step_fp32_equivalent_tflops": round(value / world * EXECUTED_FLOP_PER_CLIP_TRAIN / 1e12, 2)}
+            if isolated:
+                isolated = dict(isolated)
+                isolated.pop("frac_of_fp32_mfma_peak", None)
+                if isolated.get("tflops"):
+                    isolated["fp32_equivalent_tflops"] = isolated.pop("tflops")
+                    isolated["executed_tflops"] = round(isolated["fp32_equivalent_tflops"] * nprod * 10.0 / 9.0, 1)
+                    isolated["frac_of_bf16_mfma_peak"] = round(isolated["executed_tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
+                out["roofline"]["isolated"] = isolated
+            out["split_kernels"] = sorted(k for k in summ if k.endswith("_split"))
+            out["fp32_kernels_left"] = sorted(k for k in summ if not k.endswith("_split"))
         if bf16:   # which roof binds the family: the larger of (algorithmic FLOPs / 2.5 PFLOP/s dense bf16) and (algorithmic bytes / 8 TB/s)
             by = sum(summ[k]["bytes"] for k in fam)
             fl_ = sum(summ[k]["flops"] for k in fam)
@@ -560,9 +590,9 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
     return out
 
 
-def slim(leg):
-    """a secondary leg without the per-kernel tables (the headline line stays readable)"""
-    return {k: v for k, v in leg.items() if k not in ("kernel_ms_per_step", "kernel_tflops", "kernel_ms_per_step_isolated")}
+def slim(leg, keep=()):
+    """a secondary leg without the per-kernel tables (the headline line stays readable); `keep`: tables to keep"""
+    return {k: v for k, v in leg.items() if k in keep or k not in ("kernel_ms_per_step", "kernel_tflops", "kernel_ms_per_step_isolated")}
 
 
 def main():
@@ -585,9 +615,9 @@ def main():
                     help="skip the 3 extra untimed steps that measure the dominant kernel family with the side stream off "
                          "(profile runs: keeps the launch counts at warmup + steps)")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only (profile runs)")
-    ap.add_argument("--secondary", default="bf16,pathB,pathB_pad250,config5",
+    ap.add_argument("--secondary", default="f32_split,bf16,pathB,pathB_pad250,config5",
                     help="comma list of the secondary legs run in the same process BEFORE the fp32 headline and reported under "
-                         "'secondary': bf16 = configs[2] (sustained: >= 3 s of untimed load first), pathB = configs[3], pathB_pad250 = "
+                         "'secondary': f32_split = configs[1] with the GEMM contractions on the fp16 matrix pipe (fp32 storage and results), bf16 = configs[2] (sustained: >= 3 s of untimed load first), pathB = configs[3], pathB_pad250 = "
                          "configs[3] on the reference loader's real input (x250 up-sampling on the GPU), config5 = configs[4] (120 "
                          "classes, bone stream)")
     ap.add_argument("--quick", action="store_true", help="tests: secondary legs of a few steps without warm-up seconds")
@@ -624,7 +654,11 @@ def main():
             q = args.quick
             sec = {}
             for n in names:
-                if n == "bf16":
+                if n == "f32_split":
+                    # the fp32 engine with its GEMM contractions on the fp16 matrix pipe (same storage, same parity tolerances)
+                    r = stgcn_leg(args, "f32_split", 4 if q else 100, 3, 0.0 if q else 3.0, rank, world, dev, not q, first_run=False,
+                                  instrument_steps=2 if q else 5)
+                elif n == "bf16":
                     r = stgcn_leg(args, "bf16", 4 if q else 150, 3, 0.0 if q else 3.0, rank, world, dev, False, first_run=not q,
                                   instrument_steps=2 if q else 5)
                 elif n == "pathB":
@@ -650,7 +684,7 @@ def main():
                 else:
                     raise SystemExit("unknown secondary leg %r" % n)
                 if rank == 0:
-                    sec[n] = slim(r)
+                    sec[n] = slim(r, ("kernel_ms_per_step_isolated",) if n == "f32_split" else ())
         sust = args.sustained_steps if args.steps < args.sustained_steps else 0
         head = stgcn_leg(args, args.mfma, args.steps, args.warmup, args.warm_seconds, rank, world, dev, not args.no_isolated_pass,
                          stream=args.stream, sustained_steps=sust)

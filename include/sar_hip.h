@@ -318,6 +318,19 @@ int sar_bn_add_relu_bwd_apply_f32(const float* dy, const float* y, const float* 
                                   const float* k1, const float* k2, const float* k3,
                                   const float* rk1, const float* rk2, const float* rk3,
                                   float* du, float* dr, float* dz_out, int C, int64_t n, int64_t ld, sar_stream_t s);
+/* The same passes with an operand-bound by-product for the split arithmetic (cells: see sar_amax_f32): amax_y / amax_du /
+ * amax_out is RAISED to the largest |value| the pass wrote to y / du / out -- what a separate sar_amax_f32 pass over that tensor
+ * would give, without reading it again (28 such passes cost 2.1 ms of a 39 ms f32_split step). */
+int sar_bn_add_relu_fwd_mask_amax_f32(const float* u, const float* scale, const float* shift, int res_kind, const float* r,
+                                      const float* res_scale, const float* res_shift, float* y, void* mask, uint32_t* amax_y,
+                                      int C, int64_t n, int64_t ld, sar_stream_t s);
+int sar_bn_add_relu_bwd_apply_mask_amax_f32(const float* dy, const void* mask, const float* u, const float* r,
+                                            const float* k1, const float* k2, const float* k3,
+                                            const float* rk1, const float* rk2, const float* rk3,
+                                            float* du, float* dr, float* dz_out, uint32_t* amax_du, int C, int64_t n, int64_t ld,
+                                            sar_stream_t s);
+int sar_affine2_amax_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
+                         float* out, uint32_t* amax_out, int C, int64_t n, int64_t ld, sar_stream_t s);
 /* generic row-affine: out = k1[c]*a + k2[c]*b + k3[c]  (BN backward apply: dg from dz1 and g) */
 int sar_affine2_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
                     float* out, int C, int64_t n, int64_t ld, sar_stream_t s);

@@ -331,6 +331,25 @@ template <int VEC> __device__ __forceinline__ void st(float* p, const float (&r)
   else *p = r[0];
 }
 
+// amax by-product of a row-wise pass (the operand bounds of the split arithmetic, include/sar_hip.h: cells): the block's largest
+// |value| as float bits; one atomic max per workgroup, and only when it would raise the cell (maxima are order-independent)
+__device__ __forceinline__ void block_amax(unsigned m, unsigned* __restrict__ cell) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  __shared__ unsigned wm[TPB / 64];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = wm[0];
+#pragma unroll
+    for (int i = 1; i < TPB / 64; ++i) a = wm[i] > a ? wm[i] : a;
+    if (a > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, a);
+  }
+}
+
 // mask (VEC == 4 only): one byte per float4 of y, bit j = element j > 0, row stride ldm / 4 bytes -- read by the two backward
 // passes instead of y (sar_bn_add_relu_*_mask_f32)
 template <int VEC>
@@ -338,11 +357,13 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
                                                               const float* __restrict__ sh, int res_kind,
                                                               const float* __restrict__ r, const float* __restrict__ rsc,
                                                               const float* __restrict__ rsh, float* __restrict__ y,
-                                                              int64_t n, int64_t ldm, unsigned char* __restrict__ mask = nullptr) {
+                                                              int64_t n, int64_t ldm, unsigned char* __restrict__ mask = nullptr,
+                                                              unsigned* __restrict__ amax = nullptr) {
   const int c = blockIdx.y;
   const float a = sc[c], b = sh[c];
   const float ra = (res_kind == 2) ? rsc[c] : 1.f, rb = (res_kind == 2) ? rsh[c] : 0.f;
   const int64_t base = (int64_t)c * ldm;
+  float am = 0.f;   // y >= 0
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float uv[VEC], rv[VEC], o[VEC];
     ld<VEC>(u + base + i, uv);
@@ -352,6 +373,7 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
       float z = fmaf(uv[j], a, b);
       if (res_kind) z += fmaf(rv[j], ra, rb);
       o[j] = fmaxf(z, 0.f);
+      if (amax) am = fmaxf(am, o[j]);   // uniform
     }
     st<VEC>(y + base + i, o);
     if (VEC == 4 && mask) {   // uniform
@@ -361,6 +383,7 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
       mask[(base + i) >> 2] = (unsigned char)mb;
     }
   }
+  if (amax) block_amax(__float_as_uint(am), amax);
 }
 
 template <int VEC, bool TAIL = false>
@@ -423,11 +446,12 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ u, const float* __restrict__ r,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3, const float* __restrict__ rk1,
     const float* __restrict__ rk2, const float* __restrict__ rk3, float* du, float* dr, float* dz_out, int64_t n,
-    int64_t ldm, const unsigned char* __restrict__ mask = nullptr) {
+    int64_t ldm, const unsigned char* __restrict__ mask = nullptr, unsigned* __restrict__ amax = nullptr) {
   const int c = blockIdx.y;
   const int64_t base = (int64_t)c * ldm;
   const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
   const float b1 = dr ? rk1[c] : 0.f, b2 = dr ? rk2[c] : 0.f, b3 = dr ? rk3[c] : 0.f;
+  float am = 0.f;
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float g[VEC], yv[VEC], uv[VEC], rv[VEC], o1[VEC], o2[VEC], o3[VEC];
     ld<VEC>(dy + base + i, g);
@@ -446,29 +470,37 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
       const float dz = ((mb >> j) & 1u) ? g[j] : 0.f;
       o3[j] = dz;
       o1[j] = fmaf(a1, dz, fmaf(a2, uv[j], a3));
+      if (amax) am = fmaxf(am, fabsf(o1[j]));   // uniform
       if (dr) o2[j] = fmaf(b1, dz, fmaf(b2, rv[j], b3));
     }
     st<VEC>(du + base + i, o1);
     if (dr) st<VEC>(dr + base + i, o2);
     if (dz_out) st<VEC>(dz_out + base + i, o3);
   }
+  if (amax) block_amax(__float_as_uint(am), amax);
 }
 
 template <int VEC>
 __global__ __launch_bounds__(TPB) void affine2_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       const float* __restrict__ k1, const float* __restrict__ k2,
-                                                      const float* __restrict__ k3, float* out, int64_t n, int64_t ldm) {
+                                                      const float* __restrict__ k3, float* out, int64_t n, int64_t ldm,
+                                                      unsigned* __restrict__ amax = nullptr) {
   const int c = blockIdx.y;
   const int64_t base = (int64_t)c * ldm;
   const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
+  float am = 0.f;
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float av[VEC], bv[VEC], o[VEC];
     ld<VEC>(a + base + i, av);
     ld<VEC>(b + base + i, bv);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = fmaf(a1, av[j], fmaf(a2, bv[j], a3));
+    for (int j = 0; j < VEC; ++j) {
+      o[j] = fmaf(a1, av[j], fmaf(a2, bv[j], a3));
+      if (amax) am = fmaxf(am, fabsf(o[j]));   // uniform
+    }
     st<VEC>(out + base + i, o);
   }
+  if (amax) block_amax(__float_as_uint(am), amax);
 }
 
 inline bool vec4_ok(int64_t n, int64_t ldm, std::initializer_list<const void*> ptrs) {
@@ -772,9 +804,9 @@ extern "C" int sar_bn_add_relu_fwd_f32(const float* u, const float* sc, const fl
 }
 
 // the block tail with a 1-bit ReLU mask (include/sar_hip.h): rows of 4-element groups only (n, ld multiples of 4, 16-byte aligned)
-extern "C" int sar_bn_add_relu_fwd_mask_f32(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
-                                            const float* rsc, const float* rsh, float* y, void* mask, int C, int64_t n, int64_t ldm,
-                                            sar_stream_t s) {
+static int bn_add_relu_fwd_mask_impl(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
+                                     const float* rsc, const float* rsh, float* y, void* mask, uint32_t* amax, int C, int64_t n, int64_t ldm,
+                                     sar_stream_t s) {
   SAR_REQUIRE(u && sc && sh && y && mask && C > 0 && n > 0 && ldm >= n, "sar_bn_add_relu_fwd_mask: bad arguments");
   SAR_REQUIRE(res_kind >= 0 && res_kind <= 2 && (res_kind == 0 || r) && (res_kind != 2 || (rsc && rsh)),
               "sar_bn_add_relu_fwd_mask: residual arguments");
@@ -783,9 +815,20 @@ extern "C" int sar_bn_add_relu_fwd_mask_f32(const float* u, const float* sc, con
     return SAR_E_UNSUP;
   }
   hipLaunchKernelGGL(bn_add_relu_fwd_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), u, sc, sh, res_kind, r, rsc,
-                     rsh, y, n, ldm, (unsigned char*)mask);
+                     rsh, y, n, ldm, (unsigned char*)mask, amax);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_fwd_mask_f32");
   return 0;
+}
+extern "C" int sar_bn_add_relu_fwd_mask_f32(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
+                                            const float* rsc, const float* rsh, float* y, void* mask, int C, int64_t n, int64_t ldm,
+                                            sar_stream_t s) {
+  return bn_add_relu_fwd_mask_impl(u, sc, sh, res_kind, r, rsc, rsh, y, mask, nullptr, C, n, ldm, s);
+}
+extern "C" int sar_bn_add_relu_fwd_mask_amax_f32(const float* u, const float* sc, const float* sh, int res_kind, const float* r,
+                                                 const float* rsc, const float* rsh, float* y, void* mask, uint32_t* amax_y, int C,
+                                                 int64_t n, int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(amax_y != nullptr, "sar_bn_add_relu_fwd_mask_amax: null cell");
+  return bn_add_relu_fwd_mask_impl(u, sc, sh, res_kind, r, rsc, rsh, y, mask, amax_y, C, n, ldm, s);
 }
 
 extern "C" int sar_bn_add_relu_bwd_reduce_mask_f32(const float* dy, const void* mask, const float* u, const float* r,
@@ -803,10 +846,10 @@ extern "C" int sar_bn_add_relu_bwd_reduce_mask_f32(const float* dy, const void* 
   return 0;
 }
 
-extern "C" int sar_bn_add_relu_bwd_apply_mask_f32(const float* dy, const void* mask, const float* u, const float* r,
-                                                  const float* k1, const float* k2, const float* k3, const float* rk1,
-                                                  const float* rk2, const float* rk3, float* du, float* dr, float* dz_out,
-                                                  int C, int64_t n, int64_t ldm, sar_stream_t s) {
+static int bn_add_relu_bwd_apply_mask_impl(const float* dy, const void* mask, const float* u, const float* r,
+                                           const float* k1, const float* k2, const float* k3, const float* rk1,
+                                           const float* rk2, const float* rk3, float* du, float* dr, float* dz_out, uint32_t* amax,
+                                           int C, int64_t n, int64_t ldm, sar_stream_t s) {
   SAR_REQUIRE(dy && mask && u && k1 && k2 && k3 && du && C > 0 && n > 0 && ldm >= n, "sar_bn_add_relu_bwd_apply_mask: bad arguments");
   SAR_REQUIRE(!dr || (r && rk1 && rk2 && rk3), "sar_bn_add_relu_bwd_apply_mask: residual arguments");
   if (!vec4_ok(n, ldm, {dy, u, r, du, dr, dz_out})) {
@@ -814,9 +857,22 @@ extern "C" int sar_bn_add_relu_bwd_apply_mask_f32(const float* dy, const void* m
     return SAR_E_UNSUP;
   }
   hipLaunchKernelGGL(bn_add_relu_bwd_apply_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), dy, (const float*)nullptr,
-                     u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, n, ldm, (const unsigned char*)mask);
+                     u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, n, ldm, (const unsigned char*)mask, amax);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_mask_f32");
   return 0;
+}
+extern "C" int sar_bn_add_relu_bwd_apply_mask_f32(const float* dy, const void* mask, const float* u, const float* r,
+                                                  const float* k1, const float* k2, const float* k3, const float* rk1,
+                                                  const float* rk2, const float* rk3, float* du, float* dr, float* dz_out,
+                                                  int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  return bn_add_relu_bwd_apply_mask_impl(dy, mask, u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, nullptr, C, n, ldm, s);
+}
+extern "C" int sar_bn_add_relu_bwd_apply_mask_amax_f32(const float* dy, const void* mask, const float* u, const float* r,
+                                                       const float* k1, const float* k2, const float* k3, const float* rk1,
+                                                       const float* rk2, const float* rk3, float* du, float* dr, float* dz_out,
+                                                       uint32_t* amax_du, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(amax_du != nullptr, "sar_bn_add_relu_bwd_apply_mask_amax: null cell");
+  return bn_add_relu_bwd_apply_mask_impl(dy, mask, u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, amax_du, C, n, ldm, s);
 }
 
 extern "C" int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,
@@ -871,18 +927,27 @@ extern "C" int sar_bn_add_relu_bwd_apply_f32(const float* dy, const float* y, co
   return 0;
 }
 
-extern "C" int sar_affine2_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
-                               float* out, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+static int affine2_impl(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
+                        float* out, uint32_t* amax, int C, int64_t n, int64_t ldm, sar_stream_t s) {
   SAR_REQUIRE(a && b && k1 && k2 && k3 && out && C > 0 && n > 0 && ldm >= n, "sar_affine2: bad arguments");
   if (vec4_ok(n, ldm, {a, b, out})) {
     hipLaunchKernelGGL(affine2_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), a, b, k1, k2, k3, out, n,
-                       ldm);
+                       ldm, amax);
   } else {
     hipLaunchKernelGGL(affine2_kernel<1>, dim3(row_blocks(n, 1), C), dim3(TPB), 0, as_stream(s), a, b, k1, k2, k3, out, n,
-                       ldm);
+                       ldm, amax);
   }
   SAR_LAUNCH_CHECK("sar_affine2_f32");
   return 0;
+}
+extern "C" int sar_affine2_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
+                               float* out, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  return affine2_impl(a, b, k1, k2, k3, out, nullptr, C, n, ldm, s);
+}
+extern "C" int sar_affine2_amax_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
+                                    float* out, uint32_t* amax_out, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+  SAR_REQUIRE(amax_out != nullptr, "sar_affine2_amax: null cell");
+  return affine2_impl(a, b, k1, k2, k3, out, amax_out, C, n, ldm, s);
 }
 
 extern "C" int sar_pool_fwd_f32(const float* y, int64_t ldm, int C, int B, int TV, int Mp, float* feat, sar_stream_t s) {

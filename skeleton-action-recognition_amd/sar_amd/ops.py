@@ -380,7 +380,18 @@ def relu_mask(u):
     return torch.empty((Cc, u.stride(0) // 4), dtype=torch.uint8, device=u.device)
 
 
-def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, mask=None):
+def bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, mask=None, amax_cell=None):
+    """amax_cell: the bound cell of y (split arithmetic): raised by the pass itself when the masked kernel runs, else by a
+    separate sar_amax_f32 pass"""
+    if mask is not None and amax_cell is not None:
+        check(L.load().sar_bn_add_relu_fwd_mask_amax_f32(ptr(u), ptr(sc), ptr(sh), res_kind, ptr(r), ptr(rsc), ptr(rsh), ptr(y), ptr(mask),
+                                                         ptr(amax_cell), u.shape[0], u.shape[1], u.stride(0), stream_ptr()),
+              "sar_bn_add_relu_fwd_mask_amax_f32")
+        return
+    if amax_cell is not None:
+        bn_add_relu_fwd(u, sc, sh, res_kind, r, rsc, rsh, y, mask)
+        amax(y, amax_cell)
+        return
     if mask is not None:
         check(L.load().sar_bn_add_relu_fwd_mask_f32(ptr(u), ptr(sc), ptr(sh), res_kind, ptr(r), ptr(rsc), ptr(rsh), ptr(y), ptr(mask),
                                                     u.shape[0], u.shape[1], u.stride(0), stream_ptr()), "sar_bn_add_relu_fwd_mask_f32")
@@ -442,9 +453,20 @@ def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None, tail=None, mask=None):
     return partials, nparts
 
 
-def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask=None):
+def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask=None, amax_cell=None):
+    """amax_cell: the bound cell of du (split arithmetic), see bn_add_relu_fwd"""
     Cc, n = u.shape
     rk = rk or (None, None, None)
+    if mask is not None and amax_cell is not None:
+        check(L.load().sar_bn_add_relu_bwd_apply_mask_amax_f32(ptr(dy), ptr(mask), ptr(u), ptr(r), ptr(k[0]), ptr(k[1]), ptr(k[2]),
+                                                               ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(du), ptr(dr), ptr(dz_out),
+                                                               ptr(amax_cell), Cc, n, u.stride(0), stream_ptr()),
+              "sar_bn_add_relu_bwd_apply_mask_amax_f32")
+        return
+    if amax_cell is not None:
+        bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask)
+        amax(du, amax_cell)
+        return
     if mask is not None:
         check(L.load().sar_bn_add_relu_bwd_apply_mask_f32(ptr(dy), ptr(mask), ptr(u), ptr(r), ptr(k[0]), ptr(k[1]), ptr(k[2]),
                                                           ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(du), ptr(dr), ptr(dz_out), Cc, n,
@@ -455,8 +477,12 @@ def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask=None):
                                                  u.stride(0), stream_ptr()), "sar_bn_add_relu_bwd_apply_f32")
 
 
-def affine2(a, b, k, out):
+def affine2(a, b, k, out, amax_cell=None):
     Cc, n = a.shape
+    if amax_cell is not None:
+        check(L.load().sar_affine2_amax_f32(ptr(a), ptr(b), ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(out), ptr(amax_cell), Cc, n, a.stride(0),
+                                            stream_ptr()), "sar_affine2_amax_f32")
+        return
     check(L.load().sar_affine2_f32(ptr(a), ptr(b), ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(out), Cc, n, a.stride(0),
                                    stream_ptr()), "sar_affine2_f32")
 

@@ -415,8 +415,8 @@ class STGCN:
             r1 = ops.graph_dense_fwd(y3, self.A, g, KS, f, V, B * T, stats=training)
         else:
             gimg = self._simg(pre + "gcn.f") if training else None
-            if gimg is not None and self._f16:
-                ops.amax(X, self._cell(i, 3))       # the bound of the block input: graph convolution (src) and its weight gradient
+            if gimg is not None and self._f16 and i == 0:
+                ops.amax(X, self._cell(i, 3))       # the bound of the block input (blocks > 0: written by the previous block's tail)
             r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
                                Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi,
                                **self._split_args(gimg, self._cell(i, 3), self._img(pre + "gcn.f")))
@@ -454,8 +454,11 @@ class STGCN:
         y = torch.empty((f, n_out), dtype=torch.float32, device=dev)
         res_kind = {"none": 0, "identity": 1, "conv": 2}[kind]
         ymask = ops.relu_mask(y) if training else None     # 1 bit per element: what the BatchNorm-backward passes read instead of y
+        # (split arithmetic: y is the next block's graph-convolution operand; its bound is a by-product of this pass)
+        ycell = self._cell(i + 1, 3) if (training and self._f16 and i + 1 < len(self.blocks)
+                                         and self._simg("l%d.gcn.f" % (i + 1)) is not None) else None
         ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r,
-                            rbn.scale if rbn else None, rbn.shift if rbn else None, y, mask=ymask)
+                            rbn.scale if rbn else None, rbn.shift if rbn else None, y, mask=ymask, amax_cell=ycell)
         if training:
             saved["blocks"].append(dict(X=X, g=g, u=u, r=r, y=y, ymask=ymask, T=T, To=To, pad=pad, cin=cin, f=f, s=s, kind=kind, y3=y3))
         if keep is not None:
@@ -621,14 +624,13 @@ class STGCN:
         du = torch.empty_like(u)
         dr = torch.empty_like(r) if kind == "conv" else None
         dz = dY if (kind == "identity" and gated is None) else None  # in place: dY becomes the pre-ReLU gradient for the skip path (already gated: nothing to write)
+        ducell = self._cell(i, 1) if (self._f16 and self._simg(pre + "tcn.b") is not None) else None   # the bound of du: by-product
         ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz,
-                                  mask=sb.get("ymask"))
+                                  mask=sb.get("ymask"), amax_cell=ducell)
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
         wt = self.g[pre + "tcn.kernel"]
         flat_w = self.grad[self.offsets[pre + "tcn.kernel"]:self.offsets[pre + "tcn.bias"] + f]
         simg = self._simg(pre + "tcn.b")
-        if simg is not None and self._f16:
-            ops.amax(du, self._cell(i, 1))       # the bound of du: data gradient (src) and weight gradient (dout)
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
             pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
@@ -647,7 +649,8 @@ class STGCN:
         ops.bn_bwd_finalize(pm[0], pm[1], pm[1] * 2, 2, 0, 1, f, n_in, self.p[pre + "bn1.gamma"], bn1.mean, bn1.rstd,
                             self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
         dg = dz1
-        ops.affine2(dz1, g, (bn1.k1, bn1.k2, bn1.k3), dg)                # BN1 backward apply (in place)
+        dgcell = self._cell(i, 2) if (self._f16 and self._simg(pre + "gcn.b") is not None) else None      # the bound of dg: by-product
+        ops.affine2(dz1, g, (bn1.k1, bn1.k2, bn1.k3), dg, amax_cell=dgcell)   # BN1 backward apply (in place)
         flat_g = self.grad[self.offsets[pre + "gcn.kernel"]:self.offsets[pre + "gcn.bias"] + KS * f]
         if self.dense_A:
             return self._graph_backward_dense(i, sb, dg, dY, dr, B, flat_g)
@@ -665,8 +668,6 @@ class STGCN:
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
         sgimg = self._simg(pre + "gcn.b")
-        if sgimg is not None and self._f16:
-            ops.amax(dg, self._cell(i, 2))         # the bound of dg: graph data gradient (src) and weight gradient (dout)
         if below is not None and aux is not None:
             # dX = gate_{i-1}(W^T dg . A^T + skip gradient) and block i - 1's BatchNorm-backward sums in one epilogue
             bn2b = self.bn["l%d.bn2" % (i - 1)]
