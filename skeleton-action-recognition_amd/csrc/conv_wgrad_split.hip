@@ -323,12 +323,270 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   }
 }
 
+// ---- GraphConvTD (models/gcn.py:199-209) weight / bias gradient in the split arithmetics:
+//   dW_k[c][m] = sum_n z_k[c, n] dout[m, n],  z_k[c, (t,w)] = sum_v x[c, (t,v)] A_k[v, w];   db_k[m] = sum_n dout[m, n] colsum(A_k)[w(n)]
+// Same structure as the temporal kernel with the three adjacency slices in the place of the nine taps: a tile = 4 frames (100
+// positions, 7 k-steps of 16), the three gathered images z_k are built by the stager (<= 4 gathered loads per element straight from
+// global memory -- the frame is in L1 / L2 --, the fp32 kernel's fma chain, then the split into the conditioned operand's three
+// images), [slice][term][32 rows][120] 2-byte elements = 69 KB: two workgroups per CU.  A wave owns 32 src channels x 64 dout channels
+// x 3 slices (96 accumulator registers); at M <= 128 / 64 the wave groups split the tile's k-steps (WK = 2 / 4 slabs per group).
+constexpr int GFT = 4, GKP = GFT * VJ, GKS = (GKP + 15) / 16, GRS = 120;
+template <int AR, int WK, int NZ0, int NZ1, int NZ2>
+__global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS k) {
+  constexpr int NT = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), V = VJ, KS = GKS, RS = GRS;
+  constexpr int NZ[3] = {NZ0, NZ1, NZ2};
+  constexpr int WMM = 4 / WK, MBLK = 64 * WMM;
+  constexpr int RPP = (NZ0 + NZ1 + NZ2 > 6) ? 1 : 2;   // rows per stager pass (gathered loads in flight: 2 x sum(NZ) per row)
+  static_assert(RS >= KS * 16 && (RS * 2) % 16 == 0 && ((RS / 2) / 4) % 2 == 1, "row stride: 16-byte rows, conflict-free 16-byte reads");
+  __shared__ __attribute__((aligned(16))) unsigned short Zs[3 * NT * CB * RS];
+  __shared__ __attribute__((aligned(16))) float csl[3 * KS * 16];   // colsum(A_k) of every tile position (0 beyond the live ones)
+  const sar_wgrad_desc& d = k.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wmm = wave % WMM, kh = wave / WMM;
+
+  int sg, by, bz;
+  {
+    const int nyz = k.gy * k.gz, ngrp = d.nsplit / WK, nwork = ngrp * nyz;
+    const int per = (nwork + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int w = xcd * per + slot;
+    if (slot >= per || w >= nwork) return;
+    sg = w / nyz;
+    const int yz = w - sg * nyz;
+    bz = yz / k.gy;
+    by = yz - bz * k.gy;
+  }
+  const int m0 = by * MBLK + wmm * 64, c0 = bz * CB;
+  const int ngrp = d.nsplit / WK;
+
+  int ea = 0, eb = 0;
+  if (ar_f16(AR)) {   // a gathered value is a weighted sum of <= 4 source values: bound(src) x the largest sum of |weights| (<= 4 lists x 3 V)
+    float gmax = 1.f;
+    for (int i = 0; i < 3 * V; ++i) {
+      float sm = 0.f;
+      for (int j = 0; j < 4; ++j) sm += fabsf(d.g_wt[i * 4 + j]);
+      gmax = fmaxf(gmax, sm);
+    }
+    ea = scale_exp(__float_as_uint(__uint_as_float(*k.src_bound) * gmax));
+    eb = scale_exp(*k.dout_bound);
+  }
+  const float sa = __builtin_ldexpf(1.f, ea), sb = __builtin_ldexpf(1.f, eb);
+  for (int i = tid; i < 3 * KS * 16; i += 256) {
+    const int kk = i / (KS * 16), p = i - kk * (KS * 16);
+    csl[i] = (p < GKP && d.g_colsum) ? d.g_colsum[kk * V + p % V] : 0.f;
+  }
+
+  // this lane's two adjacent tile positions and their gather entries (offsets inside the tile, floats)
+  int goff[3][2][4];
+  float gwt[3][2][4];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int p = 2 * lane + e;
+    const bool live = p < GKP;
+    const int fo = live ? p / V : 0, w = live ? p - fo * V : 0;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < NZ[kk]) {
+          goff[kk][e][j] = fo * V + d.g_idx[(kk * V + w) * 4 + j];
+          gwt[kk][e][j] = live ? d.g_wt[(kk * V + w) * 4 + j] : 0.f;
+        }
+  }
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][mb][r] = 0.f;
+  float bsum[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  const bool do_bias = d.bsize > 0 && bz == 0;   // uniform
+
+  const int tps = (k.ntiles + ngrp - 1) / ngrp;
+  const int tile_lo = sg * tps;
+  const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
+  const int seq = d.T_src * V;
+  const unsigned a_base = (unsigned)(uintptr_t)Zs + (unsigned)((l31 * RS + 8 * hi) * 2);
+  typedef const u32x4 __attribute__((address_space(3))) * lds_u128;
+  constexpr unsigned REJECT = 0xf0000000u;
+  const int64_t dbytes = (int64_t)d.M * d.ld_dout * 4;
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.dout, 0, (unsigned)(dbytes < (int64_t)REJECT ? dbytes : (int64_t)REJECT), 0x00020000);
+  unsigned drow[2];
+  bool mrow_ok[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    mrow_ok[mb] = (m0 + 32 * mb + l31) < d.M;
+    drow[mb] = (unsigned)(((int64_t)(mrow_ok[mb] ? m0 + 32 * mb + l31 : 0) * d.ld_dout) * 4);
+  }
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int b = tile / k.TPS;
+    const int t0 = (tile - b * k.TPS) * GFT;
+    const int nlive = ((t0 + GFT <= d.T_out) ? GFT : d.T_out - t0) * V;   // live positions of this tile
+    const int n0 = t0 * V;
+    __syncthreads();   // closing: every wave has read its last fragment of the previous tile (and csl is written)
+    // ---- build the three gathered images of rows c0 .. c0 + 31: wave w takes rows w, w + 4, ..; two rows per pass
+    {
+      const float* src_t = d.src + (int64_t)b * seq + n0;
+#pragma unroll 1
+      for (int rp = 0; rp < 8 / RPP; ++rp) {
+        float x[RPP][3][2][4];
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) {
+          const int row = wave + 4 * (rp * RPP + q);
+          const int c = c0 + row;
+          const float* rowp_ = src_t + (int64_t)(c < d.Kc ? c : 0) * d.ld_src;
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (j < NZ[kk]) x[q][kk][e][j] = (2 * lane + e < nlive) ? rowp_[goff[kk][e][j]] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) {
+          const int row = wave + 4 * (rp * RPP + q);
+          const bool rok = c0 + row < d.Kc;
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            float z[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float zz = gwt[kk][e][0] * x[q][kk][e][0];
+#pragma unroll
+              for (int j = 1; j < 4; ++j)
+                if (j < NZ[kk]) zz = fmaf(gwt[kk][e][j], x[q][kk][e][j], zz);
+              z[e] = (rok && 2 * lane + e < nlive) ? (ar_f16(AR) ? zz * sa : zz) : 0.f;
+            }
+            unsigned w[NT];
+            split2<AR, true>(z[0], z[1], w);
+            if (2 * lane < RS) {
+#pragma unroll
+              for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Zs[((kk * NT + t) * CB + row) * RS + 2 * lane]) = w[t];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // opening: the images are complete
+
+    auto load_dout = [&](int ks, u32x4 (&raw)[2][2]) {
+      const int pos = 16 * ks + 8 * hi;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const unsigned vo = (mrow_ok[mb] && pos < nlive) ? drow[mb] + (unsigned)(((int64_t)b * seq + n0 + pos) * 4) : REJECT;
+        raw[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 0, 0);
+        raw[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 16, 0);
+      }
+    };
+    u32x4 raw[2][2][2];
+    load_dout(kh, raw[0]);
+#pragma unroll 1
+    for (int ks = kh; ks < KS; ks += 2 * WK) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int kc = ks + half * WK;
+        if (kc < KS) {
+          if (kc + WK < KS) load_dout(kc + WK, raw[half ^ 1]);
+          const int nv = nlive - (16 * kc + 8 * hi);   // live elements of this lane's fragment
+          unsigned bw[2][NTB][4];
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            float dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              dv[j] = __uint_as_float(raw[half][mb][j >> 2][j & 3]);
+              dv[j] = j < nv ? dv[j] : 0.f;
+            }
+            if (do_bias) {
+#pragma unroll
+              for (int kk = 0; kk < 3; ++kk) {
+                const float4 c0v = *reinterpret_cast<const float4*>(&csl[kk * KS * 16 + 16 * kc + 8 * hi]);
+                const float4 c1v = *reinterpret_cast<const float4*>(&csl[kk * KS * 16 + 16 * kc + 8 * hi + 4]);
+                float sacc = bsum[kk][mb];
+                sacc = fmaf(dv[0], c0v.x, sacc), sacc = fmaf(dv[1], c0v.y, sacc), sacc = fmaf(dv[2], c0v.z, sacc), sacc = fmaf(dv[3], c0v.w, sacc);
+                sacc = fmaf(dv[4], c1v.x, sacc), sacc = fmaf(dv[5], c1v.y, sacc), sacc = fmaf(dv[6], c1v.z, sacc), sacc = fmaf(dv[7], c1v.w, sacc);
+                bsum[kk][mb] = sacc;
+              }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              unsigned w[NTB];
+              split2<AR, false>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
+#pragma unroll
+              for (int t = 0; t < NTB; ++t) bw[mb][t][p] = w[t];
+            }
+          }
+          const unsigned a_ks = a_base + kc * 32;
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            u32x4 aq[NT];
+#pragma unroll
+            for (int tm = 0; tm < NT; ++tm) aq[tm] = *(lds_u128)(uintptr_t)(a_ks + (kk * NT + tm) * (CB * RS * 2));
+#pragma unroll
+            for (int p = 0; p < NPROD; ++p) {
+              const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+#pragma unroll
+              for (int mb = 0; mb < 2; ++mb) {
+                const u32x4 bq = u32x4{bw[mb][j][0], bw[mb][j][1], bw[mb][j][2], bw[mb][j][3]};
+                if (ar_f16(AR))
+                  acc[kk][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&aq[i]),
+                                                                      *reinterpret_cast<const f16x8*>(&bq), acc[kk][mb], 0, 0, 0);
+                else
+                  acc[kk][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&aq[i]),
+                                                                       *reinterpret_cast<const bf16x8*>(&bq), acc[kk][mb], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  float* slab = d.slab + (int64_t)(sg * WK + kh) * (d.wsize + d.bsize);
+  const float unscale = __builtin_ldexpf(1.f, -(ea + eb));
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int m = m0 + 32 * mb + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + mfma_row(r, hi);
+        if (c < d.Kc && m < d.M) slab[(int64_t)kk * d.w_stride_tap + (int64_t)c * d.w_stride_c + m] = acc[kk][mb][r] * unscale;
+      }
+      if (do_bias) {
+        const float t = bsum[kk][mb] + __shfl_xor(bsum[kk][mb], 32);
+        if (hi == 0 && m < d.M) slab[d.wsize + kk * d.M + m] = t;
+      }
+    }
+}
+
 // which kernel: WK (1 or 2), or 0 = not built (the caller keeps sar_conv_wgrad_f32)
 int wgrad_split_wk(const sar_wgrad_desc& d, int arith) {
   if (arith != AR_B6 && arith != AR_H3A) return 0;
+  if (d.mode == SAR_CONV_GRAPH) {   // 3 slices, no folded prologue, <= 4-entry gather lists; the 3-channel first layer keeps its streaming kernel
+    if (d.taps != 3 || d.V != VJ || d.T_src != d.T_out || d.pro_scale || d.Kc < 16 || d.Kc > 256 || !d.g_idx || !d.g_wt) return 0;
+    for (int i = 0; i < 3; ++i)
+      if (d.nz[i] < 1 || d.nz[i] > 4) return 0;
+    return d.M > 128 ? 1 : (d.M > 64 ? 2 : 4);
+  }
   if (d.mode != SAR_CONV_TEMPORAL || d.taps != TAPS || d.V != VJ || d.stride != 1 || d.T_src != d.T_out) return 0;
   if (d.Kc < 8 || d.Kc > 256 || d.pad < 0 || d.pad > 8) return 0;
   return d.M > 64 ? 1 : 2;
+}
+
+template <int AR, int NZ0, int NZ1, int NZ2>
+void launch_graph_wgrad_split(const WgradKS& k, int wk, dim3 grid, hipStream_t st) {
+  if (wk == 1) hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 1, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
+  else if (wk == 2) hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 2, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 4, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
 }
 
 template <int AR>
@@ -337,6 +595,18 @@ int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, cons
   k.d = d;
   k.src_bound = sb;
   k.dout_bound = db;
+  if (d.mode == SAR_CONV_GRAPH) {
+    k.TPS = (d.T_out + GFT - 1) / GFT;
+    k.ntiles = d.B * k.TPS;
+    k.gy = (d.M + 256 / wk - 1) / (256 / wk);
+    k.gz = (d.Kc + CB - 1) / CB;
+    const int nwork = (d.nsplit / wk) * k.gy * k.gz;
+    const dim3 grid(((nwork + 7) / 8) * 8);
+    if (d.nz[0] == 1 && d.nz[1] == 1) launch_graph_wgrad_split<AR, 1, 1, 4>(k, wk, grid, st);
+    else if (d.nz[0] == 1 && d.nz[2] == 1) launch_graph_wgrad_split<AR, 1, 4, 1>(k, wk, grid, st);
+    else launch_graph_wgrad_split<AR, 4, 4, 4>(k, wk, grid, st);
+    return 0;
+  }
   const int seq = d.T_out * d.V;
   k.TPS = (seq + Cfg<AR>::KT - 1) / Cfg<AR>::KT;
   k.ntiles = d.B * k.TPS;
@@ -356,6 +626,10 @@ extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, i
   const int wk = wgrad_split_wk(*d, arith);
   if (!wk) return SAR_E_UNSUP;
   if (wk_out) *wk_out = wk;
+  if (d->mode == SAR_CONV_GRAPH) {
+    if (tile_positions) *tile_positions = GKP;
+    return ((d->M + 256 / wk - 1) / (256 / wk)) * ((d->Kc + CB - 1) / CB);
+  }
   if (tile_positions) *tile_positions = arith == AR_H3A ? Cfg<AR_H3A>::KT : Cfg<AR_B6>::KT;
   return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
 }
@@ -365,8 +639,8 @@ extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const ui
   SAR_REQUIRE(d != nullptr, "sar_conv_wgrad_split: null descriptor");
   const int wk = wgrad_split_wk(*d, arith);
   if (!wk) {
-    sar_set_error("sar_conv_wgrad_split: built for the 9-tap temporal convolution at V = 25, stride 1, 8 <= Kc <= 256 in the "
-                  "arithmetics bf16x6 / f16x3a (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
+    sar_set_error("sar_conv_wgrad_split: built for the 9-tap temporal convolution at V = 25, stride 1, 8 <= Kc <= 256 and the graph "
+                  "convolution at V = 25, 16 <= Kc <= 256 without a folded prologue, in the arithmetics bf16x6 / f16x3a (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
                   d->mode, d->taps, d->V, d->stride, d->Kc, arith);
     return SAR_E_UNSUP;
   }
@@ -379,7 +653,9 @@ extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const ui
   SAR_REQUIRE((int64_t)d->T_src * d->V < (1 << 28), "sar_conv_wgrad_split: sequence row too long");
   SAR_REQUIRE((int64_t)d->M * d->ld_dout * 4 < 0xf0000000ll, "sar_conv_wgrad_split: dout larger than 3.75 GiB");
   SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv_wgrad_split: pro_scale/pro_shift mismatch");
-  SAR_REQUIRE(d->wsize > 0 && (d->bsize == 0 || d->bsize == d->M), "sar_conv_wgrad_split: bad slab sizes");
+  SAR_REQUIRE(d->wsize > 0 && (d->bsize == 0 || d->bsize == (d->mode == SAR_CONV_GRAPH ? 3 : 1) * (int64_t)d->M),
+              "sar_conv_wgrad_split: bad slab sizes");
+  SAR_REQUIRE(d->mode != SAR_CONV_GRAPH || d->bsize == 0 || d->g_colsum, "sar_conv_wgrad_split: the graph bias gradient needs g_colsum");
   SAR_REQUIRE(arith != AR_H3A || (src_bound && dout_bound), "sar_conv_wgrad_split: the fp16 arithmetic needs the operand bounds");
   if (arith == AR_H3A) launch_wgrad_split<AR_H3A>(*d, wk, src_bound, dout_bound, as_stream(s));
   else launch_wgrad_split<AR_B6>(*d, wk, src_bound, dout_bound, as_stream(s));

@@ -261,6 +261,15 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     d = WgradDesc()
     d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
     d.taps, d.stride, d.pad, d.pro_relu = taps, stride, pad, int(pro_relu)
+    _f32(src), _f32(dout)
+    d.src, d.ld_src, d.dout, d.ld_dout = ptr(src), src.stride(0), ptr(dout), dout.stride(0)
+    if pro is not None:
+        d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
+    if tables is not None:
+        d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
+        for i in range(3):
+            d.nz[i] = tables.nz[i]
+        d.g_flags = tables.g_flags
     # split="bf16x6" / "f16x3a": the split arithmetic of csrc/conv_wgrad_split.hip where it is built (bounds = (src_bound,
     # dout_bound) cells for the fp16 arithmetic, None = computed here by device kernels); other shapes stay on the fp32 kernel
     if split == "default":
@@ -274,6 +283,8 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
             if nsplit is None:      # one round of the 512 resident workgroups (two per CU)
                 ntiles = B * ((T_out * V + kt.value - 1) // kt.value)
                 nsplit = max(1, min(ntiles, 512 // sp_blocks)) * wk.value
+            else:
+                nsplit = (nsplit + wk.value - 1) // wk.value * wk.value
     split = split if sp_blocks > 0 else None
     ct = 32 if (mode == L.SAR_CONV_TEMPORAL and taps == 9) else 64
     # (a bf16 graph weight gradient was built and measured: with the adjacency gather in its stager it ran 1.7x SLOWER
@@ -299,14 +310,6 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
         target = _WGRADG_SLOTS if (mode == L.SAR_CONV_GRAPH and ft == 2) else (_WGRAD1_SLOTS if taps == 1 else _WGRAD9_SLOTS)
         nsplit = max(1, min(ntiles, (target + wgs - 1) // wgs))
     d.nsplit = nsplit
-    _f32(src), _f32(dout)
-    d.src, d.ld_src, d.dout, d.ld_dout = ptr(src), src.stride(0), ptr(dout), dout.stride(0)
-    if pro is not None:
-        d.pro_scale, d.pro_shift = ptr(_f32(pro[0])), ptr(_f32(pro[1]))
-    if tables is not None:
-        d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
-        for i in range(3):
-            d.nz[i] = tables.nz[i]
     d.w_stride_tap, d.w_stride_c, d.wsize, d.bsize = w_stride_tap, w_stride_c, wsize, bsize
     slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
     d.slab = ptr(slab)

@@ -655,9 +655,12 @@ class STGCN:
         if self.dense_A:
             return self._graph_backward_dense(i, sb, dg, dY, dr, B, flat_g)
         # ---- graph conv: weight / bias gradient
+        gw_split = self.split if ("gwgrad" in _SPLIT_KINDS and self._simg(pre + "gcn.f") is not None
+                                  and self._simg(pre + "gcn.b") is not None) else None      # (both bounds exist: X from the forward, dg above)
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_GRAPH, X, dg, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS, tables=self.tab_fwd,
-            w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, bf16=self.bf16), X, dg)
+            w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, bf16=self.bf16, split=gw_split,
+            bounds=(self._cell(i, 3), self._cell(i, 2)) if self._f16 else None), X, dg)
         dXres = self._residual_backward(i, sb, dr, B)
         # ---- graph conv data gradient (+ skip-path gradient)
         gimg = self._img(pre + "gcn.b")
