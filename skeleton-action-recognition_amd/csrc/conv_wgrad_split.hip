@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     };
     u32x4 raw[2][2];
     load_dout(kh, raw[0]);
+    SAR_LDS_SKEW();   // this wave reads the window late: the next tile's stager must wait at the closing barrier
 #pragma unroll 1
     for (int ks = kh; ks < KS; ks += 2 * WK) {
 #pragma unroll
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     };
     u32x4 raw[2][2][2];
     load_dout(kh, raw[0]);
+    SAR_LDS_SKEW();
 #pragma unroll 1
     for (int ks = kh; ks < KS; ks += 2 * WK) {
 #pragma unroll

@@ -41,7 +41,7 @@ def get_parser():
     parser.add_argument('--save-scores', action='store_true',
                         help='write the test-set class probabilities of every checkpointed epoch (scores-N.npy, for score fusion '
                              'of separately trained streams with tools/fuse_scores.py)')
-    parser.add_argument('--mfma', default='fp32', choices=['fp32', 'bf16', 'bf16_operands'],
+    parser.add_argument('--mfma', default='fp32', choices=['fp32', 'f32_split', 'f32_split_bf16x6', 'bf16', 'bf16_operands'],
                         help="arithmetic of the convolutions' matrix products: fp32 (the reference's); bf16 = bf16 activations in HBM + bf16 operands, fp32 "
                              "accumulation, BatchNorm statistics and master weights; bf16_operands = bf16 operands only")
     parser.add_argument('--base-lr', type=float, default=1e-1, help='initial learning rate')

@@ -48,7 +48,9 @@ class Model(torch.nn.Module):
         """stream (not in the reference's constructor, which reads pre-computed files): 'joint', 'bone', 'joint_motion'
         or 'bone_motion' -- the bone (data_gen/gen_bone_data.py) and motion (data_gen/gen_motion_data.py) transforms are
         applied on the fly to JOINT input inside the data_bn prologue, bit-exactly.
-        mfma: 'fp32' (the reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 everything else: sar_amd/stgcn.py)."""
+        mfma: 'fp32' (the reference's arithmetic on the fp32 MFMA), 'f32_split' (fp32 storage and results, the contractions as three
+        products of fp16 terms on the fp16 matrix pipe: same parity tolerances, 1.6x the training rate; 'f32_split_bf16x6': six
+        products of bf16 terms) or 'bf16' (bf16 activations and MFMA operands, fp32 everything else: sar_amd/stgcn.py)."""
         super().__init__()
         assert stream in ("joint", "bone", "joint_motion", "bone_motion"), stream
         from sar_amd.bone import NTU_BONE_PAIRS

@@ -105,6 +105,29 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert sec["pathB"]["n_gpus"] == 2 and sec["pathB"]["value"] > 0 and len(sec["pathB"]["per_rank_ms"]) == 2
 
 
+def test_bench_eight_ranks_rehearsal(tmp_path):
+    """the driver's 8-GPU command line rehearsed on ONE GPU -- `python bench.py --gpus 8 --quick --batch 2`
+    with all eight ranks on cuda:0 over gloo (SAR_BENCH_SHARE_GPU=1): the self-launch, the rendezvous port, the MAX-agreed warm-up
+    loop of Leg.run, per_rank_ms of length 8, every secondary leg at world 8, a clean exit.  (What it cannot rehearse is RCCL
+    over xGMI itself: tests/test_gpu_rccl.py runs the RCCL branches on a one-rank communicator.)"""
+    env = dict(os.environ, SAR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--quick", "--batch", "2", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--sustained-steps", "0", "--warm-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert len(out["per_rank_ms"]) == 8 and all(t > 0 for t in out["per_rank_ms"]) and out["allreduce_ms"] is not None
+    assert out["grad_buckets"] == 3 and out["config"]["parallelism"] == "dp8"
+    sec = out["secondary"]
+    for name in ("f32_split", "bf16", "pathB", "pathB_pad250", "config5"):
+        assert sec[name]["n_gpus"] == 8 and sec[name]["value"] > 0 and len(sec[name]["per_rank_ms"]) == 8, name
+    assert sec["f32_split"]["dtype"] == "f32" and "f16x3a" in sec["f32_split"]["config"]["workload"]
+
+
 def _write_npy_dataset(d, n, T, classes, split):
     """<d>/<split>_data_joint.npy + <d>/<split>_label.pkl (data_gen/gen_joint_data.py:138-151); clip i carries its id in
     its first coordinate so that a rank's trace says which clips it trained on."""

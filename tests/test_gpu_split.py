@@ -1,0 +1,227 @@
+"""GPU parity of the split arithmetics (csrc/conv_gemm_split.hip, conv_wgrad_split.hip) beyond the fp32 parity suites that run them
+through tests/conftest.py's `arith_mode`: the RANGE behaviour of the fp16 arithmetic (f16x3a) -- operand bounds, wide dynamic
+range, sums that exceed the source bound, scale invariance, saturation instead of infinities -- and the bound kernels themselves.
+Reference: float64 torch on the CPU (oracle primitives), tolerance = the fp32 kernels' 2e-5 (norm-wise)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stgcn as O
+from util import to_cn, from_cn, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+ARITHS = ["f16x3a", "bf16x6"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from sar_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _bits(x):
+    return np.float32(x).view(np.uint32).item()
+
+
+def _cell(dev, value):
+    return torch.tensor([_bits(value)], dtype=torch.int64).to(torch.int32).to(dev) if _bits(value) < 2 ** 31 else None
+
+
+def test_amax_and_bound_kernels(dev):
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for shape, ld in (((7, 1001), 1001), ((64, 4000), 4096), ((3, 16), 16)):
+        x = torch.randn(shape[0], ld, generator=g)[:, :shape[1]]
+        x[shape[0] // 2, shape[1] // 3] = -37.5
+        xd = x.to(dev)
+        if ld != shape[1]:
+            buf = torch.zeros(shape[0], ld, device=dev)
+            buf[:, :shape[1]] = xd
+            buf[:, shape[1]:] = 1e9            # beyond n: must not be read
+            xd = buf[:, :shape[1]]
+        cell = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.amax(xd, cell)
+        assert cell.item() == _bits(37.5)
+        ops.amax(xd * 0.5, cell)               # a cell is only ever RAISED
+        assert cell.item() == _bits(37.5)
+    gamma, beta = torch.randn(40, generator=g), torch.randn(40, generator=g)
+    cell = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.bn_bound(gamma.to(dev), beta.to(dev), 960000, cell)
+    want = (gamma.abs().double() * np.sqrt(960000 - 1) + beta.abs().double()).max().item()
+    got = np.uint32(cell.item()).view(np.float32).item()
+    assert want <= got <= want * 1.002
+    src = torch.tensor([_bits(3.25)], dtype=torch.int32, device=dev)
+    cell.zero_()
+    ops.affine_bound(gamma.to(dev), beta.to(dev), src, cell)
+    want = gamma.abs().max().item() * 3.25 + beta.abs().max().item()
+    got = np.uint32(cell.item()).view(np.float32).item()
+    assert want <= got <= want * 1.002
+
+
+def test_samuelson_bound_holds_for_heavy_tails(dev):
+    """|gamma (x - mean) rstd + beta| <= |gamma| sqrt(n - 1) + |beta| for ANY data normalised by its own statistics -- a single
+    outlier in otherwise constant data reaches sqrt(n - 1) exactly"""
+    n = 4096
+    x = torch.zeros(n, dtype=torch.float64)
+    x[17] = 1e6
+    z = (x - x.mean()) / x.var(unbiased=False).sqrt()
+    assert abs(z.abs().max().item() - np.sqrt(n - 1)) < 1e-6
+
+
+def _temporal_case(dev, f, T, B, s, seed, src_scale=None):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, f, T, 25, generator=g)
+    if src_scale is not None:
+        x = x * src_scale
+    kernel = torch.randn(9, 1, f, f, generator=g) * 0.05
+    bias = torch.randn(f, generator=g) * 0.1
+    return x, kernel, bias
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("f,T,s", [(64, 23, 1), (128, 20, 2)])
+def test_temporal_forward_and_gradients_with_a_gradient_like_source(dev, arith, f, T, s):
+    """a source with 40 binades between its channels and a few huge outliers (what du / dg look like): the data gradient (src = the
+    wide operand) and the weight gradient (dout = the wide operand) against float64"""
+    from sar_amd import ops, _lib as L
+    B = 2
+    g = torch.Generator().manual_seed(f + T)
+    To, pad, _ = O.same_pad(T, 9, s)
+    du = torch.randn(B, f, To, 25, generator=g) * torch.logspace(-12, 0, f).view(1, f, 1, 1) * 1e-4
+    du[0, 3, 1, 7] = 0.3          # an outlier 1e3 .. 1e15 above everything else
+    gx = torch.randn(B, f, T, 25, generator=g).double()
+    sc = (1 + 0.2 * torch.randn(f, generator=g)).double(); sh = (0.3 * torch.randn(f, generator=g)).double()
+    kernel = (torch.randn(9, 1, f, f, generator=g) * 0.05).double().requires_grad_(True)
+    bias = torch.zeros(f, dtype=torch.float64, requires_grad=True)
+    pre = (gx * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    y = O.temporal_conv(torch.relu(pre), kernel, bias, s)
+    g_pre, g_k, g_b = torch.autograd.grad(y, (pre, kernel, bias), du.double())
+    scd, shd = sc.float().to(dev), sh.float().to(dev)
+    # data gradient, mask open everywhere (the ReLU mask is the fp32 suites' business): compare with the unmasked float64 gradient
+    ones = torch.ones_like(pre)
+    y2 = O.temporal_conv(pre * ones, kernel, bias, s)
+    g_lin, = torch.autograd.grad(y2, pre, du.double())
+    wT = torch.empty((9, f, f), device=dev)
+    ops.transpose(kernel.detach().float().to(dev).contiguous(), wT, 9, f, f)
+    dz = torch.empty((f, B * T * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(du).to(dev), dz, wT, f * f, f, B=B, V=25, T_src=To, T_out=T, Kc=f, M=f, taps=9, stride=s,
+                  pad=pad, transposed=True, split=arith)
+    torch.cuda.synchronize()
+    got = from_cn(dz.cpu(), B, T, 25)
+    assert rel_err(got, g_lin) < TOL
+    # per output CHANNEL too: W mixes the source channels, so every output row sees the large ones; but the rows of the outlier's
+    # receptive field must not swamp the others
+    far = torch.ones(T, dtype=torch.bool)
+    far[max(0, 1 * s - 8):1 * s + 9] = False
+    assert rel_err(got[0][:, far], g_lin[0][:, far]) < TOL
+    if s == 1:
+        flat = torch.zeros(9 * f * f + f, device=dev)
+        ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx.float()).to(dev), to_cn(du).to(dev), flat, B=B, V=25, T_src=T, T_out=To, Kc=f, M=f,
+                       taps=9, stride=s, pad=pad, pro=(scd, shd), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f,
+                       bsize=f, split=arith)
+        torch.cuda.synchronize()
+        gk = flat[:9 * f * f].cpu().view(9, 1, f, f)
+        assert rel_err(gk, g_k) < TOL
+        # column m of dW sums dout row m only: the 1e-12-scaled rows must be as accurate (relative to themselves) as the large ones
+        for m in (0, f // 2, f - 1):
+            assert rel_err(gk[..., m], g_k[..., m]) < 5 * TOL, m
+        assert rel_err(flat[9 * f * f:].cpu(), g_b) < TOL
+
+
+def test_f16_results_scale_exactly_with_a_power_of_two(dev):
+    """the operand scale is a power of two taken from the bound: src * 2^k gives the same term images, hence out * 2^k BIT FOR BIT"""
+    from sar_amd import ops, _lib as L
+    f, T, B = 64, 12, 2
+    x, kernel, _ = _temporal_case(dev, f, T, B, 1, 5)
+    outs = []
+    for k in (0, -60, 50):
+        out = torch.empty((f, B * T * 25), device=dev)
+        ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x * 2.0 ** k).to(dev), out, kernel.to(dev), f * f, f, B=B, V=25, T_src=T, T_out=T,
+                      Kc=f, M=f, taps=9, stride=1, pad=4, split="f16x3a")
+        torch.cuda.synchronize()
+        outs.append(out.cpu().double() * 2.0 ** -k)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_a_stale_bound_saturates_instead_of_overflowing(dev):
+    """a bound 2^20 too small (a caller's bug): values clamp at the fp16 maximum -- a wrong, FINITE result, never inf / nan"""
+    from sar_amd import ops, _lib as L
+    f, T, B = 64, 10, 1
+    x, kernel, _ = _temporal_case(dev, f, T, B, 1, 6)
+    img, wb = ops._pack_split_single(kernel.to(dev), f * f, f, 9, f, f, "f16x3a")
+    small = torch.tensor([_bits(x.abs().max().item() * 2.0 ** -20)], dtype=torch.int32, device=dev)
+    out = torch.empty((f, B * T * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), out, kernel.to(dev), f * f, f, B=B, V=25, T_src=T, T_out=T, Kc=f, M=f,
+                  taps=9, stride=1, pad=4, split="f16x3a", packed=img, bounds=(small, wb))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("transpose", [False, True])
+def test_graph_conv_with_sums_beyond_the_source_bound(dev, arith, transpose):
+    """the transposed NTU lists hold sums of four joints with weight 1: the gathered value reaches 4x the source's amax (the first
+    version of the kernel scaled from amax alone and saturated exactly there)"""
+    from sar_amd import ops, _lib as L
+    from oracle.graph import spatial_adjacency
+    A = spatial_adjacency().astype(np.float32)
+    tab = ops.GraphTables(A, dev, transpose)
+    B, cin, f, T = 2, 64, 64, 7
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, cin, T, 25, generator=g) * 0.1
+    x[:, :, :, [1, 2, 4, 8, 12, 16]] = 1.0            # every entry of the dense lists at the amax, same sign
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    Aeff = torch.tensor(A).double()
+    if transpose:
+        Aeff = Aeff.transpose(1, 2)
+    ref = O.graph_conv_td(x.double(), kernel.double(), torch.zeros(3 * f, dtype=torch.float64), Aeff)
+    out = torch.empty((f, B * T * 25), device=dev)
+    ops.conv_gemm(L.SAR_CONV_GRAPH, to_cn(x).to(dev), out, kernel.to(dev), f, 3 * f, B=B, V=25, T_src=T, T_out=T, Kc=cin, M=f, taps=3,
+                  tables=tab, split=arith)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), B, T, 25), ref) < TOL
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_graph_weight_gradient_with_a_wide_range_dout(dev, arith):
+    from sar_amd import ops, _lib as L
+    from oracle.graph import spatial_adjacency
+    A = spatial_adjacency().astype(np.float32)
+    tab = ops.GraphTables(A, dev, False)
+    B, cin, f, T = 2, 64, 128, 9
+    g = torch.Generator().manual_seed(11)
+    x = torch.relu(torch.randn(B, cin, T, 25, generator=g)).double().requires_grad_(True)
+    kernel = (torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1).double().requires_grad_(True)
+    bias = torch.zeros(3 * f, dtype=torch.float64, requires_grad=True)
+    dout = torch.randn(B, f, T, 25, generator=g) * torch.logspace(-10, 0, f).view(1, f, 1, 1) * 1e-5
+    y = O.graph_conv_td(x, kernel, bias, torch.tensor(A).double())
+    gk, gb = torch.autograd.grad(y, (kernel, bias), dout.double())
+    flat = torch.zeros(cin * 3 * f + 3 * f, device=dev)
+    ops.conv_wgrad(L.SAR_CONV_GRAPH, to_cn(x.detach().float()).to(dev), to_cn(dout).to(dev), flat, B=B, V=25, T_src=T, T_out=T, Kc=cin,
+                   M=f, taps=3, tables=tab, w_stride_tap=f, w_stride_c=3 * f, wsize=cin * 3 * f, bsize=3 * f, split=arith)
+    torch.cuda.synchronize()
+    got = flat[:cin * 3 * f].cpu().view(1, 1, cin, 3 * f)
+    assert rel_err(got, gk) < TOL
+    for m in (0, f // 2, f - 1):          # output channel m of every slice: its own scale
+        cols = [m, f + m, 2 * f + m]
+        assert rel_err(got[..., cols], gk[..., cols]) < 5 * TOL, m
+    assert rel_err(flat[cin * 3 * f:].cpu(), gb) < TOL
+
+
+def test_pack_reports_each_items_amax(dev):
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(3)
+    flat = torch.randn(9 * 64 * 64 + 3 * 64 * 128, generator=g)
+    flat[100] = 5.5
+    flat[9 * 64 * 64 + 77] = -0.75 * 16
+    pk = ops.PackedSplitWeights("f16x3a")
+    pk.add("t", 0, 64 * 64, 64, 1, 9, 64, 64)
+    pk.add("g", 9 * 64 * 64, 128, 3 * 128, 1, 3, 64, 128)
+    pk.finalize(dev)
+    pk.refresh(flat.to(dev))
+    torch.cuda.synchronize()
+    assert pk.bound("t").item() == _bits(flat[:9 * 64 * 64].abs().max().item())
+    assert pk.bound("g").item() == _bits(flat[9 * 64 * 64:].abs().max().item())
