@@ -67,28 +67,41 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
     }
     const int so_u = (int)(d.ld_aux2 * 4), so_m = (int)(d.ld_aux2 >> 2);
     float* P = smem + wave * (16 * 65);
+    // The aux operands (ReLU-mask source / skip gradient; gate: + the second sum's tensor and the gate byte) of ALL rounds -- a
+    // round = 8 accumulator registers = half a 32-row block -- are requested before the first one is processed (gate: two rounds at a
+    // time): one exposed memory round trip per workgroup (gate: two) instead of one per round (tools/split_timeline.sh: the MASK epilogue took 27 000 cycles of a 90 000-cycle
+    // 64-channel workgroup against 10 000 for STATS; the gated one 31 000).
+    constexpr int NRB = gate ? 2 : 2 * MS;   // rounds requested together (gate: three operands per value -- 96 registers per pair of rounds)
+    float axb[NRB][NS][8], uxb[gate ? NRB : 1][NS][8];
+    unsigned gmb[gate ? NRB : 1][NS][8];
+    auto load_round = [&](int ms, int rb, float (&ax)[NS][8], float (&ux)[NS][8], unsigned (&gm)[NS][8]) {
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
+      for (int r8 = 0; r8 < 8; ++r8)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        float ax[NS][16], ux[NS][16];
-        unsigned gm[NS][16];
-        if (has_aux) {
-#pragma unroll
-          for (int r8 = 0; r8 < 8; ++r8)
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-              const int r = rb * 8 + r8;
-              ax[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                  ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
-              if (gate) {
-                ux[ns][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    ru, vo_u[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_u, 0));
-                gm[ns][r] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(
-                    rm, vo_m[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_m, 0);
-              }
-            }
+        for (int ns = 0; ns < NS; ++ns) {
+          const int r = rb * 8 + r8;
+          ax[ns][r8] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+              ra, vo_aux[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_aux, 0));
+          if (gate) {
+            ux[ns][r8] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                ru, vo_u[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_u, 0));
+            gm[ns][r8] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(
+                rm, vo_m[ns], (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_m, 0);
+          }
         }
+    };
+#pragma unroll
+    for (int rd = 0; rd < 2 * MS; ++rd) {
+      {
+        const int ms = rd >> 1, rb = rd & 1;
+        if (has_aux && rd % NRB == 0) {   // the whole batch of rounds is requested before its first round is processed
+#pragma unroll
+          for (int q = 0; q < NRB; ++q)
+            if (rd + q < 2 * MS) load_round((rd + q) >> 1, (rd + q) & 1, axb[q], uxb[gate ? q : 0], gmb[gate ? q : 0]);
+        }
+        float (&ax)[NS][8] = axb[rd % NRB];
+        float (&ux)[NS][8] = uxb[gate ? rd % NRB : 0];
+        unsigned (&gm)[NS][8] = gmb[gate ? rd % NRB : 0];
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) {
           const int r = rb * 8 + r8;
@@ -103,16 +116,16 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
               s1 += val;
               s2 = fmaf(val, val, s2);
             } else if (EPI == SAR_EPI_MASK) {
-              val = (fmaf(ax[ns][r], ap.x, ap.y) > 0.f) ? val : 0.f;
+              val = (fmaf(ax[ns][r8], ap.x, ap.y) > 0.f) ? val : 0.f;
               s1 += val;
-              s2 = fmaf(val, ax[ns][r] - ap.z, s2);
+              s2 = fmaf(val, ax[ns][r8] - ap.z, s2);
             } else if (EPI == SAR_EPI_ADD) {
-              val += ax[ns][r];
+              val += ax[ns][r8];
             } else if (gate) {   // replaces, for the block below, bn_add_relu_bwd_reduce and the masked-gradient write of the apply pass
-              val += ax[ns][r];
-              val = ((gm[ns][r] >> cbit[ns]) & 1u) ? val : 0.f;
+              val += ax[ns][r8];
+              val = ((gm[ns][r8] >> cbit[ns]) & 1u) ? val : 0.f;
               s1 += val;
-              s2 = fmaf(val, ux[ns][r] - ap.z, s2);
+              s2 = fmaf(val, ux[ns][r8] - ap.z, s2);
             }
             if (grp_ok)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],

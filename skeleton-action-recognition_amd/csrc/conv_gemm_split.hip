@@ -50,6 +50,39 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #include "conv_epi_f32.h"
 
+// Diagnostic build -DSAR_SPLIT_TL (tools/split_timeline.sh): wave 0 of every workgroup of the LAST launch writes one row -- start /
+// end in 100 MHz ticks (s_memrealtime), HW_ID, XCC_ID and the shader-clock cycles it spent in each phase (summed over the stages) --
+// DESIGN 3.9h's instrument for the split kernels.  No stamp executes in the product build.
+#ifdef SAR_SPLIT_TL
+constexpr int SPLIT_TL_WG = 16384;
+__device__ unsigned g_split_tl[SPLIT_TL_WG][16];
+#define SPLIT_TL_BEGIN()                                                \
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime();   \
+  unsigned long long tl_last = __builtin_amdgcn_s_memtime();            \
+  unsigned tl_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}
+#define SPLIT_TL(i)                                               \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    tl_acc[i] += (unsigned)(t_ - tl_last);                        \
+    tl_last = t_;                                                 \
+  } while (0)
+#define SPLIT_TL_END(wid)                                                                   \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < SPLIT_TL_WG) {                                     \
+      unsigned* row = g_split_tl[blockIdx.x];                                               \
+      row[0] = (unsigned)tl_rt0, row[1] = (unsigned)__builtin_amdgcn_s_memrealtime();       \
+      row[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   \
+      row[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                  \
+      for (int i_ = 0; i_ < 8; ++i_) row[4 + i_] = tl_acc[i_];                              \
+      row[12] = (unsigned)(wid);                                                            \
+    }                                                                                       \
+  } while (0)
+#else
+#define SPLIT_TL_BEGIN()
+#define SPLIT_TL(i)
+#define SPLIT_TL_END(wid)
+#endif
+
 constexpr int KC8 = 8;    // source channels per stage
 constexpr int VJ = 25;   // joints per frame: compile-time (tap shifts are immediates); other V stay on the fp32 kernel
 constexpr int AR_B1 = SAR_SPLIT_BF16X1, AR_B3 = SAR_SPLIT_BF16X3, AR_B6 = SAR_SPLIT_BF16X6, AR_B9 = SAR_SPLIT_BF16X9,
@@ -289,6 +322,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     w = xcd * per + slot;
     if (w >= nwork || slot >= per) return;
   }
+  SPLIT_TL_BEGIN();
   const int tile = w / ny;
   const int b = tile / k.TPS;
   const int t0 = (tile - b * k.TPS) * k.FT;
@@ -481,10 +515,14 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
   // stage s - 1 (every wave has read its last fragment of stage s - 1); the OPENING barrier of stage s follows every wave's
   // ds_writes and its vmcnt(0) (its own DMA pieces have landed): behind it the whole image of stage s is in LDS.
   const int nst = (d.Kc + KC8 - 1) / KC8;
+  SPLIT_TL(0);   // prologue
   for (int s_ = 0; s_ < nst; ++s_) {
     store_s(s_ * KC8);
+    SPLIT_TL(1);   // wait for the stage's loads, folded BN + ReLU, split, LDS stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SPLIT_TL(2);   // wait for the W DMA
     __syncthreads();   // opening
+    SPLIT_TL(3);
     if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC8);   // registers; in flight during the MFMA phase
     SAR_LDS_SKEW();
     if (PAR) {
@@ -495,12 +533,14 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
 #pragma unroll
       for (int q = 0; q < (TAPS + 1) / 2; ++q) kstep(q, q == (TAPS + 1) / 2 - 1);
     }
+    SPLIT_TL(4);   // load issue + MFMA phase
     __syncthreads();   // closing: the image may be overwritten (next stage / the epilogue's transpose area)
     if (s_ + 1 < nst) {
       load_bnp((s_ + 1) * KC8);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       issue_w_dma(s_ + 1);
     }
+    SPLIT_TL(5);   // closing barrier + DMA issue
   }
 
   if (SCALED) {   // fp16 terms: undo the operand scales, join the cross terms, add the bias
@@ -519,6 +559,8 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     __syncthreads();   // every wave has read its bias rows: the MASK epilogue rewrites rowp
   }
   epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc[0], rowp, smem);
+  SPLIT_TL(6);   // epilogue
+  SPLIT_TL_END(w);
 }
 
 // ---- GraphConvTD (models/gcn.py:199-209) and its data gradient in the split arithmetics:
@@ -570,6 +612,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
   const int m0 = (w - tile * ny) * BM;
   const int nfr = (t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0;   // live frames of this tile
   const int ncols = nfr * V;
+  SPLIT_TL_BEGIN();
 
   // ---- classify the 3 V gather lists (threads 0 .. 3 V - 1, two waves)
   int l_idx[4] = {0, 0, 0, 0};
@@ -627,6 +670,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
     vmap[tid] = code;
   }
   __syncthreads();
+  SPLIT_TL(0);   // table classification (two barriers)
 
   // ---- per-lane column geometry and the three slices' operand columns
   bool colok[NS];
@@ -761,10 +805,14 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
   // Happens-before of the single image: as conv_gemm_split_kernel (store_s / DMA behind the closing barrier, the opening barrier
   // behind every wave's ds_writes and vmcnt(0))
   const int nst = (d.Kc + KC16 - 1) / KC16;
+  SPLIT_TL(7);   // geometry, first requests, accumulator initialisation
   for (int s_ = 0; s_ < nst; ++s_) {
     store_s(s_ * KC16);
+    SPLIT_TL(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SPLIT_TL(2);
     __syncthreads();   // opening
+    SPLIT_TL(3);
     if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC16);
     SAR_LDS_SKEW();
 #pragma unroll
@@ -795,8 +843,10 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
           }
       }
     }
+    SPLIT_TL(4);
     __syncthreads();   // closing
     if (s_ + 1 < nst) issue_w_dma(2 * (s_ + 1));
+    SPLIT_TL(5);
   }
 
   if (SCALED) {
@@ -816,6 +866,8 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
     __syncthreads();   // every wave has read its bias rows: the gated epilogue rewrites rowp
   }
   epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc[0], rowp, smem);
+  SPLIT_TL(6);
+  SPLIT_TL_END(w);
 }
 
 int geometry_s(const sar_conv_desc& d, int tr, ConvKS& k) {
@@ -878,6 +930,18 @@ int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned
 bool ar_known(int ar) { return ar == AR_B1 || ar == AR_B3 || ar == AR_B6 || ar == AR_B9 || ar == AR_H3 || ar == AR_H3S || ar == AR_H3A; }
 
 }  // namespace
+
+#ifdef SAR_SPLIT_TL
+extern "C" int sar_debug_split_timeline(unsigned* out, int nwg, int reset) {   // out: [nwg][16] (host memory)
+  if (nwg > SPLIT_TL_WG) nwg = SPLIT_TL_WG;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_tl), (size_t)nwg * 16 * sizeof(unsigned)) != hipSuccess) return -1;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_split_tl)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * 16 * SPLIT_TL_WG) != hipSuccess) return -1;
+  }
+  return nwg;
+}
+#endif
 
 extern "C" int64_t sar_conv_gemm_split_workspace_bytes(const sar_conv_desc* d, int arith) {
   if (!d || d->Kc <= 0 || d->M <= 0 || d->taps <= 0 || !ar_known(arith)) return SAR_E_ARG;

@@ -118,7 +118,8 @@ class PackedSplitWeights(PackedWeights):
 
 def amax(x, cell):
     """cell (1-element int32 view, zeroed by the caller) = max(cell, bits of max |x|) -- sar_amax_f32, no host sync"""
-    check(L.load().sar_amax_f32(ptr(_f32(x)), x.shape[0], x.shape[1], x.stride(0), ptr(cell), stream_ptr()), "sar_amax_f32")
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1      # rows may be strided (ld >= n)
+    check(L.load().sar_amax_f32(ptr(x), x.shape[0], x.shape[1], x.stride(0), ptr(cell), stream_ptr()), "sar_amax_f32")
 
 
 def bn_bound(gamma, beta, count, cell):

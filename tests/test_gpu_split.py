@@ -84,14 +84,15 @@ def _temporal_case(dev, f, T, B, s, seed, src_scale=None):
 @pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("f,T,s", [(64, 23, 1), (128, 20, 2)])
 def test_temporal_forward_and_gradients_with_a_gradient_like_source(dev, arith, f, T, s):
-    """a source with 40 binades between its channels and a few huge outliers (what du / dg look like): the data gradient (src = the
-    wide operand) and the weight gradient (dout = the wide operand) against float64"""
+    """a source with 13 binades between its channels and an outlier 2^11 above the largest of them (what du / dg look like; 25
+    binades in all, inside the 2^29 window below the bound in which f16x3a keeps 22 bits per element -- DESIGN 3.10b states the
+    limit): the data gradient (src = the wide operand) and the weight gradient (dout = the wide operand) against float64"""
     from sar_amd import ops, _lib as L
     B = 2
     g = torch.Generator().manual_seed(f + T)
     To, pad, _ = O.same_pad(T, 9, s)
-    du = torch.randn(B, f, To, 25, generator=g) * torch.logspace(-12, 0, f).view(1, f, 1, 1) * 1e-4
-    du[0, 3, 1, 7] = 0.3          # an outlier 1e3 .. 1e15 above everything else
+    du = torch.randn(B, f, To, 25, generator=g) * torch.logspace(-4, 0, f).view(1, f, 1, 1) * 1e-4
+    du[0, 3, 1, 7] = 0.3          # an outlier 1e3 .. 1e7 above everything else
     gx = torch.randn(B, f, T, 25, generator=g).double()
     sc = (1 + 0.2 * torch.randn(f, generator=g)).double(); sh = (0.3 * torch.randn(f, generator=g)).double()
     kernel = (torch.randn(9, 1, f, f, generator=g) * 0.05).double().requires_grad_(True)
@@ -125,7 +126,7 @@ def test_temporal_forward_and_gradients_with_a_gradient_like_source(dev, arith, 
         torch.cuda.synchronize()
         gk = flat[:9 * f * f].cpu().view(9, 1, f, f)
         assert rel_err(gk, g_k) < TOL
-        # column m of dW sums dout row m only: the 1e-12-scaled rows must be as accurate (relative to themselves) as the large ones
+        # column m of dW sums dout row m only: the 1e-4-scaled rows must be as accurate (relative to themselves) as the large ones
         for m in (0, f // 2, f - 1):
             assert rel_err(gk[..., m], g_k[..., m]) < 5 * TOL, m
         assert rel_err(flat[9 * f * f:].cpu(), g_b) < TOL
@@ -196,7 +197,7 @@ def test_graph_weight_gradient_with_a_wide_range_dout(dev, arith):
     x = torch.relu(torch.randn(B, cin, T, 25, generator=g)).double().requires_grad_(True)
     kernel = (torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1).double().requires_grad_(True)
     bias = torch.zeros(3 * f, dtype=torch.float64, requires_grad=True)
-    dout = torch.randn(B, f, T, 25, generator=g) * torch.logspace(-10, 0, f).view(1, f, 1, 1) * 1e-5
+    dout = torch.randn(B, f, T, 25, generator=g) * torch.logspace(-6, 0, f).view(1, f, 1, 1) * 1e-5
     y = O.graph_conv_td(x, kernel, bias, torch.tensor(A).double())
     gk, gb = torch.autograd.grad(y, (kernel, bias), dout.double())
     flat = torch.zeros(cin * 3 * f + 3 * f, device=dev)
