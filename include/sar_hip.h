@@ -101,6 +101,9 @@ enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3,
  * the listed joint and builds only the n remaining lists per frame (csrc/conv_graph_cn8.hip), bit-identical with the kernel
  * that builds every gathered tile.  A count that is too small makes the excess lists read as empty (wrong result, no fault). */
 #define SAR_GRAPH_FEW_DENSE 4
+/* g_flags: the caller asserts that slice 0's gather lists are the identity ({(w, 1.0)} for every joint w: the self-links of the
+ * 'spatial' strategy, graph/tools.py:22-30).  The split graph weight gradient then stages the raw tile once (csrc/conv_wgrad_split.hip). */
+#define SAR_GRAPH_SLICE0_IDENTITY 8
 #define SAR_GRAPH_FEW_DENSE_SHIFT 8
 typedef struct sar_conv_desc {
   int32_t mode;        /* SAR_CONV_* */
@@ -230,7 +233,8 @@ int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int6
 /* The weight / bias gradient of the same operator in the split arithmetics SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A
  * (csrc/conv_wgrad_split.hip; SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A): same descriptor and slab contract as sar_conv_wgrad_f32 (slabs reduced by sar_slab_reduce_f32),
  * src_bound / dout_bound = bound cells of pro(src) / dout for the fp16 arithmetic.  Built for the 9-tap TEMPORAL operator at
- * V = 25, stride 1, 8 <= Kc <= 256; other shapes: SAR_E_UNSUP (keep sar_conv_wgrad_f32).  nsplit must be a multiple of the wk
+ * V = 25, stride 1 or stride 2 with pad 3 and T_src = 2 T_out, 8 <= Kc <= 256, and for the GRAPH operator at V = 25, 16 <= Kc <= 256
+ * without a folded prologue; other shapes: SAR_E_UNSUP (keep sar_conv_wgrad_f32).  nsplit must be a multiple of the wk
  * that sar_conv_wgrad_split_blocks reports (at M <= 64 two wave pairs of a workgroup split a tile's k-steps and write two slabs);
  * that query returns the weight blocks per slab group (or SAR_E_UNSUP) and the positions per tile: a launch has
  * (nsplit / wk) * blocks workgroups, two resident per CU. */

@@ -1,4 +1,5 @@
-// conv_wgrad_split.hip -- weight / bias gradient of the 9-tap temporal convolution (stride 1) with fp32 results on the fp16 /
+// conv_wgrad_split.hip -- weight / bias gradient of the 9-tap temporal convolution (stride 1; stride 2 through parity images) and of
+// the graph convolution with fp32 results on the fp16 /
 // bf16 matrix pipe (the "split" arithmetic of conv_gemm_split.hip; gfx950).
 //
 //   dW[tap][c][m] = sum_n pro(src)[c, n + (tap - pad) V] * dout[m, n]        (tf.GradientTape of the Conv2D [9,1],
@@ -52,11 +53,16 @@ constexpr int ar_pj(int ar, int p) {
   constexpr int j6[6] = {2, 0, 1, 1, 0, 0};
   return ar == AR_H3A ? (p == 0 ? 1 : 0) : j6[p];
 }
-template <int AR> struct Cfg {
+// S2 (stride 2, TF-SAME pad 3 of an even T: models/stgcn.py:117,120): out frame t reads src frame 2 t + tap - 3.  The src frames are
+// de-interleaved by parity into two images in the coordinates of the dout positions -- E: frame 2 i at (i, v), O: frame 2 i + 1 --
+// in which a tap is again a shift by whole frames: odd taps read E at n + 25 (tap - 3) / 2, even taps O at n + 25 (tap - 4) / 2.
+// Both images cover [n0 - 50, n0 + KT + 50): with KT = 96 the row is as long as stride 1's (392 elements).
+template <int AR, int S2 = 0> struct Cfg {
   static constexpr int NT = ar_nta(AR);                 // src images in LDS
-  static constexpr int KT = 192;                         // positions per tile (multiple of 16): 3 x 32 x 394 x 2 B = 75.6 KB
+  static constexpr int KT = S2 ? 96 : 192;               // dout positions per tile (multiple of 16): 3 x 32 x 394 x 2 B = 75.6 KB
   static constexpr int KS = KT / 16;
-  static constexpr int WIN = KT + (TAPS - 1) * VJ;       // src window
+  static constexpr int WIN2 = KT + 4 * VJ;               // S2: positions per parity image
+  static constexpr int WIN = S2 ? 2 * WIN2 : KT + (TAPS - 1) * VJ;   // src window (S2: E | O)
   static constexpr int RS = ((WIN + 2 + 1) / 2 * 2) + ((((WIN + 2 + 1) / 2) & 1) ? 0 : 2);   // row stride (elements): >= WIN + 2, RS / 2 odd
   static constexpr int NCH = (WIN + 127) / 128;          // stager chunks of 128 positions (a lane owns two adjacent positions)
   static_assert((RS / 2) % 2 == 1 && RS >= WIN + 2, "row stride");
@@ -118,9 +124,9 @@ struct WgradKS {
 };
 
 // WK = 1: four waves side by side along m (128 dout channels); WK = 2: two along m, the pairs split the k-steps (M <= 64)
-template <int AR, int WK>
+template <int AR, int WK, int S2>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS k) {
-  using C = Cfg<AR>;
+  using C = Cfg<AR, S2>;
   constexpr int NT = C::NT, NTB = ar_ntb(AR), NPROD = ar_nprod(AR), KT = C::KT, KS = C::KS, WIN = C::WIN, RS = C::RS, NCH = C::NCH, V = VJ;
   constexpr int WMM = 4 / WK, MBLK = 32 * WMM;
   __shared__ __attribute__((aligned(16))) unsigned short Hs[NT * CB * RS];
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   const int tile_lo = sg * tps;
   const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
   const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
-  const int seq = d.T_src * V;   // stride 1: T_src == T_out
+  const int seq = d.T_out * V;        // dout positions per sequence
+  const int seq_src = d.T_src * V;    // (stride 1: the same)
 
   // LDS read base of this lane: row l31, element 8 * hi
   const unsigned a_base = (unsigned)(uintptr_t)Hs + (unsigned)((l31 * RS + 8 * hi) * 2);
@@ -190,8 +197,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     __syncthreads();   // closing: every wave has read its last fragment of the previous tile (and bnp is written)
     // ---- stage the src window [n0 - pad V, n0 - pad V + WIN) of rows c0 .. c0 + 31: wave w takes rows w, w + 4, ..
     {
-      const float* src_b = d.src + (int64_t)b * seq;
+      const float* src_b = d.src + (int64_t)b * seq_src;
       const int p_lo = n0 - d.pad * V;
+      // this lane's window columns and their src positions (the same for every row): stride 1 -- consecutive positions; S2 -- column
+      // q of image E / O is dout-space position n0 - 50 + q = (i, v), i.e. src frame 2 i (+ 1)
+      int spos[NCH][2];
+      bool sok[NCH][2];
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int col = 2 * lane + 128 * j + e;
+          if (S2) {
+            const int img = col >= C::WIN2 ? 1 : 0, q = col - img * C::WIN2;
+            const int nn = n0 - 2 * V + q;
+            const int i = floordiv(nn, V), v = nn - i * V;
+            const int fr = 2 * i + img;
+            sok[j][e] = col < WIN && fr >= 0 && fr < d.T_src;
+            spos[j][e] = sok[j][e] ? fr * V + v : -1;
+          } else {
+            const int pa = p_lo + col;
+            sok[j][e] = col < WIN && (unsigned)pa < (unsigned)seq_src;
+            spos[j][e] = pa;
+          }
+        }
 #pragma unroll 1
       for (int rh = 0; rh < 2; ++rh) {
         float x[4][NCH][2];
@@ -201,12 +230,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
           const int c = c0 + row;
           const int cg = c < d.Kc ? c : 0;
           const __amdgpu_buffer_rsrc_t rs =
-              __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq * 4, 0x00020000);
+              __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq_src * 4, 0x00020000);
 #pragma unroll
-          for (int j = 0; j < NCH; ++j) {
-            const int pa = p_lo + 2 * lane + 128 * j;   // negative / past-the-end offsets: rejected by the range check -> 0
-            x[q][j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, pa * 4, 0, 0));
-            x[q][j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (pa + 1) * 4, 0, 0));
+          for (int j = 0; j < NCH; ++j) {   // negative / past-the-end offsets: rejected by the range check -> 0
+            x[q][j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, spos[j][0] * 4, 0, 0));
+            x[q][j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, spos[j][1] * 4, 0, 0));
           }
         }
 #pragma unroll
@@ -217,11 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
 #pragma unroll
           for (int j = 0; j < NCH; ++j) {
             const int col = 2 * lane + 128 * j;
-            const int pa = p_lo + col;
-            const bool ok0 = rok && col < WIN && (unsigned)pa < (unsigned)seq;
-            const bool ok1 = rok && col + 1 < WIN && (unsigned)(pa + 1) < (unsigned)seq;
-            const float v0 = ok0 ? fmaxf(fmaf(x[q][j][0], ps.x, ps.y), relu_lo) : 0.f;   // TF-SAME padding stays exactly 0
-            const float v1 = ok1 ? fmaxf(fmaf(x[q][j][1], ps.x, ps.y), relu_lo) : 0.f;
+            const float v0 = (rok && sok[j][0]) ? fmaxf(fmaf(x[q][j][0], ps.x, ps.y), relu_lo) : 0.f;   // TF-SAME padding stays exactly 0
+            const float v1 = (rok && sok[j][1]) ? fmaxf(fmaf(x[q][j][1], ps.x, ps.y), relu_lo) : 0.f;
             unsigned w[NT];
             split2<AR, true>(v0, v1, w);
             if (col < RS) {
@@ -276,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
           const unsigned a_ks = a_base + kc * 32;
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
-            const int e = t * V;   // window start in elements; V odd: parity of t
+            // window start in elements: stride 1 -- t V (V odd: the parity of t); S2 -- image E for odd taps, O for even ones, shifted by
+            // whole frames: (floor((t - 3) / 2) + 2) V inside the image
+            const int e = S2 ? ((t & 1) ? 0 : C::WIN2) + ((t - 3 - ((t & 1) ? 0 : 1)) / 2 + 2) * V : t * V;
             u32x4 aq[NT];
 #pragma unroll
             for (int tm = 0; tm < NT; ++tm) {
@@ -331,14 +358,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
 // global memory -- the frame is in L1 / L2 --, the fp32 kernel's fma chain, then the split into the conditioned operand's three
 // images), [slice][term][32 rows][120] 2-byte elements = 69 KB: two workgroups per CU.  A wave owns 32 src channels x 64 dout channels
 // x 3 slices (96 accumulator registers); at M <= 128 / 64 the wave groups split the tile's k-steps (WK = 2 / 4 slabs per group).
-constexpr int GFT = 4, GKP = GFT * VJ, GKS = (GKP + 15) / 16, GRS = 120;
-template <int AR, int WK, int NZ0, int NZ1, int NZ2>
+constexpr int GFT = 4, GKP = GFT * VJ, GKS = (GKP + 15) / 16, GRS = 120, GRAW = 101;   // raw tile: 32 rows x 101 floats (odd stride)
+template <int AR, int WK, int NZ0, int NZ1, int NZ2, bool S0ID>
 __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS k) {
   constexpr int NT = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), V = VJ, KS = GKS, RS = GRS;
   constexpr int NZ[3] = {NZ0, NZ1, NZ2};
   constexpr int WMM = 4 / WK, MBLK = 64 * WMM;
-  constexpr int RPP = (NZ0 + NZ1 + NZ2 > 6) ? 1 : 2;   // rows per stager pass (gathered loads in flight: 2 x sum(NZ) per row)
+  constexpr int RPP = (NZ0 + NZ1 + NZ2 > 6) ? 1 : 2;   // generic stager: rows per pass
   static_assert(RS >= KS * 16 && (RS * 2) % 16 == 0 && ((RS / 2) / 4) % 2 == 1, "row stride: 16-byte rows, conflict-free 16-byte reads");
+  static_assert(CB * GRAW * 4 <= NT * CB * RS * 2, "the raw tile fits the area of slice 0's images");
   __shared__ __attribute__((aligned(16))) unsigned short Zs[3 * NT * CB * RS];
   __shared__ __attribute__((aligned(16))) float csl[3 * KS * 16];   // colsum(A_k) of every tile position (0 beyond the live ones)
   const sar_wgrad_desc& d = k.d;
@@ -431,6 +459,68 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     const int nlive = ((t0 + GFT <= d.T_out) ? GFT : d.T_out - t0) * V;   // live positions of this tile
     const int n0 = t0 * V;
     __syncthreads();   // closing: every wave has read its last fragment of the previous tile (and csl is written)
+    if constexpr (S0ID) {
+    // ---- raw tile: rows c0 .. c0 + 31 (wave w takes rows w, w + 4, ..), this lane's two adjacent positions; every load first.  It
+    // lives in the LDS area of slice 0's images: slice 0 is the identity (SAR_GRAPH_SLICE0_IDENTITY), so its images are the split of
+    // the lane's OWN raw values, which stay in registers across the barrier that frees the raw tile.
+    float* rawt = reinterpret_cast<float*>(&Zs[0]);
+    float xr[8][2];
+    {
+      const float* src_t = d.src + (int64_t)b * seq + n0;
+      const unsigned tb = (unsigned)(seq - n0) * 4;   // the sequence's remaining bytes: positions beyond it are rejected -> 0
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + wave + 4 * q;   // wave-uniform: the row part of the address is a scalar descriptor
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_t + (int64_t)(c < d.Kc ? c : 0) * d.ld_src), 0,
+                                                                            c < d.Kc ? tb : 0u, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          xr[q][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (2 * lane + e < nlive) ? (2 * lane + e) * 4 : 0x7fffffff, 0, 0));
+      }
+      if (2 * lane < GKP) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          rawt[(wave + 4 * q) * GRAW + 2 * lane] = xr[q][0];
+          rawt[(wave + 4 * q) * GRAW + 2 * lane + 1] = xr[q][1];
+        }
+      }
+    }
+    __syncthreads();   // the raw tile is complete
+    // ---- slices 1 and 2: gathered from the raw tile (a wave builds the rows it staged; the barrier above covers all rows)
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+      const int row = wave + 4 * q;
+      const float* rr = rawt + row * GRAW;
+#pragma unroll
+      for (int kk = 1; kk < 3; ++kk) {
+        float z[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float zz = gwt[kk][e][0] * rr[goff[kk][e][0]];
+#pragma unroll
+          for (int j = 1; j < 4; ++j)
+            if (j < NZ[kk]) zz = fmaf(gwt[kk][e][j], rr[goff[kk][e][j]], zz);
+          z[e] = (2 * lane + e < nlive) ? (ar_f16(AR) ? zz * sa : zz) : 0.f;   // (rows beyond Kc are zero in the raw tile)
+        }
+        unsigned w[NT];
+        split2<AR, true>(z[0], z[1], w);
+        if (2 * lane < RS) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Zs[((kk * NT + t) * CB + row) * RS + 2 * lane]) = w[t];
+        }
+      }
+    }
+    __syncthreads();   // every wave has gathered from the raw tile: its area becomes slice 0's images
+    if (2 * lane < RS) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        unsigned w[NT];
+        split2<AR, true>(ar_f16(AR) ? xr[q][0] * sa : xr[q][0], ar_f16(AR) ? xr[q][1] * sa : xr[q][1], w);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Zs[(t * CB + wave + 4 * q) * RS + 2 * lane]) = w[t];
+      }
+    }
+    } else {
     // ---- build the three gathered images of rows c0 .. c0 + 31: wave w takes rows w, w + 4, ..; two rows per pass
     {
       const float* src_t = d.src + (int64_t)b * seq + n0;
@@ -474,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
           }
         }
       }
+    }
     }
     __syncthreads();   // opening: the images are complete
 
@@ -579,16 +670,17 @@ int wgrad_split_wk(const sar_wgrad_desc& d, int arith) {
       if (d.nz[i] < 1 || d.nz[i] > 4) return 0;
     return d.M > 128 ? 1 : (d.M > 64 ? 2 : 4);
   }
-  if (d.mode != SAR_CONV_TEMPORAL || d.taps != TAPS || d.V != VJ || d.stride != 1 || d.T_src != d.T_out) return 0;
+  if (d.mode != SAR_CONV_TEMPORAL || d.taps != TAPS || d.V != VJ) return 0;
+  if (!((d.stride == 1 && d.T_src == d.T_out) || (d.stride == 2 && d.pad == 3 && d.T_src == 2 * d.T_out))) return 0;
   if (d.Kc < 8 || d.Kc > 256 || d.pad < 0 || d.pad > 8) return 0;
   return d.M > 64 ? 1 : 2;
 }
 
-template <int AR, int NZ0, int NZ1, int NZ2>
+template <int AR, int NZ0, int NZ1, int NZ2, bool S0ID>
 void launch_graph_wgrad_split(const WgradKS& k, int wk, dim3 grid, hipStream_t st) {
-  if (wk == 1) hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 1, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
-  else if (wk == 2) hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 2, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
-  else hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 4, NZ0, NZ1, NZ2>), grid, dim3(256), 0, st, k);
+  if (wk == 1) hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 1, NZ0, NZ1, NZ2, S0ID>), grid, dim3(256), 0, st, k);
+  else if (wk == 2) hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 2, NZ0, NZ1, NZ2, S0ID>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((graph_wgrad_split_kernel<AR, 4, NZ0, NZ1, NZ2, S0ID>), grid, dim3(256), 0, st, k);
 }
 
 template <int AR>
@@ -604,20 +696,25 @@ int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, cons
     k.gz = (d.Kc + CB - 1) / CB;
     const int nwork = (d.nsplit / wk) * k.gy * k.gz;
     const dim3 grid(((nwork + 7) / 8) * 8);
-    if (d.nz[0] == 1 && d.nz[1] == 1) launch_graph_wgrad_split<AR, 1, 1, 4>(k, wk, grid, st);
-    else if (d.nz[0] == 1 && d.nz[2] == 1) launch_graph_wgrad_split<AR, 1, 4, 1>(k, wk, grid, st);
-    else launch_graph_wgrad_split<AR, 4, 4, 4>(k, wk, grid, st);
+    const bool s0id = (d.g_flags & SAR_GRAPH_SLICE0_IDENTITY) != 0 && d.nz[0] == 1;   // the raw tile through LDS (one trip per tile)
+    if (d.nz[0] == 1 && d.nz[1] == 1) s0id ? launch_graph_wgrad_split<AR, 1, 1, 4, true>(k, wk, grid, st) : launch_graph_wgrad_split<AR, 1, 1, 4, false>(k, wk, grid, st);
+    else if (d.nz[0] == 1 && d.nz[2] == 1) s0id ? launch_graph_wgrad_split<AR, 1, 4, 1, true>(k, wk, grid, st) : launch_graph_wgrad_split<AR, 1, 4, 1, false>(k, wk, grid, st);
+    else launch_graph_wgrad_split<AR, 4, 4, 4, false>(k, wk, grid, st);
     return 0;
   }
   const int seq = d.T_out * d.V;
-  k.TPS = (seq + Cfg<AR>::KT - 1) / Cfg<AR>::KT;
+  const int kt = d.stride == 2 ? Cfg<AR, 1>::KT : Cfg<AR, 0>::KT;
+  k.TPS = (seq + kt - 1) / kt;
   k.ntiles = d.B * k.TPS;
   k.gy = (d.M + 128 / wk - 1) / (128 / wk);
   k.gz = (d.Kc + CB - 1) / CB;
   const int nwork = (d.nsplit / wk) * k.gy * k.gz;
   const dim3 grid(((nwork + 7) / 8) * 8), block(256);
-  if (wk == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 1>), grid, block, 0, st, k);
-  else hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 2>), grid, block, 0, st, k);
+  if (d.stride == 2) {
+    if (wk == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 1, 1>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 2, 1>), grid, block, 0, st, k);
+  } else if (wk == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 1, 0>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 2, 0>), grid, block, 0, st, k);
   return 0;
 }
 
@@ -632,7 +729,7 @@ extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, i
     if (tile_positions) *tile_positions = GKP;
     return ((d->M + 256 / wk - 1) / (256 / wk)) * ((d->Kc + CB - 1) / CB);
   }
-  if (tile_positions) *tile_positions = arith == AR_H3A ? Cfg<AR_H3A>::KT : Cfg<AR_B6>::KT;
+  if (tile_positions) *tile_positions = d->stride == 2 ? Cfg<AR_H3A, 1>::KT : Cfg<AR_H3A, 0>::KT;
   return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
 }
 
@@ -641,7 +738,7 @@ extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const ui
   SAR_REQUIRE(d != nullptr, "sar_conv_wgrad_split: null descriptor");
   const int wk = wgrad_split_wk(*d, arith);
   if (!wk) {
-    sar_set_error("sar_conv_wgrad_split: built for the 9-tap temporal convolution at V = 25, stride 1, 8 <= Kc <= 256 and the graph "
+    sar_set_error("sar_conv_wgrad_split: built for the 9-tap temporal convolution at V = 25, stride 1 (or 2 with pad 3, even T), 8 <= Kc <= 256 and the graph "
                   "convolution at V = 25, 16 <= Kc <= 256 without a folded prologue, in the arithmetics bf16x6 / f16x3a (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
                   d->mode, d->taps, d->V, d->stride, d->Kc, arith);
     return SAR_E_UNSUP;

@@ -44,6 +44,8 @@ class GraphTables:
         cnt = (wnp != 0).sum(axis=2)
         first = np.take_along_axis(wnp, np.argmax(wnp != 0, axis=2)[..., None], axis=2)[..., 0]
         self.n_dense_lists = int(((cnt > 1) | ((cnt == 1) & (first != 1.0))).sum())
+        if self.slice0_identity:
+            self.g_flags |= L.SAR_GRAPH_SLICE0_IDENTITY
         if self.n_dense_lists <= 16:
             self.g_flags |= L.SAR_GRAPH_FEW_DENSE | (self.n_dense_lists << L.SAR_GRAPH_FEW_DENSE_SHIFT)
 
