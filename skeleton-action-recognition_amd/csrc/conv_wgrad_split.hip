@@ -191,71 +191,86 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
       __builtin_amdgcn_make_buffer_rsrc((void*)d.dout, 0, (unsigned)(dbytes < (int64_t)REJECT ? dbytes : (int64_t)REJECT), 0x00020000);
   const unsigned drow = (unsigned)(((int64_t)(mrow_ok ? m0 + l31 : 0) * d.ld_dout) * 4);
 
+  // ---- the stager.  A tile's window is staged in two passes of four rows per wave; the loads of the FIRST pass of tile i + 1 are
+  // requested in front of the MFMA phase of tile i (32 registers across the k-loop): one exposed memory round trip per tile instead
+  // of two.  Geometry (this lane's window columns and their src positions, the same for every row): stride 1 -- consecutive
+  // positions; S2 -- column q of image E / O is dout-space position n0 - 50 + q = (i, v), i.e. src frame 2 i (+ 1).
+  auto geometry = [&](int n0, int (&spos)[NCH][2], bool (&sok)[NCH][2]) {
+    const int p_lo = n0 - d.pad * V;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int col = 2 * lane + 128 * j + e;
+        if (S2) {
+          const int img = col >= C::WIN2 ? 1 : 0, q = col - img * C::WIN2;
+          const int nn = n0 - 2 * V + q;
+          const int i = floordiv(nn, V), v = nn - i * V;
+          const int fr = 2 * i + img;
+          sok[j][e] = col < WIN && fr >= 0 && fr < d.T_src;
+          spos[j][e] = sok[j][e] ? fr * V + v : -1;
+        } else {
+          const int pa = p_lo + col;
+          sok[j][e] = col < WIN && (unsigned)pa < (unsigned)seq_src;
+          spos[j][e] = pa;
+        }
+      }
+  };
+  auto issue_pass = [&](int b, int rh, const int (&spos)[NCH][2], float (&x)[4][NCH][2]) {
+    const float* src_b = d.src + (int64_t)b * seq_src;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + wave + 4 * (rh * 4 + q);
+      const int cg = c < d.Kc ? c : 0;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq_src * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {   // negative / past-the-end offsets: rejected by the range check -> 0
+        x[q][j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, spos[j][0] * 4, 0, 0));
+        x[q][j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, spos[j][1] * 4, 0, 0));
+      }
+    }
+  };
+  auto convert_pass = [&](int rh, const bool (&sok)[NCH][2], const float (&x)[4][NCH][2]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = wave + 4 * (rh * 4 + q);
+      const bool rok = c0 + row < d.Kc;
+      const float2 ps = bnp[row];
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int col = 2 * lane + 128 * j;
+        const float v0 = (rok && sok[j][0]) ? fmaxf(fmaf(x[q][j][0], ps.x, ps.y), relu_lo) : 0.f;   // TF-SAME padding stays exactly 0
+        const float v1 = (rok && sok[j][1]) ? fmaxf(fmaf(x[q][j][1], ps.x, ps.y), relu_lo) : 0.f;
+        unsigned w[NT];
+        split2<AR, true>(v0, v1, w);
+        if (col < RS) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
+        }
+      }
+    }
+  };
+  float xa[4][NCH][2];
+  if (tile_lo < tile_hi) {
+    int spos[NCH][2];
+    bool sok[NCH][2];
+    const int b0 = tile_lo / k.TPS;
+    geometry((tile_lo - b0 * k.TPS) * KT, spos, sok);
+    issue_pass(b0, 0, spos, xa);
+  }
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int b = tile / k.TPS;
     const int n0 = (tile - b * k.TPS) * KT;
     __syncthreads();   // closing: every wave has read its last fragment of the previous tile (and bnp is written)
-    // ---- stage the src window [n0 - pad V, n0 - pad V + WIN) of rows c0 .. c0 + 31: wave w takes rows w, w + 4, ..
     {
-      const float* src_b = d.src + (int64_t)b * seq_src;
-      const int p_lo = n0 - d.pad * V;
-      // this lane's window columns and their src positions (the same for every row): stride 1 -- consecutive positions; S2 -- column
-      // q of image E / O is dout-space position n0 - 50 + q = (i, v), i.e. src frame 2 i (+ 1)
       int spos[NCH][2];
       bool sok[NCH][2];
-#pragma unroll
-      for (int j = 0; j < NCH; ++j)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int col = 2 * lane + 128 * j + e;
-          if (S2) {
-            const int img = col >= C::WIN2 ? 1 : 0, q = col - img * C::WIN2;
-            const int nn = n0 - 2 * V + q;
-            const int i = floordiv(nn, V), v = nn - i * V;
-            const int fr = 2 * i + img;
-            sok[j][e] = col < WIN && fr >= 0 && fr < d.T_src;
-            spos[j][e] = sok[j][e] ? fr * V + v : -1;
-          } else {
-            const int pa = p_lo + col;
-            sok[j][e] = col < WIN && (unsigned)pa < (unsigned)seq_src;
-            spos[j][e] = pa;
-          }
-        }
-#pragma unroll 1
-      for (int rh = 0; rh < 2; ++rh) {
-        float x[4][NCH][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = wave + 4 * (rh * 4 + q);
-          const int c = c0 + row;
-          const int cg = c < d.Kc ? c : 0;
-          const __amdgpu_buffer_rsrc_t rs =
-              __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq_src * 4, 0x00020000);
-#pragma unroll
-          for (int j = 0; j < NCH; ++j) {   // negative / past-the-end offsets: rejected by the range check -> 0
-            x[q][j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, spos[j][0] * 4, 0, 0));
-            x[q][j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, spos[j][1] * 4, 0, 0));
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = wave + 4 * (rh * 4 + q);
-          const bool rok = c0 + row < d.Kc;
-          const float2 ps = bnp[row];
-#pragma unroll
-          for (int j = 0; j < NCH; ++j) {
-            const int col = 2 * lane + 128 * j;
-            const float v0 = (rok && sok[j][0]) ? fmaxf(fmaf(x[q][j][0], ps.x, ps.y), relu_lo) : 0.f;   // TF-SAME padding stays exactly 0
-            const float v1 = (rok && sok[j][1]) ? fmaxf(fmaf(x[q][j][1], ps.x, ps.y), relu_lo) : 0.f;
-            unsigned w[NT];
-            split2<AR, true>(v0, v1, w);
-            if (col < RS) {
-#pragma unroll
-              for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
-            }
-          }
-        }
-      }
+      geometry(n0, spos, sok);
+      float xb[4][NCH][2];
+      issue_pass(b, 1, spos, xb);
+      convert_pass(0, sok, xa);   // requested in front of the previous tile's MFMA phase
+      convert_pass(1, sok, xb);
     }
     __syncthreads();   // opening: the window is complete
 
@@ -269,6 +284,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     };
     u32x4 raw[2][2];
     load_dout(kh, raw[0]);
+    if (tile + 1 < tile_hi) {   // the first pass of the next tile: in flight during this tile's k-steps
+      int spos[NCH][2];
+      bool sok[NCH][2];
+      const int bn = (tile + 1) / k.TPS;
+      geometry((tile + 1 - bn * k.TPS) * KT, spos, sok);
+      issue_pass(bn, 0, spos, xa);
+    }
     SAR_LDS_SKEW();   // this wave reads the window late: the next tile's stager must wait at the closing barrier
 #pragma unroll 1
     for (int ks = kh; ks < KS; ks += 2 * WK) {
