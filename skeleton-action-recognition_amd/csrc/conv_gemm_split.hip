@@ -59,7 +59,7 @@ __device__ unsigned g_split_tl[SPLIT_TL_WG][16];
 #define SPLIT_TL_BEGIN()                                                \
   const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime();   \
   unsigned long long tl_last = __builtin_amdgcn_s_memtime();            \
-  unsigned tl_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}
+  unsigned tl_acc[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}
 #define SPLIT_TL(i)                                               \
   do {                                                            \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
@@ -73,8 +73,8 @@ __device__ unsigned g_split_tl[SPLIT_TL_WG][16];
       row[0] = (unsigned)tl_rt0, row[1] = (unsigned)__builtin_amdgcn_s_memrealtime();       \
       row[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   \
       row[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                  \
-      for (int i_ = 0; i_ < 8; ++i_) row[4 + i_] = tl_acc[i_];                              \
-      row[12] = (unsigned)(wid);                                                            \
+      for (int i_ = 0; i_ < 10; ++i_) row[4 + i_] = tl_acc[i_];                             \
+      row[14] = (unsigned)(wid);                                                            \
     }                                                                                       \
   } while (0)
 #else
@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     __syncthreads();   // opening
     SPLIT_TL(3);
     if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC8);   // registers; in flight during the MFMA phase
+    SPLIT_TL(8);   // load issue
     SAR_LDS_SKEW();
     if (PAR) {
 #pragma unroll
@@ -710,6 +711,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
   const int svo = tid < ncols ? tid * 4 : 0x7fffffff;   // rejected -> 0
   const int vt = tid >> 1, vh = tid & 1;
   const bool vact = vt < nfr * nd;
+  const bool wave_virt = wave * 32 < nfr * nd;   // wave-uniform: this wave owns virtual joints (the others skip their 32 loads)
   int vvo[4];
   float vwt[4];
   {
@@ -718,9 +720,12 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       vwt[j] = vact ? vl_wt[l * 4 + j] : 0.f;
-      vvo[j] = (vact && vwt[j] != 0.f) ? (tf * V + vl_idx[l * 4 + j]) * 4 : 0x7fffffff;
+      // byte offset from row c0 + q of the stage: the lane's channel half (8 rows further) + the gathered column; an unused entry
+      // reads the tile's first float (weight 0)
+      vvo[j] = (int)(((int64_t)vh * 8 * d.ld_src + ((vact && vwt[j] != 0.f) ? tf * V + vl_idx[l * 4 + j] : 0)) * 4);
     }
   }
+  const unsigned vbytes = (unsigned)(8 * d.ld_src * 4) + tile_bytes;   // one descriptor per q covers both halves' rows
   float sreg[2][8], vreg[4][8];
   auto issue_s_loads = [&](int c0) {
 #pragma unroll
@@ -732,13 +737,18 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_t + (int64_t)cg * d.ld_src), 0, tile_bytes, 0x00020000);
         sreg[h][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo, 0, 0));
       }
+    // The virtual joints' gathered loads: BUFFER loads (the lane's channel half rides in its byte offset), unconditional per lane,
+    // inside ONE wave-uniform branch.  (Plain pointer loads here were FLAT loads: they count in lgkmcnt too and complete out of
+    // order, so the first LDS fragment read of the MFMA phase waited for all 32 of them -- 3 000 cycles per stage on the wave every
+    // other wave waits for, more than the stage's MFMA phase; tools/split_timeline.sh.)
+    if (wave_virt) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {   // (per-lane channel: the descriptor is per lane -> plain pointers through one whole-tile descriptor)
-      const int c = c0 + 8 * vh + q;
-      const int cg = c < d.Kc ? c : 0;
-      const float* row = src_t + (int64_t)cg * d.ld_src;
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + q;   // Kc % 16 == 0: both halves' rows exist
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_t + (int64_t)c * d.ld_src), 0, vbytes, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) vreg[j][q] = (vvo[j] != 0x7fffffff) ? row[vvo[j] >> 2] : 0.f;
+        for (int j = 0; j < 4; ++j) vreg[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vvo[j], 0, 0));
+      }
     }
   };
   auto store_s = [&](int c0) {
@@ -814,6 +824,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k
     __syncthreads();   // opening
     SPLIT_TL(3);
     if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC16);
+    SPLIT_TL(8);   // load issue
     SAR_LDS_SKEW();
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {

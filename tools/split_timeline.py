@@ -66,9 +66,9 @@ for (cin, f, T, s) in shapes:
         ncu = len(np.unique(cu))
         span = en.max()
         resid = life.sum() / (ncu * span)
-        ph = rows[:, 4:12].mean(axis=0)
-        ghz = rows[:, 4:12].sum() / max(life.sum(), 1)
+        ph = rows[:, 4:14].mean(axis=0)
+        ghz = rows[:, 4:14].sum() / max(life.sum(), 1)
         print("[%3d->%3d T%3d] %-7s %7.1f us | %5d wgs on %d CUs, lifetime %.1f us (p10 %.1f p90 %.1f), resident/CU %.2f, %.2f GHz | cycles: "
-              "tables %.0f, geometry+init %.0f, store %.0f, dma-wait %.0f, open-barrier %.0f, mfma %.0f, close-barrier %.0f, epilogue %.0f (sum %.0f)"
+              "tables %.0f, geometry+init %.0f, store %.0f, dma-wait %.0f, open-barrier %.0f, load-issue %.0f, mfma %.0f, close-barrier %.0f, epilogue %.0f (sum %.0f)"
               % (cin, f, T, name, e0.elapsed_time(e1) * 1e3, len(rows), ncu, life.mean() / 1e3, np.percentile(life, 10) / 1e3,
-                 np.percentile(life, 90) / 1e3, resid, ghz, ph[0], ph[7], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph.sum()))
+                 np.percentile(life, 90) / 1e3, resid, ghz, ph[0], ph[7], ph[1], ph[2], ph[3], ph[8], ph[4], ph[5], ph[6], ph.sum()))
