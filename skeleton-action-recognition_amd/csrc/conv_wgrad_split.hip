@@ -35,6 +35,39 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build -DSAR_SPLIT_TL (tools/split_timeline.sh): wave 0 of every workgroup of the LAST launch writes one row -- start /
+// end in 100 MHz ticks (s_memrealtime), HW_ID, XCC_ID and the shader-clock cycles it spent in each phase (summed over the stages) --
+// DESIGN 3.9h's instrument for the split kernels.  No stamp executes in the product build.
+#ifdef SAR_SPLIT_TL
+constexpr int WSPLIT_TL_WG = 16384;
+__device__ unsigned g_wsplit_tl[WSPLIT_TL_WG][16];
+#define SPLIT_TL_BEGIN()                                                \
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime();   \
+  unsigned long long tl_last = __builtin_amdgcn_s_memtime();            \
+  unsigned tl_acc[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}
+#define SPLIT_TL(i)                                               \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    tl_acc[i] += (unsigned)(t_ - tl_last);                        \
+    tl_last = t_;                                                 \
+  } while (0)
+#define SPLIT_TL_END(wid)                                                                   \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < WSPLIT_TL_WG) {                                     \
+      unsigned* row = g_wsplit_tl[blockIdx.x];                                               \
+      row[0] = (unsigned)tl_rt0, row[1] = (unsigned)__builtin_amdgcn_s_memrealtime();       \
+      row[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   \
+      row[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                  \
+      for (int i_ = 0; i_ < 10; ++i_) row[4 + i_] = tl_acc[i_];                             \
+      row[14] = (unsigned)(wid);                                                            \
+    }                                                                                       \
+  } while (0)
+#else
+#define SPLIT_TL_BEGIN()
+#define SPLIT_TL(i)
+#define SPLIT_TL_END(wid)
+#endif
+
 constexpr int VJ = 25, TAPS = 9, CB = 32;
 constexpr int AR_B6 = SAR_SPLIT_BF16X6, AR_H3A = SAR_SPLIT_F16X3A;
 constexpr float H3_LO = 2048.f;
@@ -152,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   }
   const int m0 = by * MBLK + wmm * 32, c0 = bz * CB;
   const int ngrp = d.nsplit / WK;
+  SPLIT_TL_BEGIN();
 
   int ea = 0, eb = 0;
   if (ar_f16(AR)) {
@@ -191,9 +225,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
       __builtin_amdgcn_make_buffer_rsrc((void*)d.dout, 0, (unsigned)(dbytes < (int64_t)REJECT ? dbytes : (int64_t)REJECT), 0x00020000);
   const unsigned drow = (unsigned)(((int64_t)(mrow_ok ? m0 + l31 : 0) * d.ld_dout) * 4);
 
-  // ---- the stager.  A tile's window is staged in two passes of four rows per wave; the loads of the FIRST pass of tile i + 1 are
-  // requested in front of the MFMA phase of tile i (32 registers across the k-loop): one exposed memory round trip per tile instead
-  // of two.  Geometry (this lane's window columns and their src positions, the same for every row): stride 1 -- consecutive
+  // ---- the stager.  A tile's window is staged in two passes of four rows per wave.  (Requesting the first pass of tile i + 1 in
+  // front of the MFMA phase of tile i -- 32 registers across the k-loop -- gained 5 %; the registers buy more as the per-tap fragment
+  // pipeline of the k-loop.)  Geometry (this lane's window columns and their src positions, the same for every row): stride 1 -- consecutive
   // positions; S2 -- column q of image E / O is dout-space position n0 - 50 + q = (i, v), i.e. src frame 2 i (+ 1).
   auto geometry = [&](int n0, int (&spos)[NCH][2], bool (&sok)[NCH][2]) {
     const int p_lo = n0 - d.pad * V;
@@ -251,30 +285,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
       }
     }
   };
-  float xa[4][NCH][2];
-  if (tile_lo < tile_hi) {
-    int spos[NCH][2];
-    bool sok[NCH][2];
-    const int b0 = tile_lo / k.TPS;
-    geometry((tile_lo - b0 * k.TPS) * KT, spos, sok);
-    issue_pass(b0, 0, spos, xa);
-  }
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int b = tile / k.TPS;
     const int n0 = (tile - b * k.TPS) * KT;
+    SPLIT_TL(0);   // prologue / loop overhead
     __syncthreads();   // closing: every wave has read its last fragment of the previous tile (and bnp is written)
-    {
-      int spos[NCH][2];
-      bool sok[NCH][2];
-      geometry(n0, spos, sok);
-      float xb[4][NCH][2];
-      issue_pass(b, 1, spos, xb);
-      convert_pass(0, sok, xa);   // requested in front of the previous tile's MFMA phase
-      convert_pass(1, sok, xb);
-    }
-    __syncthreads();   // opening: the window is complete
-
-    // ---- k-steps of this wave (WK = 2: the second wave pair takes the odd ones)
+    SPLIT_TL(1);   // closing barrier
+    // dout fragments come straight from global memory, one k-step ahead; the first one is requested here, in front of the stager.
+    // (Three k-steps ahead in a ring of four register sets: measured equal -- the fragment's latency is not what a k-step waits for.)
     const bool ragged = n0 + KT > seq;   // the tile reaches past the end of the sequence: mask dout per element
     auto load_dout = [&](int ks, u32x4 (&raw)[2]) {
       const int pos = n0 + 16 * ks + 8 * hi;
@@ -284,14 +302,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     };
     u32x4 raw[2][2];
     load_dout(kh, raw[0]);
-    if (tile + 1 < tile_hi) {   // the first pass of the next tile: in flight during this tile's k-steps
+    {
       int spos[NCH][2];
       bool sok[NCH][2];
-      const int bn = (tile + 1) / k.TPS;
-      geometry((tile + 1 - bn * k.TPS) * KT, spos, sok);
-      issue_pass(bn, 0, spos, xa);
+      geometry(n0, spos, sok);
+#pragma unroll 1
+      for (int rh = 0; rh < 2; ++rh) {
+        float x[4][NCH][2];
+        issue_pass(b, rh, spos, x);
+        convert_pass(rh, sok, x);
+      }
     }
+    SPLIT_TL(2);   // stager: requests, wait, convert, LDS stores
+    __syncthreads();   // opening: the window is complete
+    SPLIT_TL(3);   // opening barrier
+
+    // ---- k-steps of this wave (WK = 2: the second wave pair takes the odd ones)
     SAR_LDS_SKEW();   // this wave reads the window late: the next tile's stager must wait at the closing barrier
+    // The nine taps' fragments run through a ring of THREE register sets: the dwords of tap t + 2 (of the next k-step behind tap 7)
+    // are requested before the MFMAs of tap t issue, the order pinned with sched_barrier.  tools/wsplit_timeline.py: a k-step took
+    // 2 780 cycles for 864 of matrix work -- left to the compiler every tap was read -> s_waitcnt -> multiply (35 waits per k-step);
+    // one tap ahead (3 MFMAs + 12 funnel shifts = ~150 cycles) is less than the LDS round trip with eight waves reading.
+    auto tap_elem = [&](int t) {   // window start in elements: stride 1 -- t V (V odd: the parity of t); S2 -- image E for odd
+      // taps, O for even ones, shifted by whole frames: (floor((t - 3) / 2) + 2) V inside the image
+      return S2 ? ((t & 1) ? 0 : C::WIN2) + ((t - 3 - ((t & 1) ? 0 : 1)) / 2 + 2) * V : t * V;
+    };
+    unsigned fw[3][NT][5];
+    auto load_tap = [&](unsigned a_ks, int t, unsigned (&w)[NT][5]) {
+      const int e = tap_elem(t);
+#pragma unroll
+      for (int tm = 0; tm < NT; ++tm) {
+        lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (CB * RS * 2) + (e & ~1) * 2);
+#pragma unroll
+        for (int i = 0; i < 4 + (e & 1); ++i) w[tm][i] = p[i];
+      }
+    };
+    if (kh < KS) {
+      load_tap(a_base + kh * 32, 0, fw[0]);
+      load_tap(a_base + kh * 32, 1, fw[1]);
+    }
 #pragma unroll 1
     for (int ks = kh; ks < KS; ks += 2 * WK) {
 #pragma unroll
@@ -321,23 +370,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
             for (int t = 0; t < NTB; ++t) bw[t][p] = w[t];
           }
           const unsigned a_ks = a_base + kc * 32;
+          const bool more = kc + WK < KS;   // wave-uniform
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
-            // window start in elements: stride 1 -- t V (V odd: the parity of t); S2 -- image E for odd taps, O for even ones, shifted by
-            // whole frames: (floor((t - 3) / 2) + 2) V inside the image
-            const int e = S2 ? ((t & 1) ? 0 : C::WIN2) + ((t - 3 - ((t & 1) ? 0 : 1)) / 2 + 2) * V : t * V;
+            if (t + 2 < TAPS) load_tap(a_ks, t + 2, fw[(t + 2) % 3]);
+            else if (more) load_tap(a_ks + WK * 32, t + 2 - TAPS, fw[(t + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int e = tap_elem(t);
             u32x4 aq[NT];
 #pragma unroll
             for (int tm = 0; tm < NT; ++tm) {
-              if ((e & 1) == 0) {
-                lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (CB * RS * 2) + e * 2);
-                aq[tm] = u32x4{p[0], p[1], p[2], p[3]};
-              } else {
-                lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (CB * RS * 2) + (e - 1) * 2);
-                const unsigned w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
-                aq[tm] = u32x4{__builtin_amdgcn_alignbyte(w1, w0, 2), __builtin_amdgcn_alignbyte(w2, w1, 2),
-                               __builtin_amdgcn_alignbyte(w3, w2, 2), __builtin_amdgcn_alignbyte(w4, w3, 2)};
-              }
+              const unsigned (&w)[5] = fw[t % 3][tm];
+              if ((e & 1) == 0) aq[tm] = u32x4{w[0], w[1], w[2], w[3]};
+              else
+                aq[tm] = u32x4{__builtin_amdgcn_alignbyte(w[1], w[0], 2), __builtin_amdgcn_alignbyte(w[2], w[1], 2),
+                               __builtin_amdgcn_alignbyte(w[3], w[2], 2), __builtin_amdgcn_alignbyte(w[4], w[3], 2)};
             }
 #pragma unroll
             for (int p = 0; p < NPROD; ++p) {
@@ -350,12 +397,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&aq[i]),
                                                                  *reinterpret_cast<const bf16x8*>(&bq), acc[t], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
     }
+    SPLIT_TL(4);   // k-steps
   }
 
+  SPLIT_TL(4);   // the last tile's k-steps (the others are booked with the loop overhead 0)
   // ---- this wave's slab: rows c (registers), columns m (lanes: contiguous)
   float* slab = d.slab + (int64_t)(sg * WK + kh) * (d.wsize + d.bsize);
   const float unscale = __builtin_ldexpf(1.f, -(ea + eb));
@@ -371,6 +421,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     bsum += __shfl_xor(bsum, 32);
     if (hi == 0 && m < d.M) slab[d.wsize + m] = bsum;
   }
+  SPLIT_TL(5);   // slab stores
+  SPLIT_TL_END(tile_hi - tile_lo);
 }
 
 // ---- GraphConvTD (models/gcn.py:199-209) weight / bias gradient in the split arithmetics:
@@ -481,6 +533,20 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     const int nlive = ((t0 + GFT <= d.T_out) ? GFT : d.T_out - t0) * V;   // live positions of this tile
     const int n0 = t0 * V;
     __syncthreads();   // closing: every wave has read its last fragment of the previous tile (and csl is written)
+    // the dout fragments of this wave's first two k-steps are requested here, in front of the stager: they land while the images
+    // are built (conv_wgrad_split_kernel: a fragment requested one k-step ahead stalled every k-step)
+    auto load_dout = [&](int ks, u32x4 (&raw)[2][2]) {
+      const int pos = 16 * ks + 8 * hi;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const unsigned vo = (mrow_ok[mb] && pos < nlive) ? drow[mb] + (unsigned)(((int64_t)b * seq + n0 + pos) * 4) : REJECT;
+        raw[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 0, 0);
+        raw[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 16, 0);
+      }
+    };
+    u32x4 raw[3][2][2];
+    load_dout(kh, raw[0]);
+    if (kh + WK < KS) load_dout(kh + WK, raw[1]);
     if constexpr (S0ID) {
     // ---- raw tile: rows c0 .. c0 + 31 (wave w takes rows w, w + 4, ..), this lane's two adjacent positions; every load first.  It
     // lives in the LDS area of slice 0's images: slice 0 is the identity (SAR_GRAPH_SLICE0_IDENTITY), so its images are the split of
@@ -590,25 +656,14 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     }
     __syncthreads();   // opening: the images are complete
 
-    auto load_dout = [&](int ks, u32x4 (&raw)[2][2]) {
-      const int pos = 16 * ks + 8 * hi;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const unsigned vo = (mrow_ok[mb] && pos < nlive) ? drow[mb] + (unsigned)(((int64_t)b * seq + n0 + pos) * 4) : REJECT;
-        raw[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 0, 0);
-        raw[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 16, 0);
-      }
-    };
-    u32x4 raw[2][2][2];
-    load_dout(kh, raw[0]);
     SAR_LDS_SKEW();
 #pragma unroll 1
-    for (int ks = kh; ks < KS; ks += 2 * WK) {
+    for (int ks = kh; ks < KS; ks += 3 * WK) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < 3; ++half) {   // a ring of three register sets, two k-steps ahead
         const int kc = ks + half * WK;
         if (kc < KS) {
-          if (kc + WK < KS) load_dout(kc + WK, raw[half ^ 1]);
+          if (kc + 2 * WK < KS) load_dout(kc + 2 * WK, raw[(half + 2) % 3]);
           const int nv = nlive - (16 * kc + 8 * hi);   // live elements of this lane's fragment
           unsigned bw[2][NTB][4];
 #pragma unroll
@@ -741,6 +796,18 @@ int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, cons
 }
 
 }  // namespace
+
+#ifdef SAR_SPLIT_TL
+extern "C" int sar_debug_wsplit_timeline(unsigned* out, int nwg, int reset) {   // out: [nwg][16] (host memory)
+  if (nwg > WSPLIT_TL_WG) nwg = WSPLIT_TL_WG;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wsplit_tl), (size_t)nwg * 16 * sizeof(unsigned)) != hipSuccess) return -1;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wsplit_tl)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * 16 * WSPLIT_TL_WG) != hipSuccess) return -1;
+  }
+  return nwg;
+}
+#endif
 
 extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, int* wk_out, int* tile_positions) {
   if (!d) return SAR_E_ARG;
