@@ -361,8 +361,9 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
         kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
         bf16 = mfma in ("bf16", "bf16_operands")
         desc = {"fp32": "fp32",
-                "f32_split": "fp32 (fp32 storage and results; GEMM contractions as 3 products of 2 fp16 terms per operand on the fp16 "
-                             "matrix pipe, fp32 accumulation: csrc/conv_gemm_split.hip f16x3a: three images of the well-conditioned operand, two of the other)",
+                "f32_split": "fp32 (fp32 storage and results; every fp32 product of the GEMM contractions = 3 exact products of fp16 terms on the "
+                             "fp16 matrix pipe, fp32 accumulation: csrc/conv_*_split.hip f16x3a -- three term images of the "
+                             "well-conditioned operand, two of the wide-range one, operand bounds kept on the device)",
                 "f32_split_bf16x6": "fp32 (fp32 storage and results; GEMM contractions as 6 products of 3 bf16 terms per operand on the "
                                     "bf16 matrix pipe, fp32 accumulation: csrc/conv_gemm_split.hip bf16x6)",
                 "bf16": "bf16 (bf16 CN8 activations in HBM, bf16 MFMA operands; fp32 accumulation, BatchNorm statistics, master "

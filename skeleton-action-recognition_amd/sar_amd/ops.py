@@ -46,7 +46,9 @@ class GraphTables:
         self.n_dense_lists = int(((cnt > 1) | ((cnt == 1) & (first != 1.0))).sum())
         if self.slice0_identity:
             self.g_flags |= L.SAR_GRAPH_SLICE0_IDENTITY
-        if self.n_dense_lists <= 16:
+        # (<= 12: what the read-gather kernels hold as virtual joints of a V = 25 tile -- conv_graph_cn8.hip needs 2 FT nv <= 256 --;
+        # denser tables keep the unit-builder / fp32 kernels and the unfused block tail)
+        if self.n_dense_lists <= 12:
             self.g_flags |= L.SAR_GRAPH_FEW_DENSE | (self.n_dense_lists << L.SAR_GRAPH_FEW_DENSE_SHIFT)
 
 

@@ -152,6 +152,7 @@ class STGCN:
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.velocity = torch.zeros(total, dtype=torch.float32, device=dev)
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._lr_host = None      # the value lr_dev holds (sgd_step skips the fill while the schedule keeps the rate); None = unknown
         self.packed = None
         if self.cn8:       # bf16 operand images of EVERY conv weight, both orientations, refreshed by one launch per forward
             pk = ops.PackedWeights()
@@ -325,6 +326,7 @@ class STGCN:
 
     def load_params(self, params):
         """params: dict name -> tensor in the oracle / Keras layouts (incl. optional moving stats, 'A' ignored)."""
+        self._lr_host = None      # (a restored engine re-writes the device-side learning rate at its next step)
         for k, v in params.items():
             if k in self.p:
                 self.p[k].copy_(v.to(torch.float32).reshape(self.shapes[k]))

@@ -24,7 +24,7 @@ def force_ddp():
     return os.environ.get("SAR_FORCE_DDP", "0") == "1"
 
 
-def ddp_active(world_size=None):
+def ddp_active():
     """True when gradients have to be exchanged: a process group exists and it has more than one rank (or the one-rank
     rehearsal switch is set)."""
     if not (dist.is_available() and dist.is_initialized()):
@@ -109,8 +109,12 @@ class RunAhead:
         self.depth = int(os.environ.get("SAR_MAX_STEPS_IN_FLIGHT", "2"))
         self._events = []
 
+    def set_depth(self, depth):
+        """change the bound and forget the recorded steps (probes: tools/runahead_probe.py)"""
+        self.depth, self._events = int(depth), []
+
     def step_issued(self):
-        if self.depth <= 0:
+        if self.depth <= 0 or not torch.cuda.is_available():
             return
         ev = torch.cuda.Event()
         ev.record()
@@ -160,9 +164,14 @@ class Trainer:
         self.buckets_last_step = 0  # collectives issued by the last step (tests, bench)
 
     def step(self, x, labels):
-        """One train_step (main_gnn.py:219-239).  Returns (logits, loss) as device tensors (no host sync)."""
+        """One train_step (main_gnn.py:219-239).  Returns (logits, loss) as device tensors; nothing in the step reads them back.
+        The host does block here on the event of the step before the previous one (RunAhead, SAR_MAX_STEPS_IN_FLIGHT, default
+        2): it bounds the queue, not the GPU."""
         gbs = x.shape[0] * self.world_size
         ddp = ddp_active()
+        if ddp:     # the loss scale 1 / global batch and the exchange must agree on the number of ranks
+            assert self.world_size == dist.get_world_size(), "Trainer(world_size=%d) inside a process group of %d ranks" % (
+                self.world_size, dist.get_world_size())
         timing = self.comm_events is not None and ddp
         if not ddp:
             logits, loss = self.engine.loss_and_grad(x, labels, gbs)
@@ -232,13 +241,17 @@ class SpectrogramTrainer:
         return self._radar_bucket
 
     def step(self, x, labels, lr):
-        """Returns (logits, loss) device tensors; no host synchronisation.  Under data parallelism every gradient is
+        """Returns (logits, loss) device tensors; nothing in the step reads them back (the host blocks only on the event of the
+        step before the previous one: RunAhead).  Under data parallelism every gradient is
         produced already divided by the world size (the loss scale), the flat resnet gradient buffer is exchanged in four
         buckets -- [layer4 + fc], [layer3], [layer2], [conv1 + layer1] -- each as soon as backward has finished it (its
         weight gradients come off the second stream), and the trainable radar parameters share one more small bucket."""
         model, eng, world = self.model, self.eng, self.world_size
         train_radar = self.train_radar()
         ddp = ddp_active()
+        if ddp:
+            assert self.world_size == dist.get_world_size(), "SpectrogramTrainer(world_size=%d) inside a process group of %d ranks" % (
+                self.world_size, dist.get_world_size())
         timing = self.comm_events is not None and ddp
         if timing:
             t0 = torch.cuda.Event(enable_timing=True)

@@ -226,3 +226,37 @@ def test_pack_reports_each_items_amax(dev):
     torch.cuda.synchronize()
     assert pk.bound("t").item() == _bits(flat[:9 * 64 * 64].abs().max().item())
     assert pk.bound("g").item() == _bits(flat[9 * 64 * 64:].abs().max().item())
+
+
+@pytest.mark.parametrize("mode", ["f32_split", "f32_split_bf16x6"])
+def test_split_engines_match_the_float64_oracle(dev, mode):
+    """both split arithmetics as ENGINE modes (the fp32 parity suites run "f32_split" through tests/conftest.py; this is the x6 form's
+    whole-step check beside it): logits, loss and every mask-conditioned gradient within the fp32 tolerance 1e-4"""
+    from sar_amd.stgcn import STGCN
+    from sar_amd import ops
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True), (128, 1, True)]
+    p = O.randomize_affine(O.init_params(11, seed=31, dtype=torch.float64, blocks=blocks), seed=32)
+    x, y = O.synthetic_batch(2, seed=31, T=24, num_classes=11)
+    eng = STGCN(num_classes=11, device=dev, blocks=blocks, mfma=mode)
+    assert eng.split == {"f32_split": "f16x3a", "f32_split_bf16x6": "bf16x6"}[mode] and eng.spacked is not None
+    eng.load_params(p)
+    keep = {}
+    eng.forward(x.to(dev), training=True, keep=keep)
+    B, T = x.shape[0] * x.shape[4], x.shape[2]
+    masks = {}
+    for i, (f, s, _) in enumerate(blocks):
+        To = -(-T // s)
+        bn1 = eng.bn["l%d.bn1" % i]
+        h = torch.empty_like(keep["l%d.g" % i])
+        ops.bn_add_relu_fwd(keep["l%d.g" % i], bn1.scale, bn1.shift, 0, None, None, None, h)
+        masks["l%d.h" % i] = from_cn((h > 0).cpu(), B, T, 25)
+        masks["l%d.y" % i] = from_cn((keep["l%d.y" % i] > 0).cpu(), B, To, 25)
+        T = To
+    logits_ref, loss_ref, grads_ref, _, _ = O.loss_and_grads(p, x.double(), y, blocks=blocks, masks=masks)
+    eng.load_params(p)
+    logits, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu(), logits_ref) < 1e-4 and rel_err(loss.cpu(), loss_ref.reshape(1)) < 1e-4
+    for k, g in grads_ref.items():
+        if g.abs().max().item() > 1e-9:
+            assert rel_err(eng.g[k].cpu(), g) < 1e-4, k

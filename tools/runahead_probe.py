@@ -19,7 +19,7 @@ eng = STGCN(device=dev, mfma=mfma)
 tr = Trainer(eng, batch_size=64)
 batches = [synthetic_clips(64, dev, seed=i) for i in range(4)]
 for depth in (2, 0, 1, 4, 2):
-    tr.run_ahead.depth, tr.run_ahead._events = depth, []
+    tr.run_ahead.set_depth(depth)
     for i in range(5):
         tr.step(*batches[i % 4])
     torch.cuda.synchronize()
