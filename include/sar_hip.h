@@ -471,6 +471,20 @@ typedef struct sar_conv2d_desc {
 int sar_conv2d_nparts(const sar_conv2d_desc* d);
 int sar_conv2d_gemm_f32(const sar_conv2d_desc* d, sar_stream_t s);
 int sar_conv2d_wgrad_f32(const sar_conv2d_desc* d, sar_stream_t s);
+/* The 3x3 / stride-1 / pad-1 convolutions of the BasicBlocks (models/resnet18.py:5-14,37-61) and their data gradients with fp32
+ * results on the fp16 / bf16 matrix pipe: the split arithmetic of sar_conv_gemm_split (SAR_SPLIT_F16X3A / SAR_SPLIT_BF16X6 only) on
+ * the sar_conv2d_desc operator -- same descriptor, fp32 storage, epilogues (NONE / STATS / MASK / ADD) and partial-sum contract
+ * ([M][sar_conv2d_gemm_split_nparts][2]) as sar_conv2d_gemm_f32; csrc/conv2d_split.hip.  `packed` = the term images written by
+ * sar_pack_weights_split_batch from an item with taps = 9 (tap = kh * 3 + kw), G = ceil(Kc / 8).  A descriptor with transposed = 1
+ * (stride 1: the data gradient is a convolution of dout with mirrored taps) takes the image of THAT view of the weights: item
+ * element (tap, c, m) = W[8 - tap][m][c] (a negative tap stride, sc and sm exchanged) -- the kernel itself does not look at
+ * `transposed`.  src_bound / w_bound: as sar_conv_gemm_split.  Built for H_src = H_out, W_src = W_out, 8 <= Kc <= 512, M % 8 == 0,
+ * windows of at most 511 staged pixels ((rows per tile + 2) (W + 2), tiles of 256 output pixels), flags == 0; anything else
+ * returns SAR_E_UNSUP (the nparts query too) and the caller keeps sar_conv2d_gemm_f32.  d->W and d->ctx are ignored. */
+int64_t sar_conv2d_gemm_split_workspace_bytes(const sar_conv2d_desc* d, int arith);
+int sar_conv2d_gemm_split_nparts(const sar_conv2d_desc* d);
+int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const void* packed, const uint32_t* src_bound,
+                          const uint32_t* w_bound, sar_stream_t s);
 /* Data gradient of a ONE-input-channel conv (the 7x7/2 stem, models/resnet18.py:159): dx[b][h][w] = sum_{kh,kw,m}
  * dout[m][(b, (h+pad-kh)/s, (w+pad-kw)/s)] * w_packed[kh*KW+kw][m] over the taps that divide evenly.  Needed only
  * when the image itself depends on trainable parameters (VirtualRadar location / wavelength). */

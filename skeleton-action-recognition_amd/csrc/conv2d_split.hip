@@ -1,0 +1,348 @@
+// conv2d_split.hip -- the 3x3 / stride-1 convolutions of the 1-channel ResNet-18 (models/resnet18.py:5-14,26-72: conv3x3 of the
+// BasicBlocks) and their data gradients with fp32 results on the fp16 / bf16 matrix pipe: the "split" arithmetic of
+// conv_gemm_split.hip (read its header and split_terms.h first) carried over to "image rows x image columns" (gfx950).
+//
+//   out[m, (b,h,w)] = sum_{kh,kw} sum_c W[kh][kw][c][m] * pro(src)[c, (b, h + kh - 1, w + kw - 1)]   (zero outside the image) ; epilogue
+//
+// The data gradient of such a convolution IS such a convolution of dout with the taps mirrored and (c, m) exchanged: the caller
+// packs that view of the weight tensor (sar_pack_weights_split_batch items address elements by strides; a negative tap stride
+// mirrors) and passes the transposed descriptor; one kernel serves both.
+//
+// Design (MI355X) = conv_gemm_split_kernel's, with conv2d.hip's padded image:
+//  * tile 64 (m) x 256 columns = TH whole output rows of ONE image (64x64: 4 rows, 32x32: 8, 16x16: the image) or NI whole images
+//    (8x8: 4); 4 waves side by side, wave tile 64 x 64.
+//  * stage = 8 source channels; the staged window is the tile's rows + one halo row above / below, each row with one zero column left /
+//    right, MATERIALISED in LDS ((TH + 2) x (W + 2) units per image, <= 511): a tap (kh, kw) is the uniform unit offset
+//    kh (W + 2) + kw and the inner loop carries no bounds logic.  The 16 k of one MFMA are 8 channels x 2 taps (lanes 32-63 read the
+//    next tap): nine taps = five k-steps, the last one half empty (zero weight slot / zero column).
+//  * weights: term images [term][tap][G][M] written once per step by sar_pack_weights_split_batch, a stage's 27 pieces of 64 rows
+//    by LDS-DMA; source: split in the stager behind the folded BatchNorm + ReLU (padding stays exactly 0).
+//  * 50 KB of LDS (f16x3a): three workgroups per CU.  Epilogue: conv_epi_f32.h (NONE / STATS / MASK / ADD), partial sums
+//    [M][4 ntiles][2].
+#include "sar_common.h"
+#include <type_traits>
+
+namespace {
+
+#include "split_terms.h"
+
+#include "conv_epi_f32.h"
+
+constexpr int KC8 = 8;   // source channels per stage
+
+struct C2S {
+  sar_conv_desc d;   // the fields the shared epilogue and the stager read: M, Kc, src, out, aux*, pro_*, partials, epi
+  const uint4* wp;   // term images [term][tap][G][M]
+  int G;
+  int B, H, W, TH, TPI, NI, Wq, IRW, RW, nparts, ntiles, ny;
+  const unsigned* src_bound;
+  const unsigned* w_bound;
+};
+
+template <int AR>
+__global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel(const C2S k) {
+  constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR);
+  constexpr bool SCALED = ar_f16(AR);
+  constexpr int TAPS = 9, BM = 64, MS = 2, NS = 2, WN = 4;
+  constexpr int ZCOL = 511, SCOLS = ZCOL + 1, CJ = 2;
+  constexpr int WPIECES = NTA * TAPS, ZSLOT = WPIECES * 64;
+  constexpr int WU = ZSLOT + 64, SU = NTB * SCOLS;
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area aliases the image
+  constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
+  constexpr int PPW = (WPIECES + 3) / 4;
+  constexpr int KCMAX = 512;
+  __shared__ uint4 smem_u[IMG_U + BM + KCMAX / 2];   // image | per-row parameters (float4) | folded BN (scale, shift) per src channel
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + WU;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  float2* bnp = reinterpret_cast<float2*>(smem_u + IMG_U + BM);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave;
+  // workgroup -> (tile, row block), XCD-aware: the row blocks of a tile sit on one XCD (conv_gemm.hip)
+  const int ny = k.ny, nwork = k.ntiles * ny;
+  int w = blockIdx.x;
+  {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;
+  }
+  const int tile = w / ny;
+  const int b = k.NI > 1 ? tile * k.NI : tile / k.TPI;
+  const int h0 = k.NI > 1 ? 0 : (tile - b * k.TPI) * k.TH;
+  const int m0 = (w - tile * ny) * BM;
+  const int H = k.H, W = k.W, Wq = k.Wq, opix = H * W;
+
+  // ---- per-lane column geometry: column p of the tile = pixel (image im, row hl, column wo); its unit of tap (kh, kw) sits at
+  // boff + kh Wq + kw of the staged window (origin: row h0 - 1, column -1 of image im)
+  bool colok[NS];
+  int64_t coln[NS];
+  int boff[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    const int im = k.NI > 1 ? p / opix : 0;
+    const int pp = p - im * opix;
+    int hl = pp / W;
+    int wo = pp - hl * W;
+    colok[ns] = im < k.NI && (b + im) < k.B && hl < k.TH && (h0 + hl) < H;
+    if (!colok[ns]) { hl = 0; wo = 0; }
+    const int bi = b + (colok[ns] ? im : 0);
+    coln[ns] = ((int64_t)bi * H + (h0 + hl)) * W + wo;
+    boff[ns] = (colok[ns] ? im * k.IRW : 0) + hl * Wq + wo;   // a dead column reads pixel (0, 0) of the window: zeroed behind the loop
+  }
+  // k-step q multiplies taps 2 q (lanes 0-31) and 2 q + 1 (lanes 32-63); the 10th tap does not exist (zero slot / zero column)
+  const int abase = hi * 64 + l31;
+
+  int ea = 0, ew = 0;   // fp16 arithmetics: operand scale exponents (wave-uniform)
+  if (SCALED) {
+    ea = scale_exp(*k.src_bound);
+    ew = scale_exp(*k.w_bound);
+  }
+  const float h3_sa = __builtin_ldexpf(1.f, ea);
+  for (int c = tid; c < KCMAX; c += 256) {   // the folded prologue, with the source scale folded in (a power of two: exact)
+    float2 p = make_float2(h3_sa, 0.f);
+    if (d.pro_scale && c < d.Kc) p = make_float2(d.pro_scale[c] * h3_sa, d.pro_shift[c] * h3_sa);
+    bnp[c] = p;
+  }
+  if (tid < NTB) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid >= 64 && tid < 128) Wl[ZSLOT + tid - 64] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16 acc[MS][NS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+
+  const int img = opix;
+  const float* src_b = d.src + (int64_t)b * img;
+
+  // ---- source staging: a lane owns staged elements tid and tid + 256; offsets and masks once
+  int svo[CJ];
+  bool sok[CJ];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int e = tid + 256 * j;
+    const int im = e / k.IRW, ei = e - im * k.IRW;
+    const int r = ei / Wq, q = ei - r * Wq;
+    const int hs = h0 - 1 + r, ws = q - 1;
+    sok[j] = e < k.RW && (b + im) < k.B && (unsigned)hs < (unsigned)H && (unsigned)ws < (unsigned)W;   // else zero padding
+    svo[j] = sok[j] ? (im * img + hs * W + ws) * 4 : 0;
+  }
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  float sreg[CJ][8];
+  auto issue_s_loads = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + q;
+      const int cg = c < d.Kc ? c : 0;   // wave-uniform
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, k.NI * img * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) sreg[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo[j], 0, 0));
+    }
+  };
+  float psc[8], psh[8];
+  auto load_bnp = [&](int c0) {   // ahead of the stage's W DMA (an LDS read behind an LDS-DMA makes the compiler wait for the DMA)
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      const float4 p2 = *reinterpret_cast<const float4*>(&bnp[c0 + 2 * q2]);
+      psc[2 * q2] = p2.x, psh[2 * q2] = p2.y, psc[2 * q2 + 1] = p2.z, psh[2 * q2 + 1] = p2.w;
+    }
+  };
+  auto store_s = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float val = fmaxf(fmaf(sreg[j][q], psc[q], psh[q]), relu_lo);
+        v[q] = (sok[j] && c0 + q < d.Kc) ? val : 0.f;   // zero padding stays exactly 0 behind the folded BatchNorm
+      }
+      uint4 u[NTB];
+      split8<AR, false>(v, u, 1.f);
+      if ((j + 1) * 256 <= ZCOL || tid + 256 * j < ZCOL) {
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) Sl[t * SCOLS + tid + 256 * j] = u[t];
+      }
+    }
+  };
+  // ---- weight pieces by LDS-DMA: piece p = term * 9 + tap = 64 rows of one (term, tap) of channel group g
+  const unsigned wbytes = (unsigned)((int64_t)NTA * TAPS * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;   // rows beyond M: rejected -> 0
+  auto issue_w_dma = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + 4 * i;   // wave-uniform
+      if (p < WPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + p * 64), 16, wvo, (p * k.G + g) * d.M * 16, 0, 0);
+    }
+  };
+
+  issue_s_loads(0);
+  __syncthreads();   // bnp, zero column / slot
+  load_bnp(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  issue_w_dma(0);
+
+  auto kstep = [&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    constexpr bool last = q == 4;
+    uint4 a[NTA][MS], bq[NTB][NS];
+    const bool dead = last && hi;   // this lane's half of the last k-step has no tap
+#pragma unroll
+    for (int t = 0; t < NTA; ++t)
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[dead ? ZSLOT + l31 + ms * 32 : t * (TAPS * 64) + abase + q * 128 + ms * 32];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      constexpr int t0 = 2 * q, t1 = 2 * q + 1;   // tap (kh, kw) = unit offset kh Wq + kw
+      const int to = hi ? (t1 / 3) * Wq + (t1 % 3) : (t0 / 3) * Wq + (t0 % 3);
+      const int bo = dead ? ZCOL : boff[ns] + to;
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) bq[t][ns] = Sl[t * SCOLS + bo];
+    }
+#pragma unroll
+    for (int p = 0; p < NPROD; ++p) {
+      const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          if (ar_f16(AR))
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8*>(&a[i][ms]),
+                                                                 *reinterpret_cast<f16x8*>(&bq[j][ns]), acc[ms][ns], 0, 0, 0);
+          else
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[i][ms]),
+                                                                  *reinterpret_cast<bf16x8*>(&bq[j][ns]), acc[ms][ns], 0, 0, 0);
+        }
+    }
+  };
+
+  // Happens-before of the single image (conv_gemm_split.hip): store_s(s) and the W DMA of stage s write the image behind the CLOSING
+  // barrier of stage s - 1; the OPENING barrier of stage s follows every wave's ds_writes and its vmcnt(0) (its DMA pieces landed).
+  const int nst = (d.Kc + KC8 - 1) / KC8;
+  for (int s_ = 0; s_ < nst; ++s_) {
+    store_s(s_ * KC8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // opening
+    if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC8);   // registers; in flight during the MFMA phase
+    SAR_LDS_SKEW();
+    kstep(std::integral_constant<int, 0>());
+    kstep(std::integral_constant<int, 1>());
+    kstep(std::integral_constant<int, 2>());
+    kstep(std::integral_constant<int, 3>());
+    kstep(std::integral_constant<int, 4>());
+    __syncthreads();   // closing: the image may be overwritten (next stage / the epilogue's transpose area)
+    if (s_ + 1 < nst) {
+      load_bnp((s_ + 1) * KC8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_w_dma(s_ + 1);
+    }
+  }
+
+  {   // undo the operand scales; dead columns hold exact zeros (the epilogue's sums run over them)
+    const float c0 = SCALED ? __builtin_ldexpf(1.f, -(ea + ew)) : 1.f;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = colok[ns] ? acc[ms][ns][r] * c0 : 0.f;
+  }
+  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp, smem);
+}
+
+bool ar_built(int ar) { return ar == AR_B6 || ar == AR_H3A; }
+
+// the launches this unit is built for; fills the geometry
+bool geometry_2s(const sar_conv2d_desc& d, C2S& k) {
+  if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1) return false;
+  if (d.H_src != d.H_out || d.W_src != d.W_out) return false;
+  if (d.Kc < 8 || d.Kc > 512 || (d.M & 7) || d.flags) return false;
+  const int H = d.H_out, W = d.W_out, opix = H * W;
+  if (W > 256 || opix <= 0) return false;
+  k.B = d.B, k.H = H, k.W = W, k.Wq = W + 2;
+  if (opix <= 128) {
+    k.NI = 256 / opix, k.TH = H, k.TPI = 1;
+    k.IRW = (H + 2) * (W + 2), k.RW = k.NI * k.IRW;
+    k.ntiles = (d.B + k.NI - 1) / k.NI;
+  } else {
+    k.NI = 1, k.TH = 256 / W < H ? 256 / W : H, k.TPI = (H + k.TH - 1) / k.TH;
+    k.IRW = k.RW = (k.TH + 2) * (W + 2);
+    k.ntiles = d.B * k.TPI;
+  }
+  if (k.RW > 511) return false;
+  k.ny = (d.M + 63) / 64;
+  k.nparts = k.ntiles * 4;
+  k.G = (d.Kc + 7) / 8;
+  return true;
+}
+
+void fill_desc(const sar_conv2d_desc& d, sar_conv_desc& o) {
+  o = sar_conv_desc{};
+  o.mode = SAR_CONV_TEMPORAL;
+  o.B = d.B, o.Kc = d.Kc, o.M = d.M;
+  o.pro_relu = d.pro_relu, o.epi = d.epi;
+  o.src = d.src, o.ld_src = d.ld_src;
+  o.out = d.out, o.ld_out = d.ld_out;
+  o.pro_scale = d.pro_scale, o.pro_shift = d.pro_shift;
+  o.aux = d.aux, o.ld_aux = d.ld_aux, o.aux_scale = d.aux_scale, o.aux_shift = d.aux_shift, o.aux_mean = d.aux_mean;
+  o.partials = d.partials;
+}
+
+}  // namespace
+
+extern "C" int64_t sar_conv2d_gemm_split_workspace_bytes(const sar_conv2d_desc* d, int arith) {
+  if (!d || d->Kc <= 0 || d->M <= 0 || d->KH <= 0 || d->KW <= 0 || !ar_built(arith)) return SAR_E_ARG;
+  return (int64_t)ar_nta(arith) * d->KH * d->KW * ((d->Kc + 7) / 8) * d->M * 16;
+}
+
+extern "C" int sar_conv2d_gemm_split_nparts(const sar_conv2d_desc* d) {
+  if (!d || d->B <= 0 || d->M <= 0) return SAR_E_ARG;
+  C2S k;
+  if (!geometry_2s(*d, k)) return SAR_E_UNSUP;
+  return k.nparts;
+}
+
+extern "C" int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const void* packed, const uint32_t* src_bound,
+                                     const uint32_t* w_bound, sar_stream_t s) {
+  SAR_REQUIRE(d != nullptr && packed != nullptr, "sar_conv2d_gemm_split: null descriptor / weight image");
+  SAR_REQUIRE(((uintptr_t)packed & 15) == 0, "sar_conv2d_gemm_split: the weight image must be 16-byte aligned");
+  SAR_REQUIRE(ar_built(arith), "sar_conv2d_gemm_split: built for bf16x6 / f16x3a (arith %d)", arith);
+  SAR_REQUIRE(!ar_f16(arith) || (src_bound && w_bound), "sar_conv2d_gemm_split: fp16 arithmetics need the operand bounds");
+  SAR_REQUIRE(d->B > 0 && d->Kc > 0 && d->M > 0 && d->H_src > 0 && d->W_src > 0, "sar_conv2d_gemm_split: bad sizes");
+  C2S k;
+  if (!geometry_2s(*d, k)) {
+    sar_set_error("sar_conv2d_gemm_split: built for 3x3 / stride 1 / pad 1, 8 <= Kc <= 512, M %% 8 == 0, windows of <= 511 staged pixels "
+                  "(%dx%d, stride %d, pad %d, Kc %d, M %d, %dx%d): use sar_conv2d_gemm_f32",
+                  d->KH, d->KW, d->stride, d->pad, d->Kc, d->M, d->H_out, d->W_out);
+    return SAR_E_UNSUP;
+  }
+  const int64_t npix = (int64_t)d->B * d->H_out * d->W_out;
+  SAR_REQUIRE(d->src && d->out, "sar_conv2d_gemm_split: null src/out");
+  SAR_REQUIRE(d->ld_src >= npix && d->ld_out >= npix, "sar_conv2d_gemm_split: leading dimension smaller than B*H*W");
+  SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv2d_gemm_split: pro_scale/pro_shift mismatch");
+  SAR_REQUIRE(d->ld_out < (1 << 22) && d->ld_aux < (1 << 22), "sar_conv2d_gemm_split: leading dimension too large (2^22 columns)");
+  SAR_REQUIRE(sar_conv2d_gemm_split_workspace_bytes(d, arith) < (1ll << 31), "sar_conv2d_gemm_split: weight tensor too large");
+  SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv2d_gemm_split: bad epilogue %d", d->epi);
+  if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials, "sar_conv2d_gemm_split: partials required");
+  if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD) SAR_REQUIRE(d->aux && d->ld_aux >= npix, "sar_conv2d_gemm_split: aux required");
+  if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->aux_scale && d->aux_shift, "sar_conv2d_gemm_split: aux affine required");
+  fill_desc(*d, k.d);
+  k.wp = (const uint4*)packed;
+  k.src_bound = src_bound;
+  k.w_bound = w_bound;
+  const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
+  if (arith == AR_H3A) hipLaunchKernelGGL((conv2d_split_kernel<AR_H3A>), grid, block, 0, as_stream(s), k);
+  else hipLaunchKernelGGL((conv2d_split_kernel<AR_B6>), grid, block, 0, as_stream(s), k);
+  SAR_LAUNCH_CHECK("sar_conv2d_gemm_split");
+  return 0;
+}

@@ -123,6 +123,9 @@ SIGNATURES = {
     "sar_conv2d_nparts": (_i, [C.POINTER(Conv2dDesc)]),
     "sar_conv2d_gemm_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
     "sar_conv2d_wgrad_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
+    "sar_conv2d_gemm_split_workspace_bytes": (_i64, [C.POINTER(Conv2dDesc), _i]),
+    "sar_conv2d_gemm_split_nparts": (_i, [C.POINTER(Conv2dDesc)]),
+    "sar_conv2d_gemm_split": (_i, [C.POINTER(Conv2dDesc), _i, _fp, _fp, _fp, _fp]),
     "sar_permute3_f32": (_i, [_fp, _fp, _i, _i, _i, _i64, _i64, _i64, _fp]),
     "sar_permute3_batch_f32": (_i, [_fp, _fp, _fp, _i, _i64, _fp]),
     "sar_bn_relu_maxpool_fwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i64, _i64, _fp]),

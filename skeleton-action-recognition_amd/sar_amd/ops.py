@@ -651,12 +651,44 @@ def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, p
     return d
 
 
+def conv2d_split_applicable(*, KH, KW, stride, pad, Kc, M, H_src, W_src, H_out, W_out, aux_even_pixels=False, **_):
+    """shapes csrc/conv2d_split.hip is built for (3x3 / stride 1 / pad 1, windows of <= 511 staged pixels); the others stay fp32"""
+    if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and H_src == H_out and W_src == W_out):
+        return False
+    if not (8 <= Kc <= 512 and M % 8 == 0 and not aux_even_pixels):
+        return False
+    opix = H_out * W_out
+    rw = (256 // opix) * (H_out + 2) * (W_out + 2) if opix <= 128 else (min(H_out, 256 // W_out) + 2) * (W_out + 2) if W_out <= 256 else 1 << 30
+    return rw <= 511
+
+
+def _pack_split_conv2d(W, w_stride_tap, w_stride_c, Kc, M, arith, transposed):
+    """one 3x3 tensor stored (tap, c, m), packed on the spot (kernel tests): (image, w_bound).  transposed: W is the DATA-GRADIENT
+    operand layout (tap, m, c) of the forward tensor as the fp32 kernel takes it (element (tap, c', m') of the call = weight of
+    forward tap `tap`); the split kernel wants the mirrored taps: item element (tap, c', m') = W[8 - tap][c'][m']."""
+    pk = PackedSplitWeights(arith)
+    if transposed:
+        pk.add("w", 8 * w_stride_tap, -w_stride_tap, w_stride_c, 1, 9, Kc, M)
+    else:
+        pk.add("w", 0, w_stride_tap, w_stride_c, 1, 9, Kc, M)
+    pk.finalize(W.device)
+    pk.refresh(W)
+    return pk.image("w"), pk.bound("w")
+
+
 def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, aux=None, aux_affine=None, aux_mean=None,
-                aux_even_pixels=False, ctx=None, **geo):
-    """sar_conv2d_gemm_f32.  Returns (partials, nparts) when the epilogue reduces.  aux_even_pixels: SAR_C2D_AUX_EVEN_PIXELS
+                aux_even_pixels=False, ctx=None, split="default", packed=None, bounds=None, **geo):
+    """sar_conv2d_gemm_f32 -- or, with split="f16x3a" / "bf16x6" on the shapes conv2d_split_applicable() names, the fp32-accurate
+    split arithmetic on the fp16 / bf16 matrix pipe (sar_conv2d_gemm_split; `packed` = the PackedSplitWeights image of the launch's
+    view of the weights or None = pack here from W; bounds = (src_bound, w_bound) cells, None = computed here by device kernels).
+    Returns (partials, nparts) when the epilogue reduces.  aux_even_pixels: SAR_C2D_AUX_EVEN_PIXELS
     (aux is the compact data gradient of the parallel 1x1 / stride 2 convolution, added at the even pixels only).
     ctx: an L.Context whose side streams the call may fan out over (None: the current stream only)."""
     lib = L.load()
+    if split == "default":
+        split = DEFAULT_SPLIT
+    if split not in ("f16x3a", "bf16x6") or not conv2d_split_applicable(aux_even_pixels=aux_even_pixels, **geo):
+        split = None
     d = _conv2d_desc(src, **geo)
     d.ctx = ctx.handle if ctx is not None else None
     d.flags = L.SAR_C2D_AUX_EVEN_PIXELS if aux_even_pixels else 0
@@ -670,15 +702,27 @@ def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, au
     partials = None
     nparts = 0
     if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
-        nparts = lib.sar_conv2d_nparts(C.byref(d))
+        nparts = lib.sar_conv2d_gemm_split_nparts(C.byref(d)) if split else lib.sar_conv2d_nparts(C.byref(d))
         if nparts <= 0:
             check(nparts or -1, "sar_conv2d_nparts")
         partials = torch.empty((geo["M"], nparts, 2), dtype=torch.float32, device=src.device)
         d.partials = ptr(partials)
     n_conv = geo["B"] * (geo["H_src"] * geo["W_src"] if geo.get("transposed") else geo["H_out"] * geo["W_out"])
     flops = 2.0 * geo["M"] * geo["Kc"] * geo["KH"] * geo["KW"] * n_conv
-    with profiler.region("conv2d_%dx%d%s" % (geo["KH"], geo["KW"], "_dgrad" if geo.get("transposed") else "") + _shape_tag(geo), flops):
-        check(lib.sar_conv2d_gemm_f32(C.byref(d), stream_ptr()), "sar_conv2d_gemm_f32")
+    tag = "conv2d_%dx%d%s" % (geo["KH"], geo["KW"], "_dgrad" if geo.get("transposed") else "")
+    if split:
+        w_bound = bounds[1] if bounds is not None else None
+        if packed is None:
+            packed, w_bound = _pack_split_conv2d(W, w_stride_tap, w_stride_c, geo["Kc"], geo["M"], split, bool(geo.get("transposed")))
+        src_bound = bounds[0] if bounds is not None else None
+        if split.startswith("f16") and src_bound is None:
+            src_bound = _src_bound_single(src, geo.get("pro"))
+        with profiler.region(tag + "_split" + _shape_tag(geo), flops):
+            check(lib.sar_conv2d_gemm_split(C.byref(d), L.SAR_SPLIT[split], ptr(packed), ptr(src_bound), ptr(w_bound), stream_ptr()),
+                  "sar_conv2d_gemm_split")
+    else:
+        with profiler.region(tag + _shape_tag(geo), flops):
+            check(lib.sar_conv2d_gemm_f32(C.byref(d), stream_ptr()), "sar_conv2d_gemm_f32")
     return (partials, nparts) if partials is not None else None
 
 

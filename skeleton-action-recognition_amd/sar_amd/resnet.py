@@ -17,11 +17,16 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .stgcn import _BN
+from .stgcn import _BN, SPLIT_ARITH
 
 BN_EPS = 1e-5            # torch BatchNorm2d defaults (models/resnet18.py norm_layer = nn.BatchNorm2d)
 BN_KEEP = 0.9            # running = 0.9*running + 0.1*batch  (torch momentum 0.1)
 LAYERS = [2, 2, 2, 2]    # models/resnet18.py:274
+# arithmetic of an engine built without an explicit `mfma` (the parity suites run once per value, tests/conftest.py):
+# "fp32" = fp32 MFMA kernels; "f32_split" / "f32_split_bf16x6" = fp32 results on the fp16 / bf16 matrix pipe for the 3x3 / stride-1
+# convolutions (csrc/conv2d_split.hip), everything else unchanged
+DEFAULT_MFMA = __import__("os").environ.get("SAR_MFMA_PATHB", "fp32")
+_SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS_PATHB", "fwd,dgrad,wgrad").split(","))
 
 
 class _Conv:
@@ -31,9 +36,12 @@ class _Conv:
 
 
 class ResNet18:
-    def __init__(self, num_classes=60, num_filters=64, device="cuda", seed=0):
+    def __init__(self, num_classes=60, num_filters=64, device="cuda", seed=0, mfma=None):
         L.load()
         self.device = torch.device(device)
+        self.mfma = mfma or DEFAULT_MFMA
+        assert self.mfma == "fp32" or self.mfma in SPLIT_ARITH, self.mfma
+        self.split = SPLIT_ARITH.get(self.mfma)
         self.num_classes, self.nf = num_classes, num_filters
         self.shapes, self.convs, self.bn_names, self.blocks = {}, {}, [], []
 
@@ -102,6 +110,22 @@ class ResNet18:
         pb.finalize(dev)
         self._perm_bwd = pb
         self._wb = z(off)
+        # Split arithmetic: the term images of every 3x3 / stride-1 weight tensor -- forward view (tap, c, m) and data-gradient view
+        # (mirrored taps, c and m exchanged: include/sar_hip.h sar_conv2d_gemm_split) -- written by ONE launch per step from the
+        # master weights, and the bound cells of the source operands (zeroed once per step; raised by the producing passes)
+        self.spacked, self._cells, self._cell_of = None, None, {}
+        if self.split and dev.type == "cuda":
+            sp = ops.PackedSplitWeights(self.split)
+            for name, cv in self.convs.items():
+                if cv.k == 3 and cv.stride == 1 and 8 <= cv.cin <= 512 and cv.cout % 8 == 0 and cv.cout <= 512:
+                    src, cc = self.offsets[name + ".weight"], cv.cin * cv.cout
+                    sp.add((name, "f"), src, cc, cv.cout, 1, 9, cv.cin, cv.cout)
+                    sp.add((name, "b"), src + 8 * cc, -cc, 1, cv.cout, 9, cv.cout, cv.cin)
+                    for kind in ("f", "b"):
+                        self._cell_of[(name, kind)] = len(self._cell_of)
+            sp.finalize(dev)
+            self.spacked = sp
+            self._cells = torch.zeros(max(1, len(self._cell_of)), dtype=torch.int32, device=dev)
         # Gradient buckets for the data-parallel exchange (main_spectrogram.py:118-119), in the order backward() completes
         # them: [layer4 + fc], [layer3], [layer2], [conv1 + bn1 + layer1].  Each is a contiguous slice of the flat gradient
         # buffer (parameters are laid out in declaration order), so that a bucket can be all-reduced while the earlier layers are
@@ -166,6 +190,9 @@ class ResNet18:
     # ------------------------------------------------------------------ weights
     def _pack(self, need_bwd):
         """(tap, m, c) data-gradient layout of every conv weight: one launch per training step."""
+        if need_bwd and self.spacked is not None:
+            self.spacked.refresh(self.flat)
+            self._cells.zero_()
         if need_bwd:            # only the backward pass reads the data-gradient layouts: off the forward's critical path
             if self._side is None:
                 self._perm_bwd.run(self.flat, self._wb)
@@ -184,14 +211,32 @@ class ResNet18:
         o, n = self.offsets[name + ".weight"], self._woff[name][1]
         return self.flat[o:o + n]                      # the stored weights ARE the forward operand
 
-    def _conv_fwd(self, name, X, B, H, W, training, pro=None):
+    def _cell(self, name, kind):
+        """bound cell of the source operand of conv `name`'s forward ("f") / data gradient ("b") on the split kernels, else None"""
+        i = self._cell_of.get((name, kind)) if self._cells is not None else None
+        return None if i is None else self._cells[i:i + 1]
+
+    def _split_args(self, name, kind, training=True):
+        """arithmetic keyword arguments of ops.conv2d_gemm for conv `name` (training steps only: inference keeps the fp32 kernels)"""
+        want = {"f": "fwd", "b": "dgrad"}[kind] in _SPLIT_KINDS
+        if not training or self.spacked is None or (name, kind) not in self._cell_of or not want:
+            return dict(split=None)
+        return dict(split=self.split, packed=self.spacked.image((name, kind)),
+                    bounds=(self._cell(name, kind), self.spacked.bound((name, kind))))
+
+    def _conv_fwd(self, name, X, B, H, W, training, pro=None, bn_src=None):
+        """bn_src: (BatchNorm name, sample count) of the folded prologue -- the source bound of the split kernels is then the Samuelson
+        bound of that train-mode BatchNorm (no pass over the data); without a prologue the producer of X has raised the cell."""
         cv = self.convs[name]
         Ho, Wo = (H + 2 * cv.pad - cv.k) // cv.stride + 1, (W + 2 * cv.pad - cv.k) // cv.stride + 1
         out = torch.empty((cv.cout, B * Ho * Wo), dtype=torch.float32, device=X.device)
+        sa = self._split_args(name, "f", training)
+        if sa["split"] and bn_src is not None:
+            ops.bn_bound(self.p[bn_src[0] + ".weight"], self.p[bn_src[0] + ".bias"], bn_src[1], self._cell(name, "f"))
         r = ops.conv2d_gemm(X, out, self._w(name), cv.cin * cv.cout, cv.cout,
                             epi=L.SAR_EPI_STATS if training else L.SAR_EPI_NONE, B=B, Kc=cv.cin, M=cv.cout, H_src=H,
                             W_src=W, H_out=Ho, W_out=Wo, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro,
-                            pro_relu=pro is not None)
+                            pro_relu=pro is not None, **sa)
         return out, r, Ho, Wo
 
     def _bn_stats(self, name, r, count, training):
@@ -222,10 +267,14 @@ class ResNet18:
             keep["conv1"], keep["pool"] = c0, h
         saved = dict(x0=X0, c0=c0, B=B, H=H, W=W, H1=H1, W1=W1, H2=H2, W2=W2, blocks=[])
         Hc, Wc = H2, W2
-        for pre, inpl, planes, stride, ds in self.blocks:
+        if training and self._cell(self.blocks[0][0] + "conv1", "f") is not None:
+            # the stem tail is max-pool(relu(bn1(c0))): bounded by bn1's Samuelson bound
+            ops.bn_bound(self.p["bn1.weight"], self.p["bn1.bias"], B * H1 * W1, self._cell(self.blocks[0][0] + "conv1", "f"))
+        for bi_, (pre, inpl, planes, stride, ds) in enumerate(self.blocks):
             c1, r1, Ho, Wo = self._conv_fwd(pre + "conv1", h, B, Hc, Wc, training)
             b1 = self._bn_stats(pre + "bn1", r1, B * Ho * Wo, training)
-            c2, r2, _, _ = self._conv_fwd(pre + "conv2", c1, B, Ho, Wo, training, pro=(b1.scale, b1.shift))
+            c2, r2, _, _ = self._conv_fwd(pre + "conv2", c1, B, Ho, Wo, training, pro=(b1.scale, b1.shift),
+                                          bn_src=(pre + "bn1", B * Ho * Wo))
             b2 = self._bn_stats(pre + "bn2", r2, B * Ho * Wo, training)
             dsc = bd = None
             if ds:
@@ -233,8 +282,10 @@ class ResNet18:
                 bd = self._bn_stats(pre + "downsample.1", rd, B * Ho * Wo, training)
             y = torch.empty_like(c2)
             ymask = ops.relu_mask(y) if training else None  # 1 bit per element: what the BatchNorm-backward passes read instead of y
+            nxt = self.blocks[bi_ + 1][0] + "conv1" if bi_ + 1 < len(self.blocks) else None
             ops.bn_add_relu_fwd(c2, b2.scale, b2.shift, 2 if ds else 1, dsc if ds else h, bd.scale if ds else None,
-                                bd.shift if ds else None, y, mask=ymask)
+                                bd.shift if ds else None, y, mask=ymask,
+                                amax_cell=self._cell(nxt, "f") if (training and nxt) else None)   # the next block's source bound
             if training:
                 saved["blocks"].append(dict(X=h, c1=c1, c2=c2, dsc=dsc, y=y, ymask=ymask, H=Hc, W=Wc, Ho=Ho, Wo=Wo))
             if keep is not None:
@@ -273,7 +324,7 @@ class ResNet18:
         dx = torch.empty((cv.cin, B * H * W), dtype=torch.float32, device=dout.device)
         r = ops.conv2d_gemm(dout, dx, self._w(name, True), cv.cout * cv.cin, cv.cin, B=B, Kc=cv.cout, M=cv.cin, H_src=Ho,
                             W_src=Wo, H_out=H, W_out=W, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, transposed=True,
-                            ctx=self._ctx, **epi)
+                            ctx=self._ctx, **self._split_args(name, "b"), **epi)
         return dx, r
 
     def _bn_bwd(self, name, part, nparts, chan_stride, part_stride, off2, count):
@@ -334,13 +385,14 @@ class ResNet18:
                     self._bn_bwd(pre + "downsample.1", part, nparts, nparts * 4, 4, 2, n_out)
             dc2 = torch.empty_like(c2)
             ddsc = torch.empty_like(dsc) if ds else None
-            ops.bn_add_relu_bwd_apply(dY, y, c2, dsc, (b2.k1, b2.k2, b2.k3), rk, dc2, ddsc, None if ds else dY, mask=sb.get("ymask"))
+            ops.bn_add_relu_bwd_apply(dY, y, c2, dsc, (b2.k1, b2.k2, b2.k3), rk, dc2, ddsc, None if ds else dY, mask=sb.get("ymask"),
+                                      amax_cell=self._cell(pre + "conv2", "b"))      # bound of dc2 for conv2's split data gradient
             # conv2 (input = relu(bn1(c1)), folded)
             self._conv_wgrad(pre + "conv2", c1, dc2, B, Ho, Wo, Ho, Wo, pro=(b1.scale, b1.shift))
             dz1, pm = self._conv_dgrad(pre + "conv2", dc2, B, Ho, Wo, Ho, Wo, epi=L.SAR_EPI_MASK, aux=c1,
                                        aux_affine=(b1.scale, b1.shift), aux_mean=b1.mean)
             self._bn_bwd(pre + "bn1", pm[0], pm[1], pm[1] * 2, 2, 1, n_out)
-            ops.affine2(dz1, c1, (b1.k1, b1.k2, b1.k3), dz1)            # dc1 in place
+            ops.affine2(dz1, c1, (b1.k1, b1.k2, b1.k3), dz1, amax_cell=self._cell(pre + "conv1", "b"))      # dc1 in place (+ its bound)
             self._conv_wgrad(pre + "conv1", X, dz1, B, H, W, Ho, Wo)
             aux, even = dY, False
             if ds:

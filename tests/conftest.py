@@ -23,7 +23,9 @@ def golden_dir():
 # ---- the fp32 parity suites run once per ARITHMETIC of the fp32-storage engine: "fp32" = the fp32 MFMA kernels,
 # "f32_split" = fp32 results on the fp16 matrix pipe (csrc/conv_gemm_split.hip), SAME tolerances.  The mode is the default of every
 # ops.conv_gemm / conv_wgrad call and of every STGCN built without an explicit `mfma` in these modules.
-SPLIT_SUITES = {"test_gpu_stgcn_kernels.py", "test_gpu_stgcn_model.py", "test_gpu_batch64.py"}
+SPLIT_SUITES = {"test_gpu_stgcn_kernels.py", "test_gpu_stgcn_model.py", "test_gpu_batch64.py",
+                # Path B: the 3x3 / stride-1 convolutions of the resnet on csrc/conv2d_split.hip
+                "test_gpu_conv2d_kernels.py", "test_gpu_conv2d_bs32.py", "test_gpu_resnet.py"}
 ARITH_MODES = ["fp32", "f32_split"]
 
 
@@ -38,10 +40,10 @@ def arith_mode(request):
     if mode == "fp32":
         yield mode
         return
-    from sar_amd import ops, stgcn
-    old = (ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA)
-    ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA = stgcn.SPLIT_ARITH[mode], mode
+    from sar_amd import ops, stgcn, resnet
+    old = (ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA, resnet.DEFAULT_MFMA)
+    ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA, resnet.DEFAULT_MFMA = stgcn.SPLIT_ARITH[mode], mode, mode
     try:
         yield mode
     finally:
-        ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA = old
+        ops.DEFAULT_SPLIT, stgcn.DEFAULT_MFMA, resnet.DEFAULT_MFMA = old

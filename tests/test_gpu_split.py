@@ -260,3 +260,52 @@ def test_split_engines_match_the_float64_oracle(dev, mode):
     for k, g in grads_ref.items():
         if g.abs().max().item() > 1e-9:
             assert rel_err(eng.g[k].cpu(), g) < 1e-4, k
+
+
+# ---------------------------------------------------------------------------------------------- Path B: csrc/conv2d_split.hip
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 64, 64, 64, 2), (512, 512, 8, 8, 7), (128, 128, 32, 32, 1), (256, 256, 16, 16, 3),
+                                            (24, 40, 20, 20, 2), (16, 8, 10, 12, 5), (8, 72, 7, 9, 9)])
+def test_conv2d_3x3_forward_and_masked_data_gradient(dev, arith, cin, cout, H, W, B):
+    """3x3 / stride 1 / pad 1 (models/resnet18.py:5-14) on the split kernels: forward behind a folded BatchNorm + ReLU with the
+    BatchNorm sums, and the data gradient with the ReLU-mask epilogue and its centred sums, at the resnet's four resolutions
+    (several images per tile, batches that do not fill the last tile, rectangular images) against float64 torch."""
+    import torch.nn.functional as F
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(cin + 3 * cout + H + B)
+    cn = lambda t: t.permute(1, 0, 2, 3).reshape(t.shape[1], -1).contiguous()
+    uncn = lambda y, b, h, w: y.reshape(y.shape[0], b, h, w).permute(1, 0, 2, 3)
+    x = torch.randn(B, cin, H, W, generator=g).double()
+    x[0, 0, 0, 0] = 300.0                                    # a source with outliers: the bound sits far above the bulk
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).double().requires_grad_(True)
+    sc, sh = (1 + 0.2 * torch.randn(cin, generator=g)).double(), (0.3 * torch.randn(cin, generator=g)).double()
+    hin = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    y = F.conv2d(hin, w, None, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g).double() * torch.exp(3 * torch.randn(y.shape, generator=g)).double()   # gradient-like
+    gh, = torch.autograd.grad(y, hin, dy)
+    geo = dict(B=B, Kc=cin, M=cout, H_src=H, W_src=W, H_out=H, W_out=W, KH=3, KW=3, stride=1, pad=1)
+    assert ops.conv2d_split_applicable(**geo)
+    wf = w.detach().float().permute(2, 3, 1, 0).reshape(-1).contiguous().to(dev)          # (tap, c, m)
+    wb = w.detach().float().permute(2, 3, 0, 1).reshape(-1).contiguous().to(dev)          # (tap, m, c): the fp32 data gradient's operand
+    xd = cn(x.float()).to(dev)
+    out = torch.empty((cout, B * H * W), device=dev)
+    r = ops.conv2d_gemm(xd, out, wf, cin * cout, cout, epi=L.SAR_EPI_STATS, pro=(sc.float().to(dev), sh.float().to(dev)),
+                        pro_relu=True, split=arith, **geo)
+    torch.cuda.synchronize()
+    assert rel_err(uncn(out.cpu(), B, H, W), y.detach()) < TOL
+    part = r[0].cpu().double().sum(1)
+    assert (part[:, 0] - y.detach().sum(dim=(0, 2, 3))).abs().max() < TOL * y.detach().abs().sum(dim=(0, 2, 3)).max()
+    assert rel_err(part[:, 1], (y.detach() ** 2).sum(dim=(0, 2, 3))) < TOL
+    # data gradient with the ReLU mask of an upstream BatchNorm (aux = its pre-activation) and the centred second sum
+    aux = torch.randn(cin, B * H * W, generator=g)
+    asc, ash, amu = 1 + 0.1 * torch.randn(cin, generator=g), 0.2 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
+    dx = torch.empty((cin, B * H * W), device=dev)
+    rg = ops.conv2d_gemm(cn(dy.float()).to(dev), dx, wb, cout * cin, cin, epi=L.SAR_EPI_MASK, aux=aux.to(dev),
+                         aux_affine=(asc.to(dev), ash.to(dev)), aux_mean=amu.to(dev), split=arith, B=B, Kc=cout, M=cin, H_src=H,
+                         W_src=W, H_out=H, W_out=W, KH=3, KW=3, stride=1, pad=1, transposed=True)
+    torch.cuda.synchronize()
+    keep = (aux.double() * asc.double().view(-1, 1) + ash.double().view(-1, 1)) > 0
+    want = cn(gh) * keep
+    assert rel_err(dx.cpu(), want) < TOL
+    pg = rg[0].cpu().double().sum(1)
+    assert rel_err(pg[:, 1], (want * (aux.double() - amu.double().view(-1, 1))).sum(1)) < 5 * TOL
