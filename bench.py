@@ -473,7 +473,7 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
     return out                   #  hipMalloc for every tensor of its first steps)
 
 
-def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrument_steps=0, num_pad_frames=None):
+def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrument_steps=0, num_pad_frames=None, mfma="fp32"):
     """Path B: VirtualRadar (signal + STFT/log-magnitude/column select) -> resnet18 fwd+bwd -> Adam; bs = --batch per GPU
     (configs[3] uses 32)."""
     import torch
@@ -483,7 +483,8 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
     from models.resnet import Model
     bs = 32 if args.batch == 64 else args.batch
     pad = args.num_pad_frames if num_pad_frames is None else num_pad_frames
-    model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=pad)
+    model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=pad, mfma=mfma)
+    split = mfma != "fp32"
     trainer = SpectrogramTrainer(model, 1e-3, world_size=world)      # the product step of main_spectrogram.py
     batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
     leg = Leg(world, dev)
@@ -556,6 +557,30 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
             "final_loss": round(float(loss.item()), 5),
         }
+        if split:
+            # the launches on csrc/conv2d_split.hip: roofline on the fp16 / bf16 matrix pipe with the FLOPs actually executed
+            # (3 products per fp32 product -- 6 for bf16x6 --, forward / data gradient x 10 / 9: nine taps in five k-steps)
+            nprod = 6 if mfma.endswith("bf16x6") else 3
+            fs = [k for k in summ if "_split" in k]
+            ms_s = sum(summ[k]["ms"] for k in fs)
+            fl_s = sum(summ[k]["flops"] for k in fs)
+            exe = sum(summ[k]["flops"] * nprod * (1.0 if "wgrad" in k else 10.0 / 9.0) for k in fs) / (ms_s * 1e-3) / 1e12 if ms_s > 0 else 0.0
+            calls_s = sum(summ[k]["calls"] for k in fs)
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "resnet18 fp32 training step", "resnet18 fp32 training step (fp32 storage and results; the 3x3 / stride-1 convolutions as %d exact "
+                "products of %s terms per fp32 product on the matrix pipe, fp32 accumulation: csrc/conv2d_split.hip)"
+                % (nprod, "bf16" if nprod == 6 else "fp16"))
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv2d split kernels (3x3 / stride 1: forward, data gradient%s); IN-STEP figure: HIP events over the "
+                                           "timed region" % (", weight gradient" if any("wgrad" in k for k in fs) else ""),
+                "achieved": round(exe, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
+                "executed_flops_per_algorithmic_flop": "%d (x 10 / 9 forward / data gradient)" % nprod,
+                "fp32_equivalent_tflops": round(fl_s / (ms_s * 1e-3) / 1e12, 1) if ms_s > 0 else 0.0,
+                "fp32_mfma_peak_for_reference": PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "launches": calls_s, "avg_launch_ms": round(ms_s / max(calls_s, 1), 4),
+                "split_kernels_ms_per_step": round(ms_s / ksteps, 3),
+                "fp32_conv_kernels_left_ms_per_step": {k: round(summ[k]["ms"] / ksteps, 3) for k in sorted(summ)
+                                                       if k.startswith("conv2d") and "_split" not in k}}
         if pad:
             # The front end that only this variant has: per-clip smoothing + spline pieces, then the radar signal of 300 x pad
             # frames with every frame's 150 coordinates evaluated from the cubic pieces in float64.  Its binding unit is the
@@ -616,7 +641,7 @@ def main():
                     help="skip the 3 extra untimed steps that measure the dominant kernel family with the side stream off "
                          "(profile runs: keeps the launch counts at warmup + steps)")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only (profile runs)")
-    ap.add_argument("--secondary", default="f32_split,bf16,pathB,pathB_pad250,config5",
+    ap.add_argument("--secondary", default="f32_split,bf16,pathB,pathB_f32_split,pathB_pad250,config5",
                     help="comma list of the secondary legs run in the same process BEFORE the fp32 headline and reported under "
                          "'secondary': f32_split = configs[1] with the GEMM contractions on the fp16 matrix pipe (fp32 storage and results), bf16 = configs[2] (sustained: >= 3 s of untimed load first), pathB = configs[3], pathB_pad250 = "
                          "configs[3] on the reference loader's real input (x250 up-sampling on the GPU), config5 = configs[4] (120 "
@@ -642,7 +667,8 @@ def main():
     rank, world, dev = rank_setup(args)
     cpu_ok = rank == 0 and world == 1 and not args.no_cpu_baseline
     if args.workload == "spectrogram":
-        out = spectrogram_leg(args, args.steps, args.warmup, args.warm_seconds, rank, world, dev)
+        assert args.mfma in ("fp32", "f32_split", "f32_split_bf16x6"), "the spectrogram workload has no bf16 engine"
+        out = spectrogram_leg(args, args.steps, args.warmup, args.warm_seconds, rank, world, dev, mfma=args.mfma)
         if cpu_ok:
             out["cpu_baseline"] = cpu_baseline_spectrogram(2 if args.num_pad_frames else 4, num_pad_frames=args.num_pad_frames)
     else:
@@ -667,6 +693,10 @@ def main():
                                         num_pad_frames=0)
                     if r is not None and cpu_ok and not q:
                         r["cpu_baseline"] = cpu_baseline_spectrogram(4)
+                elif n == "pathB_f32_split":
+                    # configs[3] with the resnet's 3x3 / stride-1 convolutions on the fp16 matrix pipe (fp32 storage and results)
+                    r = spectrogram_leg(args, 4 if q else 250, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
+                                        num_pad_frames=0, mfma="f32_split")
                 elif n == "pathB_pad250":
                     r = spectrogram_leg(args, 4 if q else 120, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
                                         num_pad_frames=250)

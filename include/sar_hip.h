@@ -479,7 +479,7 @@ int sar_conv2d_wgrad_f32(const sar_conv2d_desc* d, sar_stream_t s);
  * (stride 1: the data gradient is a convolution of dout with mirrored taps) takes the image of THAT view of the weights: item
  * element (tap, c, m) = W[8 - tap][m][c] (a negative tap stride, sc and sm exchanged) -- the kernel itself does not look at
  * `transposed`.  src_bound / w_bound: as sar_conv_gemm_split.  Built for H_src = H_out, W_src = W_out, 8 <= Kc <= 512, M % 8 == 0,
- * windows of at most 511 staged pixels ((rows per tile + 2) (W + 2), tiles of 256 output pixels), flags == 0; anything else
+ * windows of at most 512 staged pixels ((rows per tile + 2) (W + 2), tiles of 256 output pixels), flags == 0; anything else
  * returns SAR_E_UNSUP (the nparts query too) and the caller keeps sar_conv2d_gemm_f32.  d->W and d->ctx are ignored. */
 int64_t sar_conv2d_gemm_split_workspace_bytes(const sar_conv2d_desc* d, int arith);
 int sar_conv2d_gemm_split_nparts(const sar_conv2d_desc* d);

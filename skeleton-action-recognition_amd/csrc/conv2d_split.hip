@@ -12,7 +12,7 @@
 //  * tile 64 (m) x 256 columns = TH whole output rows of ONE image (64x64: 4 rows, 32x32: 8, 16x16: the image) or NI whole images
 //    (8x8: 4); 4 waves side by side, wave tile 64 x 64.
 //  * stage = 8 source channels; the staged window is the tile's rows + one halo row above / below, each row with one zero column left /
-//    right, MATERIALISED in LDS ((TH + 2) x (W + 2) units per image, <= 511): a tap (kh, kw) is the uniform unit offset
+//    right, MATERIALISED in LDS ((TH + 2) x (W + 2) units per image, <= 512): a tap (kh, kw) is the uniform unit offset
 //    kh (W + 2) + kw and the inner loop carries no bounds logic.  The 16 k of one MFMA are 8 channels x 2 taps (lanes 32-63 read the
 //    next tap): nine taps = five k-steps, the last one half empty (zero weight slot / zero column).
 //  * weights: term images [term][tap][G][M] written once per step by sar_pack_weights_split_batch, a stage's 27 pieces of 64 rows
@@ -20,6 +20,7 @@
 //  * 50 KB of LDS (f16x3a): three workgroups per CU.  Epilogue: conv_epi_f32.h (NONE / STATS / MASK / ADD), partial sums
 //    [M][4 ntiles][2].
 #include "sar_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -35,18 +36,24 @@ struct C2S {
   const uint4* wp;   // term images [term][tap][G][M]
   int G;
   int B, H, W, TH, TPI, NI, Wq, IRW, RW, nparts, ntiles, ny;
+  int rb_major;      // workgroup order: 0 = the row blocks of a tile are neighbours (one XCD reads a source tile once), 1 = the tiles of a
+                     // row block are (one XCD reads 1 / ny of the weight images: small feature maps with large weight tensors)
   const unsigned* src_bound;
   const unsigned* w_bound;
 };
 
-template <int AR>
-__global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel(const C2S k) {
+// NS: 32-column blocks per wave (2: tiles of 256 columns; 1: 128).  DEEP: both operand images double-buffered, ONE barrier per
+// stage, the W DMA and the source loads of stage s + 1 in flight during the matrix phase of stage s -- for launches of at most a
+// few workgroups per CU (small feature maps), where no other workgroup hides a stage's load latencies: 78-94 KB of LDS.
+template <int AR, int NS, int DEEP>
+__global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (AR == AR_H3A ? 3 : 2)) void conv2d_split_kernel(const C2S k) {
   constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR);
   constexpr bool SCALED = ar_f16(AR);
-  constexpr int TAPS = 9, BM = 64, MS = 2, NS = 2, WN = 4;
-  constexpr int ZCOL = 511, SCOLS = ZCOL + 1, CJ = 2;
-  constexpr int WPIECES = NTA * TAPS, ZSLOT = WPIECES * 64;
-  constexpr int WU = ZSLOT + 64, SU = NTB * SCOLS;
+  constexpr int TAPS = 9, BM = 64, MS = 2, WN = 4;
+  constexpr int CJ = NS, ZCOL = 256 * CJ, SCOLS = ZCOL + 1;   // staged elements 0 .. 256 CJ - 1, then the always-zero column
+  constexpr int NBUF = DEEP ? 2 : 1;
+  constexpr int WPIECES = NTA * TAPS, WPB = WPIECES * 64, ZSLOT = NBUF * WPB;   // weight pieces of 64 units per buffer, then the zero slot
+  constexpr int WU = ZSLOT + 64, SUB = NTB * SCOLS, SU = NBUF * SUB;
   constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area aliases the image
   constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
   constexpr int PPW = (WPIECES + 3) / 4;
@@ -72,10 +79,10 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel
     w = xcd * per + slot;
     if (w >= nwork || slot >= per) return;
   }
-  const int tile = w / ny;
+  const int tile = k.rb_major ? w % k.ntiles : w / ny;
   const int b = k.NI > 1 ? tile * k.NI : tile / k.TPI;
   const int h0 = k.NI > 1 ? 0 : (tile - b * k.TPI) * k.TH;
-  const int m0 = (w - tile * ny) * BM;
+  const int m0 = (k.rb_major ? w / k.ntiles : w - tile * ny) * BM;
   const int H = k.H, W = k.W, Wq = k.Wq, opix = H * W;
 
   // ---- per-lane column geometry: column p of the tile = pixel (image im, row hl, column wo); its unit of tap (kh, kw) sits at
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel
     if (d.pro_scale && c < d.Kc) p = make_float2(d.pro_scale[c] * h3_sa, d.pro_shift[c] * h3_sa);
     bnp[c] = p;
   }
-  if (tid < NTB) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < NBUF * NTB) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
   if (tid >= 64 && tid < 128) Wl[ZSLOT + tid - 64] = make_uint4(0u, 0u, 0u, 0u);
   f32x16 acc[MS][NS];
 #pragma unroll
@@ -156,33 +163,33 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel
       psc[2 * q2] = p2.x, psh[2 * q2] = p2.y, psc[2 * q2 + 1] = p2.z, psh[2 * q2 + 1] = p2.w;
     }
   };
-  auto store_s = [&](int c0) {
+  auto store_piece = [&](int c0, int buf, auto J) {   // staged element tid + 256 j: folded BN + ReLU, split, NTB ds_write_b128
+    constexpr int j = decltype(J)::value;
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < CJ; ++j) {
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float val = fmaxf(fmaf(sreg[j][q], psc[q], psh[q]), relu_lo);
-        v[q] = (sok[j] && c0 + q < d.Kc) ? val : 0.f;   // zero padding stays exactly 0 behind the folded BatchNorm
-      }
-      uint4 u[NTB];
-      split8<AR, false>(v, u, 1.f);
-      if ((j + 1) * 256 <= ZCOL || tid + 256 * j < ZCOL) {
-#pragma unroll
-        for (int t = 0; t < NTB; ++t) Sl[t * SCOLS + tid + 256 * j] = u[t];
-      }
+    for (int q = 0; q < 8; ++q) {
+      const float val = fmaxf(fmaf(sreg[j][q], psc[q], psh[q]), relu_lo);
+      v[q] = (sok[j] && c0 + q < d.Kc) ? val : 0.f;   // zero padding stays exactly 0 behind the folded BatchNorm
     }
+    uint4 u[NTB];
+    split8<AR, false>(v, u, 1.f);
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) Sl[buf * SUB + t * SCOLS + tid + 256 * j] = u[t];
+  };
+  auto store_s = [&](int c0, int buf) {
+    store_piece(c0, buf, std::integral_constant<int, 0>());
+    if constexpr (CJ == 2) store_piece(c0, buf, std::integral_constant<int, 1>());
   };
   // ---- weight pieces by LDS-DMA: piece p = term * 9 + tap = 64 rows of one (term, tap) of channel group g
   const unsigned wbytes = (unsigned)((int64_t)NTA * TAPS * k.G * d.M * 16);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
   const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;   // rows beyond M: rejected -> 0
-  auto issue_w_dma = [&](int g) {
+  auto issue_w_dma = [&](int g, int buf) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int p = wave + 4 * i;   // wave-uniform
       if (p < WPIECES)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + p * 64), 16, wvo, (p * k.G + g) * d.M * 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + buf * WPB + p * 64), 16, wvo, (p * k.G + g) * d.M * 16, 0, 0);
     }
   };
 
@@ -190,25 +197,31 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel
   __syncthreads();   // bnp, zero column / slot
   load_bnp(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  issue_w_dma(0);
+  issue_w_dma(0, 0);
 
-  auto kstep = [&](auto Q) {
+  // A k-step = fetch (NTA MS + NTB NS ds_read_b128) + NPROD MS NS MFMAs.  The fragments of k-step q + 1 are requested BEFORE the
+  // MFMAs of k-step q issue (two register sets, the order pinned by sched_barrier): left to the compiler every group of four
+  // reads was followed by s_waitcnt and its MFMAs in the same four registers -- with one or two waves per SIMD (small feature
+  // maps) the LDS round trips were exposed: 6 000 cycles per stage for 1 920 of matrix work.
+  uint4 fa[2][NTA][MS], fb[2][NTB][NS];
+  auto fetch = [&](auto Q, int buf, uint4 (&a)[NTA][MS], uint4 (&bq)[NTB][NS]) {
     constexpr int q = decltype(Q)::value;
     constexpr bool last = q == 4;
-    uint4 a[NTA][MS], bq[NTB][NS];
     const bool dead = last && hi;   // this lane's half of the last k-step has no tap
 #pragma unroll
     for (int t = 0; t < NTA; ++t)
 #pragma unroll
-      for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[dead ? ZSLOT + l31 + ms * 32 : t * (TAPS * 64) + abase + q * 128 + ms * 32];
+      for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[dead ? ZSLOT + l31 + ms * 32 : buf * WPB + t * (TAPS * 64) + abase + q * 128 + ms * 32];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       constexpr int t0 = 2 * q, t1 = 2 * q + 1;   // tap (kh, kw) = unit offset kh Wq + kw
       const int to = hi ? (t1 / 3) * Wq + (t1 % 3) : (t0 / 3) * Wq + (t0 % 3);
       const int bo = dead ? ZCOL : boff[ns] + to;
 #pragma unroll
-      for (int t = 0; t < NTB; ++t) bq[t][ns] = Sl[t * SCOLS + bo];
+      for (int t = 0; t < NTB; ++t) bq[t][ns] = Sl[buf * SUB + t * SCOLS + bo];
     }
+  };
+  auto mma = [&](uint4 (&a)[NTA][MS], uint4 (&bq)[NTB][NS]) {
 #pragma unroll
     for (int p = 0; p < NPROD; ++p) {
       const int i = ar_pi(AR, p), j = ar_pj(AR, p);
@@ -225,27 +238,116 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel
         }
     }
   };
-
-  // Happens-before of the single image (conv_gemm_split.hip): store_s(s) and the W DMA of stage s write the image behind the CLOSING
-  // barrier of stage s - 1; the OPENING barrier of stage s follows every wave's ds_writes and its vmcnt(0) (its DMA pieces landed).
-  const int nst = (d.Kc + KC8 - 1) / KC8;
-  for (int s_ = 0; s_ < nst; ++s_) {
-    store_s(s_ * KC8);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // opening
-    if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC8);   // registers; in flight during the MFMA phase
-    SAR_LDS_SKEW();
-    kstep(std::integral_constant<int, 0>());
-    kstep(std::integral_constant<int, 1>());
-    kstep(std::integral_constant<int, 2>());
-    kstep(std::integral_constant<int, 3>());
-    kstep(std::integral_constant<int, 4>());
-    __syncthreads();   // closing: the image may be overwritten (next stage / the epilogue's transpose area)
-    if (s_ + 1 < nst) {
-      load_bnp((s_ + 1) * KC8);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_w_dma(s_ + 1);
+  auto ksteps = [&](int buf) {
+    if constexpr (!DEEP) {   // three workgroups per CU hide the round trips; 168 registers do not hold a second fragment set
+      fetch(std::integral_constant<int, 0>(), buf, fa[0], fb[0]);
+      mma(fa[0], fb[0]);
+      fetch(std::integral_constant<int, 1>(), buf, fa[0], fb[0]);
+      mma(fa[0], fb[0]);
+      fetch(std::integral_constant<int, 2>(), buf, fa[0], fb[0]);
+      mma(fa[0], fb[0]);
+      fetch(std::integral_constant<int, 3>(), buf, fa[0], fb[0]);
+      mma(fa[0], fb[0]);
+      fetch(std::integral_constant<int, 4>(), buf, fa[0], fb[0]);
+      mma(fa[0], fb[0]);
+      return;
     }
+    fetch(std::integral_constant<int, 0>(), buf, fa[0], fb[0]);
+    fetch(std::integral_constant<int, 1>(), buf, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, 2>(), buf, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, 3>(), buf, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, 4>(), buf, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[0], fb[0]);
+  };
+  // DEEP: the matrix phase of stage s with the stager work of stage s + 1 INSIDE it -- with one or two waves per SIMD nothing else
+  // fills the vector ALU / memory issue slots while the matrix pipe runs, and a wave issues in order: the split of a staged
+  // element (~75 vector instructions) is placed between the MFMAs of a k-step (one MFMA, then six vector instructions), the
+  // requests of stage s + 2 behind the last read of the staging registers.  (tools/c2s_probe.py: matrix phase, stager and W DMA
+  // of a 512-channel 8 x 8 launch took 82 + 50 + 25 us one after the other.)
+  auto mma_with = [&](uint4 (&a)[NTA][MS], uint4 (&bq)[NTB][NS], auto&& other) {
+    other();
+    mma(a, bq);
+#pragma unroll
+    for (int i = 0; i < NPROD * MS * NS; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    }
+  };
+  auto ksteps_deep = [&](int buf, int c1, bool more2) {
+    fetch(std::integral_constant<int, 0>(), buf, fa[0], fb[0]);
+    fetch(std::integral_constant<int, 1>(), buf, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // (behind the last stage the pieces write zeros into the image nobody reads any more: no branch inside the interleaved region)
+    mma_with(fa[0], fb[0], [&] { store_piece(c1, buf ^ 1, std::integral_constant<int, 0>()); });
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, 2>(), buf, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_with(fa[1], fb[1], [&] { if constexpr (CJ == 2) store_piece(c1, buf ^ 1, std::integral_constant<int, 1>()); });
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, 3>(), buf, fa[1], fb[1]);
+    if (more2) issue_s_loads(c1 + KC8);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, 4>(), buf, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa[0], fb[0]);
+  };
+
+  const int nst = (d.Kc + KC8 - 1) / KC8;
+  if constexpr (!DEEP) {
+    // Happens-before of the single image (conv_gemm_split.hip): store_s(s) and the W DMA of stage s write the image behind the CLOSING
+    // barrier of stage s - 1; the OPENING barrier of stage s follows every wave's ds_writes and its vmcnt(0) (its DMA pieces landed).
+    for (int s_ = 0; s_ < nst; ++s_) {
+      store_s(s_ * KC8, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // opening
+      if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC8);   // registers; in flight during the MFMA phase
+      SAR_LDS_SKEW();
+      ksteps(0);
+      __syncthreads();   // closing: the image may be overwritten (next stage / the epilogue's transpose area)
+      if (s_ + 1 < nst) {
+        load_bnp((s_ + 1) * KC8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_w_dma(s_ + 1, 0);
+      }
+    }
+  } else {
+    // Two images.  Stage s multiplies image s & 1.  Behind the barrier of stage s every wave has finished its reads of stage s - 1
+    // (image (s + 1) & 1) and written its part of image s & 1: the W DMA of stage s + 1 and store_s(s + 1) -- whose loads were
+    // requested a stage ago -- fill image (s + 1) & 1, then the loads of stage s + 2 are requested, then the matrix phase of
+    // stage s runs.  Vector-memory order inside a stage: W DMA (s + 1), loads (s + 2) -- so at the top of stage s + 1 vmcnt(8 CJ)
+    // (the loads may stay in flight) says this wave's DMA pieces have landed; the last stage has no loads behind its DMA.
+    store_s(0, 0);
+    if (nst > 1) issue_s_loads(KC8);
+    for (int s_ = 0; s_ < nst; ++s_) {
+      const int buf = s_ & 1;
+      if (s_ + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * CJ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s_ + 1 < nst) {
+        load_bnp((s_ + 1) * KC8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_w_dma(s_ + 1, buf ^ 1);
+      }
+      SAR_LDS_SKEW();
+      ksteps_deep(buf, (s_ + 1) * KC8, s_ + 2 < nst);
+    }
+    __syncthreads();   // the epilogue's transpose area aliases the images
   }
 
   {   // undo the operand scales; dead columns hold exact zeros (the epilogue's sums run over them)
@@ -262,28 +364,55 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_kernel
 
 bool ar_built(int ar) { return ar == AR_B6 || ar == AR_H3A; }
 
-// the launches this unit is built for; fills the geometry
-bool geometry_2s(const sar_conv2d_desc& d, C2S& k) {
+// the launches this unit is built for; fills the geometry for tiles of `tcols` (256 / 128) output pixels
+bool geometry_2s(const sar_conv2d_desc& d, C2S& k, int tcols) {
   if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1) return false;
   if (d.H_src != d.H_out || d.W_src != d.W_out) return false;
   if (d.Kc < 8 || d.Kc > 512 || (d.M & 7) || d.flags) return false;
   const int H = d.H_out, W = d.W_out, opix = H * W;
-  if (W > 256 || opix <= 0) return false;
+  if (W > tcols || opix <= 0) return false;
   k.B = d.B, k.H = H, k.W = W, k.Wq = W + 2;
-  if (opix <= 128) {
-    k.NI = 256 / opix, k.TH = H, k.TPI = 1;
+  if (opix <= tcols / 2) {
+    k.NI = tcols / opix, k.TH = H, k.TPI = 1;
     k.IRW = (H + 2) * (W + 2), k.RW = k.NI * k.IRW;
     k.ntiles = (d.B + k.NI - 1) / k.NI;
   } else {
-    k.NI = 1, k.TH = 256 / W < H ? 256 / W : H, k.TPI = (H + k.TH - 1) / k.TH;
+    k.NI = 1, k.TH = tcols / W < H ? tcols / W : H, k.TPI = (H + k.TH - 1) / k.TH;
     k.IRW = k.RW = (k.TH + 2) * (W + 2);
     k.ntiles = d.B * k.TPI;
   }
-  if (k.RW > 511) return false;
+  if (k.RW > 2 * tcols) return false;
   k.ny = (d.M + 63) / 64;
   k.nparts = k.ntiles * 4;
   k.G = (d.Kc + 7) / 8;
   return true;
+}
+
+// Which kernel a descriptor takes: 0 = three workgroups per CU, tiles of 256 pixels (large launches: the other workgroups of the CU
+// hide a stage's latencies); 1 = double-buffered, 256; 2 = double-buffered, 128 (small feature maps: twice the workgroups).
+// SAR_C2S_VARIANT=0/1/2 pins it (experiments).  -1: not built.
+int pick_variant(const sar_conv2d_desc& d, C2S& k) {
+  static const int pinned = [] { const char* e = getenv("SAR_C2S_VARIANT"); return e ? atoi(e) : -1; }();
+  C2S k256, k128;
+  const bool ok256 = geometry_2s(d, k256, 256), ok128 = geometry_2s(d, k128, 128);
+  if (!ok256 && !ok128) return -1;
+  int v;
+  if (pinned >= 0 && pinned <= 2 && (pinned == 2 ? ok128 : ok256)) v = pinned;
+  else if (!ok256) v = 2;
+  else {
+    // measured (tools/c2s_probe.py, bs = 32: variants 0 / 1 / 2 in us): 64 ch 64x64 (512 workgroups of 256 pixels) 44 / 56 / 57;
+    // 128 ch 32x32 (256) 55 / 50 / 45; 256 ch 16x16 (128) 96 / 88 / 60; 512 ch 8x8 (64) 185 / 167 / 113 -- fp32 MFMA: 92 / 97 / 107 / 139
+    const int nwork = k256.ntiles * k256.ny;
+    v = nwork >= 2 * 256 ? 0 : (ok128 ? 2 : 1);
+  }
+  k = v == 2 ? k128 : k256;
+  {   // L2 footprint of one XCD (1 / 8 of the workgroups): all weight images + 1 / 8 of the source, or 1 / 8 of the weights + (all / part of) the source
+    static const int pin_rb = [] { const char* e = getenv("SAR_C2S_RB_MAJOR"); return e ? atoi(e) : -1; }();
+    const double wbytes = 3.0 * 9 * k.G * d.M * 16, sbytes = 4.0 * d.Kc * d.B * d.H_out * d.W_out;
+    const double per_tile = wbytes + sbytes / 8, per_rb = wbytes / 8 + sbytes * (k.ny >= 8 ? 1.0 : k.ny / 8.0);
+    k.rb_major = pin_rb >= 0 ? pin_rb : (per_rb < per_tile ? 1 : 0);
+  }
+  return v;
 }
 
 void fill_desc(const sar_conv2d_desc& d, sar_conv_desc& o) {
@@ -308,7 +437,7 @@ extern "C" int64_t sar_conv2d_gemm_split_workspace_bytes(const sar_conv2d_desc* 
 extern "C" int sar_conv2d_gemm_split_nparts(const sar_conv2d_desc* d) {
   if (!d || d->B <= 0 || d->M <= 0) return SAR_E_ARG;
   C2S k;
-  if (!geometry_2s(*d, k)) return SAR_E_UNSUP;
+  if (pick_variant(*d, k) < 0) return SAR_E_UNSUP;
   return k.nparts;
 }
 
@@ -320,8 +449,9 @@ extern "C" int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const 
   SAR_REQUIRE(!ar_f16(arith) || (src_bound && w_bound), "sar_conv2d_gemm_split: fp16 arithmetics need the operand bounds");
   SAR_REQUIRE(d->B > 0 && d->Kc > 0 && d->M > 0 && d->H_src > 0 && d->W_src > 0, "sar_conv2d_gemm_split: bad sizes");
   C2S k;
-  if (!geometry_2s(*d, k)) {
-    sar_set_error("sar_conv2d_gemm_split: built for 3x3 / stride 1 / pad 1, 8 <= Kc <= 512, M %% 8 == 0, windows of <= 511 staged pixels "
+  const int variant = pick_variant(*d, k);
+  if (variant < 0) {
+    sar_set_error("sar_conv2d_gemm_split: built for 3x3 / stride 1 / pad 1, 8 <= Kc <= 512, M %% 8 == 0, windows of <= 512 staged pixels "
                   "(%dx%d, stride %d, pad %d, Kc %d, M %d, %dx%d): use sar_conv2d_gemm_f32",
                   d->KH, d->KW, d->stride, d->pad, d->Kc, d->M, d->H_out, d->W_out);
     return SAR_E_UNSUP;
@@ -341,8 +471,16 @@ extern "C" int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const 
   k.src_bound = src_bound;
   k.w_bound = w_bound;
   const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
-  if (arith == AR_H3A) hipLaunchKernelGGL((conv2d_split_kernel<AR_H3A>), grid, block, 0, as_stream(s), k);
-  else hipLaunchKernelGGL((conv2d_split_kernel<AR_B6>), grid, block, 0, as_stream(s), k);
+  hipStream_t st = as_stream(s);
+  if (arith == AR_H3A) {
+    if (variant == 0) hipLaunchKernelGGL((conv2d_split_kernel<AR_H3A, 2, 0>), grid, block, 0, st, k);
+    else if (variant == 1) hipLaunchKernelGGL((conv2d_split_kernel<AR_H3A, 2, 1>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((conv2d_split_kernel<AR_H3A, 1, 1>), grid, block, 0, st, k);
+  } else {
+    if (variant == 0) hipLaunchKernelGGL((conv2d_split_kernel<AR_B6, 2, 0>), grid, block, 0, st, k);
+    else if (variant == 1) hipLaunchKernelGGL((conv2d_split_kernel<AR_B6, 2, 1>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((conv2d_split_kernel<AR_B6, 1, 1>), grid, block, 0, st, k);
+  }
   SAR_LAUNCH_CHECK("sar_conv2d_gemm_split");
   return 0;
 }

@@ -42,6 +42,9 @@ def get_parser():
                         help='frame-rate up-sampling factor of utils.Dataset (utils.py:105, default 250), applied on the GPU inside '
                              'the radar layer (Gaussian smoothing + cubic interpolation, never materialised); 0 = feed the clips as they are')
     parser.add_argument('--sigma', type=int, default=3, help='sigma of the Gaussian smoothing before up-sampling (utils.py:105)')
+    parser.add_argument('--mfma', default='fp32', choices=['fp32', 'f32_split', 'f32_split_bf16x6'],
+                        help="(not in the reference) arithmetic of the resnet's 3x3 / stride-1 convolutions: fp32 MFMA, or fp32 results on "
+                             "the fp16 / bf16 matrix pipe (csrc/conv2d_split.hip; same parity tolerances)")
     parser.add_argument('--synthetic', action='store_true')
     parser.add_argument('--synthetic-size', type=int, default=2048)
     parser.add_argument('--max-iters', type=int, default=0)
@@ -89,7 +92,7 @@ def main():
         data = {x: NpySkeletonData(arg.data_path.format(x), arg.label_path.format(x), num_classes=arg.num_classes)
                 for x in ['train', 'val']}
     model = Model(num_classes=arg.num_classes, num_filters=arg.num_filters, device=dev, num_pad_frames=arg.num_pad_frames,
-                  sigma=arg.sigma)
+                  sigma=arg.sigma, mfma=arg.mfma)
     eng = model.base_model.engine
     trainer = SpectrogramTrainer(model, arg.base_lr, world_size=world)
     log = open(os.path.join(arg.log_dir, "scalars.jsonl"), "a") if rank == 0 else None

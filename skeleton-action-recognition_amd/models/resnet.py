@@ -9,12 +9,12 @@ from models.resnet18 import resnet18
 
 
 class Model(torch.nn.Module):
-    def __init__(self, num_classes=60, num_filters=64, image_size=256, device='cuda:0', num_pad_frames=0, sigma=3):
+    def __init__(self, num_classes=60, num_filters=64, image_size=256, device='cuda:0', num_pad_frames=0, sigma=3, mfma=None):
         """num_pad_frames = P > 0 (not in the reference's constructor): feed RAW clips and let the radar layer apply
         utils.Dataset.pad_frames (smoothing + x P cubic up-sampling, the reference's CPU data-loader step) on the GPU."""
         super().__init__()
         self.num_pad_frames, self.sigma = num_pad_frames, sigma
-        self.base_model = resnet18(num_classes=num_classes, num_filters=num_filters, device=device)
+        self.base_model = resnet18(num_classes=num_classes, num_filters=num_filters, device=device, mfma=mfma)      # mfma: models/resnet18.py
         self.virtual_radar = VirtualRadar(wavelength=5e-4, device=device)
         self.image_size = image_size
 

@@ -22,9 +22,10 @@ class _ResNetFunction(torch.autograd.Function):
 
 
 class ResNet(torch.nn.Module):
-    def __init__(self, num_classes=1000, num_filters=64, device="cuda", seed=0):
+    def __init__(self, num_classes=1000, num_filters=64, device="cuda", seed=0, mfma=None):
+        """mfma (not in the reference): "fp32" | "f32_split" | "f32_split_bf16x6" -- sar_amd.resnet.ResNet18; None = its default"""
         super().__init__()
-        self.engine = ResNet18(num_classes=num_classes, num_filters=num_filters, device=device, seed=seed)
+        self.engine = ResNet18(num_classes=num_classes, num_filters=num_filters, device=device, seed=seed, mfma=mfma)
         self._names = list(self.engine.shapes)
         for k in self._names:
             self.register_parameter(k.replace(".", "_"), torch.nn.Parameter(self.engine.p[k]))

@@ -652,14 +652,14 @@ def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, p
 
 
 def conv2d_split_applicable(*, KH, KW, stride, pad, Kc, M, H_src, W_src, H_out, W_out, aux_even_pixels=False, **_):
-    """shapes csrc/conv2d_split.hip is built for (3x3 / stride 1 / pad 1, windows of <= 511 staged pixels); the others stay fp32"""
+    """shapes csrc/conv2d_split.hip is built for (3x3 / stride 1 / pad 1, windows of <= 512 staged pixels); the others stay fp32"""
     if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and H_src == H_out and W_src == W_out):
         return False
     if not (8 <= Kc <= 512 and M % 8 == 0 and not aux_even_pixels):
         return False
     opix = H_out * W_out
     rw = (256 // opix) * (H_out + 2) * (W_out + 2) if opix <= 128 else (min(H_out, 256 // W_out) + 2) * (W_out + 2) if W_out <= 256 else 1 << 30
-    return rw <= 511
+    return rw <= 512
 
 
 def _pack_split_conv2d(W, w_stride_tap, w_stride_c, Kc, M, arith, transposed):

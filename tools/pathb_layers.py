@@ -1,4 +1,4 @@
-"""Per-layer kernel time of the Path B step (diagnostic): SAR_PROFILE_SHAPES=1 SAR_WGRAD_STREAM=0 python tools/pathb_layers.py
+"""Per-layer kernel time of the Path B step (diagnostic): SAR_PROFILE_SHAPES=1 SAR_WGRAD_STREAM=0 python tools/pathb_layers.py [batch [mfma]]
 Prints, per conv geometry, launches per step, ms per step and TFLOP/s (HIP events, side stream off so that durations are clean)."""
 import os
 import sys
@@ -16,7 +16,7 @@ from models.resnet import Model  # noqa: E402
 def main():
     bs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     dev = torch.device("cuda:0")
-    model = Model(num_classes=60, device=dev)
+    model = Model(num_classes=60, device=dev, mfma=sys.argv[2] if len(sys.argv) > 2 else "fp32")
     trainer = SpectrogramTrainer(model, 1e-3, 1)
     x, y = synthetic_clips(bs, dev, seed=0)
     for _ in range(3):
