@@ -485,6 +485,15 @@ int64_t sar_conv2d_gemm_split_workspace_bytes(const sar_conv2d_desc* d, int arit
 int sar_conv2d_gemm_split_nparts(const sar_conv2d_desc* d);
 int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const void* packed, const uint32_t* src_bound,
                           const uint32_t* w_bound, sar_stream_t s);
+/* Weight gradient of the same convolutions on the split arithmetic (csrc/conv_wgrad_split.hip instantiated for images: the batch is
+ * one flat sequence of B H W positions, a tap a shift of it; the image borders are handled by masking one element of a dout fragment /
+ * redirecting a src fragment to a zero row).  Same descriptor fields and slab contract as sar_conv2d_wgrad_f32 (slab[nsplit][9 Kc M] in
+ * (tap, c, m) order, summed by sar_slab_reduce_f32 in slab order); src_bound = bound of pro(src) (the well-conditioned operand: three term
+ * images), dout_bound = bound of dout (two).  Built for 3x3 / stride 1 / pad 1, W in {8, 16, 32, 64}, Kc >= 8, M >= 8, B H W < 2^22;
+ * anything else: SAR_E_UNSUP.  sar_conv2d_wgrad_split_blocks: host query -- workgroups per slab group (return value), *wk = slabs a
+ * group writes (nsplit must be a multiple), *tile_positions = positions per tile (256). */
+int sar_conv2d_wgrad_split_blocks(const sar_conv2d_desc* d, int arith, int* wk, int* tile_positions);
+int sar_conv2d_wgrad_split(const sar_conv2d_desc* d, int arith, const uint32_t* src_bound, const uint32_t* dout_bound, sar_stream_t s);
 /* Data gradient of a ONE-input-channel conv (the 7x7/2 stem, models/resnet18.py:159): dx[b][h][w] = sum_{kh,kw,m}
  * dout[m][(b, (h+pad-kh)/s, (w+pad-kw)/s)] * w_packed[kh*KW+kw][m] over the taps that divide evenly.  Needed only
  * when the image itself depends on trainable parameters (VirtualRadar location / wavelength). */

@@ -27,6 +27,21 @@
 #include "sar_common.h"
 #include <type_traits>
 
+// This file is compiled twice: as itself (part 0: the ST-GCN operators and their entry points) and through conv2d_wgrad_split.hip
+// (part 1: the same temporal kernel instantiated for the 3x3 convolutions of the resnet, W2 > 0, and its entry point).
+#ifndef SAR_WSPLIT_PART
+#define SAR_WSPLIT_PART 0
+#endif
+
+struct WgradKS {     // kernel argument (the same definition in every part)
+  sar_wgrad_desc d;
+  int TPS, ntiles, gy, gz;
+  int H2, seq2;      // W2 kernels: image height, positions of the flattened batch (B H W2)
+  float invH2;
+  const unsigned* src_bound;
+  const unsigned* dout_bound;
+};
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -90,15 +105,23 @@ constexpr int ar_pj(int ar, int p) {
 // de-interleaved by parity into two images in the coordinates of the dout positions -- E: frame 2 i at (i, v), O: frame 2 i + 1 --
 // in which a tap is again a shift by whole frames: odd taps read E at n + 25 (tap - 3) / 2, even taps O at n + 25 (tap - 4) / 2.
 // Both images cover [n0 - 50, n0 + KT + 50): with KT = 96 the row is as long as stride 1's (392 elements).
-template <int AR, int S2 = 0> struct Cfg {
+// W2 > 0 (part 1): the 3x3 / stride-1 / pad-1 convolution on images of width W2 (a power of two >= 8), the whole batch flattened
+// into ONE sequence of B H W2 positions.  Tap (kh, kw) is the shift (kh - 1) W2 + (kw - 1) of the flat position -- exact except at
+// the image borders, where the shifted read lands in a neighbouring row / image instead of the zero padding: a chunk of 8 positions
+// lies inside one image row (W2 % 8 == 0), so the left / right border costs one masked element of the dout fragment (kw = 0: the
+// chunk's first element when it starts a row; kw = 2: its last when it ends one) and the top / bottom border redirects the src
+// fragment read of the chunk to an always-zero row of the LDS image (kh = 0 in the first image row, kh = 2 in the last).
+template <int AR, int S2 = 0, int W2 = 0> struct Cfg {
   static constexpr int NT = ar_nta(AR);                 // src images in LDS
-  static constexpr int KT = S2 ? 96 : 192;               // dout positions per tile (multiple of 16): 3 x 32 x 394 x 2 B = 75.6 KB
+  static constexpr int KT = W2 ? 256 : (S2 ? 96 : 192);  // dout positions per tile (multiple of 16): 3 x 32 x 394 x 2 B = 75.6 KB
   static constexpr int KS = KT / 16;
   static constexpr int WIN2 = KT + 4 * VJ;               // S2: positions per parity image
-  static constexpr int WIN = S2 ? 2 * WIN2 : KT + (TAPS - 1) * VJ;   // src window (S2: E | O)
+  static constexpr int WIN = W2 ? KT + 2 * W2 + 2 : (S2 ? 2 * WIN2 : KT + (TAPS - 1) * VJ);   // src window (S2: E | O)
   static constexpr int RS = ((WIN + 2 + 1) / 2 * 2) + ((((WIN + 2 + 1) / 2) & 1) ? 0 : 2);   // row stride (elements): >= WIN + 2, RS / 2 odd
   static constexpr int NCH = (WIN + 127) / 128;          // stager chunks of 128 positions (a lane owns two adjacent positions)
+  static constexpr int ROWS = CB + (W2 ? 1 : 0);         // rows per term image (W2: + the always-zero row)
   static_assert((RS / 2) % 2 == 1 && RS >= WIN + 2, "row stride");
+  static_assert(W2 == 0 || (W2 >= 8 && W2 <= 64 && (W2 & (W2 - 1)) == 0 && S2 == 0), "image width: a power of two in [8, 64]");
 };
 
 __host__ __device__ __forceinline__ int scale_exp(unsigned bound_bits) {   // conv_gemm_split.hip
@@ -149,20 +172,15 @@ __device__ __forceinline__ void split2(float x, float y, unsigned (&w)[WSIDE ? a
   }
 }
 
-struct WgradKS {
-  sar_wgrad_desc d;
-  int TPS, ntiles, gy, gz;
-  const unsigned* src_bound;
-  const unsigned* dout_bound;
-};
 
 // WK = 1: four waves side by side along m (128 dout channels); WK = 2: two along m, the pairs split the k-steps (M <= 64)
-template <int AR, int WK, int S2>
+template <int AR, int WK, int S2, int W2 = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS k) {
-  using C = Cfg<AR, S2>;
+  using C = Cfg<AR, S2, W2>;
   constexpr int NT = C::NT, NTB = ar_ntb(AR), NPROD = ar_nprod(AR), KT = C::KT, KS = C::KS, WIN = C::WIN, RS = C::RS, NCH = C::NCH, V = VJ;
+  constexpr int ROWS = C::ROWS;
   constexpr int WMM = 4 / WK, MBLK = 32 * WMM;
-  __shared__ __attribute__((aligned(16))) unsigned short Hs[NT * CB * RS];
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[NT * ROWS * RS];
   __shared__ float2 bnp[256];
   const sar_wgrad_desc& d = k.d;
   const int tid = threadIdx.x;
@@ -198,6 +216,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     if (tid < CB && d.pro_scale && c0 + tid < d.Kc) p = make_float2(d.pro_scale[c0 + tid] * sa, d.pro_shift[c0 + tid] * sa);
     if (tid < CB) bnp[tid] = p;
   }
+  if constexpr (W2 > 0) {   // the always-zero row of every term image
+    for (int i = tid; i < NT * (RS / 2); i += 256)
+      *reinterpret_cast<unsigned*>(&Hs[((i / (RS / 2)) * ROWS + CB) * RS + 2 * (i % (RS / 2))]) = 0u;
+  }
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -211,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   const int tile_lo = sg * tps;
   const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
   const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
-  const int seq = d.T_out * V;        // dout positions per sequence
-  const int seq_src = d.T_src * V;    // (stride 1: the same)
+  const int seq = W2 ? k.seq2 : d.T_out * V;        // dout positions per sequence
+  const int seq_src = W2 ? k.seq2 : d.T_src * V;    // (stride 1: the same)
 
   // LDS read base of this lane: row l31, element 8 * hi
   const unsigned a_base = (unsigned)(uintptr_t)Hs + (unsigned)((l31 * RS + 8 * hi) * 2);
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   // pipeline of the k-loop.)  Geometry (this lane's window columns and their src positions, the same for every row): stride 1 -- consecutive
   // positions; S2 -- column q of image E / O is dout-space position n0 - 50 + q = (i, v), i.e. src frame 2 i (+ 1).
   auto geometry = [&](int n0, int (&spos)[NCH][2], bool (&sok)[NCH][2]) {
-    const int p_lo = n0 - d.pad * V;
+    const int p_lo = W2 ? n0 - (W2 + 1) : n0 - d.pad * V;
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
         split2<AR, true>(v0, v1, w);
         if (col < RS) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
+          for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * ROWS + row) * RS + col]) = w[t];
         }
       }
     }
@@ -325,21 +347,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     // one tap ahead (3 MFMAs + 12 funnel shifts = ~150 cycles) is less than the LDS round trip with eight waves reading.
     auto tap_elem = [&](int t) {   // window start in elements: stride 1 -- t V (V odd: the parity of t); S2 -- image E for odd
       // taps, O for even ones, shifted by whole frames: (floor((t - 3) / 2) + 2) V inside the image
-      return S2 ? ((t & 1) ? 0 : C::WIN2) + ((t - 3 - ((t & 1) ? 0 : 1)) / 2 + 2) * V : t * V;
+      return W2 ? (t / 3) * W2 + (t % 3) : S2 ? ((t & 1) ? 0 : C::WIN2) + ((t - 3 - ((t & 1) ? 0 : 1)) / 2 + 2) * V : t * V;
+    };
+    // W2: which LDS address the src fragment of tap t is read from for the chunk of k-step kc_ -- the window, or the zero row when
+    // the tap leaves the image through its top (kh = 0, first row) / bottom (kh = 2, last row) border
+    const unsigned a_zero = (unsigned)(uintptr_t)Hs + (unsigned)(CB * RS * 2);
+    auto chunk_edges = [&](int kc_, bool& top, bool& bot) {
+      const int row = (n0 + 16 * kc_ + 8 * hi) / (W2 ? W2 : 1);
+      const int img = (int)(((float)row + 0.5f) * k.invH2);
+      const int h = row - img * k.H2;
+      top = h == 0, bot = h == k.H2 - 1;
     };
     unsigned fw[3][NT][5];
     auto load_tap = [&](unsigned a_ks, int t, unsigned (&w)[NT][5]) {
       const int e = tap_elem(t);
 #pragma unroll
       for (int tm = 0; tm < NT; ++tm) {
-        lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (CB * RS * 2) + (e & ~1) * 2);
+        lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (ROWS * RS * 2) + (e & ~1) * 2);
 #pragma unroll
         for (int i = 0; i < 4 + (e & 1); ++i) w[tm][i] = p[i];
       }
     };
+    auto tap_base = [&](unsigned a_ks, int t, bool top, bool bot) {
+      if constexpr (W2 > 0) {
+        if (t < 3) return top ? a_zero : a_ks;
+        if (t >= 6) return bot ? a_zero : a_ks;
+      }
+      return a_ks;
+    };
+    bool top_n = false, bot_n = false;   // W2: border flags of the chunk whose first taps are in the ring
     if (kh < KS) {
-      load_tap(a_base + kh * 32, 0, fw[0]);
-      load_tap(a_base + kh * 32, 1, fw[1]);
+      if constexpr (W2 > 0) chunk_edges(kh, top_n, bot_n);
+      load_tap(tap_base(a_base + kh * 32, 0, top_n, bot_n), 0, fw[0]);
+      load_tap(tap_base(a_base + kh * 32, 1, top_n, bot_n), 1, fw[1]);
     }
 #pragma unroll 1
     for (int ks = kh; ks < KS; ks += 2 * WK) {
@@ -371,10 +411,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
           }
           const unsigned a_ks = a_base + kc * 32;
           const bool more = kc + WK < KS;   // wave-uniform
+          const bool top_c = top_n, bot_c = bot_n;
+          unsigned bwl0[NTB], bwr3[NTB];   // W2: dword 0 / 3 of the dout fragment with the row's first / last element masked
+          if constexpr (W2 > 0) {
+            const int pos = n0 + 16 * kc + 8 * hi;
+            const unsigned ml = (pos & (W2 - 1)) == 0 ? 0xffff0000u : 0xffffffffu;
+            const unsigned mr = ((pos + 8) & (W2 - 1)) == 0 ? 0x0000ffffu : 0xffffffffu;
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) bwl0[t] = bw[t][0] & ml, bwr3[t] = bw[t][3] & mr;
+            if (more) chunk_edges(kc + WK, top_n, bot_n);
+          }
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
-            if (t + 2 < TAPS) load_tap(a_ks, t + 2, fw[(t + 2) % 3]);
-            else if (more) load_tap(a_ks + WK * 32, t + 2 - TAPS, fw[(t + 2) % 3]);
+            if (t + 2 < TAPS) load_tap(tap_base(a_ks, t + 2, top_c, bot_c), t + 2, fw[(t + 2) % 3]);
+            else if (more) load_tap(tap_base(a_ks + WK * 32, t + 2 - TAPS, top_n, bot_n), t + 2 - TAPS, fw[(t + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);
             const int e = tap_elem(t);
             u32x4 aq[NT];
@@ -389,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
 #pragma unroll
             for (int p = 0; p < NPROD; ++p) {
               const int i = ar_pi(AR, p), j = ar_pj(AR, p);
-              const u32x4 bq = u32x4{bw[j][0], bw[j][1], bw[j][2], bw[j][3]};
+              const u32x4 bq = u32x4{(W2 > 0 && t % 3 == 0) ? bwl0[j] : bw[j][0], bw[j][1], bw[j][2], (W2 > 0 && t % 3 == 2) ? bwr3[j] : bw[j][3]};
               if (ar_f16(AR))
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&aq[i]),
                                                                 *reinterpret_cast<const f16x8*>(&bq), acc[t], 0, 0, 0);
@@ -425,6 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   SPLIT_TL_END(tile_hi - tile_lo);
 }
 
+#if SAR_WSPLIT_PART == 0
 // ---- GraphConvTD (models/gcn.py:199-209) weight / bias gradient in the split arithmetics:
 //   dW_k[c][m] = sum_n z_k[c, n] dout[m, n],  z_k[c, (t,w)] = sum_v x[c, (t,v)] A_k[v, w];   db_k[m] = sum_n dout[m, n] colsum(A_k)[w(n)]
 // Same structure as the temporal kernel with the three adjacency slices in the place of the nine taps: a tile = 4 frames (100
@@ -850,3 +901,96 @@ extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const ui
   SAR_LAUNCH_CHECK("sar_conv_wgrad_split");
   return 0;
 }
+
+#else   // ---------------------------------------------------------------------------- part 1 / 2: the resnet's 3x3 / stride-1 convolutions
+}  // namespace
+// dW[kh][kw][c][m] = sum_{b,h,w} pro(src)[c, (b, h + kh - 1, w + kw - 1)] * dout[m, (b, h, w)]   (models/resnet18.py:5-14 backward).
+// Part 1 holds the f16x3a instantiations and the entry points, part 2 the bf16x6 ones (two compiler jobs).
+int sar_c2d_wsplit_b6(const WgradKS& k, int wk, int W, dim3 grid, hipStream_t st);
+
+namespace {
+template <int AR, int W2>
+void launch_c2d_w(const WgradKS& k, int wk, dim3 grid, hipStream_t st) {
+  if (wk == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 1, 0, W2>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 2, 0, W2>), grid, dim3(256), 0, st, k);
+}
+template <int AR>
+int launch_c2d(const WgradKS& k, int wk, int W, dim3 grid, hipStream_t st) {
+  switch (W) {
+    case 8: launch_c2d_w<AR, 8>(k, wk, grid, st); return 0;
+    case 16: launch_c2d_w<AR, 16>(k, wk, grid, st); return 0;
+    case 32: launch_c2d_w<AR, 32>(k, wk, grid, st); return 0;
+    case 64: launch_c2d_w<AR, 64>(k, wk, grid, st); return 0;
+  }
+  return SAR_E_UNSUP;
+}
+}  // namespace
+#if SAR_WSPLIT_PART == 2
+int sar_c2d_wsplit_b6(const WgradKS& k, int wk, int W, dim3 grid, hipStream_t st) { return launch_c2d<AR_B6>(k, wk, W, grid, st); }
+#else
+namespace {
+// WK (1 or 2) of a descriptor, or 0 = not built (the caller keeps sar_conv2d_wgrad_f32)
+int c2d_wsplit_wk(const sar_conv2d_desc& d, int arith) {
+  if (arith != AR_B6 && arith != AR_H3A) return 0;
+  if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.H_src != d.H_out || d.W_src != d.W_out) return 0;
+  const int W = d.W_out;
+  if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
+  if (d.Kc < 8 || d.M < 8 || d.H_out < 1 || (int64_t)d.B * d.H_out * W >= (1 << 22)) return 0;
+  return d.M > 64 ? 1 : 2;
+}
+}  // namespace
+
+extern "C" int sar_conv2d_wgrad_split_blocks(const sar_conv2d_desc* d, int arith, int* wk_out, int* tile_positions) {
+  if (!d) return SAR_E_ARG;
+  const int wk = c2d_wsplit_wk(*d, arith);
+  if (!wk) return SAR_E_UNSUP;
+  if (wk_out) *wk_out = wk;
+  if (tile_positions) *tile_positions = Cfg<AR_H3A, 0, 8>::KT;
+  return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
+}
+
+extern "C" int sar_conv2d_wgrad_split(const sar_conv2d_desc* d, int arith, const uint32_t* src_bound, const uint32_t* dout_bound,
+                                      sar_stream_t s) {
+  SAR_REQUIRE(d != nullptr, "sar_conv2d_wgrad_split: null descriptor");
+  const int wk = c2d_wsplit_wk(*d, arith);
+  if (!wk) {
+    sar_set_error("sar_conv2d_wgrad_split: built for 3x3 / stride 1 / pad 1 on images of width 8 / 16 / 32 / 64, Kc >= 8, M >= 8, in the "
+                  "arithmetics bf16x6 / f16x3a (%dx%d, stride %d, pad %d, %dx%d, Kc %d, M %d, arith %d): use sar_conv2d_wgrad_f32",
+                  d->KH, d->KW, d->stride, d->pad, d->H_out, d->W_out, d->Kc, d->M, arith);
+    return SAR_E_UNSUP;
+  }
+  const int64_t npos = (int64_t)d->B * d->H_out * d->W_out;
+  SAR_REQUIRE(d->B > 0 && d->src && d->dout && d->slab, "sar_conv2d_wgrad_split: null src/dout/slab or B <= 0");
+  SAR_REQUIRE(d->nsplit >= wk && d->nsplit % wk == 0 && d->nsplit <= 65535,
+              "sar_conv2d_wgrad_split: nsplit %d must be a positive multiple of %d", d->nsplit, wk);
+  SAR_REQUIRE(d->ld_src >= npos && d->ld_dout >= npos, "sar_conv2d_wgrad_split: leading dimension smaller than B*H*W");
+  SAR_REQUIRE((int64_t)d->M * d->ld_dout * 4 < 0xf0000000ll, "sar_conv2d_wgrad_split: dout larger than 3.75 GiB");
+  SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv2d_wgrad_split: pro_scale/pro_shift mismatch");
+  SAR_REQUIRE(arith != AR_H3A || (src_bound && dout_bound), "sar_conv2d_wgrad_split: the fp16 arithmetic needs the operand bounds");
+  WgradKS k;
+  k.d = sar_wgrad_desc{};
+  k.d.mode = SAR_CONV_TEMPORAL;
+  k.d.B = 1, k.d.V = VJ, k.d.T_src = 1, k.d.T_out = 1;
+  k.d.Kc = d->Kc, k.d.M = d->M, k.d.taps = TAPS, k.d.stride = 1, k.d.pad = 1, k.d.pro_relu = d->pro_relu;
+  k.d.nsplit = d->nsplit;
+  k.d.src = d->src, k.d.ld_src = d->ld_src, k.d.dout = d->dout, k.d.ld_dout = d->ld_dout;
+  k.d.pro_scale = d->pro_scale, k.d.pro_shift = d->pro_shift;
+  k.d.slab = d->slab;
+  k.d.w_stride_tap = (int64_t)d->Kc * d->M, k.d.w_stride_c = d->M;
+  k.d.wsize = (int64_t)TAPS * d->Kc * d->M, k.d.bsize = 0;
+  k.src_bound = src_bound, k.dout_bound = dout_bound;
+  k.H2 = d->H_out, k.seq2 = (int)npos, k.invH2 = 1.0f / (float)d->H_out;
+  const int kt = Cfg<AR_H3A, 0, 8>::KT;
+  k.TPS = (int)((npos + kt - 1) / kt);
+  k.ntiles = k.TPS;
+  k.gy = (d->M + 128 / wk - 1) / (128 / wk);
+  k.gz = (d->Kc + CB - 1) / CB;
+  const int nwork = (d->nsplit / wk) * k.gy * k.gz;
+  const dim3 grid(((nwork + 7) / 8) * 8);
+  const int rc = arith == AR_H3A ? launch_c2d<AR_H3A>(k, wk, d->W_out, grid, as_stream(s)) : sar_c2d_wsplit_b6(k, wk, d->W_out, grid, as_stream(s));
+  if (rc) return rc;
+  SAR_LAUNCH_CHECK("sar_conv2d_wgrad_split");
+  return 0;
+}
+#endif
+#endif

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("SAR_HIP_LIB") or os.path.join(_HERE, "libsar_hip.so")
 
 SAR_CONV_GRAPH, SAR_CONV_TEMPORAL = 0, 1
 SAR_EPI_NONE, SAR_EPI_STATS, SAR_EPI_MASK, SAR_EPI_ADD, SAR_EPI_ADD_GATE = 0, 1, 2, 3, 4
+SAR_E_ARG, SAR_E_UNSUP = -1, -2
 SAR_GRAPH_WT_BF16_EXACT = 1
 SAR_GRAPH_FEW_DENSE = 4
 SAR_GRAPH_SLICE0_IDENTITY = 8
@@ -126,6 +127,8 @@ SIGNATURES = {
     "sar_conv2d_gemm_split_workspace_bytes": (_i64, [C.POINTER(Conv2dDesc), _i]),
     "sar_conv2d_gemm_split_nparts": (_i, [C.POINTER(Conv2dDesc)]),
     "sar_conv2d_gemm_split": (_i, [C.POINTER(Conv2dDesc), _i, _fp, _fp, _fp, _fp]),
+    "sar_conv2d_wgrad_split_blocks": (_i, [C.POINTER(Conv2dDesc), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sar_conv2d_wgrad_split": (_i, [C.POINTER(Conv2dDesc), _i, _fp, _fp, _fp]),
     "sar_permute3_f32": (_i, [_fp, _fp, _i, _i, _i, _i64, _i64, _i64, _fp]),
     "sar_permute3_batch_f32": (_i, [_fp, _fp, _fp, _i, _i64, _fp]),
     "sar_bn_relu_maxpool_fwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i64, _i64, _fp]),

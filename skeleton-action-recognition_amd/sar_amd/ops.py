@@ -729,13 +729,44 @@ def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, au
 _C2D_WG_SLOTS = int(__import__("os").environ.get("SAR_C2D_WG_SLOTS", "512"))
 
 
-def conv2d_wgrad(src, dout, dW_tcm, **geo):
-    """dW in (tap, c, m) layout -> dW_tcm (flat, taps*Kc*M floats)."""
+def conv2d_wgrad(src, dout, dW_tcm, *, split="default", bounds=None, **geo):
+    """dW in (tap, c, m) layout -> dW_tcm (flat, taps*Kc*M floats): sar_conv2d_wgrad_f32 -- or, with split="f16x3a" / "bf16x6" on 3x3 /
+    stride 1 / pad 1 at image widths 8 / 16 / 32 / 64, sar_conv2d_wgrad_split (fp32 results on the fp16 / bf16 matrix pipe; bounds =
+    (src_bound, dout_bound) cells, None = computed here by device kernels).  Slabs are summed in slab order either way."""
     lib = L.load()
+    if split == "default":
+        split = DEFAULT_SPLIT
+    if split not in ("f16x3a", "bf16x6"):
+        split = None
     d = _conv2d_desc(src, **geo)
     d.dout, d.ld_dout = ptr(_f32(dout)), dout.stride(0)
     taps = geo["KH"] * geo["KW"]
     n = taps * geo["Kc"] * geo["M"]
+    flops = 2.0 * geo["M"] * geo["Kc"] * taps * geo["B"] * geo["H_out"] * geo["W_out"]
+    if split:
+        wk, kt = C.c_int(0), C.c_int(0)
+        wgs = lib.sar_conv2d_wgrad_split_blocks(C.byref(d), L.SAR_SPLIT[split], C.byref(wk), C.byref(kt))
+        if wgs == L.SAR_E_UNSUP:
+            split = None
+        else:
+            check(0 if wgs > 0 else (wgs or -1), "sar_conv2d_wgrad_split_blocks")
+    if split:
+        ntiles = (geo["B"] * geo["H_out"] * geo["W_out"] + kt.value - 1) // kt.value
+        groups = max(1, min(ntiles, (_C2D_WG_SLOTS + wgs - 1) // wgs))      # one round of the resident workgroups (2 per CU)
+        nsplit = groups * wk.value
+        d.nsplit = nsplit
+        slab = torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
+        d.slab = ptr(slab)
+        sb, db = bounds if bounds is not None else (None, None)
+        if split.startswith("f16"):
+            if sb is None:
+                sb = _src_bound_single(src, geo.get("pro"))
+            if db is None:
+                db = _src_bound_single(dout, None)
+        with profiler.region("conv2d_wgrad_3x3_split" + _shape_tag(geo), flops):
+            check(lib.sar_conv2d_wgrad_split(C.byref(d), L.SAR_SPLIT[split], ptr(sb), ptr(db), stream_ptr()), "sar_conv2d_wgrad_split")
+        check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")
+        return
     wgs = ((geo["M"] + 63) // 64) * max(1, (geo["Kc"] + 31) // 32)
     # one round of the 512 resident workgroups (2 per CU): measured 22 % faster than 768 / 1024 in isolation (the kernels do not
     # fit 3 per CU, so a larger grid runs a second, partly filled round)
@@ -743,7 +774,6 @@ def conv2d_wgrad(src, dout, dW_tcm, **geo):
     d.nsplit = nsplit
     slab = torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
     d.slab = ptr(slab)
-    flops = 2.0 * geo["M"] * geo["Kc"] * taps * geo["B"] * geo["H_out"] * geo["W_out"]
     with profiler.region("conv2d_wgrad_%dx%d" % (geo["KH"], geo["KW"]) + _shape_tag(geo), flops):
         check(lib.sar_conv2d_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv2d_wgrad_f32")
     check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")

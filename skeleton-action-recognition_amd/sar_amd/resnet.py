@@ -306,9 +306,13 @@ class ResNet18:
         cv = self.convs[name]
         o, n = self.offsets[name + ".weight"], self._woff[name][1]
 
+        sa = dict(split=None)      # split kernels: the source bound is the forward's cell, the dout bound the data gradient's
+        if self.spacked is not None and (name, "f") in self._cell_of and "wgrad" in _SPLIT_KINDS:
+            sa = dict(split=self.split, bounds=(self._cell(name, "f"), self._cell(name, "b")))
+
         def run():
             ops.conv2d_wgrad(X, dout, self.grad[o:o + n], B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k,
-                             KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None)
+                             KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None, **sa)
         if self._side is None:
             run()
         else:       # ordered after everything issued so far; X / dout must outlive the side stream's use

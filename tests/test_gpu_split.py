@@ -309,3 +309,29 @@ def test_conv2d_3x3_forward_and_masked_data_gradient(dev, arith, cin, cout, H, W
     assert rel_err(dx.cpu(), want) < TOL
     pg = rg[0].cpu().double().sum(1)
     assert rel_err(pg[:, 1], (want * (aux.double() - amu.double().view(-1, 1))).sum(1)) < 5 * TOL
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 64, 64, 64, 2), (512, 512, 8, 8, 7), (128, 128, 32, 32, 1), (256, 256, 16, 16, 3),
+                                            (24, 40, 12, 16, 2), (8, 72, 5, 8, 9), (40, 8, 3, 32, 3)])
+def test_conv2d_3x3_weight_gradient(dev, arith, cin, cout, H, W, B):
+    """weight gradient of the 3x3 / stride 1 / pad 1 convolution on the split kernels (the batch as one flat sequence: image borders by
+    masked dout elements / the zero row) behind a folded BatchNorm + ReLU, with a gradient-like dout; against float64 torch."""
+    import torch.nn.functional as F
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(2 * cin + cout + H + W + B)
+    cn = lambda t: t.permute(1, 0, 2, 3).reshape(t.shape[1], -1).contiguous()
+    x = torch.randn(B, cin, H, W, generator=g).double()
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    sc, sh = (1 + 0.2 * torch.randn(cin, generator=g)).double(), (0.3 * torch.randn(cin, generator=g)).double()
+    hin = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    y = F.conv2d(hin, w, None, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g).double() * torch.exp(2 * torch.randn(y.shape, generator=g)).double()
+    gw, = torch.autograd.grad(y, w, dy)
+    geo = dict(B=B, Kc=cin, M=cout, H_src=H, W_src=W, H_out=H, W_out=W, KH=3, KW=3, stride=1, pad=1)
+    tmp = torch.empty(9 * cin * cout, device=dev)
+    ops.conv2d_wgrad(cn(x.float()).to(dev), cn(dy.float()).to(dev), tmp, pro=(sc.float().to(dev), sh.float().to(dev)), pro_relu=True,
+                     split=arith, **geo)
+    torch.cuda.synchronize()
+    got = tmp.cpu().view(3, 3, cin, cout).permute(3, 2, 0, 1)
+    assert rel_err(got, gw) < TOL
