@@ -482,6 +482,12 @@ int sar_conv2d_wgrad_f32(const sar_conv2d_desc* d, sar_stream_t s);
  * windows of at most 512 staged pixels ((rows per tile + 2) (W + 2), tiles of 256 output pixels), flags == 0; anything else
  * returns SAR_E_UNSUP (the nparts query too) and the caller keeps sar_conv2d_gemm_f32.  d->W and d->ctx are ignored. */
 int64_t sar_conv2d_gemm_split_workspace_bytes(const sar_conv2d_desc* d, int arith);
+ /* Small feature maps (a launch of <= 1 workgroup per CU with a long contraction: 8x8 x 512 channels) divide the channel stages among
+ * up to 8 workgroups per output tile when the caller provides a workspace in d->slab (sar_conv2d_gemm_split_slab_bytes(d) bytes, 0 = no
+ * K-split planned for this shape; 16-byte aligned; d->slab == NULL: one workgroup per tile): raw fp32 partial tiles, then a second
+ * launch that sums them in a fixed order and applies the epilogue.  The partial-sum count (nparts) depends on it: query
+ * sar_conv2d_gemm_split_nparts with d->slab set as it will be in the call. */
+int64_t sar_conv2d_gemm_split_slab_bytes(const sar_conv2d_desc* d);
 int sar_conv2d_gemm_split_nparts(const sar_conv2d_desc* d);
 int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const void* packed, const uint32_t* src_bound,
                           const uint32_t* w_bound, sar_stream_t s);

@@ -36,6 +36,10 @@ struct C2S {
   const uint4* wp;   // term images [term][tap][G][M]
   int G;
   int B, H, W, TH, TPI, NI, Wq, IRW, RW, nparts, ntiles, ny;
+  int ksplit;        // > 1 (DEEP kernels): the channel stages are divided among ksplit workgroups per output tile, each storing its raw fp32
+                     // partial tile into slab[part][M][npix]; conv2d_split_reduce_kernel sums them in order and applies the epilogue
+  float* slab;
+  int64_t npix;
   int rb_major;      // workgroup order: 0 = the row blocks of a tile are neighbours (one XCD reads a source tile once), 1 = the tiles of a
                      // row block are (one XCD reads 1 / ny of the weight images: small feature maps with large weight tensors)
   const unsigned* src_bound;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
   const int l31 = lane & 31, hi = lane >> 5;
   const int wn = wave;
   // workgroup -> (tile, row block), XCD-aware: the row blocks of a tile sit on one XCD (conv_gemm.hip)
-  const int ny = k.ny, nwork = k.ntiles * ny;
+  const int ny = k.ny, nwork = k.ntiles * ny * k.ksplit;
   int w = blockIdx.x;
   {
     const int per = (nwork + 7) / 8;
@@ -79,6 +83,8 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
     w = xcd * per + slot;
     if (w >= nwork || slot >= per) return;
   }
+  const int kpart = w % k.ksplit;
+  w /= k.ksplit;
   const int tile = k.rb_major ? w % k.ntiles : w / ny;
   const int b = k.NI > 1 ? tile * k.NI : tile / k.TPI;
   const int h0 = k.NI > 1 ? 0 : (tile - b * k.TPI) * k.TH;
@@ -193,11 +199,14 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
     }
   };
 
-  issue_s_loads(0);
+  // this workgroup's channel stages (ksplit == 1: all of them)
+  const int nst_all = (d.Kc + KC8 - 1) / KC8;
+  const int s_lo = (int)((int64_t)kpart * nst_all / k.ksplit), nst = (int)((int64_t)(kpart + 1) * nst_all / k.ksplit);
+  issue_s_loads(s_lo * KC8);
   __syncthreads();   // bnp, zero column / slot
-  load_bnp(0);
+  load_bnp(s_lo * KC8);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  issue_w_dma(0, 0);
+  issue_w_dma(s_lo, 0);
 
   // A k-step = fetch (NTA MS + NTB NS ds_read_b128) + NPROD MS NS MFMAs.  The fragments of k-step q + 1 are requested BEFORE the
   // MFMAs of k-step q issue (two register sets, the order pinned by sched_barrier): left to the compiler every group of four
@@ -308,11 +317,10 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
     mma(fa[0], fb[0]);
   };
 
-  const int nst = (d.Kc + KC8 - 1) / KC8;
   if constexpr (!DEEP) {
     // Happens-before of the single image (conv_gemm_split.hip): store_s(s) and the W DMA of stage s write the image behind the CLOSING
     // barrier of stage s - 1; the OPENING barrier of stage s follows every wave's ds_writes and its vmcnt(0) (its DMA pieces landed).
-    for (int s_ = 0; s_ < nst; ++s_) {
+    for (int s_ = s_lo; s_ < nst; ++s_) {
       store_s(s_ * KC8, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // opening
@@ -329,13 +337,13 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
   } else {
     // Two images.  Stage s multiplies image s & 1.  Behind the barrier of stage s every wave has finished its reads of stage s - 1
     // (image (s + 1) & 1) and written its part of image s & 1: the W DMA of stage s + 1 and store_s(s + 1) -- whose loads were
-    // requested a stage ago -- fill image (s + 1) & 1, then the loads of stage s + 2 are requested, then the matrix phase of
-    // stage s runs.  Vector-memory order inside a stage: W DMA (s + 1), loads (s + 2) -- so at the top of stage s + 1 vmcnt(8 CJ)
+    // requested a stage ago -- fill image (s + 1) & 1 and the loads of stage s + 2 are requested, all of it INSIDE the matrix phase
+    // of stage s (ksteps_deep).  Vector-memory order inside a stage: W DMA (s + 1), loads (s + 2) -- so at the top of stage s + 1 vmcnt(8 CJ)
     // (the loads may stay in flight) says this wave's DMA pieces have landed; the last stage has no loads behind its DMA.
-    store_s(0, 0);
-    if (nst > 1) issue_s_loads(KC8);
-    for (int s_ = 0; s_ < nst; ++s_) {
-      const int buf = s_ & 1;
+    store_s(s_lo * KC8, 0);
+    if (s_lo + 1 < nst) issue_s_loads((s_lo + 1) * KC8);
+    for (int s_ = s_lo; s_ < nst; ++s_) {
+      const int buf = (s_ - s_lo) & 1;
       if (s_ + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * CJ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -359,7 +367,69 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) acc[ms][ns][r] = colok[ns] ? acc[ms][ns][r] * c0 : 0.f;
   }
+  if (k.ksplit > 1) {   // raw partial tile -> slab[kpart]; the reduce kernel applies the epilogue
+    sar_conv_desc ds = d;
+    ds.out = k.slab + (int64_t)kpart * d.M * k.npix;
+    ds.ld_out = k.npix;
+    ds.epi = SAR_EPI_NONE;
+    epilogue_b<MS, NS, WN, BM>(ds, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp, smem);
+    return;
+  }
   epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp, smem);
+}
+
+// out[m, n] = epilogue(sum_p slab[p][m][n]) in slab order, partial sums [M][nparts][2] with nparts = chunks of 1024 columns
+// (blockIdx.x = chunk, blockIdx.y = row): the second pass of a K-split launch.  One thread = four consecutive columns.
+constexpr int RED_COLS = 1024;
+__global__ __launch_bounds__(256) void conv2d_split_reduce_kernel(const sar_conv_desc d, const float* __restrict__ slab, int ksplit,
+                                                                  int64_t npix, int nparts) {
+  const int m = blockIdx.y, chunk = blockIdx.x;
+  const int64_t col = (int64_t)chunk * RED_COLS + 4 * threadIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  if (col < npix) {
+    const float* p = slab + (int64_t)m * npix + col;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int q = 1; q < ksplit; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)q * d.M * npix);
+      v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+    }
+    float e[4] = {v.x, v.y, v.z, v.w};
+    if (d.epi == SAR_EPI_MASK || d.epi == SAR_EPI_ADD) {
+      const float4 a4 = *reinterpret_cast<const float4*>(d.aux + (int64_t)m * d.ld_aux + col);
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      if (d.epi == SAR_EPI_ADD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] += a[j];
+      } else {
+        const float sc = d.aux_scale[m], sh = d.aux_shift[m], mu = d.aux_mean ? d.aux_mean[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          e[j] = fmaf(a[j], sc, sh) > 0.f ? e[j] : 0.f;
+          s1 += e[j];
+          s2 = fmaf(e[j], a[j] - mu, s2);
+        }
+      }
+    } else if (d.epi == SAR_EPI_STATS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1 += e[j];
+        s2 = fmaf(e[j], e[j], s2);
+      }
+    }
+    *reinterpret_cast<float4*>(d.out + (int64_t)m * d.ld_out + col) = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  if (d.epi == SAR_EPI_STATS || d.epi == SAR_EPI_MASK) {   // fixed order: lanes by xor tree, then the four waves
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o), s2 += __shfl_xor(s2, o);
+    __shared__ float w1[4], w2[4];
+    if ((threadIdx.x & 63) == 0) w1[threadIdx.x >> 6] = s1, w2[threadIdx.x >> 6] = s2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float* pp = d.partials + ((int64_t)m * nparts + chunk) * 2;
+      pp[0] = (w1[0] + w1[1]) + (w1[2] + w1[3]);
+      pp[1] = (w2[0] + w2[1]) + (w2[2] + w2[3]);
+    }
+  }
 }
 
 bool ar_built(int ar) { return ar == AR_B6 || ar == AR_H3A; }
@@ -391,7 +461,7 @@ bool geometry_2s(const sar_conv2d_desc& d, C2S& k, int tcols) {
 // Which kernel a descriptor takes: 0 = three workgroups per CU, tiles of 256 pixels (large launches: the other workgroups of the CU
 // hide a stage's latencies); 1 = double-buffered, 256; 2 = double-buffered, 128 (small feature maps: twice the workgroups).
 // SAR_C2S_VARIANT=0/1/2 pins it (experiments).  -1: not built.
-int pick_variant(const sar_conv2d_desc& d, C2S& k) {
+int pick_variant(const sar_conv2d_desc& d, C2S& k, int64_t* want_slab = nullptr) {
   static const int pinned = [] { const char* e = getenv("SAR_C2S_VARIANT"); return e ? atoi(e) : -1; }();
   C2S k256, k128;
   const bool ok256 = geometry_2s(d, k256, 256), ok128 = geometry_2s(d, k128, 128);
@@ -406,6 +476,25 @@ int pick_variant(const sar_conv2d_desc& d, C2S& k) {
     v = nwork >= 2 * 256 ? 0 : (ok128 ? 2 : 1);
   }
   k = v == 2 ? k128 : k256;
+  // K-split for launches that leave most of the chip idle (DEEP kernels only): workgroups up to ~2 per CU, at least 8 stages each;
+  // needs the caller's workspace (d.slab: sar_conv2d_gemm_split_slab_bytes) and 16-byte rows.  SAR_C2S_KSPLIT pins it (experiments).
+  k.ksplit = 1, k.slab = nullptr, k.npix = (int64_t)d.B * d.H_out * d.W_out;
+  if (v != 0 && (k.npix & 3) == 0) {
+    static const int pin_ks = [] { const char* e = getenv("SAR_C2S_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int nwork = k.ntiles * k.ny, nst = k.G;
+    int ks = 1;
+    while (ks < 8 && nwork * ks * 2 <= 512 && nst / (ks * 2) >= 8) ks *= 2;
+    if (pin_ks > 0) ks = pin_ks;
+    if (ks > 1 && ks <= nst && ks <= 8) k.ksplit = ks;   // planned; used when the caller provides the workspace (below)
+  }
+  if (want_slab) *want_slab = k.ksplit > 1 ? (int64_t)k.ksplit * d.M * k.npix * 4 : 0;
+  if (k.ksplit > 1 && d.slab && (d.ld_out & 3) == 0 && (d.ld_aux & 3) == 0 && ((uintptr_t)d.out & 15) == 0 &&
+      ((uintptr_t)d.aux & 15) == 0 && ((uintptr_t)d.slab & 15) == 0) {
+    k.slab = d.slab;
+    k.nparts = (int)((k.npix + RED_COLS - 1) / RED_COLS);
+  } else {
+    k.ksplit = 1;
+  }
   {   // L2 footprint of one XCD (1 / 8 of the workgroups): all weight images + 1 / 8 of the source, or 1 / 8 of the weights + (all / part of) the source
     static const int pin_rb = [] { const char* e = getenv("SAR_C2S_RB_MAJOR"); return e ? atoi(e) : -1; }();
     const double wbytes = 3.0 * 9 * k.G * d.M * 16, sbytes = 4.0 * d.Kc * d.B * d.H_out * d.W_out;
@@ -470,7 +559,7 @@ extern "C" int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const 
   k.wp = (const uint4*)packed;
   k.src_bound = src_bound;
   k.w_bound = w_bound;
-  const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
+  const dim3 grid(((k.ntiles * k.ny * k.ksplit + 7) / 8) * 8), block(256);
   hipStream_t st = as_stream(s);
   if (arith == AR_H3A) {
     if (variant == 0) hipLaunchKernelGGL((conv2d_split_kernel<AR_H3A, 2, 0>), grid, block, 0, st, k);
@@ -481,6 +570,16 @@ extern "C" int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const 
     else if (variant == 1) hipLaunchKernelGGL((conv2d_split_kernel<AR_B6, 2, 1>), grid, block, 0, st, k);
     else hipLaunchKernelGGL((conv2d_split_kernel<AR_B6, 1, 1>), grid, block, 0, st, k);
   }
+  if (k.ksplit > 1)
+    hipLaunchKernelGGL(conv2d_split_reduce_kernel, dim3(k.nparts, d->M), dim3(256), 0, st, k.d, (const float*)k.slab, k.ksplit, k.npix, k.nparts);
   SAR_LAUNCH_CHECK("sar_conv2d_gemm_split");
   return 0;
+}
+
+extern "C" int64_t sar_conv2d_gemm_split_slab_bytes(const sar_conv2d_desc* d) {
+  if (!d || d->B <= 0 || d->M <= 0 || d->H_out <= 0 || d->W_out <= 0) return SAR_E_ARG;
+  C2S k;
+  int64_t want = 0;
+  if (pick_variant(*d, k, &want) < 0) return SAR_E_UNSUP;
+  return want;
 }

@@ -126,6 +126,7 @@ SIGNATURES = {
     "sar_conv2d_wgrad_f32": (_i, [C.POINTER(Conv2dDesc), _fp]),
     "sar_conv2d_gemm_split_workspace_bytes": (_i64, [C.POINTER(Conv2dDesc), _i]),
     "sar_conv2d_gemm_split_nparts": (_i, [C.POINTER(Conv2dDesc)]),
+    "sar_conv2d_gemm_split_slab_bytes": (_i64, [C.POINTER(Conv2dDesc)]),
     "sar_conv2d_gemm_split": (_i, [C.POINTER(Conv2dDesc), _i, _fp, _fp, _fp, _fp]),
     "sar_conv2d_wgrad_split_blocks": (_i, [C.POINTER(Conv2dDesc), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sar_conv2d_wgrad_split": (_i, [C.POINTER(Conv2dDesc), _i, _fp, _fp, _fp]),

@@ -701,6 +701,12 @@ def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, au
     d.aux_mean = ptr(_f32(aux_mean))
     partials = None
     nparts = 0
+    kslab = None
+    if split:      # small feature maps: workspace of the K-split (sar_hip.h), 0 bytes = not planned for this shape
+        nb = lib.sar_conv2d_gemm_split_slab_bytes(C.byref(d))
+        if nb > 0:
+            kslab = torch.empty(nb // 4, dtype=torch.float32, device=src.device)
+            d.slab = ptr(kslab)
     if epi in (L.SAR_EPI_STATS, L.SAR_EPI_MASK):
         nparts = lib.sar_conv2d_gemm_split_nparts(C.byref(d)) if split else lib.sar_conv2d_nparts(C.byref(d))
         if nparts <= 0:

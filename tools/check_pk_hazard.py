@@ -24,7 +24,11 @@ PAT = re.compile(r"\s*v_pk_(fma|mul|add)_f32 (v\[\d+:\d+\]), ([^,]+), ([^,\s]+)(
 # passes, the fp32 conv kernels that keep the shapes without a split form, on the main or the weight-gradient stream).  Path B
 # (conv2d / radar), ST-GIN and the dense-adjacency kernels only ever run beside fp32 MFMAs (measured exact): not gated.
 GATED_UNITS = ["conv_gemm_cn8", "conv_gemm_cn8_dma", "conv_graph_cn8", "conv_wgrad_cn8", "elementwise_cn8", "conv_gemm_split",
-               "conv_wgrad_split", "conv_gemm_bf16", "conv_wgrad_bf16", "elementwise", "conv_gemm", "conv_wgrad"]
+               "conv_wgrad_split", "conv_gemm_bf16", "conv_wgrad_bf16", "elementwise", "conv_gemm", "conv_wgrad",
+               # Path B in f32_split mode: the fp32 conv2d kernels (stride 2, 1x1, stem) run beside the fp16 MFMAs of the split kernels
+               "conv2d_split", "conv2d_wgrad_split", "conv2d_wgrad_split_b6", "conv2d_fwd", "conv2d_dgrad", "conv2d_dgrad_s2",
+               "conv2d_wgrad", "conv2d_wgrad_v0", "conv2d_wgrad_v1", "conv2d_wgrad_v2", "conv2d_wgrad_v3", "conv2d_wgrad_v4",
+               "conv2d_wgrad_v5", "conv2d_wgrad_v6"]
 
 
 def scan_text(lines):
