@@ -485,7 +485,10 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
     pad = args.num_pad_frames if num_pad_frames is None else num_pad_frames
     model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=pad, mfma=mfma)
     split = mfma != "fp32"
-    trainer = SpectrogramTrainer(model, 1e-3, world_size=world)      # the product step of main_spectrogram.py
+    # the product step of main_spectrogram.py; split arithmetic, one process: a step is ONE hipGraph launch (the host needs longer to
+    # issue the step's ~300 launches than the GPU to run them).  SAR_PATHB_GRAPH=0 / 1 overrides.
+    use_graph = os.environ.get("SAR_PATHB_GRAPH", "1" if (split and world == 1) else "0") == "1" and world == 1
+    trainer = SpectrogramTrainer(model, 1e-3, world_size=world, graph=use_graph)
     batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
     leg = Leg(world, dev)
 
@@ -508,15 +511,19 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
             graphs.append(g)
     timer = profiler.KernelTimer()
     ksteps = steps
+    if use_graph and instrument_steps == 0:
+        instrument_steps = 3      # a replayed step passes no profiler region: the per-kernel table comes from eager steps behind the timed ones
     if graphs is None:
         if instrument_steps == 0:
             profiler.install(timer)
         res = leg.run(step, steps, 0, 0.0, trainer)
         profiler.install(None)
         if instrument_steps > 0:
+            trainer.graph = False
             profiler.install(timer)
             leg.run(step, instrument_steps, 0)
             profiler.install(None)
+            trainer.graph = use_graph
             ksteps = instrument_steps
     else:
         res = leg.run(lambda i: graphs[i % 4].replay(), steps, 0, 0.0, None)
@@ -543,7 +550,7 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
                                    "synthetic NTU clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
                                    % (" up-sampled x%d on the GPU (the reference loader's default, utils.py:105,134-140)" % pad
                                       if pad else "", args.classes, bs),
-                       "global_batch": bs * world, "parallelism": "dp%d" % world},
+                       "global_batch": bs * world, "parallelism": "dp%d" % world, "hip_graph_step": bool(use_graph)},
             "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches); IN-STEP "
                                                     "figure: HIP events over the timed region, weight-gradient kernels on a second stream",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

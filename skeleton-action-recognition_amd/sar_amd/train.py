@@ -207,8 +207,14 @@ class SpectrogramTrainer:
     (each rank's loss is the mean over its own clips), like DataParallel's gather + mean (main_spectrogram.py:118-119):
     the 1 / world factor rides in the loss scale and the exchange is a SUM, bucketed and overlapped with backward."""
 
-    def __init__(self, model, base_lr, world_size=1):
+    def __init__(self, model, base_lr, world_size=1, graph=False):
+        """graph=True: a step on a batch shape seen before is ONE hipGraph launch (its ~300 kernel launches -- on two streams --
+        captured once, inputs copied into the captured step's buffers): with the resnet's convolutions on the split kernels a step at
+        bs = 32 takes the GPU ~5 ms and the host ~6 ms to ISSUE (20 us of Python per launch).  Single process, frozen radar parameters
+        only (the default of main_spectrogram.py); anything else takes the eager path.  The returned (logits, loss) are then the
+        captured step's buffers, overwritten by the next step."""
         self.model, self.eng, self.world_size = model, model.base_model.engine, world_size
+        self.graph, self._graphs = bool(graph), {}
         self.radar_params = list(model.virtual_radar.parameters())
         self.radar_opt = torch.optim.Adam(self.radar_params, lr=base_lr)   # main_spectrogram.py:106 hyper-parameters
         self.comm_events = None      # a list while a bench times the exchange: (start, end) events around it
@@ -241,6 +247,36 @@ class SpectrogramTrainer:
         return self._radar_bucket
 
     def step(self, x, labels, lr):
+        """One train step (eager, or a hipGraph replay: __init__)."""
+        if not (self.graph and x.is_cuda and not ddp_active() and not self.train_radar()):
+            return self._step(x, labels, lr)
+        eng = self.eng
+        key = (tuple(x.shape), x.dtype, tuple(labels.shape), labels.dtype)
+        st = self._graphs.get(key)
+        if st is None:
+            # this call's step runs eagerly on copies that become the captured step's inputs (it also makes every lazily built
+            # table and the learning-rate cell current, so that the capture records kernels only); then the capture (executes nothing)
+            sx, sy = x.clone(), labels.clone()
+            out = self._step(sx, sy, lr, run_ahead=False)
+            out = tuple(t.clone() for t in out)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                cap = self._step(sx, sy, lr, run_ahead=False)
+            self._graphs[key] = (g, sx, sy, cap)
+            self.run_ahead.step_issued()
+            return out
+        g, sx, sy, cap = st
+        if getattr(eng, "_lr_host", None) != float(lr):      # the captured step reads the rate from device memory
+            eng.lr_dev.fill_(float(lr))
+            eng._lr_host = float(lr)
+        sx.copy_(x, non_blocking=True)
+        sy.copy_(labels, non_blocking=True)
+        g.replay()
+        self.run_ahead.step_issued()
+        return cap
+
+    def _step(self, x, labels, lr, run_ahead=True):
         """Returns (logits, loss) device tensors; nothing in the step reads them back (the host blocks only on the event of the
         step before the previous one: RunAhead).  Under data parallelism every gradient is
         produced already divided by the world size (the loss scale), the flat resnet gradient buffer is exchanged in four
@@ -285,7 +321,8 @@ class SpectrogramTrainer:
             for g in self.radar_opt.param_groups:
                 g['lr'] = lr
             self.radar_opt.step()
-        self.run_ahead.step_issued()
+        if run_ahead:
+            self.run_ahead.step_issued()
         return logits, loss
 
 

@@ -232,3 +232,25 @@ def test_spectrogram_train_step_is_bitwise_deterministic(dev):
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, cur))
     assert torch.isfinite(ref[2]).all() and ref[2].abs().max() > 0
+
+
+def test_graph_captured_train_step_equals_the_eager_step(dev):
+    """SpectrogramTrainer(graph=True): the step replayed as ONE hipGraph launch (two streams, ~300 kernels) leaves the same parameters
+    and Adam state as the eager step, bit for bit, over several steps with changing inputs and a changing learning rate."""
+    from sar_amd.train import SpectrogramTrainer, synthetic_clips
+    from models.resnet import Model
+    outs = []
+    for graph in (False, True):
+        model = Model(num_classes=60, num_filters=16, device=dev)
+        tr = SpectrogramTrainer(model, 1e-3, world_size=1, graph=graph)
+        losses = []
+        for i in range(5):
+            x, y = synthetic_clips(4, dev, seed=i)
+            _, loss = tr.step(x, y, 1e-3 if i < 3 else 5e-4)
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+        eng = model.base_model.engine
+        outs.append((eng.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone(), torch.stack(losses)))
+        assert (len(tr._graphs) == 1) == graph
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
