@@ -190,6 +190,8 @@ def rank_setup(args):
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if os.environ.get("SAR_MAIN_PRIORITY", "0") == "1":      # experiment: the step's main chain on a high-priority stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     rank, world = init_distributed(dev, backend="gloo" if share else "nccl")    # SAR_FORCE_DDP=1: also for ONE rank
     return rank, world, dev
 

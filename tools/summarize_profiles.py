@@ -64,6 +64,8 @@ if BF16:   # conv_gemm_cn8_kernel<TR, TAPS = 9, ...> / the deep-prefetch variant
            or r["kernel"].startswith(("conv_gemm_cn8_db_kernel<", "conv_gemm_cn8_dma_kernel<"))]
 elif MODE == "pathB":
     fam = [r for r in rows if r["kernel"].startswith("conv2d_gemm_kernel")]
+elif MODE == "pathB_f32_split":   # the 3x3 / stride-1 forward / data-gradient launches of conv2d_split_kernel<arith, NS, DEEP>
+    fam = [r for r in rows if r["kernel"].startswith("conv2d_split_kernel<")]
 elif MODE.startswith("f32_split"):   # the 9-tap temporal forward / data-gradient launches of conv_gemm_split_kernel<TR, arith, WIDE>
     fam = [r for r in rows if r["kernel"].startswith("conv_gemm_split_kernel<")]
 else:
@@ -92,10 +94,10 @@ summary = {
     "commit": commit,          # the tree the profiled build was made from (bench.py quotes it next to roofline.traffic)
     "command": ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0%s ; "
                 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-                "--no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0%s") % ((EXTRA or {"bf16": " --mfma bf16", "pathB": " --workload spectrogram", "f32_split": " --mfma f32_split", "f32_split_bf16x6": " --mfma f32_split_bf16x6"}.get(MODE, ""),) * 2),
+                "--no-cpu-baseline --no-isolated-pass --no-secondary --warm-seconds 0%s") % ((EXTRA or {"bf16": " --mfma bf16", "pathB": " --workload spectrogram", "f32_split": " --mfma f32_split", "f32_split_bf16x6": " --mfma f32_split_bf16x6", "pathB_f32_split": " --workload spectrogram --mfma f32_split (SAR_PATHB_GRAPH=0)"}.get(MODE, ""),) * 2),
     "hbm_rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a coalesced stream; calibrated on "
                 "sgd_nesterov / bn_add_relu_fwd / affine2 whose byte counts are known)",
-    "dominant_family": {"bf16": "conv_gemm_cn8_kernel<9 taps> + conv_gemm_cn8_dma_kernel (9-tap data gradients with LDS-DMA staging)", "pathB": "conv2d_gemm_kernel (3x3 / 1x1)",
+    "dominant_family": {"bf16": "conv_gemm_cn8_kernel<9 taps> + conv_gemm_cn8_dma_kernel (9-tap data gradients with LDS-DMA staging)", "pathB": "conv2d_gemm_kernel (3x3 / 1x1)", "pathB_f32_split": "conv2d_split_kernel<f16x3a> (3x3 / stride 1",
                         "f32_split": "conv_gemm_split_kernel<TR, f16x3a> (9-tap temporal", "f32_split_bf16x6": "conv_gemm_split_kernel<TR, bf16x6> (9-tap temporal"}.get(
         MODE, "conv_gemm_kernel<TEMPORAL, 9 taps>") + " (forward + data-gradient instantiations)",
     "dominant_family_launches": calls,
