@@ -190,8 +190,6 @@ def rank_setup(args):
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if os.environ.get("SAR_MAIN_PRIORITY", "0") == "1":      # experiment: the step's main chain on a high-priority stream
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     rank, world = init_distributed(dev, backend="gloo" if share else "nccl")    # SAR_FORCE_DDP=1: also for ONE rank
     return rank, world, dev
 
@@ -454,7 +452,11 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
             step_bytes = BYTES_PER_CLIP_TRAIN_BF16 if mfma == "bf16" else 2 * BYTES_PER_CLIP_TRAIN_BF16
             isolated = out["roofline"].get("isolated")
             mfma_bound = fl_ / (PEAK_BF16_MFMA_TFLOPS * 1e12) >= by / 8.0e12      # 9-tap family: 62 us at the matrix roof, 34 us at the HBM roof per launch
-            out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm",
+            out["roofline"] = {# the figure to read first: the WHOLE STEP against the HBM roof in SURVEY.md 8(d)'s convention
+                               # -- clips/s/GPU x algorithmic bytes per clip / 8 TB/s; below it the dominant kernel family on ITS binding roof
+                               "step_frac_of_hbm_roof": round(value / world * step_bytes / 8.0e12, 4),
+                               "step_algorithmic_bytes_per_clip": step_bytes,
+                               "bound": "mfma" if mfma_bound else "hbm",
                                "kernel": "9-tap temporal conv GEMMs on CN8 activations (fwd + data-grad launches); " + in_step,
                                "achieved": round(achieved, 1) if mfma_bound else round(gbs, 1),
                                "peak": PEAK_BF16_MFMA_TFLOPS if mfma_bound else 8000.0, "unit": "TFLOP/s" if mfma_bound else "GB/s",
@@ -465,10 +467,7 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
                                                if traffic else None,
                                "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
                                "avg_launch_ms": round(ms / max(calls, 1), 4),
-                               "mfma_tflops": round(achieved, 1),
-                               # whole step in SURVEY.md 8(d)'s convention: clips/s/GPU x algorithmic bytes per clip / 8 TB/s
-                               "step_frac_of_hbm_roof": round(value / world * step_bytes / 8.0e12, 4),
-                               "step_algorithmic_bytes_per_clip": step_bytes}
+                               "mfma_tflops": round(achieved, 1)}
             if isolated:
                 out["roofline"]["isolated"] = isolated
     del trainer, eng, batches    # (the cached device blocks stay with torch's allocator: the next leg reuses them instead of paying
@@ -617,9 +616,10 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
                     vk = json.load(open(vf[-1]))["kernels"].get("vr_signal_fast_kernel<1>")
                     if vk:
                         out["radar_roofline"].update(
-                            peak="1 024 SIMDs x launch duration x 2.1 GHz / 4 cycles per wave64 vector instruction",
+                            peak="1 024 SIMDs x launch duration x %.2f GHz (%s) / 4 cycles per wave64 vector instruction"
+                                 % (vk.get("clock_ghz", 2.1), "measured in the PMC pass: GRBM_GUI_ACTIVE / 8 XCDs / wall time" if "clock_ghz" in vk else "assumed"),
                             valu_wave_instructions_per_launch=vk["valu_wave_instructions_per_launch"],
-                            frac=round(vk["valu_wave_instructions_per_launch"] / (1024 * per * 1e-3 * 2.1e9 / 4), 4),
+                            frac=round(vk["valu_wave_instructions_per_launch"] / (1024 * per * 1e-3 * vk.get("clock_ghz", 2.1) * 1e9 / 4), 4),
                             frac_source="SQ_INSTS_VALU from %s (profiled build) over THIS run's launch duration" % os.path.basename(vf[-1]))
     del trainer, model, batches
     return out
