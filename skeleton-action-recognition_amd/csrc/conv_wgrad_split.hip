@@ -25,6 +25,7 @@
 //  * per k-step and wave: 27 MFMAs (f16x3a), ~80 vector instructions (split of dout, funnel shifts, bias sums), 81 dword LDS
 //    reads.
 #include "sar_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // This file is compiled twice: as itself (part 0: the ST-GCN operators and their entry points) and through conv2d_wgrad_split.hip
@@ -789,6 +790,230 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     }
 }
 
+// ---- The 9-tap temporal weight gradient at stride 1, second design ("ring"): frames at a pitch of 32 positions in LDS.
+// tools/wsplit_timeline.py on conv_wgrad_split_kernel: a k-step takes 2 800 cycles for 864 of matrix work and ~250 instructions --
+// V = 25 makes a tap shift 50 bytes, so every src fragment is read as five dwords and funnel-shifted (60 ds_read2 + 48 shifts + 37
+// address adds per k-step): the vector issue port, not latency.  Here a frame occupies 32 positions of the LDS row (joints 0-24,
+// then 7 zeros): a tap is a shift by whole frames = a multiple of 64 bytes, a src fragment ONE ds_read_b128, the 16 k of an MFMA =
+// half a padded frame (22 % of the matrix work multiplies zeros -- bought back several times by the instruction count).  The row is a
+// RING of 12 frames: a tile is 4 dout frames, its nine taps reach frames F - pad .. F - pad + 11, and the next tile (F + 4) replaces
+// only the 4 oldest frames -- the stager stages 100 new positions per 100 dout positions (the flat window staged 392 per 192); a new
+// sequence (or the first tile of a workgroup) primes all 12.  Slot of shifted frame g' = g + pad: g' mod 12; tap t of dout frame f reads
+// slot (f + t) mod 12, whatever the padding.  The new frames of tile i + 1 are REQUESTED before the k-steps of tile i (16 registers).
+constexpr int RING_F = 12, RING_FP = 32, RING_TF = 4, RING_RS = RING_F * RING_FP + 8;   // row: 392 elements = 49 units of 16 B (odd: conflict-free b128 reads)
+template <int AR, int WK>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k) {
+  constexpr int NT = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), V = VJ, RS = RING_RS, KS = 2 * RING_TF;
+  constexpr int WMM = 4 / WK, MBLK = 32 * WMM;
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[NT * CB * RS];
+  __shared__ float2 bnp[CB];
+  const sar_wgrad_desc& d = k.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wmm = wave % WMM, kh = wave / WMM;
+
+  int sg, by, bz;
+  {
+    const int nyz = k.gy * k.gz, ngrp = d.nsplit / WK, nwork = ngrp * nyz;
+    const int per = (nwork + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int w = xcd * per + slot;
+    if (slot >= per || w >= nwork) return;
+    sg = w / nyz;
+    const int yz = w - sg * nyz;
+    bz = yz / k.gy;
+    by = yz - bz * k.gy;
+  }
+  const int m0 = by * MBLK + wmm * 32, c0 = bz * CB;
+  const int ngrp = d.nsplit / WK;
+
+  int ea = 0, eb = 0;
+  if (ar_f16(AR)) {
+    ea = scale_exp(*k.src_bound);
+    eb = scale_exp(*k.dout_bound);
+  }
+  const float sa = __builtin_ldexpf(1.f, ea), sb = __builtin_ldexpf(1.f, eb);
+  {
+    float2 p = make_float2(sa, 0.f);
+    if (tid < CB && d.pro_scale && c0 + tid < d.Kc) p = make_float2(d.pro_scale[c0 + tid] * sa, d.pro_shift[c0 + tid] * sa);
+    if (tid < CB) bnp[tid] = p;
+  }
+  for (int i = tid; i < NT * CB * (RS / 2); i += 256) reinterpret_cast<unsigned*>(Hs)[i] = 0u;   // pad slots / row tails stay zero
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = d.bsize > 0 && bz == 0;
+
+  const int tps = (k.ntiles + ngrp - 1) / ngrp;
+  const int tile_lo = sg * tps;
+  const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  const int T = d.T_out;   // stride 1: T_src == T_out
+  const int seq = T * V;
+
+  typedef const u32x4 __attribute__((address_space(3))) * lds_u128;
+  const unsigned a_base = (unsigned)(uintptr_t)Hs + (unsigned)((l31 * RS + 8 * hi) * 2);
+  const bool mrow_ok = (m0 + l31) < d.M;
+  constexpr unsigned REJECT = 0xf0000000u;
+  const int64_t dbytes = (int64_t)d.M * d.ld_dout * 4;
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.dout, 0, (unsigned)(dbytes < (int64_t)REJECT ? dbytes : (int64_t)REJECT), 0x00020000);
+  const unsigned drow = (unsigned)(((int64_t)(mrow_ok ? m0 + l31 : 0) * d.ld_dout) * 4);
+
+  // ---- the stager: one group = 4 shifted frames gp .. gp + 3 (128 row elements: a lane owns two adjacent ones), 8 channel rows per wave
+  const int s_fr = lane >> 4, s_j = 2 * (lane & 15);          // frame of the group, joint (even) of this lane's pair
+  auto issue_group = [&](int b, int gp, float (&x)[8][2]) {
+    const int fr = gp + s_fr - d.pad;                          // real src frame
+    const bool fok = (unsigned)fr < (unsigned)T;
+    const float* src_b = d.src + (int64_t)b * seq;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + wave + 4 * q;
+      const int cg = c < d.Kc ? c : 0;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq * 4, 0x00020000);
+      const unsigned o0 = (fok && s_j < V) ? (unsigned)((fr * V + s_j) * 4) : REJECT, o1 = (fok && s_j + 1 < V) ? (unsigned)((fr * V + s_j + 1) * 4) : REJECT;
+      x[q][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o0, 0, 0));   // rejected -> 0
+      x[q][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o1, 0, 0));
+    }
+  };
+  auto store_group = [&](int gp, const float (&x)[8][2]) {
+    const int fr = gp + s_fr - d.pad;
+    const bool fok = (unsigned)fr < (unsigned)T;
+    const int slot = (gp + s_fr) % RING_F;
+    const int col = slot * RING_FP + s_j;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = wave + 4 * q;
+      const bool rok = c0 + row < d.Kc;
+      const float2 ps = bnp[row];
+      const float v0 = (rok && fok && s_j < V) ? fmaxf(fmaf(x[q][0], ps.x, ps.y), relu_lo) : 0.f;   // TF-SAME padding / pad joints stay exactly 0
+      const float v1 = (rok && fok && s_j + 1 < V) ? fmaxf(fmaf(x[q][1], ps.x, ps.y), relu_lo) : 0.f;
+      unsigned w[NT];
+      split2<AR, true>(v0, v1, w);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
+    }
+  };
+
+  float xn[8][2];          // the new frames of the NEXT tile, in flight during this tile's k-steps
+  bool have_next = false;
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int b = tile / k.TPS;
+    const int F = (tile - b * k.TPS) * RING_TF;
+    const bool prime = tile == tile_lo || F == 0;
+    __syncthreads();   // closing: every wave has read its last fragment of the previous tile (first tile: the zero fill, bnp)
+    auto load_dout = [&](int kc, u32x4 (&raw)[2]) {   // k-step kc: dout frame F + kc / 2, joints 16 (kc & 1) + 8 hi ..
+      const int f = F + (kc >> 1), j0 = 16 * (kc & 1) + 8 * hi;
+      const unsigned vo = (mrow_ok && f < T && j0 < V) ? drow + (unsigned)(((int64_t)b * seq + f * V + j0) * 4) : REJECT;
+      raw[0] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 0, 0);
+      raw[1] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 16, 0);
+    };
+    u32x4 raw[2][2];
+    load_dout(kh, raw[0]);
+    if (prime) {
+#pragma unroll 1
+      for (int g = 0; g < 3; ++g) {
+        float x[8][2];
+        issue_group(b, F + 4 * g, x);
+        store_group(F + 4 * g, x);
+      }
+    } else {
+      if (!have_next) issue_group(b, F + 8, xn);
+      store_group(F + 8, xn);
+    }
+    have_next = false;
+    __syncthreads();   // opening: the ring holds shifted frames F .. F + 11
+    if (tile + 1 < tile_hi) {   // the next tile's new frames (if it continues this sequence)
+      const int b1 = (tile + 1) / k.TPS, F1 = (tile + 1 - b1 * k.TPS) * RING_TF;
+      if (F1 != 0) {
+        issue_group(b1, F1 + 8, xn);
+        have_next = true;
+      }
+    }
+    SAR_LDS_SKEW();
+#pragma unroll 1
+    for (int ks = kh; ks < KS; ks += 2 * WK) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int kc = ks + half * WK;
+        if (kc < KS) {
+          if (kc + WK < KS) load_dout(kc + WK, raw[half ^ 1]);
+          const int f = F + (kc >> 1), j0 = 16 * (kc & 1) + 8 * hi;
+          float dv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dv[j] = __uint_as_float(raw[half][j >> 2][j & 3]);
+          if ((kc & 1) && hi) {   // joints 24 .. 31: only joint 24 exists (the load ran into the next frame)
+#pragma unroll
+            for (int j = 1; j < 8; ++j) dv[j] = 0.f;
+          }
+          (void)j0;
+          if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += dv[j];
+          }
+          unsigned bw[NTB][4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            unsigned w[NTB];
+            split2<AR, false>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) bw[t][p] = w[t];
+          }
+          // tap t reads slot (f + t) mod 12 of the ring, half frame kc & 1
+          const int s0 = f % RING_F;
+          const unsigned a_ks = a_base + (unsigned)((kc & 1) * 32);
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            int st = s0 + t;
+            st = st >= RING_F ? st - RING_F : st;
+            const unsigned a_t = a_ks + (unsigned)(st * (RING_FP * 2));
+            u32x4 aq[NT];
+#pragma unroll
+            for (int tm = 0; tm < NT; ++tm) aq[tm] = *(lds_u128)(uintptr_t)(a_t + tm * (CB * RS * 2));
+#pragma unroll
+            for (int p = 0; p < NPROD; ++p) {
+              const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+              const u32x4 bq = u32x4{bw[j][0], bw[j][1], bw[j][2], bw[j][3]};
+              if (ar_f16(AR))
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&aq[i]),
+                                                                *reinterpret_cast<const f16x8*>(&bq), acc[t], 0, 0, 0);
+              else
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&aq[i]),
+                                                                 *reinterpret_cast<const bf16x8*>(&bq), acc[t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  float* slab = d.slab + (int64_t)(sg * WK + kh) * (d.wsize + d.bsize);
+  const float unscale = __builtin_ldexpf(1.f, -(ea + eb));
+  const int m = m0 + l31;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + mfma_row(r, hi);
+      if (c < d.Kc && m < d.M) slab[(int64_t)t * d.w_stride_tap + (int64_t)c * d.w_stride_c + m] = acc[t][r] * unscale;
+    }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32);
+    if (hi == 0 && m < d.M) slab[d.wsize + m] = bsum;
+  }
+}
+
+// SAR_WGRAD_RING=0: the first design (flat window, conv_wgrad_split_kernel) for the stride-1 temporal weight gradient (A/B runs)
+bool wgrad_ring_on() {
+  static const bool on = [] { const char* e = getenv("SAR_WGRAD_RING"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 // which kernel: WK (1 or 2), or 0 = not built (the caller keeps sar_conv_wgrad_f32)
 int wgrad_split_wk(const sar_wgrad_desc& d, int arith) {
   if (arith != AR_B6 && arith != AR_H3A) return 0;
@@ -838,6 +1063,13 @@ int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, cons
   k.gz = (d.Kc + CB - 1) / CB;
   const int nwork = (d.nsplit / wk) * k.gy * k.gz;
   const dim3 grid(((nwork + 7) / 8) * 8), block(256);
+  if (d.stride == 1 && wgrad_ring_on()) {   // frames at pitch 32 in a ring of 12 (conv_wgrad_ring_kernel): tiles of 4 frames
+    k.TPS = (d.T_out + RING_TF - 1) / RING_TF;
+    k.ntiles = d.B * k.TPS;
+    if (wk == 1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 1>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 2>), grid, block, 0, st, k);
+    return 0;
+  }
   if (d.stride == 2) {
     if (wk == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 1, 1>), grid, block, 0, st, k);
     else hipLaunchKernelGGL((conv_wgrad_split_kernel<AR, 2, 1>), grid, block, 0, st, k);
@@ -869,7 +1101,7 @@ extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, i
     if (tile_positions) *tile_positions = GKP;
     return ((d->M + 256 / wk - 1) / (256 / wk)) * ((d->Kc + CB - 1) / CB);
   }
-  if (tile_positions) *tile_positions = d->stride == 2 ? Cfg<AR_H3A, 1>::KT : Cfg<AR_H3A, 0>::KT;
+  if (tile_positions) *tile_positions = d->stride == 2 ? Cfg<AR_H3A, 1>::KT : (wgrad_ring_on() ? RING_TF * VJ : Cfg<AR_H3A, 0>::KT);
   return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
 }
 
