@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
 // channels 8-15 of the stage), three k-steps = the three slices.  The caller asserts the list structure (SAR_GRAPH_FEW_DENSE with
 // <= 16 such lists); no folded prologue (the engines have none in front of a graph convolution).
 template <int AR>
-__global__ __launch_bounds__(256, 2) void conv_graph_split_kernel(const ConvKS k) {
+__global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_kernel(const ConvKS k) {
   constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), NACC = ar_two_acc(AR) ? 2 : 1;
   constexpr bool SCALED = ar_f16(AR);
   constexpr int BM = 64, MS = 2, NS = 2, WN = 4, V = VJ, FTG = 10, NVMAX = 16, KC16 = 16;
