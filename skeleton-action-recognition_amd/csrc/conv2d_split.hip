@@ -432,6 +432,220 @@ __global__ __launch_bounds__(256) void conv2d_split_reduce_kernel(const sar_conv
   }
 }
 
+// ---- the 3x3 / stride-2 / pad-1 DATA GRADIENT (models/resnet18.py:5-14 with stride 2: conv1 of the first block of layers 2-4) in the
+// split arithmetic.  Output pixel (2 i + py, 2 j + px) receives only the taps with kh = 1 + py (mod 2), kw = 1 + px (mod 2): four
+// parity classes, each a stride-1 correlation of the COMPACT dout grid with 1 / 2 / 2 / 4 taps at offsets (dr, dc) in {0, 1}^2
+// (kh = 0 reads dout row i + 1, kh = 2 row i, kh = 1 row i; columns alike).  One launch: blockIdx -> (class, tile, row block); a
+// workgroup's k-steps = its class's taps, each over 16 channels (lanes 32-63: channels 8-15 of the stage) -- with one or two taps per
+// 8-channel stage the stage overhead would dominate.  Tile = 128 compact pixels (4 waves x 32), window = the tile's rows + one row
+// below, each row + one column to the right (zero beyond the image), <= 256 units; the weight image is the conv's data-gradient view
+// [term][tap = kh 3 + kw][G][M] (no mirroring: the taps are addressed directly).  Epilogues: NONE / ADD (aux on the full grid, or --
+// SAR_C2D_AUX_EVEN_PIXELS -- the compact gradient of the parallel 1x1 / stride-2 convolution, added by class (0, 0) only) / MASK
+// (partial sums [M][4 classes x 4 ntiles][2]).
+struct C2F {
+  sar_conv_desc d;
+  const uint4* wp;
+  int G, B, Hc, Wc, TH, TPI, NI, Wq, IRW, RW, nparts, ntiles, ny, even_aux;
+  const unsigned* src_bound;
+  const unsigned* w_bound;
+};
+
+template <int AR>
+__global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_dgrad_s2_kernel(const C2F k) {
+  constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR);
+  constexpr bool SCALED = ar_f16(AR);
+  constexpr int BM = 64, MS = 2, NS = 1, WN = 4, KC16 = 16;
+  constexpr int ZCOL = 256, SCOLS = ZCOL + 1;
+  constexpr int WPIECES = NTA * 4 * 2, WU = WPIECES * 64, SU = NTB * 2 * SCOLS;   // weight pieces [term][tap slot][half][64 rows]; source [term][half][column]
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;
+  constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
+  constexpr int KCMAX = 512;
+  __shared__ uint4 smem_u[IMG_U + BM + KCMAX / 2];
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + WU;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  float2* bnp = reinterpret_cast<float2*>(smem_u + IMG_U + BM);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave;
+  const int ny = k.ny, nwork = k.ntiles * ny * 4;
+  int w = blockIdx.x;
+  {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;
+  }
+  // the 4-tap class first: its workgroups take twice as long as the others'
+  const int cls_i = w / (k.ntiles * ny);
+  const int cls = 3 - cls_i, py = cls >> 1, px = cls & 1;
+  w -= cls_i * (k.ntiles * ny);
+  const int tile = w / ny;
+  const int b = k.NI > 1 ? tile * k.NI : tile / k.TPI;
+  const int h0 = k.NI > 1 ? 0 : (tile - b * k.TPI) * k.TH;
+  const int m0 = (w - tile * ny) * BM;
+  const int Hc = k.Hc, Wc = k.Wc, Wq = k.Wq, cpix = Hc * Wc;
+  const int ntr = py + 1, ntc = px + 1, ntap = ntr * ntc;   // taps of this class
+
+  bool colok[NS];
+  int64_t coln[NS], colna[NS];
+  int boff[NS];
+  {
+    const int p = wn * 32 + l31;
+    const int im = k.NI > 1 ? p / cpix : 0;
+    const int pp = p - im * cpix;
+    int hl = pp / Wc;
+    int wo = pp - hl * Wc;
+    colok[0] = im < k.NI && (b + im) < k.B && hl < k.TH && (h0 + hl) < Hc;
+    if (!colok[0]) { hl = 0; wo = 0; }
+    const int bi = b + (colok[0] ? im : 0);
+    coln[0] = ((int64_t)bi * (2 * Hc) + 2 * (h0 + hl) + py) * (2 * Wc) + 2 * wo + px;
+    colna[0] = k.even_aux ? ((int64_t)bi * Hc + (h0 + hl)) * Wc + wo : coln[0];
+    boff[0] = (colok[0] ? im * k.IRW : 0) + hl * Wq + wo;
+  }
+
+  int ea = 0, ew = 0;
+  if (SCALED) {
+    ea = scale_exp(*k.src_bound);
+    ew = scale_exp(*k.w_bound);
+  }
+  const float h3_sa = __builtin_ldexpf(1.f, ea);
+  for (int c = tid; c < KCMAX; c += 256) {
+    float2 p = make_float2(h3_sa, 0.f);
+    if (d.pro_scale && c < d.Kc) p = make_float2(d.pro_scale[c] * h3_sa, d.pro_shift[c] * h3_sa);
+    bnp[c] = p;
+  }
+  if (tid < NTB * 2) Sl[tid * SCOLS + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16 acc[MS][NS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ms][0][r] = 0.f;
+
+  const float* src_b = d.src + (int64_t)b * cpix;
+  // staging: a lane owns staged element tid of the window (origin: row h0, column 0 of image im; one extra row / column of zeros)
+  int svo;
+  bool sok;
+  {
+    const int e = tid;
+    const int im = e / k.IRW, ei = e - im * k.IRW;
+    const int r = ei / Wq, q = ei - r * Wq;
+    const int hs = h0 + r;
+    sok = e < k.RW && (b + im) < k.B && hs < Hc && q < Wc;
+    svo = sok ? (im * cpix + hs * Wc + q) * 4 : 0;
+  }
+  const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
+  float sreg[KC16], psc[KC16], psh[KC16];
+  auto load_bnp = [&](int c0) {   // ahead of the stage's W DMA (an LDS read behind an LDS-DMA makes the compiler wait for the DMA)
+#pragma unroll
+    for (int q2 = 0; q2 < KC16 / 2; ++q2) {
+      const float4 p2 = *reinterpret_cast<const float4*>(&bnp[c0 + 2 * q2]);
+      psc[2 * q2] = p2.x, psh[2 * q2] = p2.y, psc[2 * q2 + 1] = p2.z, psh[2 * q2 + 1] = p2.w;
+    }
+  };
+  auto issue_s_loads = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < KC16; ++q) {
+      const int c = c0 + q;
+      const int cg = c < d.Kc ? c : 0;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, k.NI * cpix * 4, 0x00020000);
+      sreg[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo, 0, 0));
+    }
+  };
+  auto store_s = [&](int c0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float val = fmaxf(fmaf(sreg[8 * h + q], psc[8 * h + q], psh[8 * h + q]), relu_lo);
+        v[q] = (sok && c0 + 8 * h + q < d.Kc) ? val : 0.f;
+      }
+      uint4 u[NTB];
+      split8<AR, false>(v, u, 1.f);
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) Sl[(t * 2 + h) * SCOLS + tid] = u[t];
+    }
+  };
+  // weight pieces: slot s (0 .. ntap - 1) = tap (kh, kw) = (ir == 0 ? (py ? 0 : 1) : 2, ic == 0 ? (px ? 0 : 1) : 2) with s = ir ntc + ic;
+  // piece (term, slot, half) = 64 rows of channel group 2 g16 + half
+  const unsigned wbytes = (unsigned)((int64_t)NTA * 9 * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;
+  auto tap_of = [&](int s) {
+    const int ir = s / ntc, ic = s - ir * ntc;
+    const int kh = py ? (ir == 0 ? 0 : 2) : 1, kw = px ? (ic == 0 ? 0 : 2) : 1;
+    return kh * 3 + kw;
+  };
+  auto issue_w_dma = [&](int g16) {
+    const int np = NTA * ntap * 2;   // pieces of this class (wave-uniform)
+    for (int p = wave; p < np; p += 4) {
+      const int t = p / (ntap * 2), r = p - t * (ntap * 2), s = r >> 1, h = r & 1;
+      const int g = 2 * g16 + h;
+      const unsigned so = g < k.G ? (unsigned)(((t * 9 + tap_of(s)) * k.G + g) * d.M * 16) : 0u;
+      const unsigned vo = g < k.G ? wvo : 0x80000000u;   // a channel group beyond Kc: zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + ((t * 4 + s) * 2 + h) * 64), 16, vo, so, 0, 0);
+    }
+  };
+
+  issue_s_loads(0);
+  __syncthreads();
+  load_bnp(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  issue_w_dma(0);
+  const int nst = (d.Kc + KC16 - 1) / KC16;
+  for (int s_ = 0; s_ < nst; ++s_) {
+    store_s(s_ * KC16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // opening
+    if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KC16);
+    for (int s = 0; s < ntap; ++s) {   // tap slot s: kh = 0 reads the row BELOW (dr = 1), kh = 2 / 1 the row itself; columns alike
+      const int ir = s / ntc, ic = s - ir * ntc;
+      const int dr = (py && ir == 0) ? 1 : 0, dc = (px && ic == 0) ? 1 : 0;
+      uint4 a[NTA][MS], bq[NTB];
+#pragma unroll
+      for (int t = 0; t < NTA; ++t)
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[((t * 4 + s) * 2 + hi) * 64 + l31 + ms * 32];
+      const int bo = boff[0] + dr * Wq + dc;
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) bq[t] = Sl[(t * 2 + hi) * SCOLS + bo];
+#pragma unroll
+      for (int p = 0; p < NPROD; ++p) {
+        const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+          if (ar_f16(AR))
+            acc[ms][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8*>(&a[i][ms]), *reinterpret_cast<f16x8*>(&bq[j]), acc[ms][0], 0, 0, 0);
+          else
+            acc[ms][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[i][ms]), *reinterpret_cast<bf16x8*>(&bq[j]), acc[ms][0], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // closing
+    if (s_ + 1 < nst) {
+      load_bnp((s_ + 1) * KC16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_w_dma(s_ + 1);
+    }
+  }
+  {
+    const float c0 = SCALED ? __builtin_ldexpf(1.f, -(ea + ew)) : 1.f;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][0][r] = colok[0] ? acc[ms][0][r] * c0 : 0.f;
+  }
+  sar_conv_desc de = d;
+  if (k.even_aux && cls != 0) de.epi = SAR_EPI_NONE;   // the compact 1x1 gradient lands on the even pixels only
+  epilogue_b<MS, NS, WN, BM>(de, k.nparts, cls * k.ntiles + tile, 0, wn, m0, colok, coln, acc, rowp, smem, colna);
+}
+
 bool ar_built(int ar) { return ar == AR_B6 || ar == AR_H3A; }
 
 // the launches this unit is built for; fills the geometry for tiles of `tcols` (256 / 128) output pixels
@@ -504,6 +718,33 @@ int pick_variant(const sar_conv2d_desc& d, C2S& k, int64_t* want_slab = nullptr)
   return v;
 }
 
+// the stride-2 data gradient launch (conv2d_split_dgrad_s2_kernel): compact dout grid Hc x Wc -> output 2 Hc x 2 Wc
+bool geometry_2f(const sar_conv2d_desc& d, C2F& k) {
+  if (!d.transposed || d.KH != 3 || d.KW != 3 || d.stride != 2 || d.pad != 1) return false;
+  if (d.H_out != 2 * d.H_src || d.W_out != 2 * d.W_src) return false;
+  if (d.Kc < 16 || d.Kc > 512 || (d.M & 7)) return false;
+  if (d.flags & ~SAR_C2D_AUX_EVEN_PIXELS) return false;
+  if ((d.flags & SAR_C2D_AUX_EVEN_PIXELS) && d.epi != SAR_EPI_ADD) return false;
+  const int Hc = d.H_src, Wc = d.W_src, cpix = Hc * Wc;
+  if (Wc > 128 || cpix <= 0) return false;
+  k.B = d.B, k.Hc = Hc, k.Wc = Wc, k.Wq = Wc + 1;
+  if (cpix <= 64) {
+    k.NI = 128 / cpix, k.TH = Hc, k.TPI = 1;
+    k.IRW = (Hc + 1) * (Wc + 1), k.RW = k.NI * k.IRW;
+    k.ntiles = (d.B + k.NI - 1) / k.NI;
+  } else {
+    k.NI = 1, k.TH = 128 / Wc < Hc ? 128 / Wc : Hc, k.TPI = (Hc + k.TH - 1) / k.TH;
+    k.IRW = k.RW = (k.TH + 1) * (Wc + 1);
+    k.ntiles = d.B * k.TPI;
+  }
+  if (k.RW > 256) return false;
+  k.ny = (d.M + 63) / 64;
+  k.nparts = 4 * k.ntiles * 4;
+  k.G = (d.Kc + 7) / 8;
+  k.even_aux = (d.flags & SAR_C2D_AUX_EVEN_PIXELS) ? 1 : 0;
+  return true;
+}
+
 void fill_desc(const sar_conv2d_desc& d, sar_conv_desc& o) {
   o = sar_conv_desc{};
   o.mode = SAR_CONV_TEMPORAL;
@@ -525,6 +766,8 @@ extern "C" int64_t sar_conv2d_gemm_split_workspace_bytes(const sar_conv2d_desc* 
 
 extern "C" int sar_conv2d_gemm_split_nparts(const sar_conv2d_desc* d) {
   if (!d || d->B <= 0 || d->M <= 0) return SAR_E_ARG;
+  C2F kf;
+  if (geometry_2f(*d, kf)) return kf.nparts;
   C2S k;
   if (pick_variant(*d, k) < 0) return SAR_E_UNSUP;
   return k.nparts;
@@ -537,6 +780,26 @@ extern "C" int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const 
   SAR_REQUIRE(ar_built(arith), "sar_conv2d_gemm_split: built for bf16x6 / f16x3a (arith %d)", arith);
   SAR_REQUIRE(!ar_f16(arith) || (src_bound && w_bound), "sar_conv2d_gemm_split: fp16 arithmetics need the operand bounds");
   SAR_REQUIRE(d->B > 0 && d->Kc > 0 && d->M > 0 && d->H_src > 0 && d->W_src > 0, "sar_conv2d_gemm_split: bad sizes");
+  C2F kf;
+  if (geometry_2f(*d, kf)) {   // the 3x3 / stride-2 data gradient: four parity classes in one launch
+    const int64_t nout = (int64_t)d->B * d->H_out * d->W_out, nsrc = (int64_t)d->B * d->H_src * d->W_src;
+    SAR_REQUIRE(d->src && d->out && d->ld_src >= nsrc && d->ld_out >= nout, "sar_conv2d_gemm_split: null src/out or leading dimension too small");
+    SAR_REQUIRE(d->ld_out < (1 << 22) && d->ld_aux < (1 << 22), "sar_conv2d_gemm_split: leading dimension too large (2^22 columns)");
+    SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv2d_gemm_split: pro_scale/pro_shift mismatch");
+    SAR_REQUIRE(d->epi >= SAR_EPI_NONE && d->epi <= SAR_EPI_ADD, "sar_conv2d_gemm_split: bad epilogue %d", d->epi);
+    if (d->epi == SAR_EPI_MASK) SAR_REQUIRE(d->partials && d->aux_scale && d->aux_shift, "sar_conv2d_gemm_split: partials / aux affine required");
+    if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD)
+      SAR_REQUIRE(d->aux && d->ld_aux >= (kf.even_aux ? nsrc : nout), "sar_conv2d_gemm_split: aux required");
+    fill_desc(*d, kf.d);
+    kf.wp = (const uint4*)packed;
+    kf.src_bound = src_bound;
+    kf.w_bound = w_bound;
+    const dim3 grid(((kf.ntiles * kf.ny * 4 + 7) / 8) * 8), block(256);
+    if (arith == AR_H3A) hipLaunchKernelGGL((conv2d_split_dgrad_s2_kernel<AR_H3A>), grid, block, 0, as_stream(s), kf);
+    else hipLaunchKernelGGL((conv2d_split_dgrad_s2_kernel<AR_B6>), grid, block, 0, as_stream(s), kf);
+    SAR_LAUNCH_CHECK("sar_conv2d_gemm_split");
+    return 0;
+  }
   C2S k;
   const int variant = pick_variant(*d, k);
   if (variant < 0) {
@@ -578,6 +841,8 @@ extern "C" int sar_conv2d_gemm_split(const sar_conv2d_desc* d, int arith, const 
 
 extern "C" int64_t sar_conv2d_gemm_split_slab_bytes(const sar_conv2d_desc* d) {
   if (!d || d->B <= 0 || d->M <= 0 || d->H_out <= 0 || d->W_out <= 0) return SAR_E_ARG;
+  C2F kf;
+  if (geometry_2f(*d, kf)) return 0;
   C2S k;
   int64_t want = 0;
   if (pick_variant(*d, k, &want) < 0) return SAR_E_UNSUP;

@@ -9,7 +9,7 @@
 template <int MS, int NS, int WN, int BM>
 __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, int tile, int wm, int wn, int m0,
                                            const bool (&colok)[NS], const int64_t (&coln)[NS], f32x16 (&acc)[MS][NS],
-                                           float4* rowp, float* smem) {
+                                           float4* rowp, float* smem, const int64_t* colna = nullptr) {   // colna: the aux tensor's own column index (default: coln)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;
@@ -48,7 +48,7 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
-      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+      vo_aux[ns] = colok[ns] ? (unsigned)(((colna ? colna[ns] : coln[ns]) + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
     }
     const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
     // SAR_EPI_ADD_GATE: aux2 [M][ld_aux2] fp32 and its gate bytes [M][ld_aux2 / 4] (bit j of byte i = column 4 i + j)

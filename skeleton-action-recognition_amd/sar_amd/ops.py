@@ -651,8 +651,18 @@ def _conv2d_desc(src, *, B, Kc, M, H_src, W_src, H_out, W_out, KH, KW, stride, p
     return d
 
 
-def conv2d_split_applicable(*, KH, KW, stride, pad, Kc, M, H_src, W_src, H_out, W_out, aux_even_pixels=False, **_):
-    """shapes csrc/conv2d_split.hip is built for (3x3 / stride 1 / pad 1, windows of <= 512 staged pixels); the others stay fp32"""
+def conv2d_split_applicable(*, KH, KW, stride, pad, Kc, M, H_src, W_src, H_out, W_out, aux_even_pixels=False, transposed=False,
+                            epi=None, **_):
+    """shapes csrc/conv2d_split.hip is built for: 3x3 / stride 1 / pad 1 (forward and data gradient; windows of <= 512 staged pixels)
+    and the 3x3 / stride 2 / pad 1 DATA GRADIENT onto an image of exactly twice the size; the others stay fp32"""
+    if KH == 3 and KW == 3 and stride == 2 and pad == 1 and transposed:
+        if not (H_out == 2 * H_src and W_out == 2 * W_src and 16 <= Kc <= 512 and M % 8 == 0 and W_src <= 128):
+            return False
+        if aux_even_pixels and epi != L.SAR_EPI_ADD:
+            return False
+        cpix = H_src * W_src
+        rw = (128 // cpix) * (H_src + 1) * (W_src + 1) if cpix <= 64 else (min(H_src, 128 // W_src) + 1) * (W_src + 1)
+        return rw <= 256
     if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and H_src == H_out and W_src == W_out):
         return False
     if not (8 <= Kc <= 512 and M % 8 == 0 and not aux_even_pixels):
@@ -665,9 +675,10 @@ def conv2d_split_applicable(*, KH, KW, stride, pad, Kc, M, H_src, W_src, H_out, 
 def _pack_split_conv2d(W, w_stride_tap, w_stride_c, Kc, M, arith, transposed):
     """one 3x3 tensor stored (tap, c, m), packed on the spot (kernel tests): (image, w_bound).  transposed: W is the DATA-GRADIENT
     operand layout (tap, m, c) of the forward tensor as the fp32 kernel takes it (element (tap, c', m') of the call = weight of
-    forward tap `tap`); the split kernel wants the mirrored taps: item element (tap, c', m') = W[8 - tap][c'][m']."""
+    forward tap `tap`); the stride-1 split kernel (transposed="mirror") wants the mirrored taps: item element (tap, c', m') =
+    W[8 - tap][c'][m']; the stride-2 data gradient addresses the forward taps directly (no mirroring)."""
     pk = PackedSplitWeights(arith)
-    if transposed:
+    if transposed == "mirror":
         pk.add("w", 8 * w_stride_tap, -w_stride_tap, w_stride_c, 1, 9, Kc, M)
     else:
         pk.add("w", 0, w_stride_tap, w_stride_c, 1, 9, Kc, M)
@@ -687,7 +698,7 @@ def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, au
     lib = L.load()
     if split == "default":
         split = DEFAULT_SPLIT
-    if split not in ("f16x3a", "bf16x6") or not conv2d_split_applicable(aux_even_pixels=aux_even_pixels, **geo):
+    if split not in ("f16x3a", "bf16x6") or not conv2d_split_applicable(aux_even_pixels=aux_even_pixels, epi=epi, **geo):
         split = None
     d = _conv2d_desc(src, **geo)
     d.ctx = ctx.handle if ctx is not None else None
@@ -719,7 +730,8 @@ def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, au
     if split:
         w_bound = bounds[1] if bounds is not None else None
         if packed is None:
-            packed, w_bound = _pack_split_conv2d(W, w_stride_tap, w_stride_c, geo["Kc"], geo["M"], split, bool(geo.get("transposed")))
+            packed, w_bound = _pack_split_conv2d(W, w_stride_tap, w_stride_c, geo["Kc"], geo["M"], split,
+                                                 "mirror" if (geo.get("transposed") and geo["stride"] == 1) else False)
         src_bound = bounds[0] if bounds is not None else None
         if split.startswith("f16") and src_bound is None:
             src_bound = _src_bound_single(src, geo.get("pro"))

@@ -123,6 +123,11 @@ class ResNet18:
                     sp.add((name, "b"), src + 8 * cc, -cc, 1, cv.cout, 9, cv.cout, cv.cin)
                     for kind in ("f", "b"):
                         self._cell_of[(name, kind)] = len(self._cell_of)
+                elif cv.k == 3 and cv.stride == 2 and 8 <= cv.cin and cv.cin % 8 == 0 and 16 <= cv.cout <= 512:
+                    # the stride-2 data gradient (four parity classes, csrc/conv2d_split.hip): the forward taps of the (tap, m, c) view
+                    src, cc = self.offsets[name + ".weight"], cv.cin * cv.cout
+                    sp.add((name, "b"), src, cc, 1, cv.cout, 9, cv.cout, cv.cin)
+                    self._cell_of[(name, "b")] = len(self._cell_of)
             sp.finalize(dev)
             self.spacked = sp
             self._cells = torch.zeros(max(1, len(self._cell_of)), dtype=torch.int32, device=dev)

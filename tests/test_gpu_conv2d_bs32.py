@@ -46,8 +46,20 @@ def _img(t, hw, i):
 
 
 @pytest.mark.parametrize("name,cin,cout,k,s,H", LAYERS, ids=[l[0] for l in LAYERS])
-def test_conv2d_at_bs32_equals_per_image_launches(dev, name, cin, cout, k, s, H):
+def test_conv2d_at_bs32_equals_per_image_launches(dev, name, cin, cout, k, s, H, arith_mode):
+    """arith_mode "f32_split": the split kernels divide the contraction of a launch that would leave most of the chip idle among
+    several workgroups (K-split, csrc/conv2d_split.hip) -- the summation order then depends on the GRID, so a one-image launch and
+    the 32-image launch agree to rounding (<= 2e-6 of the tensor's scale) instead of bit for bit; everything else is unchanged."""
     from sar_amd import ops, _lib as L
+    exact = arith_mode == "fp32"
+
+    def same(a, b, what):
+        if exact:
+            assert torch.equal(a, b), what
+        else:
+            err = (a.double() - b.double()).abs().max().item() / max(b.abs().max().item(), 1e-30)
+            assert err <= RED_TOL, "%s: %.2e" % (what, err)
+
     pad = k // 2
     Ho = (H + 2 * pad - k) // s + 1
     hw_in, hw_out = H * H, Ho * Ho
@@ -98,13 +110,13 @@ def test_conv2d_at_bs32_equals_per_image_launches(dev, name, cin, cout, k, s, H)
         st_sum += st1
         gw_sum += wgrad(xs, ds, 1).double()
         if i in IMAGES:
-            assert torch.equal(o1, _img(out_full, hw_out, i)), "%s forward, image %d" % (name, i)
+            same(o1, _img(out_full, hw_out, i), "%s forward, image %d" % (name, i))
         if has_dgrad:
             dx1, pm1 = dgrad(ds, 1, xs)
             if pm1 is not None:
                 pm_sum += pm1
             if i in IMAGES:
-                assert torch.equal(dx1, _img(dx_full, hw_in, i)), "%s data gradient, image %d" % (name, i)
+                same(dx1, _img(dx_full, hw_in, i), "%s data gradient, image %d" % (name, i))
     torch.cuda.synchronize()
 
     def close(a, b, what):
