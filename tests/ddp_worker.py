@@ -20,7 +20,7 @@ BLOCKS = [(64, 1, False), (64, 1, True), (128, 2, True)]
 
 def global_batch(workload, n, seed=11):
     g = torch.Generator().manual_seed(seed)
-    T = 300 if workload == "spectrogram" else 24
+    T = 300 if workload.startswith("spectrogram") else 24
     x = (0.12 * torch.randn((n, 3, T, 25, 2), generator=g)).clamp_(-1.1, 0.75)
     x[1::3, :, :, :, 1] = 0                      # some single-person clips
     y = torch.randint(0, 10, (n,), generator=g)
@@ -37,12 +37,16 @@ def make_trainer(workload, dev, world):
         from sar_amd.stgcn import STGCN
         eng = STGCN(num_classes=10, device=dev, seed=5, blocks=BLOCKS, mfma="bf16")
         return eng, Trainer(eng, batch_size=4, world_size=world)
+    if workload == "stgcn_split":  # the fp32 engine with its contractions on the fp16 matrix pipe (bound cells, split weight images) under DDP
+        from sar_amd.stgcn import STGCN
+        eng = STGCN(num_classes=10, device=dev, seed=5, blocks=BLOCKS, mfma="f32_split")
+        return eng, Trainer(eng, batch_size=4, world_size=world)
     if workload == "stgin":       # the sibling model through the same model-agnostic train step (main_gnn.py --model stgin)
         from sar_amd.stgin import STGIN
         eng = STGIN(num_classes=10, device=dev, seed=5, blocks=BLOCKS)
         return eng, Trainer(eng, batch_size=4, world_size=world)
     from models.resnet import Model
-    model = Model(num_classes=10, num_filters=8, device=dev)
+    model = Model(num_classes=10, num_filters=8, device=dev, mfma="f32_split" if workload == "spectrogram_split" else "fp32")
     for name, param in model.named_parameters():     # radar parameters train: their flat bucket is exchanged too
         if 'radar_loc' in name or name.endswith('wavelength'):
             param.requires_grad = True
@@ -50,7 +54,7 @@ def make_trainer(workload, dev, world):
 
 
 def run_shard(workload, trainer, eng, x, y, dev):
-    if workload in ("stgcn", "stgin", "stgcn_bf16"):
+    if workload in ("stgcn", "stgin", "stgcn_bf16", "stgcn_split"):
         _, loss = trainer.step(x.to(dev), y.to(dev))
         extra = {}
     else:

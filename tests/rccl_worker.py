@@ -25,7 +25,7 @@ def run(workload, dev, steps=2):
     losses, nbuckets = [], []
     for i in range(steps):
         xs, ys = x[4 * i:4 * i + 4].to(dev), y[4 * i:4 * i + 4].to(dev)
-        if workload == "spectrogram":
+        if workload.startswith("spectrogram"):
             _, loss = trainer.step(xs, ys, 1e-3)
         else:
             _, loss = trainer.step(xs, ys)
@@ -33,7 +33,7 @@ def run(workload, dev, steps=2):
         losses.append(loss.detach().reshape(-1).cpu().clone())
     torch.cuda.synchronize()
     out = dict(grad=eng.grad.cpu().clone(), flat=eng.flat.cpu().clone(), loss=torch.cat(losses), nbuckets=nbuckets)
-    if workload == "spectrogram":
+    if workload.startswith("spectrogram"):
         vr = trainer.model.virtual_radar
         out.update(radar_grad=torch.cat([p.grad.reshape(-1) for p in trainer.radar_params]).cpu(),
                    radar_location=vr.radar_location.detach().cpu().clone(), wavelength=vr.wavelength.detach().cpu().clone())

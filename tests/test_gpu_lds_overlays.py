@@ -34,6 +34,10 @@ def test_conv_kernels_pass_their_parity_tests_with_a_sleeping_wave_in_front_of_e
                           "tests/test_gpu_cn8.py", "-k", "graph_conv or temporal or residual"])
     tail = r.stdout[-1500:]
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (tail, r.stderr[-1500:])
+    # the split kernels' single / double images (temporal, graph, weight gradients, the resnet's 3x3 kernels incl. the K-split)
+    r = _pytest_with_lib("libsar_hip_ldsdebug.so", ["tests/test_gpu_split.py", "-k", "temporal or graph or conv2d"])
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (tail, r.stderr[-1500:])
 
 
 def test_the_instrument_fires_on_the_round_3_bias_row_race():

@@ -19,7 +19,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-WORKLOADS = ["stgcn", "stgcn_bf16", "stgin", "spectrogram"]
+WORKLOADS = ["stgcn", "stgcn_bf16", "stgcn_split", "stgin", "spectrogram", "spectrogram_split"]
 
 
 def _env():
@@ -49,10 +49,11 @@ def test_forced_ddp_step_on_rccl_is_bit_identical_to_the_plain_step(workload, rc
     got = torch.load(os.path.join(rccl_run, workload + ".pt"))
     assert os.environ.get("SAR_FORCE_DDP", "0") != "1"
     want = R.run(workload, torch.device("cuda", 0))          # this process: no process group, no exchange
-    assert want["nbuckets"] == ([] if workload == "spectrogram" else [0, 0])
-    if workload != "spectrogram":
+    pathb = workload.startswith("spectrogram")
+    assert want["nbuckets"] == ([] if pathb else [0, 0])
+    if not pathb:
         assert got["nbuckets"] == [2, 2]                     # ddp_worker's 3-block model: [l2 + logits], [data_bn + l0 + l1]
-    for k in ("grad", "flat", "loss") + (("radar_grad", "radar_location", "wavelength") if workload == "spectrogram" else ()):
+    for k in ("grad", "flat", "loss") + (("radar_grad", "radar_location", "wavelength") if pathb else ()):
         assert torch.equal(got[k], want[k]), k
     assert got["grad"].abs().max() > 0 and torch.isfinite(got["flat"]).all()
 
