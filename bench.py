@@ -650,7 +650,7 @@ def main():
                     help="skip the 3 extra untimed steps that measure the dominant kernel family with the side stream off "
                          "(profile runs: keeps the launch counts at warmup + steps)")
     ap.add_argument("--no-secondary", action="store_true", help="headline line only (profile runs)")
-    ap.add_argument("--secondary", default="f32_split,bf16,pathB,pathB_f32_split,pathB_pad250,config5",
+    ap.add_argument("--secondary", default="f32_split,bf16,pathB,pathB_f32_split,pathB_pad250,pathB_pad250_f32_split,config5",
                     help="comma list of the secondary legs run in the same process BEFORE the fp32 headline and reported under "
                          "'secondary': f32_split = configs[1] with the GEMM contractions on the fp16 matrix pipe (fp32 storage and results), bf16 = configs[2] (sustained: >= 3 s of untimed load first), pathB = configs[3], pathB_pad250 = "
                          "configs[3] on the reference loader's real input (x250 up-sampling on the GPU), config5 = configs[4] (120 "
@@ -711,6 +711,10 @@ def main():
                                         num_pad_frames=250)
                     if r is not None and cpu_ok and not q:
                         r["cpu_baseline"] = cpu_baseline_spectrogram(2, budget_s=8.0, num_pad_frames=250)
+                elif n == "pathB_pad250_f32_split":
+                    # the reference loader's real input (x250 up-sampling on the GPU) in front of the resnet on the split kernels
+                    r = spectrogram_leg(args, 4 if q else 120, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
+                                        num_pad_frames=250, mfma="f32_split")
                 elif n == "config5":
                     # configs[4]: two independently trained ST-GCNs (joint, bone), 120 classes.  The joint stream differs from the
                     # headline only by the 120-class head; the leg times the BONE stream (joint -> bone fused into the data_bn

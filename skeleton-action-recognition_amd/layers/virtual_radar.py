@@ -177,8 +177,12 @@ class VirtualRadar(torch.nn.Module):
         x = x.contiguous()
         B, _, T, V, M = x.shape
         lib = L.load()
-        w, radius = gaussian_weights(sigma)
-        w_dev = torch.from_numpy(w).to(x.device)
+        key = (float(sigma), x.device)      # the smoothing weights live on the device: no host copy per step (and none inside a graph capture)
+        cache = self.__dict__.setdefault("_gauss_cache", {})
+        if key not in cache:
+            w, radius = gaussian_weights(sigma)
+            cache[key] = (torch.from_numpy(w).to(x.device), radius)
+        w_dev, radius = cache[key]
         ws = torch.empty(lib.sar_upsample_workspace_bytes(B, T, V, M), dtype=torch.uint8, device=x.device)
         coef = torch.empty(lib.sar_upsample_coef_doubles(B, T, V, M), dtype=torch.float64, device=x.device)
         # algorithmic float64 work: (2 radius + 1)-tap smoothing + ~8 T flops of the tridiagonal solve per series
