@@ -486,9 +486,11 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
     pad = args.num_pad_frames if num_pad_frames is None else num_pad_frames
     model = Model(num_classes=args.classes, num_filters=64, device=dev, num_pad_frames=pad, mfma=mfma)
     split = mfma != "fp32"
-    # the product step of main_spectrogram.py; split arithmetic, one process: a step is ONE hipGraph launch (the host needs longer to
-    # issue the step's ~300 launches than the GPU to run them).  SAR_PATHB_GRAPH=0 / 1 overrides.
-    use_graph = os.environ.get("SAR_PATHB_GRAPH", "1" if (split and world == 1) else "0") == "1" and world == 1
+    # the product step of main_spectrogram.py.  SAR_PATHB_GRAPH=1: the step as ONE hipGraph launch (SpectrogramTrainer(graph=True)) --
+    # it paid (5.94 -> 4.91 ms) while the host needed 6 ms to issue the split step's ~300 launches; since sar_amd/_lib.py asks torch's
+    # C module for the raw stream (a third of the host's time per step was torch.cuda.current_stream()) the eager step is GPU-bound
+    # again and faster than the replay (4.64 vs 4.87 ms): off by default.
+    use_graph = os.environ.get("SAR_PATHB_GRAPH", "0") == "1" and world == 1
     trainer = SpectrogramTrainer(model, 1e-3, world_size=world, graph=use_graph)
     batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
     leg = Leg(world, dev)

@@ -249,6 +249,19 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """the current HIP stream of the current device as an integer handle.  torch.cuda.current_stream() builds a Stream object through
+    four Python layers (~3 us; a Path B step asks 220 times: a third of the host's time per step, tools/host_profile.py): the raw
+    query of torch's C module is used where it exists."""
+    global _raw_stream
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        get_raw, get_dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get_raw is not None and get_dev is not None:
+            _raw_stream = lambda: get_raw(get_dev())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return _raw_stream()

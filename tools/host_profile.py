@@ -1,0 +1,37 @@
+"""Where the HOST spends a train step (cProfile over eager steps; the GPU runs behind).  Usage: python tools/host_profile.py [pathB_split|pathB|stgcn_split]"""
+import cProfile
+import os
+import pstats
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "skeleton-action-recognition_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+from sar_amd.train import SpectrogramTrainer, Trainer, synthetic_clips  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "pathB_split"
+dev = torch.device("cuda:0")
+if what.startswith("pathB"):
+    from models.resnet import Model
+    model = Model(num_classes=60, device=dev, mfma="f32_split" if what.endswith("split") else "fp32")
+    tr = SpectrogramTrainer(model, 1e-3, 1)
+    x, y = synthetic_clips(32, dev, seed=0)
+    step = lambda: tr.step(x, y, 1e-3)
+else:
+    from sar_amd.stgcn import STGCN
+    eng = STGCN(num_classes=60, device=dev, mfma="f32_split")
+    tr = Trainer(eng, batch_size=64)
+    x, y = synthetic_clips(64, dev, seed=0)
+    step = lambda: tr.step(x, y)
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(22)
