@@ -683,7 +683,7 @@ def main():
         if cpu_ok:
             out["cpu_baseline"] = cpu_baseline_spectrogram(2 if args.num_pad_frames else 4, num_pad_frames=args.num_pad_frames)
     else:
-        sec = None
+        sec, deferred = None, []
         names = [] if args.no_secondary or args.mfma != "fp32" or args.stream != "joint" else [n for n in args.secondary.split(",") if n]
         if names:
             # The other BASELINE configs in the same process, driver-timed with the headline.  bf16: the SUSTAINED rate (>= 3 s of
@@ -691,6 +691,8 @@ def main():
             # leg; the headline has its own --warm-seconds of load either way, so its thermal state does not depend on them.
             q = args.quick
             sec = {}
+            deferred = []      # the CPU baselines of the Path B legs run BEHIND every GPU leg: their worker threads keep spinning for a
+            #                    while and slow the host thread that issues the next leg's launches (pathB_f32_split: 4.7 -> 5.2 ms)
             for n in names:
                 if n == "f32_split":
                     # the fp32 engine with its GEMM contractions on the fp16 matrix pipe (same storage, same parity tolerances)
@@ -703,7 +705,7 @@ def main():
                     r = spectrogram_leg(args, 4 if q else 250, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
                                         num_pad_frames=0)
                     if r is not None and cpu_ok and not q:
-                        r["cpu_baseline"] = cpu_baseline_spectrogram(4)
+                        deferred.append((n, lambda: cpu_baseline_spectrogram(4)))
                 elif n == "pathB_f32_split":
                     # configs[3] with the resnet's 3x3 / stride-1 convolutions on the fp16 matrix pipe (fp32 storage and results)
                     r = spectrogram_leg(args, 4 if q else 250, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
@@ -712,7 +714,7 @@ def main():
                     r = spectrogram_leg(args, 4 if q else 120, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
                                         num_pad_frames=250)
                     if r is not None and cpu_ok and not q:
-                        r["cpu_baseline"] = cpu_baseline_spectrogram(2, budget_s=8.0, num_pad_frames=250)
+                        deferred.append((n, lambda: cpu_baseline_spectrogram(2, budget_s=8.0, num_pad_frames=250)))
                 elif n == "pathB_pad250_f32_split":
                     # the reference loader's real input (x250 up-sampling on the GPU) in front of the resnet on the split kernels
                     r = spectrogram_leg(args, 4 if q else 120, 5, 0.0 if q else 1.0, rank, world, dev, instrument_steps=2 if q else 5,
@@ -747,6 +749,8 @@ def main():
                                      "(warm_s) and timed steps" % ", ".join(names))
         if cpu_ok:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample, classes=args.classes)
+            for n, fn in (deferred if sec else []):
+                out["secondary"][n]["cpu_baseline"] = fn()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -120,6 +120,22 @@ class PackedSplitWeights(PackedWeights):
         return self.amax[i:i + 1]
 
 
+_side_streams = {}
+
+
+def shared_side_stream(device, priority=0):
+    """ONE weight-gradient stream per (device, host thread, priority) for every engine of the process.  HIP maps streams onto a few
+    hardware queues round-robin in creation order: engines that each created their own stream (a bench process builds seven, one after
+    the other) sooner or later got one that shares its hardware queue with the main stream -- the two-stream overlap was gone and a
+    4.7 ms Path B step took 5.3 (found as a leg that was slower inside the default bench line than alone)."""
+    import threading
+    key = (torch.device(device).index or 0, threading.get_ident(), int(priority))
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device, priority=int(priority))
+    return st
+
+
 def amax(x, cell):
     """cell (1-element int32 view, zeroed by the caller) = max(cell, bits of max |x|) -- sar_amax_f32, no host sync"""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1      # rows may be strided (ld >= n)

@@ -91,7 +91,7 @@ class ResNet18:
         self._saved = None
         # weight-gradient kernels feed only the optimizer: second stream, as in sar_amd/stgcn.py (SAR_WGRAD_STREAM=0: off)
         import os
-        self._side = (torch.cuda.Stream(device=dev) if dev.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1"
+        self._side = (ops.shared_side_stream(dev) if dev.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1"
                       else None)
         # side streams of the launches that fan out (stride-2 data gradients): owned by this engine, not by the library
         with torch.cuda.device(dev):

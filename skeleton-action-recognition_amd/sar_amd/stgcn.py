@@ -104,7 +104,7 @@ class STGCN:
         self.tab_bwd = ops.GraphTables(self.A_host, self.device, transpose=True)
         # the weight-gradient stream; SAR_WGRAD_PRIO: its priority (torch convention: lower = more urgent; default 0 = same as
         # the main chain)
-        self._side = (torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SAR_WGRAD_PRIO", "0")))
+        self._side = (ops.shared_side_stream(self.device, int(os.environ.get("SAR_WGRAD_PRIO", "0")))
                       if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1" else None)
         self.motion = bool(motion)   # motion stream (data_gen/gen_motion_data.py:24-27) of the joint / bone data, on the fly
         self.bone_parent = None

@@ -53,7 +53,7 @@ class STGIN(STGCN):
         except ValueError:
             self.tab_f = self.tab_b = None
             self.identity_slice = [False] * (KS - 1)
-        self._side = (torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SAR_WGRAD_PRIO", "0")))
+        self._side = (ops.shared_side_stream(self.device, int(os.environ.get("SAR_WGRAD_PRIO", "0")))
                       if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1" else None)
         self.motion = bool(motion)
         self.bone_parent = None

@@ -97,3 +97,19 @@ def test_library_exports_no_debug_entry_points():
     from sar_amd import _lib as L
     lib = ctypes.CDLL(L.LIB_PATH)
     assert not hasattr(lib, "sar_debug_poison_lds") and not hasattr(lib, "sar_debug_occupancy")
+
+
+def test_stream_handle_follows_the_current_torch_stream():
+    """sar_amd._lib.stream_ptr() asks torch's C module for the raw stream (no Stream object per launch): it must name the stream
+    torch considers current -- default, inside a stream context, on a side stream of an engine -- and follow set_device."""
+    import torch
+    from sar_amd import _lib
+    torch.cuda.set_device(0)
+    assert _lib.stream_ptr() == torch.cuda.current_stream().cuda_stream
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    with torch.cuda.stream(s1):
+        assert _lib.stream_ptr() == s1.cuda_stream
+        with torch.cuda.stream(s2):
+            assert _lib.stream_ptr() == s2.cuda_stream != s1.cuda_stream
+        assert _lib.stream_ptr() == s1.cuda_stream
+    assert _lib.stream_ptr() == torch.cuda.current_stream().cuda_stream
