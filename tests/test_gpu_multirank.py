@@ -34,7 +34,7 @@ def _launch(workload, out):
     return [torch.load(os.path.join(out, "rank%d.pt" % k)) for k in range(2)]
 
 
-@pytest.mark.parametrize("workload", ["stgcn", "stgcn_bf16", "stgin", "spectrogram"])
+@pytest.mark.parametrize("workload", ["stgcn", "stgcn_bf16", "stgcn_split", "stgin", "spectrogram", "spectrogram_split"])
 def test_two_rank_product_step_equals_single_process_combination(workload, tmp_path):
     import ddp_worker as W
     from sar_amd.train import shard_indices
@@ -53,7 +53,7 @@ def test_two_rank_product_step_equals_single_process_combination(workload, tmp_p
         eng, trainer = W.make_trainer(workload, dev, 2)
         eng_before = eng.flat.cpu().clone()
         # capture the un-reduced local gradient: run the engine half of the step only
-        if workload in ("stgcn", "stgin", "stgcn_bf16"):
+        if workload in ("stgcn", "stgin", "stgcn_bf16", "stgcn_split"):
             eng.loss_and_grad(x[shards[r]].to(dev), y[shards[r]].to(dev), n)
             singles.append(dict(grad=eng.grad.cpu().clone()))
         else:
@@ -64,7 +64,7 @@ def test_two_rank_product_step_equals_single_process_combination(workload, tmp_p
             singles.append(dict(grad=eng.grad.cpu().clone(),
                                 radar_grad=torch.cat([p.grad.reshape(-1) for p in trainer.radar_params]).cpu()))
         torch.cuda.synchronize()
-    if workload in ("stgcn", "stgin", "stgcn_bf16"):
+    if workload in ("stgcn", "stgin", "stgcn_bf16", "stgcn_split"):
         total = singles[0]["grad"] + singles[1]["grad"]            # SUM of per-replica gradients (loss / global batch)
         assert torch.equal(ranks[0]["grad"], total)
         # the fused Nesterov step on the summed gradient from the common initial weights
