@@ -27,6 +27,38 @@
 
 namespace {
 
+// Diagnostic build -DSAR_FP32_TL (tools/fp32_timeline.sh): wave 0 of every workgroup of the LAST launch writes one
+// row -- start / end in 100 MHz ticks, HW_ID, XCC_ID, the shader-clock cycles it spent in each phase (summed over the stages).
+// No stamp executes in the product build.
+#ifdef SAR_FP32_TL
+constexpr int FP32_TL_WG = 16384;
+__device__ unsigned g_fp32_tl[FP32_TL_WG][16];
+#define FP32_TL_BEGIN()                                                 \
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime();   \
+  unsigned long long tl_last = __builtin_amdgcn_s_memtime();            \
+  unsigned tl_acc[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}
+#define FP32_TL(i)                                                \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    tl_acc[i] += (unsigned)(t_ - tl_last);                        \
+    tl_last = t_;                                                 \
+  } while (0)
+#define FP32_TL_END()                                                                        \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < FP32_TL_WG) {                                      \
+      unsigned* row = g_fp32_tl[blockIdx.x];                                                \
+      row[0] = (unsigned)tl_rt0, row[1] = (unsigned)__builtin_amdgcn_s_memrealtime();       \
+      row[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   \
+      row[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                  \
+      for (int i_ = 0; i_ < 10; ++i_) row[4 + i_] = tl_acc[i_];                             \
+    }                                                                                       \
+  } while (0)
+#else
+#define FP32_TL_BEGIN()
+#define FP32_TL(i)
+#define FP32_TL_END()
+#endif
+
 constexpr int KC = 4;  // src channels staged per main-loop iteration (2 MFMA k-steps); one S row per wave
 
 #ifndef SAR_XCD_MAP
@@ -108,6 +140,7 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
   const int b = tile / k.TPS;
   const int t0 = (tile - b * k.TPS) * k.FT;
   const int m0 = (w - tile * ny) * BM;
+  FP32_TL_BEGIN();
 
   // ---- per-lane column geometry (fixed for the whole kernel)
   bool colok[NS];
@@ -281,9 +314,11 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
 #ifndef SAR_ABLATE
 #define SAR_ABLATE 0   // diagnostic builds only (tools/ablate.sh): 1 no epilogue, 2 stage once, 4 no barriers, 16 / 32 see below
 #endif
+  FP32_TL(0);   // geometry, gather tables, stager set-up
   issue_loads(0);
   store_lds(0, smem);
   __syncthreads();
+  FP32_TL(1);   // first stage: loads -> LDS (exposed round trip) + barrier
   // accumulators start at the bias term: b[m] (temporal) or sum_k b_k[m] colsum(A_k)[v] (graph), 0 off-tile
   SAR_LDS_SKEW();   // last read of the bias rows (overlaid on buffer 1's weight region)
 #pragma unroll
@@ -312,11 +347,13 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
 #ifndef SAR_DEBUG_LDS_DROP_BIAS_BARRIER
   __syncthreads();
 #endif
+  FP32_TL(2);   // accumulator initialisation + barrier
   // one main-loop stage on LDS buffer IT (compile-time, so every LDS address is register + immediate)
   auto stage = [&](int c0, auto IT) {
     constexpr int it = decltype(IT)::value;
     const bool more = c0 + KC < d.Kc && !(SAR_ABLATE & 2);
     if (more && !(SAR_ABLATE & 16)) issue_loads(c0 + KC);   // 16: LDS stores of stale registers only
+    FP32_TL(3);   // load issue
     SAR_LDS_SKEW();   // this wave's reads of buffer IT start late: the other waves may only refill IT ^ 1 meanwhile
     const float* Wl = smem + it * TC::BUF;
     const float* S = Wl + TC::WPAD * WSTR;
@@ -425,7 +462,9 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
         }
       }
     }
+    FP32_TL(4);   // MFMA phase (operand reads + MFMAs)
     if (more && !(SAR_ABLATE & 32)) store_lds(c0 + KC, smem + (it ^ 1) * TC::BUF);
+    FP32_TL(5);   // wait for the next stage's loads + LDS stores
     if (more && (SAR_ABLATE & 32)) {   // 32: global loads only (wait for them, keep them alive, no LDS store)
 #pragma unroll
       for (int j = 0; j < SJ; ++j) asm volatile("" ::"v"(sreg[j]));
@@ -433,6 +472,7 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
       for (int i = 0; i < WIT; ++i) asm volatile("" ::"v"(wreg[i].x), "v"(wreg[i].w));
     }
     if (!(SAR_ABLATE & 4)) __syncthreads();
+    FP32_TL(6);   // stage barrier
   };
   for (int c0 = 0; c0 < d.Kc; c0 += 2 * KC) {
     stage(c0, std::integral_constant<int, 0>());
@@ -594,6 +634,8 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
       case SAR_EPI_ADD_GATE: fast_epilogue(std::integral_constant<int, SAR_EPI_ADD_GATE>()); break;
       default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
     }
+    FP32_TL(7);   // epilogue
+    FP32_TL_END();
     return;
   }
   // Generic path (M % 8 != 0: the 3-channel input layer's data gradient)
@@ -807,3 +849,15 @@ extern "C" int sar_conv_gemm_f32(const sar_conv_desc* d, sar_stream_t s) {
   SAR_LAUNCH_CHECK("sar_conv_gemm_f32");
   return 0;
 }
+
+#ifdef SAR_FP32_TL
+extern "C" int sar_debug_fp32_timeline(unsigned* out, int nwg, int reset) {   // out: [nwg][16] (host memory)
+  if (nwg > FP32_TL_WG) nwg = FP32_TL_WG;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fp32_tl), (size_t)nwg * 16 * sizeof(unsigned)) != hipSuccess) return -1;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fp32_tl)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * 16 * FP32_TL_WG) != hipSuccess) return -1;
+  }
+  return nwg;
+}
+#endif
