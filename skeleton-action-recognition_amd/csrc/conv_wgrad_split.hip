@@ -579,6 +579,26 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     drow[mb] = (unsigned)(((int64_t)(mrow_ok[mb] ? m0 + 32 * mb + l31 : 0) * d.ld_dout) * 4);
   }
 
+  // the raw tile of a tile: rows c0 .. c0 + 31 (wave w takes rows w, w + 4, ..), this lane's two adjacent positions
+  auto issue_raw = [&](int tile_, float (&x)[8][2]) {
+    const int b_ = tile_ / k.TPS;
+    const int t0_ = (tile_ - b_ * k.TPS) * GFT;
+    const int nlive_ = ((t0_ + GFT <= d.T_out) ? GFT : d.T_out - t0_) * V;
+    const int n0_ = t0_ * V;
+    const float* src_t = d.src + (int64_t)b_ * seq + n0_;
+    const unsigned tb = (unsigned)(seq - n0_) * 4;   // the sequence's remaining bytes: positions beyond it are rejected -> 0
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + wave + 4 * q;   // wave-uniform: the row part of the address is a scalar descriptor
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_t + (int64_t)(c < d.Kc ? c : 0) * d.ld_src), 0,
+                                                                          c < d.Kc ? tb : 0u, 0x00020000);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        x[q][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (2 * lane + e < nlive_) ? (2 * lane + e) * 4 : 0x7fffffff, 0, 0));
+    }
+  };
+  float xn[8][2];          // S0ID: the NEXT tile's raw values, requested in front of this tile's k-steps (one exposed round trip less per tile)
+  bool have_next = false;
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int b = tile / k.TPS;
     const int t0 = (tile - b * k.TPS) * GFT;
@@ -606,16 +626,11 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     float* rawt = reinterpret_cast<float*>(&Zs[0]);
     float xr[8][2];
     {
-      const float* src_t = d.src + (int64_t)b * seq + n0;
-      const unsigned tb = (unsigned)(seq - n0) * 4;   // the sequence's remaining bytes: positions beyond it are rejected -> 0
+      if (have_next) {   // requested in front of the previous tile's k-steps
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = c0 + wave + 4 * q;   // wave-uniform: the row part of the address is a scalar descriptor
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_t + (int64_t)(c < d.Kc ? c : 0) * d.ld_src), 0,
-                                                                            c < d.Kc ? tb : 0u, 0x00020000);
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-          xr[q][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (2 * lane + e < nlive) ? (2 * lane + e) * 4 : 0x7fffffff, 0, 0));
+        for (int q = 0; q < 8; ++q) xr[q][0] = xn[q][0], xr[q][1] = xn[q][1];
+      } else {
+        issue_raw(tile, xr);
       }
       if (2 * lane < GKP) {
 #pragma unroll
@@ -707,6 +722,13 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     }
     }
     __syncthreads();   // opening: the images are complete
+    have_next = false;
+    if constexpr (S0ID) {
+      if (tile + 1 < tile_hi) {
+        issue_raw(tile + 1, xn);
+        have_next = true;
+      }
+    }
 
     SAR_LDS_SKEW();
 #pragma unroll 1
