@@ -823,9 +823,11 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
 // sequence (or the first tile of a workgroup) primes all 12.  Slot of shifted frame g' = g + pad: g' mod 12; tap t of dout frame f reads
 // slot (f + t) mod 12, whatever the padding.  The new frames of tile i + 1 are REQUESTED before the k-steps of tile i (16 registers).
 constexpr int RING_F = 12, RING_FP = 32, RING_TF = 4, RING_RS = RING_F * RING_FP + 8;   // row: 392 elements = 49 units of 16 B (odd: conflict-free b128 reads)
-template <int AR, int WK>
+// S2 (stride 2, T_src = 2 T_out): dout frame f reads src frames 2 f + t - pad -- shifted frame 2 f + t, slot (2 f + t) mod 12; a tile is
+// TWO dout frames (4 k-steps: its taps reach 11 src frames), the next tile again replaces the 4 oldest src frames.
+template <int AR, int WK, int S2 = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k) {
-  constexpr int NT = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), V = VJ, RS = RING_RS, KS = 2 * RING_TF;
+  constexpr int NT = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), V = VJ, RS = RING_RS, TFR = S2 ? 2 : RING_TF, KS = 2 * TFR, FS = S2 ? 2 : 1;
   constexpr int WMM = 4 / WK, MBLK = 32 * WMM;
   __shared__ __attribute__((aligned(16))) unsigned short Hs[NT * CB * RS];
   __shared__ float2 bnp[CB];
@@ -875,8 +877,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
   const int tile_lo = sg * tps;
   const int tile_hi = (tile_lo + tps < k.ntiles) ? tile_lo + tps : k.ntiles;
   const float relu_lo = d.pro_relu ? 0.f : -__builtin_inff();
-  const int T = d.T_out;   // stride 1: T_src == T_out
-  const int seq = T * V;
+  const int T = d.T_out, Ts = d.T_src;   // stride 1: T_src == T_out; S2: T_src = 2 T_out
+  const int seq = T * V, seq_s = Ts * V;
 
   typedef const u32x4 __attribute__((address_space(3))) * lds_u128;
   const unsigned a_base = (unsigned)(uintptr_t)Hs + (unsigned)((l31 * RS + 8 * hi) * 2);
@@ -891,13 +893,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
   const int s_fr = lane >> 4, s_j = 2 * (lane & 15);          // frame of the group, joint (even) of this lane's pair
   auto issue_group = [&](int b, int gp, float (&x)[8][2]) {
     const int fr = gp + s_fr - d.pad;                          // real src frame
-    const bool fok = (unsigned)fr < (unsigned)T;
-    const float* src_b = d.src + (int64_t)b * seq;
+    const bool fok = (unsigned)fr < (unsigned)Ts;
+    const float* src_b = d.src + (int64_t)b * seq_s;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int c = c0 + wave + 4 * q;
       const int cg = c < d.Kc ? c : 0;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, seq_s * 4, 0x00020000);
       const unsigned o0 = (fok && s_j < V) ? (unsigned)((fr * V + s_j) * 4) : REJECT, o1 = (fok && s_j + 1 < V) ? (unsigned)((fr * V + s_j + 1) * 4) : REJECT;
       x[q][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o0, 0, 0));   // rejected -> 0
       x[q][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o1, 0, 0));
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
   };
   auto store_group = [&](int gp, const float (&x)[8][2]) {
     const int fr = gp + s_fr - d.pad;
-    const bool fok = (unsigned)fr < (unsigned)T;
+    const bool fok = (unsigned)fr < (unsigned)Ts;
     const int slot = (gp + s_fr) % RING_F;
     const int col = slot * RING_FP + s_j;
 #pragma unroll
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
   bool have_next = false;
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int b = tile / k.TPS;
-    const int F = (tile - b * k.TPS) * RING_TF;
+    const int F = (tile - b * k.TPS) * TFR;      // first dout frame; FS F = its shifted src frame
     const bool prime = tile == tile_lo || F == 0;
     __syncthreads();   // closing: every wave has read its last fragment of the previous tile (first tile: the zero fill, bnp)
     auto load_dout = [&](int kc, u32x4 (&raw)[2]) {   // k-step kc: dout frame F + kc / 2, joints 16 (kc & 1) + 8 hi ..
@@ -941,19 +943,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
 #pragma unroll 1
       for (int g = 0; g < 3; ++g) {
         float x[8][2];
-        issue_group(b, F + 4 * g, x);
-        store_group(F + 4 * g, x);
+        issue_group(b, FS * F + 4 * g, x);
+        store_group(FS * F + 4 * g, x);
       }
     } else {
-      if (!have_next) issue_group(b, F + 8, xn);
-      store_group(F + 8, xn);
+      if (!have_next) issue_group(b, FS * F + 8, xn);
+      store_group(FS * F + 8, xn);
     }
     have_next = false;
-    __syncthreads();   // opening: the ring holds shifted frames F .. F + 11
+    __syncthreads();   // opening: the ring holds shifted frames FS F .. FS F + 11
     if (tile + 1 < tile_hi) {   // the next tile's new frames (if it continues this sequence)
-      const int b1 = (tile + 1) / k.TPS, F1 = (tile + 1 - b1 * k.TPS) * RING_TF;
+      const int b1 = (tile + 1) / k.TPS, F1 = (tile + 1 - b1 * k.TPS) * TFR;
       if (F1 != 0) {
-        issue_group(b1, F1 + 8, xn);
+        issue_group(b1, FS * F1 + 8, xn);
         have_next = true;
       }
     }
@@ -987,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
             for (int t = 0; t < NTB; ++t) bw[t][p] = w[t];
           }
           // tap t reads slot (f + t) mod 12 of the ring, half frame kc & 1
-          const int s0 = f % RING_F;
+          const int s0 = (FS * f) % RING_F;
           const unsigned a_ks = a_base + (unsigned)((kc & 1) * 32);
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
@@ -1085,11 +1087,15 @@ int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, cons
   k.gz = (d.Kc + CB - 1) / CB;
   const int nwork = (d.nsplit / wk) * k.gy * k.gz;
   const dim3 grid(((nwork + 7) / 8) * 8), block(256);
-  if (d.stride == 1 && wgrad_ring_on()) {   // frames at pitch 32 in a ring of 12 (conv_wgrad_ring_kernel): tiles of 4 frames
-    k.TPS = (d.T_out + RING_TF - 1) / RING_TF;
+  if (wgrad_ring_on()) {   // frames at pitch 32 in a ring of 12 (conv_wgrad_ring_kernel): tiles of 4 dout frames (stride 2: 2)
+    const int tf = d.stride == 2 ? 2 : RING_TF;
+    k.TPS = (d.T_out + tf - 1) / tf;
     k.ntiles = d.B * k.TPS;
-    if (wk == 1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 1>), grid, block, 0, st, k);
-    else hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 2>), grid, block, 0, st, k);
+    if (d.stride == 2) {
+      if (wk == 1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 1, 1>), grid, block, 0, st, k);
+      else hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 2, 1>), grid, block, 0, st, k);
+    } else if (wk == 1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 1, 0>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((conv_wgrad_ring_kernel<AR, 2, 0>), grid, block, 0, st, k);
     return 0;
   }
   if (d.stride == 2) {
@@ -1123,7 +1129,7 @@ extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, i
     if (tile_positions) *tile_positions = GKP;
     return ((d->M + 256 / wk - 1) / (256 / wk)) * ((d->Kc + CB - 1) / CB);
   }
-  if (tile_positions) *tile_positions = d->stride == 2 ? Cfg<AR_H3A, 1>::KT : (wgrad_ring_on() ? RING_TF * VJ : Cfg<AR_H3A, 0>::KT);
+  if (tile_positions) *tile_positions = wgrad_ring_on() ? (d->stride == 2 ? 2 : RING_TF) * VJ : (d->stride == 2 ? Cfg<AR_H3A, 1>::KT : Cfg<AR_H3A, 0>::KT);
   return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
 }
 
