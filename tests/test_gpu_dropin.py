@@ -97,7 +97,7 @@ def test_npy_input_pipeline_keeps_up_with_the_gpu(tmp_path):
     same command on on-device synthetic clips.  bf16 configuration = the fastest consumer (~13.5 ms per 64 clips)."""
     import pickle
     import re
-    n = 1024
+    n = 4096      # 64 steps per epoch (1024 until round 5: at 5 850 clips/s the loader's fixed per-epoch start cost crossed the 5 % line of a 0.18 s epoch)
     rng = np.random.default_rng(0)
     d = tmp_path / "xsub"
     d.mkdir()
@@ -129,7 +129,8 @@ def test_tfrecord_input_pipeline_keeps_up_with_the_gpu(tmp_path):
     configuration, the fastest consumer."""
     import re
     from sar_amd import tfrecord as T
-    n = 2048                 # 32 steps per epoch: the loader's per-epoch start (first batch) is a few per cent of it, as in a real epoch
+    n = 4096                 # 64 steps per epoch: the loader's per-epoch start (first batch) is a few per cent of it, as in a real epoch
+    #                          (2048 until round 5: at 5 870 clips/s -- a fast box -- the fixed start cost of a 0.35 s epoch crossed the 5 % line)
     rng = np.random.default_rng(0)
     data = np.clip(0.12 * rng.standard_normal((n, 3, 300, 25, 2)), -1.1, 0.75).astype(np.float32)
     labels = rng.integers(0, 60, n)
