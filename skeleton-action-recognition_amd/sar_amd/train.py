@@ -123,6 +123,9 @@ class RunAhead:
             self._events.pop(0).synchronize()
 
 
+_comm_streams = {}
+
+
 class GradExchange:
     """SUM all-reduce of gradient buckets, overlapped with the backward pass that is still producing the earlier layers'
     gradients.  RCCL: each bucket's collective is issued asynchronously on ONE communication stream that waits for just the
@@ -139,8 +142,9 @@ class GradExchange:
                 torch.cuda.current_stream().wait_event(e)
             allreduce_sum_(flat)
             return
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=flat.device)
+        if self._stream is None:      # one communication stream per device for every trainer of the process (ops.shared_side_stream)
+            self._stream = _comm_streams.setdefault(flat.device.index or 0, None) or torch.cuda.Stream(device=flat.device)
+            _comm_streams[flat.device.index or 0] = self._stream
         for e in events:
             self._stream.wait_event(e)
         with torch.cuda.stream(self._stream):

@@ -1,4 +1,4 @@
-"""Where the HOST spends a train step (cProfile over eager steps; the GPU runs behind).  Usage: python tools/host_profile.py [pathB_split|pathB|stgcn_split]"""
+"""Where the HOST spends a train step (cProfile over eager steps; the GPU runs behind).  Usage: python tools/host_profile.py [pathB_split|pathB|stgcn_split|stgcn_bf16|stgcn]"""
 import cProfile
 import os
 import pstats
@@ -20,7 +20,7 @@ if what.startswith("pathB"):
     step = lambda: tr.step(x, y, 1e-3)
 else:
     from sar_amd.stgcn import STGCN
-    eng = STGCN(num_classes=60, device=dev, mfma="f32_split")
+    eng = STGCN(num_classes=60, device=dev, mfma={"stgcn_split": "f32_split", "stgcn_bf16": "bf16", "stgcn": "fp32"}.get(what, "f32_split"))
     tr = Trainer(eng, batch_size=64)
     x, y = synthetic_clips(64, dev, seed=0)
     step = lambda: tr.step(x, y)
