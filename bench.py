@@ -34,8 +34,25 @@ PEAK_FP64_VALU_TFLOPS = 78.6       # MI355X: packed-free fp64 vector FMA, half t
 
 
 FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<", "conv_gemm_cn8_dma_kernel<"),
-                 "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",),
+                 "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",), "pathB_f32_split": ("conv2d_split_kernel<",),
                  "f32_split": ("conv_gemm_split_kernel<",), "f32_split_bf16x6": ("conv_gemm_split_kernel<",)}
+BOX = {}        # the box calibration of this process (sar_amd/box.py), filled by main() before the first leg
+
+# What the fields of the line mean (the line itself carries numbers and identifiers of at most 120 characters; DESIGN.md sections 4 and 7
+# carry the arithmetic).  Emitted once, in front of the legs.
+LEGEND = {
+    "value": "whole-job clips/s of the leg: K timed train steps bracketed by barrier + synchronize, MAX over ranks, inputs resident in HBM",
+    "roofline.frac": "dominant kernel family: algorithmic FLOPs (split legs: EXECUTED matrix FLOPs) per launch / HIP-event launch time / guide peak",
+    "roofline.frac_of_box": "the same numerator over what THIS box sustained in the `box` probe (box_ref names the probe figure)",
+    "roofline.timing": "in_step = HIP events inside the timed step; +wgrad_stream = weight gradients overlap on a second stream (inflates it)",
+    "roofline.isolated": "the same family over 3 untimed steps with the side stream off: kernel quality without overlap",
+    "roofline.traffic": "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of the build named in traffic_src",
+    "box": "sar_amd/box.py: dense v_mfma loops (f32 32x32x2, f16/bf16 32x32x16; ~125 ms each, held clock = s_memtime/s_memrealtime) + 1 GiB float4 copy",
+    "peaks": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TF, fp16/bf16 MFMA 2500 TF dense, HBM 8000 GB/s",
+    "f32_split": "fp32 storage, statistics, epilogues, optimizer and parity tolerances; every GEMM product = 3 exact fp16-term products (f16x3a)",
+    "sustained": "100 further steps behind the contract's K, same protocol",
+    "summary": "LAST key: legs = {leg: [clips/s, ms/step, roofline.frac, frac_of_box]}; box = [f32 TF, f16 TF, f16 GHz, bf16 TF, copy GB/s]",
+}
 
 
 def measured_traffic(mode="fp32"):
@@ -47,6 +64,7 @@ def measured_traffic(mode="fp32"):
     import glob
     pat = {"pathB": "r[0-9][0-9]_pathB_kernel_summary.json", "bf16": "r[0-9][0-9]_bf16_kernel_summary.json",
            "f32_split": "r[0-9][0-9]_f32split_kernel_summary.json", "f32_split_bf16x6": "r[0-9][0-9]_f32split_bf16x6_kernel_summary.json",
+           "pathB_f32_split": "r[0-9][0-9]_pathB_f32split_kernel_summary.json",
            "bf16_operands": "r[0-9][0-9]_bf16_operands_kernel_summary.json"}.get(mode, "r[0-9][0-9]_kernel_summary.json")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
@@ -354,122 +372,85 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
         fam = [k for k in summ if k.startswith("gemm_temporal9")]
         ms = sum(summ[k]["ms"] for k in fam)
         fl = sum(summ[k]["flops"] for k in fam)
+        by = sum(summ[k]["bytes"] for k in fam)
         calls = sum(summ[k]["calls"] for k in fam)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic, traffic_src = measured_traffic(mfma)
-        kern_ms = {k: round(v["ms"] / ksteps, 3) for k, v in sorted(summ.items())}
-        kern_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}
         bf16 = mfma in ("bf16", "bf16_operands")
-        desc = {"fp32": "fp32",
-                "f32_split": "fp32 (fp32 storage and results; every fp32 product of the GEMM contractions = 3 exact products of fp16 terms on the "
-                             "fp16 matrix pipe, fp32 accumulation: csrc/conv_*_split.hip f16x3a -- three term images of the "
-                             "well-conditioned operand, two of the wide-range one, operand bounds kept on the device)",
-                "f32_split_bf16x6": "fp32 (fp32 storage and results; GEMM contractions as 6 products of 3 bf16 terms per operand on the "
-                                    "bf16 matrix pipe, fp32 accumulation: csrc/conv_gemm_split.hip bf16x6)",
-                "bf16": "bf16 (bf16 CN8 activations in HBM, bf16 MFMA operands; fp32 accumulation, BatchNorm statistics, master "
-                        "weights, optimizer)",
-                "bf16_operands": "bf16-MFMA-operand (fp32 activations in HBM)"}[mfma]
+        split = mfma in ("f32_split", "f32_split_bf16x6")
+        nprod = 3 if mfma == "f32_split" else 6
+        # every prose field of a leg is at most 120 characters (the driver's parser cuts there); LEGEND explains the vocabulary
+        what = {"fp32": "ST-GCN fp32 training step", "f32_split": "ST-GCN f32_split training step [fp32 storage+results, GEMMs = 3 fp16-term products, f16x3a]",
+                "f32_split_bf16x6": "ST-GCN f32_split_bf16x6 training step [fp32 storage+results, GEMMs = 6 bf16-term products]",
+                "bf16": "ST-GCN bf16 training step [bf16 CN8 activations, fp32 accumulate/BN/master weights]",
+                "bf16_operands": "ST-GCN training step [bf16 MFMA operands, fp32 activations]"}[mfma]
         overl = eng._side is not None
-        in_step = ("IN-STEP figure: HIP events over the timed region%s" %
-                   (", weight-gradient kernels running concurrently on a second stream (inflates the bracketed time; "
-                    "roofline.isolated = the same kernels alone)" if overl else ", single stream"))
+        common = {"timing": "in_step" + ("+wgrad_stream" if overl else ""), "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
+                  "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "traffic": traffic, "traffic_src": traffic_src}
+        if split:
+            # fp32 results on the fp16 / bf16 matrix pipe: the roof is that pipe's, priced on the MFMA FLOPs the kernels EXECUTE
+            # (products per fp32 product x the 10 tap slots per 9 taps) -- never against the fp32 MFMA peak
+            exe = achieved * nprod * 10.0 / 9.0
+            roof = {"bound": "mfma", "kernel": "conv_gemm_split_kernel 9-tap fwd+dgrad (%s)" % ("f16x3a" if nprod == 3 else "bf16x6"),
+                    "achieved": round(exe, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "executed_over_algorithmic_flops": round(nprod * 10.0 / 9.0, 3), "fp32_equivalent_tflops": round(achieved, 2),
+                    "step_fp32_equivalent_tflops": round(value / world * EXECUTED_FLOP_PER_CLIP_TRAIN / 1e12, 2),
+                    "step_frac_of_hbm_roof": round(value / world * 2 * BYTES_PER_CLIP_TRAIN_BF16 / 8.0e12, 4), **common}
+            box_key, box_num = ("f16_mfma_tflops" if nprod == 3 else "bf16_mfma_tflops"), exe
+        elif bf16:
+            # which roof binds the family: the larger of (algorithmic FLOPs / 2.5 PFLOP/s) and (algorithmic bytes / 8 TB/s)
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            step_bytes = BYTES_PER_CLIP_TRAIN_BF16 if mfma == "bf16" else 2 * BYTES_PER_CLIP_TRAIN_BF16
+            mfma_bound = fl / (PEAK_BF16_MFMA_TFLOPS * 1e12) >= by / 8.0e12
+            roof = {"step_frac_of_hbm_roof": round(value / world * step_bytes / 8.0e12, 4), "step_algorithmic_bytes_per_clip": step_bytes,
+                    "bound": "mfma" if mfma_bound else "hbm", "kernel": "conv_gemm_cn8*_kernel 9-tap fwd+dgrad",
+                    "achieved": round(achieved, 1) if mfma_bound else round(gbs, 1),
+                    "peak": PEAK_BF16_MFMA_TFLOPS if mfma_bound else 8000.0, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                    "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4) if mfma_bound else round(gbs / 8000.0, 4),
+                    "hbm_gbps": round(gbs, 1), "hbm_frac": round(gbs / 8000.0, 4), "mfma_tflops": round(achieved, 1), **common}
+            box_key, box_num = ("bf16_mfma_tflops", achieved) if mfma_bound else ("copy_gbps", gbs)
+        else:
+            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9> fwd+dgrad", "achieved": round(achieved, 2),
+                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                    "step_frac_executed_flops": round(value / world * EXECUTED_FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4), **common}
+            box_key, box_num = "f32_mfma_tflops", achieved
+        if BOX.get(box_key):
+            roof["frac_of_box"] = round(box_num / BOX[box_key], 4)
+            roof["box_ref"] = box_key
         out = {
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, **dist_info(),
-            "grad_buckets": trainer.buckets_last_step,
-            "steps": steps, "warmup": warmup, "warm_s": res["warm_s"],
-            "ms_per_step": round(dt / steps * 1e3, 3), "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"],
-            "dtype": "bf16" if bf16 else "f32",
-            "config": {"workload": "ST-GCN %s training step (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips "
-                                   "(3,300,25,2)%s, %d classes, bs=%d/GPU"
-                                   % (desc, " as the BONE stream (joint -> bone in the data_bn prologue)" if bone else "", classes,
-                                      args.batch),
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, **dist_info(), "grad_buckets": trainer.buckets_last_step,
+            "steps": steps, "warmup": warmup, "warm_s": res["warm_s"], "ms_per_step": round(dt / steps * 1e3, 3),
+            "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"], "dtype": "bf16" if bf16 else "f32",
+            "config": {"workload": "%s (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
+                                   % (what, " as the BONE stream" if bone else "", classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<TEMPORAL,9 taps> (fwd + data-grad launches); " + in_step,
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch, PMC passes of the PROFILED build (%s), not of this run" % traffic_src
-                                         if traffic else None,
-                         "algorithmic_bytes_per_launch": int(sum(summ[k]["bytes"] for k in fam) / max(calls, 1)),
-                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
-                         "step_frac_of_fp32_roof": round(value / world * FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
-                         # the same step priced on the FLOPs the kernels execute (the dense 432-MMAC einsum is never executed)
-                         "step_frac_executed_flops": round(value / world * EXECUTED_FLOP_PER_CLIP_TRAIN / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
-            "executed_flops_per_clip": EXECUTED_FLOP_PER_CLIP_TRAIN, "survey_flops_per_clip": FLOP_PER_CLIP_TRAIN,
-            "kernel_ms_per_step": kern_ms, "kernel_tflops": kern_tf, "final_loss": round(loss_val, 5),
+            "roofline": roof, "final_loss": round(loss_val, 5),
         }
         if first is not None:
             out["first_run_value"] = round(first, 2)
         if sustained is not None:
             out["sustained"] = sustained
-        if iso is not None:
+        detail = {"kernel_ms_per_step": {k: round(v["ms"] / ksteps, 3) for k, v in sorted(summ.items())},
+                  "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
+                  "executed_flops_per_clip": EXECUTED_FLOP_PER_CLIP_TRAIN, "survey_flops_per_clip": FLOP_PER_CLIP_TRAIN}
+        if iso is not None:     # the same family over 3 untimed steps with the weight-gradient side stream off: kernel quality
             ims = sum(iso[k]["ms"] for k in fam if k in iso)
             ifl = sum(iso[k]["flops"] for k in fam if k in iso)
-            iby = sum(iso[k]["bytes"] for k in fam if k in iso)
             icalls = sum(iso[k]["calls"] for k in fam if k in iso)
-            out["roofline"]["isolated"] = {
-                "what": "same kernel family, 3 untimed steps with the weight-gradient side stream off (no overlapping kernels)",
-                "tflops": round(ifl / (ims * 1e-3) / 1e12, 2) if ims > 0 else None,
-                "gbps": round(iby / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
-                "avg_launch_ms": round(ims / max(icalls, 1), 4),
-                "frac_of_fp32_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if (ims > 0 and not bf16) else None,
-                "frac_of_bf16_mfma_peak": round(ifl / (ims * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if (ims > 0 and bf16) else None}
-            out["kernel_ms_per_step_isolated"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(iso.items())}
-            out["wgrad_side_stream"] = True
-        if mfma in ("f32_split", "f32_split_bf16x6"):
-            # fp32 results on the fp16 / bf16 matrix pipe: the roof is that pipe's (2.5 PFLOP/s dense), priced on the MFMA FLOPs the
-            # kernels EXECUTE -- products per fp32 product (3 for f16x3a, 6 for bf16x6) x the 10 tap slots per 9 taps of the
-            # 9-tap kernels' k-steps -- never against the fp32 MFMA peak (a fraction > 1 there would read as work skipped)
-            nprod = 3 if mfma == "f32_split" else 6
-            exe = achieved * nprod * 10.0 / 9.0
-            isolated = out["roofline"].get("isolated")
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_split_kernel (9-tap temporal fwd + data-grad launches, %s); %s"
-                                                          % ("f16x3a" if nprod == 3 else "bf16x6", in_step),
-                               "achieved": round(exe, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
-                               "executed_over_algorithmic_flops": round(nprod * 10.0 / 9.0, 3),
-                               "fp32_equivalent_tflops": round(achieved, 2),
-                               "fp32_mfma_peak_for_reference": PEAK_FP32_MFMA_TFLOPS,
-                               "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch, PMC passes of the PROFILED build (%s), not of this run" % traffic_src
-                                               if traffic else None,
-                               "algorithmic_bytes_per_launch": int(sum(summ[k]["bytes"] for k in fam) / max(calls, 1)),
-                               "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
-                               "step_fp32_equivalent_tflops": round(value / world * EXECUTED_FLOP_PER_CLIP_TRAIN / 1e12, 2)}
-            if isolated:
-                isolated = dict(isolated)
-                isolated.pop("frac_of_fp32_mfma_peak", None)
-                if isolated.get("tflops"):
-                    isolated["fp32_equivalent_tflops"] = isolated.pop("tflops")
-                    isolated["executed_tflops"] = round(isolated["fp32_equivalent_tflops"] * nprod * 10.0 / 9.0, 1)
-                    isolated["frac_of_bf16_mfma_peak"] = round(isolated["executed_tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
-                out["roofline"]["isolated"] = isolated
-            out["split_kernels"] = sorted(k for k in summ if k.endswith("_split"))
-            out["fp32_kernels_left"] = sorted(k for k in summ if not k.endswith("_split"))
-        if bf16:   # which roof binds the family: the larger of (algorithmic FLOPs / 2.5 PFLOP/s dense bf16) and (algorithmic bytes / 8 TB/s)
-            by = sum(summ[k]["bytes"] for k in fam)
-            fl_ = sum(summ[k]["flops"] for k in fam)
-            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            step_bytes = BYTES_PER_CLIP_TRAIN_BF16 if mfma == "bf16" else 2 * BYTES_PER_CLIP_TRAIN_BF16
-            isolated = out["roofline"].get("isolated")
-            mfma_bound = fl_ / (PEAK_BF16_MFMA_TFLOPS * 1e12) >= by / 8.0e12      # 9-tap family: 62 us at the matrix roof, 34 us at the HBM roof per launch
-            out["roofline"] = {# the figure to read first: the WHOLE STEP against the HBM roof in SURVEY.md 8(d)'s convention
-                               # -- clips/s/GPU x algorithmic bytes per clip / 8 TB/s; below it the dominant kernel family on ITS binding roof
-                               "step_frac_of_hbm_roof": round(value / world * step_bytes / 8.0e12, 4),
-                               "step_algorithmic_bytes_per_clip": step_bytes,
-                               "bound": "mfma" if mfma_bound else "hbm",
-                               "kernel": "9-tap temporal conv GEMMs on CN8 activations (fwd + data-grad launches); " + in_step,
-                               "achieved": round(achieved, 1) if mfma_bound else round(gbs, 1),
-                               "peak": PEAK_BF16_MFMA_TFLOPS if mfma_bound else 8000.0, "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                               "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4) if mfma_bound else round(gbs / 8000.0, 4),
-                               "hbm_gbps": round(gbs, 1), "hbm_frac": round(gbs / 8000.0, 4),
-                               "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch, PMC passes of the PROFILED build (%s), not of this run" % traffic_src
-                                               if traffic else None,
-                               "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "launches": calls,
-                               "avg_launch_ms": round(ms / max(calls, 1), 4),
-                               "mfma_tflops": round(achieved, 1)}
-            if isolated:
-                out["roofline"]["isolated"] = isolated
+            itf = ifl / (ims * 1e-3) / 1e12 if ims > 0 else 0.0
+            iexe = itf * (nprod * 10.0 / 9.0 if split else 1.0)
+            ipeak = PEAK_BF16_MFMA_TFLOPS if (split or bf16) else PEAK_FP32_MFMA_TFLOPS
+            roof["isolated"] = {"tflops": round(iexe, 1), "frac": round(iexe / ipeak, 4), "avg_launch_ms": round(ims / max(icalls, 1), 4)}
+            if split:
+                roof["isolated"]["fp32_equivalent_tflops"] = round(itf, 2)
+            detail["kernel_ms_per_step_isolated"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(iso.items())}
+        if split:
+            detail["split_kernels"] = sorted(k for k in summ if k.endswith("_split"))
+            detail["fp32_kernels_left"] = sorted(k for k in summ if not k.endswith("_split"))
+            nonsplit = sum(v["ms"] for k, v in summ.items() if not k.endswith("_split")) / ksteps
+            out["non_split_kernel_ms_per_step"] = round(nonsplit, 3)
+        out["_detail"] = detail
     del trainer, eng, batches    # (the cached device blocks stay with torch's allocator: the next leg reuses them instead of paying
     return out                   #  hipMalloc for every tensor of its first steps)
 
@@ -541,56 +522,52 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
         calls = sum(summ[k]["calls"] for k in fam)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         value = bs * world * steps / dt
-        traffic, traffic_src = measured_traffic("pathB") if not pad else (None, None)
+        traffic, traffic_src = measured_traffic("pathB_f32_split" if split else "pathB") if not pad else (None, None)
+        nprod = 6 if mfma.endswith("bf16x6") else 3
+        front = "VirtualRadar%s -> (B,1,256,256) log-spectrogram" % (" on clips up-sampled x%d on the GPU" % pad if pad else "")
+        net = "resnet18 f32_split [3x3/s1 convs = %d %s-term products]" % (nprod, "bf16" if nprod == 6 else "fp16") if split else "resnet18 fp32"
         out = {
             "metric": "spectrogram clips/sec training (VirtualRadar + resnet18, bs=%d/GPU)" % bs,
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, **dist_info(),
             "steps": steps, "warmup": warmup, "warm_s": warm_s,
             "ms_per_step": round(dt / steps * 1e3, 3), "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VirtualRadar -> (B,1,256,256) log-spectrogram -> resnet18 fp32 training step (fwd+bwd+Adam), "
-                                   "synthetic NTU clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
-                                   % (" up-sampled x%d on the GPU (the reference loader's default, utils.py:105,134-140)" % pad
-                                      if pad else "", args.classes, bs),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s -> %s step (fwd+bwd+Adam), synthetic NTU clips, %d cls, bs=%d/GPU" % (front, net, args.classes, bs),
                        "global_batch": bs * world, "parallelism": "dp%d" % world, "hip_graph_step": bool(use_graph)},
-            "roofline": {"bound": "mfma", "kernel": "conv2d 3x3 implicit GEMMs (fwd + data-grad + weight-grad launches); IN-STEP "
-                                                    "figure: HIP events over the timed region, weight-gradient kernels on a second stream",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch of conv2d_gemm_kernel, PMC passes of the PROFILED build (%s), not of "
-                                         "this run" % traffic_src if traffic else None,
-                         "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
-                         "step_frac_of_fp32_roof": round(value / world * 13.6e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)},
-            "kernel_ms_per_step": {k: round(v["ms"] / ksteps, 3) for k, v in sorted(summ.items())},
-            "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0},
             "final_loss": round(float(loss.item()), 5),
         }
-        if split:
+        common = {"timing": "in_step+wgrad_stream", "traffic": traffic, "traffic_src": traffic_src}
+        if not split:
+            out["roofline"] = {"bound": "mfma", "kernel": "conv2d_gemm_kernel 3x3 fwd+dgrad+wgrad", "achieved": round(achieved, 2),
+                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                               "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
+                               "step_frac_of_fp32_roof": round(value / world * 13.6e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4), **common}
+            box_key, box_num = "f32_mfma_tflops", achieved
+        else:
             # the launches on csrc/conv2d_split.hip: roofline on the fp16 / bf16 matrix pipe with the FLOPs actually executed
             # (3 products per fp32 product -- 6 for bf16x6 --, forward / data gradient x 10 / 9: nine taps in five k-steps)
-            nprod = 6 if mfma.endswith("bf16x6") else 3
             fs = [k for k in summ if "_split" in k]
             ms_s = sum(summ[k]["ms"] for k in fs)
             fl_s = sum(summ[k]["flops"] for k in fs)
             exe = sum(summ[k]["flops"] * nprod * (1.0 if "wgrad" in k else 10.0 / 9.0) for k in fs) / (ms_s * 1e-3) / 1e12 if ms_s > 0 else 0.0
             calls_s = sum(summ[k]["calls"] for k in fs)
-            out["config"]["workload"] = out["config"]["workload"].replace(
-                "resnet18 fp32 training step", "resnet18 fp32 training step (fp32 storage and results; the 3x3 / stride-1 convolutions as %d exact "
-                "products of %s terms per fp32 product on the matrix pipe, fp32 accumulation: csrc/conv2d_split.hip)"
-                % (nprod, "bf16" if nprod == 6 else "fp16"))
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv2d split kernels (3x3 / stride 1: forward, data gradient%s); IN-STEP figure: HIP events over the "
-                                           "timed region" % (", weight gradient" if any("wgrad" in k for k in fs) else ""),
+                "bound": "mfma", "kernel": "conv2d split kernels 3x3/s1 fwd+dgrad%s" % ("+wgrad" if any("wgrad" in k for k in fs) else ""),
                 "achieved": round(exe, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
-                "executed_flops_per_algorithmic_flop": "%d (x 10 / 9 forward / data gradient)" % nprod,
                 "fp32_equivalent_tflops": round(fl_s / (ms_s * 1e-3) / 1e12, 1) if ms_s > 0 else 0.0,
-                "fp32_mfma_peak_for_reference": PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                "launches": calls_s, "avg_launch_ms": round(ms_s / max(calls_s, 1), 4),
-                "split_kernels_ms_per_step": round(ms_s / ksteps, 3),
-                "fp32_conv_kernels_left_ms_per_step": {k: round(summ[k]["ms"] / ksteps, 3) for k in sorted(summ)
-                                                       if k.startswith("conv2d") and "_split" not in k}}
+                "step_fp32_equivalent_tflops": round(value / world * 13.6e9 / 1e12, 2),
+                "launches": calls_s, "avg_launch_ms": round(ms_s / max(calls_s, 1), 4), "split_kernels_ms_per_step": round(ms_s / ksteps, 3),
+                "fp32_conv_kernels_left_ms_per_step": round(sum(summ[k]["ms"] for k in summ if k.startswith("conv2d") and "_split" not in k) / ksteps, 3),
+                **common}
+            box_key, box_num = ("bf16_mfma_tflops" if nprod == 6 else "f16_mfma_tflops"), exe
+        if BOX.get(box_key):
+            out["roofline"]["frac_of_box"] = round(box_num / BOX[box_key], 4)
+            out["roofline"]["box_ref"] = box_key
+        small = [k for k, v in summ.items() if v["calls"] and v["ms"] / v["calls"] < 0.025]
+        out["launch_regions_per_step"] = round(sum(v["calls"] for v in summ.values()) / ksteps, 1)
+        out["regions_under_25us_per_step"] = round(sum(summ[k]["calls"] for k in small) / ksteps, 1)
+        out["_detail"] = {"kernel_ms_per_step": {k: round(v["ms"] / ksteps, 3) for k, v in sorted(summ.items())},
+                          "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in sorted(summ.items()) if v["ms"] > 0}}
         if pad:
             # The front end that only this variant has: per-clip smoothing + spline pieces, then the radar signal of 300 x pad
             # frames with every frame's 150 coordinates evaluated from the cubic pieces in float64.  Its binding unit is the
@@ -601,35 +578,48 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
                 frames = bs * 300 * pad
                 terms = frames * 24 * 2
                 per = sig["ms"] / sig["calls"]
-                out["radar_roofline"] = {
-                    "bound": "valu", "kernel": "vr_signal_fast_kernel<SPLINE> (+ upsample_smooth / upsample_prepare kernels)",
-                    "avg_launch_ms": round(per, 4),
-                    "prepare_avg_launch_ms": round(prep["ms"] / prep["calls"], 4) if prep and prep["calls"] else None,
-                    "achieved": round(terms / (per * 1e-3) / 1e9, 2), "unit": "G (edge, body) terms/s",
-                    "spline_f64_tflops": round(sig["flops"] / sig["calls"] / (per * 1e-3) / 1e12, 3),
-                    "peak_f64_valu_tflops": PEAK_FP64_VALU_TFLOPS,
-                    "frac_of_f64_valu_peak": round(sig["flops"] / sig["calls"] / (per * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 4),
-                    "share_of_step": round((per + (prep["ms"] / prep["calls"] if prep and prep["calls"] else 0.0)) / (dt / steps * 1e3), 4),
-                    "note": "the float64 spline evaluation uses a few per cent of the fp64 vector peak: the kernel is bound by the ISSUE of "
-                            "its fp32 vector instructions (IEEE square roots / divisions, the phase's sin / cos)"}
+                rr = {"bound": "valu", "kernel": "vr_signal_fast_kernel<SPLINE>", "avg_launch_ms": round(per, 4),
+                      "prepare_avg_launch_ms": round(prep["ms"] / prep["calls"], 4) if prep and prep["calls"] else None,
+                      "achieved": round(terms / (per * 1e-3) / 1e9, 2), "unit": "G (edge, body) terms/s",
+                      "spline_f64_tflops": round(sig["flops"] / sig["calls"] / (per * 1e-3) / 1e12, 3),
+                      "share_of_step": round((per + (prep["ms"] / prep["calls"] if prep and prep["calls"] else 0.0)) / (dt / steps * 1e3), 4)}
                 import glob
                 vf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pathB_pad250_valu.json")))
                 if vf:      # SQ_INSTS_VALU of the PROFILED build (its own rocprofv3 --pmc pass), not of this run
                     vk = json.load(open(vf[-1]))["kernels"].get("vr_signal_fast_kernel<1>")
                     if vk:
-                        out["radar_roofline"].update(
-                            peak="1 024 SIMDs x launch duration x %.2f GHz (%s) / 4 cycles per wave64 vector instruction"
-                                 % (vk.get("clock_ghz", 2.1), "measured in the PMC pass: GRBM_GUI_ACTIVE / 8 XCDs / wall time" if "clock_ghz" in vk else "assumed"),
-                            valu_wave_instructions_per_launch=vk["valu_wave_instructions_per_launch"],
-                            frac=round(vk["valu_wave_instructions_per_launch"] / (1024 * per * 1e-3 * vk.get("clock_ghz", 2.1) * 1e9 / 4), 4),
-                            frac_source="SQ_INSTS_VALU from %s (profiled build) over THIS run's launch duration" % os.path.basename(vf[-1]))
+                        ghz = vk.get("clock_ghz", 2.1)
+                        rr.update(peak="1024 SIMDs x launch time x %.2f GHz / 4 cycles per wave64 VALU instruction" % ghz, clock_ghz=ghz,
+                                  valu_wave_instructions_per_launch=vk["valu_wave_instructions_per_launch"],
+                                  frac=round(vk["valu_wave_instructions_per_launch"] / (1024 * per * 1e-3 * ghz * 1e9 / 4), 4),
+                                  frac_src="SQ_INSTS_VALU from %s over this run's launch time" % os.path.basename(vf[-1]))
+                out["radar_roofline"] = rr
     del trainer, model, batches
     return out
 
 
-def slim(leg, keep=()):
-    """a secondary leg without the per-kernel tables (the headline line stays readable); `keep`: tables to keep"""
-    return {k: v for k, v in leg.items() if k in keep or k not in ("kernel_ms_per_step", "kernel_tflops", "kernel_ms_per_step_isolated")}
+def strip_detail(leg, details, name):
+    """the per-kernel tables of a leg leave the line (they were 1-2 KB per leg and pushed the legs' numbers out of the driver's tail):
+    `--detail` prints them under `detail`, and every run writes them to gpurun_out/bench_detail.json when that directory exists"""
+    if leg is not None and "_detail" in leg:
+        details[name] = leg.pop("_detail")
+    return leg
+
+
+def summary_of(head, sec, world):
+    """the compact object at the END of the line: every leg's [clips/s, ms/step, roofline.frac, frac_of_box] and
+    the box calibration -- what a reader of the line's last kilobyte needs"""
+    legs = {"fp32": head}
+    legs.update(sec or {})
+    out = {"legs": {}, "box": [BOX.get(k) for k in ("f32_mfma_tflops", "f16_mfma_tflops", "f16_mfma_clock_ghz", "bf16_mfma_tflops", "copy_gbps")]}
+    for n, r in legs.items():
+        rf = r.get("roofline", {})
+        out["legs"][n] = [r["value"], r["ms_per_step"], rf.get("frac"), rf.get("frac_of_box")]
+        if isinstance(r.get("bf16"), dict):
+            out["legs"][n + ".bf16"] = [r["bf16"]["value"], r["bf16"]["ms_per_step"], None, None]
+    if world > 1:
+        out["per_rank_ms"] = {n: [round(t, 2) for t in r["per_rank_ms"]] for n, r in legs.items()}
+    return out
 
 
 def main():
@@ -657,6 +647,9 @@ def main():
                          "'secondary': f32_split = configs[1] with the GEMM contractions on the fp16 matrix pipe (fp32 storage and results), bf16 = configs[2] (sustained: >= 3 s of untimed load first), pathB = configs[3], pathB_pad250 = "
                          "configs[3] on the reference loader's real input (x250 up-sampling on the GPU), config5 = configs[4] (120 "
                          "classes, bone stream)")
+    ap.add_argument("--detail", action="store_true",
+                    help="print the per-kernel tables (kernel_ms_per_step, kernel_tflops, isolated) of every leg under 'detail' (default: "
+                         "they go to gpurun_out/bench_detail.json only, so that the line's tail holds every leg's numbers)")
     ap.add_argument("--quick", action="store_true", help="tests: secondary legs of a few steps without warm-up seconds")
     ap.add_argument("--stream", default="joint", choices=["joint", "bone"],
                     help="input stream of the stgcn workload (bone = data_gen/gen_bone_data.py on the fly; config 5 = --classes 120 "
@@ -677,11 +670,20 @@ def main():
     import torch.distributed as dist
     rank, world, dev = rank_setup(args)
     cpu_ok = rank == 0 and world == 1 and not args.no_cpu_baseline
+    # what this box sustains, measured before the first leg on every rank (rank 0's is reported): the denominators of frac_of_box
+    from sar_amd import box as box_probe
+    BOX.update(box_probe.measure(dev, quick=args.quick))
+    details = {}
     if args.workload == "spectrogram":
         assert args.mfma in ("fp32", "f32_split", "f32_split_bf16x6"), "the spectrogram workload has no bf16 engine"
         out = spectrogram_leg(args, args.steps, args.warmup, args.warm_seconds, rank, world, dev, mfma=args.mfma)
+        strip_detail(out, details, "headline")
+        if rank == 0:
+            out["box"] = dict(BOX)
         if cpu_ok:
             out["cpu_baseline"] = cpu_baseline_spectrogram(2 if args.num_pad_frames else 4, num_pad_frames=args.num_pad_frames)
+        if rank == 0:
+            out["summary"] = summary_of(out, None, world)
     else:
         sec, deferred = None, []
         names = [] if args.no_secondary or args.mfma != "fp32" or args.stream != "joint" else [n for n in args.secondary.split(",") if n]
@@ -732,26 +734,42 @@ def main():
                 else:
                     raise SystemExit("unknown secondary leg %r" % n)
                 if rank == 0:
-                    sec[n] = slim(r, ("kernel_ms_per_step_isolated",) if n == "f32_split" else ())
+                    sec[n] = strip_detail(r, details, n)
         sust = args.sustained_steps if args.steps < args.sustained_steps else 0
         head = stgcn_leg(args, args.mfma, args.steps, args.warmup, args.warm_seconds, rank, world, dev, not args.no_isolated_pass,
                          stream=args.stream, sustained_steps=sust)
         out = None
         if rank == 0:
+            strip_detail(head, details, "headline")
             out = {"metric": "NTU-xsub clips/sec training (ST-GCN, bs=64/GPU)", "value": head["value"], "unit": "clips/s",
                    "n_gpus": world, "rccl_ranks": head["rccl_ranks"], "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                    "dtype": head["dtype"], "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
+            if cpu_ok:
+                out["cpu_baseline"] = None      # (keeps its place in front of the long objects; filled below)
+            out["box"] = dict(BOX)
+            out["legend"] = LEGEND
             out.update({k: v for k, v in head.items() if k not in out})
             if sec:
+                out["legs_order"] = "secondary legs first (%s), the headline leg last; each with its own warm-up and untimed load" % ",".join(names)
                 out["secondary"] = sec
-                out["legs_order"] = ("secondary legs (%s) first, the headline leg last; every leg has its own warm-up, untimed load "
-                                     "(warm_s) and timed steps" % ", ".join(names))
         if cpu_ok:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample, classes=args.classes)
             for n, fn in (deferred if sec else []):
                 out["secondary"][n]["cpu_baseline"] = fn()
+        if rank == 0:
+            out["summary"] = summary_of(head, sec, world)        # LAST key: what the driver's tail keeps
     if rank == 0:
+        if args.detail:
+            out["detail"] = details
+            out["summary"] = out.pop("summary")                  # ... also with the tables in the line
+        ddir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(ddir) and os.access(ddir, os.W_OK) and world == 1:
+            try:
+                with open(os.path.join(ddir, "bench_detail.json"), "w") as f:
+                    json.dump({"args": vars(args), "box": dict(BOX), "detail": details}, f)
+            except OSError:
+                pass
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

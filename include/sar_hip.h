@@ -658,6 +658,21 @@ int sar_cn_to_cn8(const float* x, int64_t ld_x, void* out, int64_t ld_out, int C
 int sar_cn8_to_cn(const void* x, int64_t ld_x, float* out, int64_t ld_out, int C, int64_t n, sar_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Box calibration (csrc/box_probe.hip; bench.py's "box" object -- no reference counterpart, measurement only): what the box
+ * this process landed on sustains, so that a line's `frac` (against the guide's peaks) can be read next to `frac_of_box`.
+ *   sar_box_mfma        dense loop of one matrix instruction: kind 0 = v_mfma_f32_32x32x2_f32, 1 = v_mfma_f32_32x32x16_f16,
+ *                       2 = v_mfma_f32_32x32x16_bf16; `blocks` workgroups of four waves, iters x 32 instructions per wave, operands
+ *                       in registers.  sink: [blocks * 256] floats (written).  clocks: NULL or [blocks][2] uint32 -- per workgroup
+ *                       the shader-clock cycles (s_memtime) and the 100 MHz ticks (s_memrealtime) it lived: their ratio x 100 MHz
+ *                       is the clock the chip HELD under this load.
+ *   sar_box_mfma_flops  floating-point operations one such launch executes (host arithmetic, no device work).
+ *   sar_box_copy_f32    dst[i] = src[i], float4 units, n % 4 == 0, 16-byte aligned: 8 n bytes of HBM traffic per launch.
+ * ------------------------------------------------------------------------------------------------ */
+int sar_box_mfma(int kind, int blocks, int iters, float* sink, uint32_t* clocks, sar_stream_t s);
+int64_t sar_box_mfma_flops(int kind, int blocks, int iters);
+int sar_box_copy_f32(const float* src, float* dst, int64_t n, sar_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-side input helpers (HOST pointers, no stream, no device work): what tf.data.TFRecordDataset's native reader does
  * for main_gnn.py:159-194 -- the reference's clips are tf.train.Example records written by
  * data_gen/gen_tfrecord_data.py:25-33,76-85.

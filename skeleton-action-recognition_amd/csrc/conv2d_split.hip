@@ -112,10 +112,12 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
   // k-step q multiplies taps 2 q (lanes 0-31) and 2 q + 1 (lanes 32-63); the 10th tap does not exist (zero slot / zero column)
   const int abase = hi * 64 + l31;
 
-  int ea = 0, ew = 0;   // fp16 arithmetics: operand scale exponents (wave-uniform)
+  int ea = 0, ew = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)   // fp16 arithmetics: operand scale exponents (wave-uniform)
   if (SCALED) {
     ea = scale_exp(*k.src_bound);
     ew = scale_exp(*k.w_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.w_bound);
   }
   const float h3_sa = __builtin_ldexpf(1.f, ea);
   for (int c = tid; c < KCMAX; c += 256) {   // the folded prologue, with the source scale folded in (a power of two: exact)
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
   }
 
   {   // undo the operand scales; dead columns hold exact zeros (the epilogue's sums run over them)
-    const float c0 = SCALED ? __builtin_ldexpf(1.f, -(ea + ew)) : 1.f;
+    const float c0 = SCALED ? (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + ew))) : 1.f;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -509,9 +511,11 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_dgrad_
   }
 
   int ea = 0, ew = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)
   if (SCALED) {
     ea = scale_exp(*k.src_bound);
     ew = scale_exp(*k.w_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.w_bound);
   }
   const float h3_sa = __builtin_ldexpf(1.f, ea);
   for (int c = tid; c < KCMAX; c += 256) {
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_dgrad_
     }
   }
   {
-    const float c0 = SCALED ? __builtin_ldexpf(1.f, -(ea + ew)) : 1.f;
+    const float c0 = SCALED ? (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + ew))) : 1.f;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll

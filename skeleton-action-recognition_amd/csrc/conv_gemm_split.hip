@@ -124,21 +124,24 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 // one workgroup; a 2^-10 margin covers the fp32 roundings of the folded evaluation
 __global__ __launch_bounds__(256) void bound_kernel(const float* __restrict__ a, const float* __restrict__ b, int C, float root,
                                                     const unsigned* __restrict__ src_cell, int mode, unsigned* __restrict__ cell) {
-  float m0 = 0.f, m1 = 0.f;
+  // maxima on the BITS of the (non-negative) values: unsigned order keeps a NaN / Inf in gamma, beta or the folded affine (fmaxf drops NaN)
+  unsigned m0 = 0u, m1 = 0u;
+  auto ubits = [](float v) { return __float_as_uint(v) & 0x7fffffffu; };
+  auto umax = [](unsigned a, unsigned b) { return a > b ? a : b; };
   for (int c = threadIdx.x; c < C; c += 256) {
     const float av = fabsf(a[c]), bv = fabsf(b[c]);
-    if (mode == 0) m0 = fmaxf(m0, fmaf(av, root, bv));
-    else m0 = fmaxf(m0, av), m1 = fmaxf(m1, bv);
+    if (mode == 0) m0 = umax(m0, ubits(fmaf(av, root, bv)));
+    else m0 = umax(m0, ubits(av)), m1 = umax(m1, ubits(bv));
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m0 = fmaxf(m0, __shfl_xor(m0, o)), m1 = fmaxf(m1, __shfl_xor(m1, o));
-  __shared__ float w0[4], w1[4];
+  for (int o = 32; o >= 1; o >>= 1) m0 = umax(m0, (unsigned)__shfl_xor((int)m0, o)), m1 = umax(m1, (unsigned)__shfl_xor((int)m1, o));
+  __shared__ unsigned w0[4], w1[4];
   if ((threadIdx.x & 63) == 0) w0[threadIdx.x >> 6] = m0, w1[threadIdx.x >> 6] = m1;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m0 = fmaxf(fmaxf(w0[0], w0[1]), fmaxf(w0[2], w0[3]));
-    m1 = fmaxf(fmaxf(w1[0], w1[1]), fmaxf(w1[2], w1[3]));
-    float v = mode == 0 ? m0 : fmaf(m0, __uint_as_float(*src_cell), m1);
+    m0 = umax(umax(w0[0], w0[1]), umax(w0[2], w0[3]));
+    m1 = umax(umax(w1[0], w1[1]), umax(w1[2], w1[3]));
+    float v = mode == 0 ? __uint_as_float(m0) : fmaf(__uint_as_float(m0), __uint_as_float(*src_cell), __uint_as_float(m1));
     v *= 1.0009765625f;
     atomicMax(cell, __float_as_uint(v));
   }
@@ -313,10 +316,12 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     if (d.bias && row < d.M) bp.x = d.bias[row];
     rowp[tid] = bp;
   }
-  int ea = 0, ew = 0;   // fp16 arithmetics: operand scale exponents (wave-uniform)
+  int ea = 0, ew = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)   // fp16 arithmetics: operand scale exponents (wave-uniform)
   if (SCALED) {
     ea = scale_exp(*k.src_bound);
     ew = scale_exp(*k.w_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.w_bound);
   }
   const float h3_sa = __builtin_ldexpf(1.f, ea);
   if (tid < KCMAX) {   // the folded prologue, with the source scale folded in (a power of two: exact)
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
   }
 
   if (SCALED) {   // fp16 terms: undo the operand scales, join the cross terms, add the bias
-    const float c0 = __builtin_ldexpf(1.f, -(ea + ew)), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
+    const float c0 = (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + ew))), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -626,10 +631,12 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
   }
 
   int ea = 0, ew = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)
   if (SCALED) {   // a virtual joint is a weighted SUM of <= 4 source values: the bound of what is staged is bound(src) x max sum |weights|
     const float gmax = fmaxf(fmaxf(gs_s[0], gs_s[1]), 1.f);
     ea = scale_exp(__float_as_uint(__uint_as_float(*k.src_bound) * gmax));
     ew = scale_exp(*k.w_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.w_bound);
   }
   const float sa = __builtin_ldexpf(1.f, ea);
   f32x16 acc[NACC][MS][NS];
@@ -791,7 +798,7 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
   }
 
   if (SCALED) {
-    const float c0 = __builtin_ldexpf(1.f, -(ea + ew)), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
+    const float c0 = (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + ew))), c1 = NACC == 2 ? c0 / H3_LO : 0.f;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll

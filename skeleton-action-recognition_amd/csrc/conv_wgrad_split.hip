@@ -125,11 +125,7 @@ template <int AR, int S2 = 0, int W2 = 0> struct Cfg {
   static_assert(W2 == 0 || (W2 >= 8 && W2 <= 64 && (W2 & (W2 - 1)) == 0 && S2 == 0), "image width: a power of two in [8, 64]");
 };
 
-__host__ __device__ __forceinline__ int scale_exp(unsigned bound_bits) {   // conv_gemm_split.hip
-  const int fl = (int)((bound_bits >> 23) & 0xffu) - 127;
-  const int e = 14 - fl;
-  return e > 100 ? 100 : (e < -100 ? -100 : e);
-}
+#include "split_scale.h"   // scale_exp, bound_nonfinite, split_unscale (shared with split_terms.h)
 
 __device__ __forceinline__ unsigned pk_bf16(float x, float y) {
   bf16x2 p;
@@ -207,9 +203,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   SPLIT_TL_BEGIN();
 
   int ea = 0, eb = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)
   if (ar_f16(AR)) {
     ea = scale_exp(*k.src_bound);
     eb = scale_exp(*k.dout_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.dout_bound);
   }
   const float sa = __builtin_ldexpf(1.f, ea), sb = __builtin_ldexpf(1.f, eb);
   {   // the folded prologue of this block's 32 channels, the src scale folded in (power of two: exact)
@@ -459,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
   SPLIT_TL(4);   // the last tile's k-steps (the others are booked with the loop overhead 0)
   // ---- this wave's slab: rows c (registers), columns m (lanes: contiguous)
   float* slab = d.slab + (int64_t)(sg * WK + kh) * (d.wsize + d.bsize);
-  const float unscale = __builtin_ldexpf(1.f, -(ea + eb));
+  const float unscale = (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + eb)));
   const int m = m0 + l31;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
@@ -517,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
   const int ngrp = d.nsplit / WK;
 
   int ea = 0, eb = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)
   if (ar_f16(AR)) {   // a gathered value is a weighted sum of <= 4 source values: bound(src) x the largest sum of |weights| (<= 4 lists x 3 V)
     float gmax = 1.f;
     for (int i = 0; i < 3 * V; ++i) {
@@ -526,6 +525,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     }
     ea = scale_exp(__float_as_uint(__uint_as_float(*k.src_bound) * gmax));
     eb = scale_exp(*k.dout_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.dout_bound);
   }
   const float sa = __builtin_ldexpf(1.f, ea), sb = __builtin_ldexpf(1.f, eb);
   for (int i = tid; i < 3 * KS * 16; i += 256) {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
   }
 
   float* slab = d.slab + (int64_t)(sg * WK + kh) * (d.wsize + d.bsize);
-  const float unscale = __builtin_ldexpf(1.f, -(ea + eb));
+  const float unscale = (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + eb)));
 #pragma unroll
   for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
@@ -853,9 +853,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
   const int ngrp = d.nsplit / WK;
 
   int ea = 0, eb = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)
   if (ar_f16(AR)) {
     ea = scale_exp(*k.src_bound);
     eb = scale_exp(*k.dout_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.dout_bound);
   }
   const float sa = __builtin_ldexpf(1.f, ea), sb = __builtin_ldexpf(1.f, eb);
   {
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
   }
 
   float* slab = d.slab + (int64_t)(sg * WK + kh) * (d.wsize + d.bsize);
-  const float unscale = __builtin_ldexpf(1.f, -(ea + eb));
+  const float unscale = (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + eb)));
   const int m = m0 + l31;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)

@@ -333,6 +333,12 @@ template <int VEC> __device__ __forceinline__ void st(float* p, const float (&r)
 
 // amax by-product of a row-wise pass (the operand bounds of the split arithmetic, include/sar_hip.h: cells): the block's largest
 // |value| as float bits; one atomic max per workgroup, and only when it would raise the cell (maxima are order-independent)
+// running maximum on the BITS of |v| (unsigned order: NaN > Inf > every finite magnitude -- fmaxf would drop a NaN and the split
+// kernels would rescale a non-finite tensor into finite fp16 terms; with the bits in the cell they emit NaN, split_scale.h)
+__device__ __forceinline__ unsigned amax_bits(unsigned m, float v) {
+  const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+  return b > m ? b : m;
+}
 __device__ __forceinline__ void block_amax(unsigned m, unsigned* __restrict__ cell) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
   const float a = sc[c], b = sh[c];
   const float ra = (res_kind == 2) ? rsc[c] : 1.f, rb = (res_kind == 2) ? rsh[c] : 0.f;
   const int64_t base = (int64_t)c * ldm;
-  float am = 0.f;   // y >= 0
+  unsigned am = 0u;   // bits of the largest |y|
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float uv[VEC], rv[VEC], o[VEC];
     ld<VEC>(u + base + i, uv);
@@ -372,8 +378,8 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
     for (int j = 0; j < VEC; ++j) {
       float z = fmaf(uv[j], a, b);
       if (res_kind) z += fmaf(rv[j], ra, rb);
-      o[j] = fmaxf(z, 0.f);
-      if (amax) am = fmaxf(am, o[j]);   // uniform
+      o[j] = z < 0.f ? 0.f : z;   // ReLU that keeps NaN (fmaxf would return 0: a diverged step must not look finite downstream)
+      if (amax) am = amax_bits(am, o[j]);   // uniform
     }
     st<VEC>(y + base + i, o);
     if (VEC == 4 && mask) {   // uniform
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_fwd_kernel(const float* __res
       mask[(base + i) >> 2] = (unsigned char)mb;
     }
   }
-  if (amax) block_amax(__float_as_uint(am), amax);
+  if (amax) block_amax(am, amax);
 }
 
 template <int VEC, bool TAIL = false>
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
   const int64_t base = (int64_t)c * ldm;
   const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
   const float b1 = dr ? rk1[c] : 0.f, b2 = dr ? rk2[c] : 0.f, b3 = dr ? rk3[c] : 0.f;
-  float am = 0.f;
+  unsigned am = 0u;
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float g[VEC], yv[VEC], uv[VEC], rv[VEC], o1[VEC], o2[VEC], o3[VEC];
     ld<VEC>(dy + base + i, g);
@@ -470,14 +476,14 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
       const float dz = ((mb >> j) & 1u) ? g[j] : 0.f;
       o3[j] = dz;
       o1[j] = fmaf(a1, dz, fmaf(a2, uv[j], a3));
-      if (amax) am = fmaxf(am, fabsf(o1[j]));   // uniform
+      if (amax) am = amax_bits(am, o1[j]);   // uniform
       if (dr) o2[j] = fmaf(b1, dz, fmaf(b2, rv[j], b3));
     }
     st<VEC>(du + base + i, o1);
     if (dr) st<VEC>(dr + base + i, o2);
     if (dz_out) st<VEC>(dz_out + base + i, o3);
   }
-  if (amax) block_amax(__float_as_uint(am), amax);
+  if (amax) block_amax(am, amax);
 }
 
 template <int VEC>
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(TPB) void affine2_kernel(const float* __restrict__ 
   const int c = blockIdx.y;
   const int64_t base = (int64_t)c * ldm;
   const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
-  float am = 0.f;
+  unsigned am = 0u;
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float av[VEC], bv[VEC], o[VEC];
     ld<VEC>(a + base + i, av);
@@ -496,11 +502,11 @@ __global__ __launch_bounds__(TPB) void affine2_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       o[j] = fmaf(a1, av[j], fmaf(a2, bv[j], a3));
-      if (amax) am = fmaxf(am, fabsf(o[j]));   // uniform
+      if (amax) am = amax_bits(am, o[j]);   // uniform
     }
     st<VEC>(out + base + i, o);
   }
-  if (amax) block_amax(__float_as_uint(am), amax);
+  if (amax) block_amax(am, amax);
 }
 
 inline bool vec4_ok(int64_t n, int64_t ldm, std::initializer_list<const void*> ptrs) {

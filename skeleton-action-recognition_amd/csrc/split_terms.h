@@ -34,12 +34,7 @@ constexpr int ar_pj(int ar, int p) {
   return ar == AR_H3A ? (p == 0 ? 1 : 0) : ar == AR_B1 ? 0 : (ar == AR_B3 || ar_f16(ar)) ? (p == 0 ? 1 : 0) : j9[p + 9 - ar_nprod(ar)];
 }
 
-// power-of-two scale exponent of an operand from (the bits of) an upper bound of its magnitudes: bound * 2^e in [2^14, 2^15)
-__host__ __device__ __forceinline__ int scale_exp(unsigned bound_bits) {
-  const int fl = (int)((bound_bits >> 23) & 0xffu) - 127;
-  const int e = 14 - fl;
-  return e > 100 ? 100 : (e < -100 ? -100 : e);
-}
+#include "split_scale.h"   // scale_exp, bound_nonfinite, split_unscale
 
 __device__ __forceinline__ unsigned pk_bf16(float x, float y) {
   bf16x2 p;

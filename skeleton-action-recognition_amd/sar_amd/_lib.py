@@ -184,6 +184,10 @@ SIGNATURES = {
     "sar_pool_bwd_cn8": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
     "sar_cn_to_cn8": (_i, [_fp, _i64, _fp, _i64, _i, _i64, _fp]),
     "sar_cn8_to_cn": (_i, [_fp, _i64, _fp, _i64, _i, _i64, _fp]),
+    # box calibration (bench.py "box"; csrc/box_probe.hip)
+    "sar_box_mfma": (_i, [_i, _i, _i, _fp, _fp, _fp]),
+    "sar_box_mfma_flops": (_i64, [_i, _i, _i]),
+    "sar_box_copy_f32": (_i, [_fp, _fp, _i64, _fp]),
     # host-side input helpers (host pointers)
     "sar_crc32c": (C.c_uint32, [_fp, _i64]),
     "sar_crc32c_sw": (C.c_uint32, [_fp, _i64]),

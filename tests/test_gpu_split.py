@@ -161,6 +161,71 @@ def test_a_stale_bound_saturates_instead_of_overflowing(dev):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf")])
+def test_a_non_finite_operand_reaches_the_outputs(dev, bad):
+    """one NaN / Inf element in the source (forward, data gradient) or in dout (weight gradient) must come out of the
+    fp16 split kernels as non-finite results, as it does out of the fp32 kernels and the reference's framework ops -- not as the
+    finite values the +-65504 operand clamp and a NaN-dropping amax would launder it into.  The bound cells carry the BITS of the
+    largest |value| under unsigned order (NaN > Inf > finite); a non-finite cell makes every output of the launch NaN."""
+    from sar_amd import ops, _lib as L
+    f, T, B = 64, 12, 2
+    x, kernel, _ = _temporal_case(dev, f, T, B, 1, 7)
+    x[1, 5, 3, 11] = bad
+    for split in (None, "f16x3a"):
+        out = torch.empty((f, B * T * 25), device=dev)
+        ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), out, kernel.to(dev), f * f, f, B=B, V=25, T_src=T, T_out=T, Kc=f, M=f,
+                      taps=9, stride=1, pad=4, split=split)
+        torch.cuda.synchronize()
+        got = from_cn(out.cpu(), B, T, 25)
+        # the fp32 kernel poisons the element's receptive field; the split kernel the whole launch: both are loud
+        assert not torch.isfinite(got[1, :, 0:8, 11]).any(), split
+    # weight gradient: a non-finite dout element
+    dout, gx = torch.randn(B, f, T, 25), torch.randn(B, f, T, 25)
+    dout[0, 2, 4, 4] = bad
+    for split in (None, "f16x3a"):
+        flat = torch.zeros(9 * f * f + f, device=dev)
+        ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(gx).to(dev), to_cn(dout).to(dev), flat, B=B, V=25, T_src=T, T_out=T, Kc=f, M=f,
+                       taps=9, stride=1, pad=4, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f, split=split)
+        torch.cuda.synchronize()
+        gk = flat[:9 * f * f].cpu().view(9, f, f)
+        assert not torch.isfinite(gk[:, :, 2]).any(), split          # output channel 2 of every tap and source channel
+        assert not torch.isfinite(flat[9 * f * f + 2].cpu()), split   # and its bias gradient
+    # the by-product bounds of the element-wise passes keep it too (fmaxf would have dropped a NaN)
+    u = torch.randn(8, 1000)
+    u[3, 77] = bad
+    cell = torch.zeros(1, dtype=torch.int32, device=dev)
+    y = torch.empty(8, 1000, device=dev)
+    mask = torch.empty(8, 250, dtype=torch.uint8, device=dev)
+    ops.bn_add_relu_fwd(u.to(dev), torch.ones(8, device=dev), torch.zeros(8, device=dev), 0, None, None, None, y, mask=mask, amax_cell=cell)
+    torch.cuda.synchronize()
+    if bad != -float("inf"):          # relu(-inf) = 0 is a finite, correct value
+        assert (cell.item() & 0xffffffff) >= 0x7f800000 and not torch.isfinite(y[3, 77].cpu())
+    # a BatchNorm whose affine parameters diverged: the Samuelson bound is non-finite as well
+    gamma = torch.ones(16)
+    gamma[5] = bad
+    cell.zero_()
+    ops.bn_bound(gamma.to(dev), torch.zeros(16, device=dev), 1000, cell)
+    assert (cell.item() & 0xffffffff) >= 0x7f800000
+
+
+def test_a_diverged_step_is_visible_in_the_split_engine(dev):
+    """engine level: one NaN weight (what a diverged optimizer step leaves behind) gives a NaN loss and NaN gradients in f32_split as
+    in fp32 -- bench.py and the training loops assert on exactly that.  (A NaN in the INPUT is swallowed by the first block's
+    folded BatchNorm + ReLU prologue, max(NaN, 0) = 0, in both arithmetics alike: not what this test is about.)"""
+    from sar_amd.stgcn import STGCN
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True)]
+    p = O.init_params(10, seed=4, dtype=torch.float64, blocks=blocks)
+    p["l1.tcn.kernel"][4, 0, 7, 9] = float("nan")
+    x, y = O.synthetic_batch(2, seed=3, T=20, num_classes=10)
+    for mode in ("fp32", "f32_split"):
+        eng = STGCN(num_classes=10, device=dev, blocks=blocks, mfma=mode)
+        eng.load_params(p)
+        logits, loss = eng.loss_and_grad(x.to(dev), y.to(dev))
+        torch.cuda.synchronize()
+        assert not torch.isfinite(loss).item(), mode
+        assert not torch.isfinite(eng.g["l0.gcn.kernel"]).all().item(), mode
+
+
 @pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("transpose", [False, True])
 def test_graph_conv_with_sums_beyond_the_source_bound(dev, arith, transpose):
