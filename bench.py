@@ -50,7 +50,9 @@ LEGEND = {
     "box": "sar_amd/box.py: dense v_mfma loops (f32 32x32x2, f16/bf16 32x32x16; ~125 ms each, held clock = s_memtime/s_memrealtime) + 1 GiB float4 copy",
     "peaks": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TF, fp16/bf16 MFMA 2500 TF dense, HBM 8000 GB/s",
     "f32_split": "fp32 storage, statistics, epilogues, optimizer and parity tolerances; every GEMM product = 3 exact fp16-term products (f16x3a)",
+    "bf16": "bf16 CN8 activations in HBM and bf16 MFMA operands; fp32 accumulation, BatchNorm statistics, master weights, optimizer",
     "sustained": "100 further steps behind the contract's K, same protocol",
+    "train step": "forward + loss + backward + gradient exchange (N > 1) + optimizer (ST-GCN: Nesterov SGD; Path B: radar -> 256x256 image -> Adam)",
     "summary": "LAST key: legs = {leg: [clips/s, ms/step, roofline.frac, frac_of_box]}; box = [f32 TF, f16 TF, f16 GHz, bf16 TF, copy GB/s]",
 }
 
@@ -380,10 +382,8 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
         split = mfma in ("f32_split", "f32_split_bf16x6")
         nprod = 3 if mfma == "f32_split" else 6
         # every prose field of a leg is at most 120 characters (the driver's parser cuts there); LEGEND explains the vocabulary
-        what = {"fp32": "ST-GCN fp32 training step", "f32_split": "ST-GCN f32_split training step [fp32 storage+results, GEMMs = 3 fp16-term products, f16x3a]",
-                "f32_split_bf16x6": "ST-GCN f32_split_bf16x6 training step [fp32 storage+results, GEMMs = 6 bf16-term products]",
-                "bf16": "ST-GCN bf16 training step [bf16 CN8 activations, fp32 accumulate/BN/master weights]",
-                "bf16_operands": "ST-GCN training step [bf16 MFMA operands, fp32 activations]"}[mfma]
+        what = {"fp32": "ST-GCN fp32", "f32_split": "ST-GCN f32_split (f16x3a)", "f32_split_bf16x6": "ST-GCN f32_split (bf16x6)",
+                "bf16": "ST-GCN bf16 (CN8)", "bf16_operands": "ST-GCN bf16-operand"}[mfma]
         overl = eng._side is not None
         common = {"timing": "in_step" + ("+wgrad_stream" if overl else ""), "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
                   "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "traffic": traffic, "traffic_src": traffic_src}
@@ -422,8 +422,8 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, **dist_info(), "grad_buckets": trainer.buckets_last_step,
             "steps": steps, "warmup": warmup, "warm_s": res["warm_s"], "ms_per_step": round(dt / steps * 1e3, 3),
             "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"], "dtype": "bf16" if bf16 else "f32",
-            "config": {"workload": "%s (fwd+bwd+Nesterov SGD), synthetic NTU-xsub clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
-                                   % (what, " as the BONE stream" if bone else "", classes, args.batch),
+            "config": {"workload": "%s train step, synthetic NTU-xsub clips (3,300,25,2)%s, %d classes, bs=%d/GPU"
+                                   % (what, " BONE stream" if bone else "", classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": roof, "final_loss": round(loss_val, 5),
         }
@@ -524,15 +524,16 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
         value = bs * world * steps / dt
         traffic, traffic_src = measured_traffic("pathB_f32_split" if split else "pathB") if not pad else (None, None)
         nprod = 6 if mfma.endswith("bf16x6") else 3
-        front = "VirtualRadar%s -> (B,1,256,256) log-spectrogram" % (" on clips up-sampled x%d on the GPU" % pad if pad else "")
-        net = "resnet18 f32_split [3x3/s1 convs = %d %s-term products]" % (nprod, "bf16" if nprod == 6 else "fp16") if split else "resnet18 fp32"
+        front = "VirtualRadar%s" % (" (x%d up-sampling)" % pad if pad else "")
+        net = "resnet18 f32_split (%s)" % ("bf16x6" if nprod == 6 else "f16x3a") if split else "resnet18 fp32"
         out = {
             "metric": "spectrogram clips/sec training (VirtualRadar + resnet18, bs=%d/GPU)" % bs,
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, **dist_info(),
             "steps": steps, "warmup": warmup, "warm_s": warm_s,
             "ms_per_step": round(dt / steps * 1e3, 3), "per_rank_ms": res["per_rank_ms"], "allreduce_ms": res["allreduce_ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s -> %s step (fwd+bwd+Adam), synthetic NTU clips, %d cls, bs=%d/GPU" % (front, net, args.classes, bs),
+            "config": {"workload": "%s -> %s train step, synthetic NTU clips, %d classes, bs=%d/GPU"
+                                   % (front, net, args.classes, bs),
                        "global_batch": bs * world, "parallelism": "dp%d" % world, "hip_graph_step": bool(use_graph)},
             "final_loss": round(float(loss.item()), 5),
         }
@@ -751,7 +752,7 @@ def main():
             out["legend"] = LEGEND
             out.update({k: v for k, v in head.items() if k not in out})
             if sec:
-                out["legs_order"] = "secondary legs first (%s), the headline leg last; each with its own warm-up and untimed load" % ",".join(names)
+                out["legs_order"] = names + ["fp32 (headline, last)"]     # each leg with its own warm-up and untimed load (warm_s)
                 out["secondary"] = sec
         if cpu_ok:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_sample, classes=args.classes)

@@ -51,6 +51,13 @@ typedef struct sar_context sar_context;
 int sar_context_create(sar_context** out);   /* 3 non-blocking side streams + 4 events; 0 or a hipError_t */
 int sar_context_destroy(sar_context* ctx);   /* waits for nothing: synchronise the caller's stream first */
 
+/* A caller-owned stream confined to the compute units whose bits are set in mask[nwords] (bit i of word j = CU 32 j + i;
+ * hipExtStreamCreateWithCUMask).  The engines put their weight-gradient stream on such a stream so that the short kernels of the main
+ * chain are not queued behind its long-lived workgroups (sar_amd/ops.py: shared_side_stream).  No reference counterpart
+ * (MirroredStrategy / DataParallel leave stream placement to the framework, main_gnn.py:257-258). */
+int sar_stream_create_cu_mask(const uint32_t* mask, int nwords, sar_stream_t* out);
+int sar_stream_destroy(sar_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused conv-GEMM on the CN layout (fp32 MFMA, v_mfma_f32_32x32x2_f32).
  *
@@ -105,6 +112,9 @@ enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3,
  * 'spatial' strategy, graph/tools.py:22-30).  The split graph weight gradient then stages the raw tile once (csrc/conv_wgrad_split.hip). */
 #define SAR_GRAPH_SLICE0_IDENTITY 8
 #define SAR_GRAPH_FEW_DENSE_SHIFT 8
+/* g_flags (sar_conv_gemm_split, GRAPH, SAR_SPLIT_F16X3A): take the one-tile-per-workgroup kernel of round 5 instead of the persistent
+ * LDS-DMA kernel (bit-identical results; kept for A/B measurements and as the cross-check of tests/test_gpu_split.py) */
+#define SAR_GRAPH_ONE_TILE_WG 16
 typedef struct sar_conv_desc {
   int32_t mode;        /* SAR_CONV_* */
   int32_t transposed;  /* TEMPORAL only */
@@ -172,10 +182,19 @@ int sar_pack_weights_bf16_batch(const float* base, const sar_pack_item* items, i
  *                     UPPER BOUND of its magnitudes that the caller keeps in device memory (`src_bound` for pro(src), `w_bound`
  *                     for W: the BITS of a non-negative float; sar_amax_f32 / sar_bn_bound_f32 / sar_affine_bound_f32 /
  *                     sar_pack_weights_split_batch produce them without a host sync): s = 2^(14 - floor(log2(bound))).  Values
- *                     beyond the bound saturate at the fp16 maximum (a stale bound gives a wrong, finite result).
+ *                     beyond the bound saturate at the fp16 maximum (a stale bound gives a wrong, finite result).  A cell that
+ *                     holds the bits of Inf / NaN -- the producers raise cells by UNSIGNED maxima of the value bits, so a
+ *                     non-finite element, BatchNorm parameter or weight ends up there -- makes EVERY output of the launch NaN:
+ *                     what the fp32 kernels and the reference's framework ops propagate from a non-finite operand, instead of
+ *                     finite values out of the clamp (csrc/split_scale.h; tests/test_gpu_split.py).
  *   X1 / X3 / X9 / F16X3 / F16X3S (two symmetric fp16 terms: loses the low term of elements 2^18 below the bound -- not enough
  *   for gradient tensors) are measured data points (tools/split_probe.py, profiles/r05_split_probe_*; 9-tap temporal only).
- * Built for the 9-tap TEMPORAL operator at V = 25, stride 1 / 2, 8 <= Kc <= 256, M % 8 == 0; anything else returns SAR_E_UNSUP
+ * Built for (i) the 9-tap TEMPORAL operator at V = 25, stride 1 / 2, 8 <= Kc <= 256, M % 8 == 0 (forward, and transposed = its
+ * data gradient), every arithmetic; and (ii) the GRAPH operator (models/gcn.py:199-209 and, with the transposed tables, its data
+ * gradient) at V = 25, taps = 3, T_src == T_out, 16 <= Kc <= 256 with Kc % 16 == 0, M % 8 == 0, no folded prologue, gather tables
+ * flagged SAR_GRAPH_FEW_DENSE with at most 16 non-trivial lists, in SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A only (F16X3A: two kernels
+ * with bit-identical results -- persistent workgroups with the raw source by LDS-DMA for the data gradients, one tile per
+ * workgroup for the forward launches; SAR_GRAPH_ONE_TILE_WG forces the latter).  Anything else returns SAR_E_UNSUP
  * (sar_conv_gemm_split_nparts too): the caller keeps sar_conv_gemm_f32 for it.  `packed` = the weight term images written by
  * sar_pack_weights_split_batch (same items as sar_pack_weights_bf16_batch, but G = ceil(Kc / 8), and an item occupies
  * sar_conv_gemm_split_workspace_bytes / 16 units = terms * taps * G * M); item_amax[nitems] receives each item's amax bits (fp16
@@ -235,7 +254,8 @@ int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int6
  * src_bound / dout_bound = bound cells of pro(src) / dout for the fp16 arithmetic.  Built for the 9-tap TEMPORAL operator at
  * V = 25, stride 1 or stride 2 with pad 3 and T_src = 2 T_out, 8 <= Kc <= 256, and for the GRAPH operator at V = 25, 16 <= Kc <= 256
  * without a folded prologue; other shapes: SAR_E_UNSUP (keep sar_conv_wgrad_f32).  nsplit must be a multiple of the wk
- * that sar_conv_wgrad_split_blocks reports (at M <= 64 two wave pairs of a workgroup split a tile's k-steps and write two slabs);
+ * that sar_conv_wgrad_split_blocks reports -- TEMPORAL: 1, or 2 at M <= 64 (two wave pairs of a workgroup split a tile's k-steps and
+ * write two slabs); GRAPH: 1 at M >= 256, 2 at M = 128, 4 at M <= 64 (the waves that do not own an M block split the k-steps);
  * that query returns the weight blocks per slab group (or SAR_E_UNSUP) and the positions per tile: a launch has
  * (nsplit / wk) * blocks workgroups, two resident per CU. */
 int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, int* wk, int* tile_positions);

@@ -818,6 +818,343 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
   SPLIT_TL_END(w);
 }
 
+// ---- The same contraction as conv_graph_split_kernel -- BIT-IDENTICAL results: same term images, same products in the same order,
+// same epilogue, same partial-sum layout -- rebuilt around what the per-workgroup timelines of round 5 showed
+// (profiles/r05_f32split_timelines.txt: a 64-channel forward workgroup lived 45 000 cycles for 7 300 cycles of matrix work and the
+// launch moved 2.2 TB/s): the source loads of a stage were in flight only during the previous stage's MFMA phase (a third of the
+// time), every workgroup classified the same 75 gather lists, rebuilt its column geometry and re-read its bias rows for ONE tile
+// of 250 columns, and the virtual joints' 32 gathered global loads per lane sat on the critical wave.
+//  * PERSISTENT workgroups: 2 per CU, each walks its XCD's tiles (tile = xcd + 8 (lane + i lanes): the row blocks of a tile and
+//    consecutive tiles share an L2); gather-list classification, column geometry, bias rows once per workgroup.
+//  * the RAW fp32 source of a stage (16 channel rows x <= 250 columns) reaches LDS by LDS-DMA (buffer_load_dwordx4 ... lds on
+//    whole lanes + one buffer_load_dword ... lds for the row's last ncols % 4 columns: row starts are only 4-byte aligned) into a
+//    ring of two buffers, issued TWO stages ahead -- across tile boundaries, so the next tile's first stages are in flight during
+//    this tile's epilogue.  No source registers, no per-lane descriptor arithmetic: four DMA instructions per wave and stage.
+//  * the stager reads the raw tile from LDS (a lane = a column, conflict-free), scales, splits into the fp16 terms and writes the
+//    single term image as before; the virtual joints (weighted sums of <= 4 joints of the same frame) are formed from the SAME raw
+//    tile -- their global gathers are gone.
+// Happens-before per stage g (buffers: raw ring g & 1, one term image Sl, one weight image Wl):
+//   [C(g-1)] -> issue W DMA(g) -> convert raw(g) -> Sl -> s_waitcnt vmcnt(0) (own raw(g+1) rows, own W(g) pieces) -> barrier B(g)
+//   -> issue raw DMA(g+2) into ring slot g & 1 (every wave is past its reads of raw(g)) -> MFMA(g) -> barrier C(g).
+//   raw(g) was issued behind B(g-2) and waited for by its issuing wave in front of B(g-1): visible to every wave behind C(g-1).
+// The epilogue's transpose area aliases Sl only (W DMA of the next tile's first stage is in flight during the epilogue); a barrier
+// E separates it from the next tile's first convert.
+template <int AR>
+__global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS k) {
+  constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR);
+  static_assert(AR == AR_H3A, "built for the engine's arithmetic (one accumulator, scaled fp16 terms)");
+  constexpr int BM = 64, MS = 2, NS = 2, WN = 4, V = VJ, FTG = 10, NVMAX = 16, KC16 = 16;
+  constexpr int VCOL0 = 256, ZCOL = VCOL0 + NVMAX * FTG, SC = ZCOL + 1;
+  constexpr int WPIECES = NTA * 6, WU = WPIECES * 64, SU = NTB * 2 * SC;
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;
+  static_assert(SU >= PAREA_U, "the epilogue's transpose area must fit the term image");
+  constexpr int PPW = (WPIECES + 3) / 4;
+  constexpr int RAWP = 256, RAW_U = KC16 * RAWP / 4;   // raw stage buffer: 16 rows of 256 floats
+  __shared__ uint4 smem_u[SU + WU + 2 * RAW_U + 2 * BM];
+  __shared__ int vmap[3 * V + 1];
+  __shared__ int vl_idx[NVMAX * 4];
+  __shared__ float vl_wt[NVMAX * 4];
+  __shared__ int nd_s[2];
+  __shared__ float gs_s[2];
+  uint4* Sl = smem_u;
+  uint4* Wl = smem_u + SU;
+  float* rawl = reinterpret_cast<float*>(smem_u + SU + WU);
+  float4* rowp_b = reinterpret_cast<float4*>(smem_u + SU + WU + 2 * RAW_U);        // bias rows (per workgroup)
+  float4* rowp_e = rowp_b + BM;                                                    // the epilogue's per-row parameters
+  float* smem = reinterpret_cast<float*>(smem_u);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave;
+  // ---- persistent assignment (gridDim.x % (8 ny) == 0): XCD = blockIdx & 7; inside an XCD slot -> (row block, tile lane)
+  const int ny = k.ny;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nlanes = (int)(gridDim.x >> 3) / ny;
+  const int my = slot % ny, tlane = slot / ny;
+  const int m0 = my * BM;
+  const int tstep = 8 * nlanes;
+  int tile = xcd + 8 * tlane;
+  if (tile >= k.ntiles) return;
+  SPLIT_TL_BEGIN();
+
+  // ---- classify the 3 V gather lists (as conv_graph_split_kernel), once per workgroup
+  int l_idx[4] = {0, 0, 0, 0};
+  float l_wt[4] = {0.f, 0.f, 0.f, 0.f};
+  int cnt = 0, first = 0;
+  bool dense = false;
+  if (tid < 3 * V) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      l_idx[j] = d.g_idx[tid * 4 + j];
+      l_wt[j] = d.g_wt[tid * 4 + j];
+    }
+#pragma unroll
+    for (int j = 3; j >= 0; --j)
+      if (l_wt[j] != 0.f) {
+        ++cnt;
+        first = j;
+      }
+    dense = cnt > 1 || (cnt == 1 && l_wt[first] != 1.f);
+  }
+  const unsigned long long dmask = __ballot(dense);
+  const int rank_w = __popcll(dmask & ((1ull << lane) - 1ull));
+  float lsum = fabsf(l_wt[0]) + fabsf(l_wt[1]) + fabsf(l_wt[2]) + fabsf(l_wt[3]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) lsum = fmaxf(lsum, __shfl_xor(lsum, o));
+  if (lane == 0 && wave < 2) {
+    nd_s[wave] = __popcll(dmask);
+    gs_s[wave] = lsum;
+  }
+  if (tid < BM) {
+    const int row = m0 + tid;
+    float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias && row < d.M) {
+      bp.x = d.bias[row];
+      bp.y = d.bias[d.M + row];
+      bp.z = d.bias[2 * d.M + row];
+    }
+    rowp_b[tid] = bp;
+  }
+  if (tid < 2 * NTB) Sl[tid * SC + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const int nd_raw = nd_s[0] + nd_s[1];
+  const int nd = nd_raw < NVMAX ? nd_raw : NVMAX;
+  if (tid < 3 * V) {
+    const int rank = (wave == 1 ? nd_s[0] : 0) + rank_w;
+    int code = -1;
+    if (dense && rank < NVMAX) {
+      code = V + rank;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vl_idx[rank * 4 + j] = l_idx[j];
+        vl_wt[rank * 4 + j] = l_wt[j];
+      }
+    } else if (cnt == 1) code = l_idx[first];
+    vmap[tid] = code;
+  }
+  __syncthreads();
+
+  // ---- tile-invariant column geometry: the three slices' operand columns of a FULL tile, the bias term's column sums
+  int pcol[NS];
+  float gcs[3][NS];
+  int baddr_full[3][NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    pcol[ns] = p;
+    const bool in = p < FTG * V;
+    const int pv = in ? p : 0;
+    const int fo = pv / V, v = pv - fo * V;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      gcs[tp][ns] = (d.g_colsum && in) ? d.g_colsum[tp * V + v] : 0.f;
+      const int code = vmap[tp * V + v];
+      int col = ZCOL;
+      if (in && code >= 0) col = code < V ? fo * V + code : VCOL0 + fo * nd + (code - V);
+      baddr_full[tp][ns] = col + hi * SC;
+    }
+  }
+  const float gmax = fmaxf(fmaxf(gs_s[0], gs_s[1]), 1.f);
+  const int ea = scale_exp(__float_as_uint(__uint_as_float(*k.src_bound) * gmax));
+  const int ew = scale_exp(*k.w_bound);
+  const bool nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.w_bound);
+  const float sa = __builtin_ldexpf(1.f, ea);
+  const float c0 = nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + ew));
+
+  // ---- the virtual joints of the stager: thread = (virtual column, channel half); gathers inside the raw tile
+  const int vt = tid >> 1, vh = tid & 1;
+  const int vtf = nd > 0 ? vt / (nd > 0 ? nd : 1) : 0;
+  const bool vact_full = nd > 0 && vt < FTG * nd;
+  int vcol[4];
+  float vwt[4];
+  {
+    const int l = vt - vtf * nd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vwt[j] = vact_full ? vl_wt[l * 4 + j] : 0.f;
+      vcol[j] = (vact_full && vwt[j] != 0.f) ? vtf * V + vl_idx[l * 4 + j] : 0;   // an unused entry reads the tile's first column (weight 0)
+    }
+  }
+
+  // ---- DMA issue.  Raw rows: wave w moves rows w, w + 4, w + 8, w + 12 of a stage.  The prefetch cursor (pf_*) runs two stages
+  // ahead of the stage being multiplied, across tile boundaries.
+  const int seq_len = d.T_src * V;
+  const int nst = d.Kc / KC16;
+  auto tile_geo = [&](int t, const float*& src_t, int& ncols_t) {
+    const int b = t / k.TPS;
+    const int t0 = (t - b * k.TPS) * k.FT;
+    const int nfr = (t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0;
+    ncols_t = nfr * V;
+    src_t = d.src + ((int64_t)b * d.T_src + t0) * V;
+  };
+  int pf_tile = tile, pf_s = 0, pf_ncols;
+  const float* pf_src;
+  tile_geo(pf_tile, pf_src, pf_ncols);
+  auto issue_raw = [&](int buf) {   // raw(pf_tile, pf_s) -> ring slot buf; advances the cursor
+    if (pf_tile < k.ntiles) {
+      const int nfull = pf_ncols >> 2, rem = pf_ncols & 3;
+      const unsigned rbytes = (unsigned)pf_ncols * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave + 4 * i;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(pf_src + (int64_t)(pf_s * KC16 + row) * d.ld_src), 0, rbytes, 0x00020000);
+        float* dst = rawl + buf * (KC16 * RAWP) + row * RAWP;
+        if (lane < nfull) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, lane * 16, 0, 0, 0);
+        if (lane < rem) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + 4 * nfull), 4, (4 * nfull + lane) * 4, 0, 0, 0);
+      }
+      if (++pf_s == nst) {
+        pf_s = 0;
+        pf_tile += tstep;
+        if (pf_tile < k.ntiles) tile_geo(pf_tile, pf_src, pf_ncols);
+      }
+    }
+  };
+  const unsigned wbytes = (unsigned)((int64_t)NTA * 3 * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;
+  auto issue_w_dma = [&](int g0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + 4 * i;   // wave-uniform
+      if (p < WPIECES) {
+        const int ts = p >> 1, h = p & 1;   // ts = term * 3 + slice
+        const int g = g0 + h;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + p * 64), 16, g < k.G ? wvo : 0x80000000u, (ts * k.G + g) * d.M * 16, 0, 0);
+      }
+    }
+  };
+
+  issue_raw(0);
+  issue_raw(1);
+  issue_w_dma(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's only exposed round trip
+  __syncthreads();
+  SPLIT_TL(0);   // classification, geometry, first requests and their round trip
+  int ring = 0;   // ring slot of the stage about to be converted
+  const int abase = hi * 64 + l31;
+
+  for (; tile < k.ntiles; tile += tstep) {
+    const int b = tile / k.TPS;
+    const int t0 = (tile - b * k.TPS) * k.FT;
+    const int nfr = (t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0;
+    const int ncols = nfr * V;
+    bool colok[NS];
+    int64_t coln[NS];
+    int baddr[3][NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      colok[ns] = pcol[ns] < ncols;
+      coln[ns] = ((int64_t)b * d.T_out + t0) * V + (colok[ns] ? pcol[ns] : 0);
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) baddr[tp][ns] = colok[ns] ? baddr_full[tp][ns] : ZCOL + hi * SC;
+    }
+    const bool vact = vact_full && vtf < nfr;
+    f32x16 acc[MS][NS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+    SPLIT_TL(7);   // per-tile geometry + accumulator initialisation
+
+    for (int s_ = 0; s_ < nst; ++s_) {
+      // ---- convert raw(ring) -> the term image
+      {
+        const float* raw = rawl + ring * (KC16 * RAWP);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float x = raw[(8 * h + q) * RAWP + tid] * sa;
+            v[q] = tid < ncols ? x : 0.f;
+          }
+          uint4 u[NTB];
+          split8<AR, false>(v, u, 1.f);
+#pragma unroll
+          for (int t = 0; t < NTB; ++t) Sl[(t * 2 + h) * SC + tid] = u[t];
+        }
+        if (vact) {   // z = sum_j wt_j x_j: the fp32 kernel's chain (conv_gemm.hip), then the split
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float* rr = raw + (8 * vh + q) * RAWP;
+            float z = vwt[0] * rr[vcol[0]];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) z = fmaf(vwt[j], rr[vcol[j]], z);
+            v[q] = z * sa;
+          }
+          uint4 u[NTB];
+          split8<AR, false>(v, u, 1.f);
+#pragma unroll
+          for (int t = 0; t < NTB; ++t) Sl[(t * 2 + vh) * SC + VCOL0 + vt] = u[t];
+        }
+      }
+      SPLIT_TL(1);   // convert
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own rows of the NEXT raw stage (issued a stage ago) and own pieces of this stage's weights
+      SPLIT_TL(2);   // DMA wait
+      __syncthreads();   // B: the term image and the weight pieces are visible; every wave is done with raw(ring)
+      SPLIT_TL(3);
+      issue_raw(ring);   // two stages ahead
+      SPLIT_TL(8);   // raw DMA issue
+      SAR_LDS_SKEW();
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) {
+        uint4 a[NTA][MS], bq[NTB][NS];
+#pragma unroll
+        for (int t = 0; t < NTA; ++t)
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[(t * 3 + tp) * 128 + abase + ms * 32];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int t = 0; t < NTB; ++t) bq[t][ns] = Sl[t * 2 * SC + baddr[tp][ns]];
+#pragma unroll
+        for (int p = 0; p < NPROD; ++p) {
+          const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+              acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8*>(&a[i][ms]),
+                                                                   *reinterpret_cast<f16x8*>(&bq[j][ns]), acc[ms][ns], 0, 0, 0);
+        }
+      }
+      SPLIT_TL(4);   // k-steps
+      __syncthreads();   // C: every wave is done with the term image and the weight pieces
+      ring ^= 1;
+      // the next stage's weights: this tile's next channel groups, or the next tile's first
+      if (s_ + 1 < nst) issue_w_dma(2 * (s_ + 1));
+      else if (tile + tstep < k.ntiles) issue_w_dma(0);
+      SPLIT_TL(5);   // closing barrier + W DMA issue
+    }
+
+    // ---- undo the operand scales, add the bias term, epilogue
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 bp = rowp_b[ms * 32 + mfma_row(r, hi)];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const float bias = fmaf(bp.z, gcs[2][ns], fmaf(bp.y, gcs[1][ns], bp.x * gcs[0][ns]));
+          const float v = acc[ms][ns][r] * c0 + bias;
+          acc[ms][ns][r] = colok[ns] ? v : 0.f;
+        }
+      }
+    epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp_e, smem);
+    SPLIT_TL(6);   // epilogue
+    __syncthreads();   // E: the transpose area (inside Sl) is free again
+    SPLIT_TL(9);
+    if (tid < 2 * NTB) Sl[tid * SC + ZCOL] = make_uint4(0u, 0u, 0u, 0u);   // (the transpose area covers the zero column of term image 0 only when SC < PAREA: rewrite, cheap)
+  }
+  SPLIT_TL_END(blockIdx.x);
+}
+
 int geometry_s(const sar_conv_desc& d, int tr, ConvKS& k) {
   const int TAPS = 9;
   k.FT = 10;                                 // 256 / 25, parity split: 2 * (128 / 25)
@@ -856,6 +1193,26 @@ int split_tr(const sar_conv_desc& d) {
   return -1;
 }
 
+// process-wide constants read once (no mutable state behind them): the experiment switch of the graph kernel and the CU count
+// which launches take conv_graph_split2_kernel: 0 none, 1 all, 2 (default) the data gradients (the forward launch is the one with the
+// BatchNorm STATS epilogue; the descriptor's `transposed` is a TEMPORAL field) -- measured alone at the ten layer
+// shapes (profiles/r06_graph_split2_kernel_bench.txt): data gradients 3.19 -> 3.00 ms per step, forward 2.53 -> 2.83
+int graph_split_v2() {
+  static const int v = [] {
+    const char* e = getenv("SAR_GRAPH_SPLIT2");
+    return !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
+  }();
+  return v;
+}
+int device_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }();
+  return n;
+}
+
 template <int AR>
 int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned* src_bound, const unsigned* w_bound, hipStream_t st) {
   ConvKS k;
@@ -866,6 +1223,14 @@ int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned
   geometry_s(d, tr, k);
   const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
   if (tr == 4) {
+    if constexpr (AR == AR_H3A) {
+      if ((graph_split_v2() == 1 || (graph_split_v2() == 2 && d.epi != SAR_EPI_STATS)) && !(d.g_flags & SAR_GRAPH_ONE_TILE_WG)) {   // persistent workgroups, two per CU (SAR_GRAPH_SPLIT2=0 / SAR_GRAPH_ONE_TILE_WG: the one-tile-per-workgroup kernel of round 5)
+        const int per = 8 * k.ny;
+        const int g2 = (2 * device_cus()) / per * per;
+        hipLaunchKernelGGL((conv_graph_split2_kernel<AR>), dim3(g2 > 0 ? g2 : per), block, 0, st, k);
+        return 0;
+      }
+    }
     if constexpr (AR == AR_B6 || AR == AR_H3A) hipLaunchKernelGGL((conv_graph_split_kernel<AR>), grid, block, 0, st, k);
     else return SAR_E_UNSUP;
   } else if (tr == 0 && d.stride == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 0>), grid, block, 0, st, k);

@@ -69,6 +69,31 @@ extern "C" int sar_context_destroy(sar_context* c) {
   return 0;
 }
 
+// A stream confined to a subset of the compute units (the caller owns it: sar_stream_destroy).  The weight-gradient stream of the
+// engines runs long-lived workgroups (340-1 050 us each, two per CU, every vector register of the SIMDs): a short kernel of the main
+// chain (the 23 BatchNorm finalisations of a step: 8 us alone, 119 us in the step) cannot be placed until one of them retires.  With
+// the side stream masked off a few CUs the main chain always finds free slots there.
+extern "C" int sar_stream_create_cu_mask(const uint32_t* mask, int nwords, sar_stream_t* out) {
+  SAR_REQUIRE(mask != nullptr && nwords > 0 && nwords <= 64 && out != nullptr, "sar_stream_create_cu_mask: bad arguments");
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask);
+  if (e != hipSuccess) {
+    sar_set_error("sar_stream_create_cu_mask: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  *out = (sar_stream_t)st;
+  return 0;
+}
+extern "C" int sar_stream_destroy(sar_stream_t s) {
+  if (!s) return 0;
+  hipError_t e = hipStreamDestroy((hipStream_t)s);
+  if (e != hipSuccess) {
+    sar_set_error("sar_stream_destroy: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
 extern "C" int sar_struct_size(int which) { return which == 0 ? (int)sizeof(sar_conv_desc) : which == 1 ? (int)sizeof(sar_wgrad_desc) : which == 2 ? (int)sizeof(sar_conv2d_desc) : -1; }
 
 namespace {

@@ -16,6 +16,7 @@ SAR_GRAPH_WT_BF16_EXACT = 1
 SAR_GRAPH_FEW_DENSE = 4
 SAR_GRAPH_SLICE0_IDENTITY = 8
 SAR_GRAPH_FEW_DENSE_SHIFT = 8
+SAR_GRAPH_ONE_TILE_WG = 16
 SAR_C2D_AUX_EVEN_PIXELS = 1
 SAR_SPLIT = {"bf16x1": 1, "bf16x3": 3, "bf16x6": 6, "bf16x9": 9, "f16x3": 103, "f16x3s": 104, "f16x3a": 105}   # include/sar_hip.h SAR_SPLIT_*
 
@@ -79,6 +80,8 @@ SIGNATURES = {
     "sar_last_error_string": (C.c_char_p, []),
     "sar_context_create": (_i, [C.POINTER(C.c_void_p)]),
     "sar_context_destroy": (_i, [_fp]),
+    "sar_stream_create_cu_mask": (_i, [_fp, _i, C.POINTER(C.c_void_p)]),
+    "sar_stream_destroy": (_i, [_fp]),
     "sar_struct_size": (_i, [_i]),
     "sar_conv_gemm_nparts": (_i, [C.POINTER(ConvDesc)]),
     "sar_conv_gemm_f32": (_i, [C.POINTER(ConvDesc), _fp]),

@@ -4,6 +4,7 @@ memory and the current HIP stream; all arithmetic happens in libsar_hip.so.
 Activations use the CN layout: a 2-D float32 tensor [C][B*T*V] (see include/sar_hip.h).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -121,6 +122,8 @@ class PackedSplitWeights(PackedWeights):
 
 
 _side_streams = {}
+GRAPH_ONE_TILE_WG = False     # tests / A-B: the round-5 graph kernel of the split arithmetic (include/sar_hip.h: SAR_GRAPH_ONE_TILE_WG)
+SIDE_CU_MASK_DEFAULT = "off"
 
 
 def shared_side_stream(device, priority=0):
@@ -132,8 +135,49 @@ def shared_side_stream(device, priority=0):
     key = (torch.device(device).index or 0, threading.get_ident(), int(priority))
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device, priority=int(priority))
+        mask = side_stream_cu_mask(device)
+        if mask is None:
+            st = torch.cuda.Stream(device=device, priority=int(priority))
+        else:
+            # a stream that leaves some CUs to the main chain (sar_stream_create_cu_mask), wrapped for torch's stream API
+            import ctypes as _C
+            words = (_C.c_uint32 * len(mask))(*mask)
+            h = _C.c_void_p()
+            with torch.cuda.device(device):
+                check(L.load().sar_stream_create_cu_mask(words, len(mask), _C.byref(h)), "sar_stream_create_cu_mask")
+            st = torch.cuda.ExternalStream(h.value, device=device)
+        _side_streams[key] = st
     return st
+
+
+def side_stream_cu_mask(device):
+    """the CU mask of the weight-gradient stream as a list of 32-bit words, or None = every CU.  SAR_SIDE_CU_MASK:
+    'off' | 'skip:<n>' (every n-th CU left to the main chain) | 'first:<k>' / 'last:<k>' (k contiguous CUs left out) | hex words"""
+    spec = os.environ.get("SAR_SIDE_CU_MASK", SIDE_CU_MASK_DEFAULT)
+    if not spec or spec == "off":
+        return None
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    nw = (ncu + 31) // 32
+    bits = [1] * ncu
+    kind, _, arg = spec.partition(":")
+    if kind == "skip":
+        n = int(arg)
+        for i in range(ncu):
+            if i % n == n - 1:
+                bits[i] = 0
+    elif kind == "first":
+        for i in range(int(arg)):
+            bits[i] = 0
+    elif kind == "last":
+        for i in range(int(arg)):
+            bits[ncu - 1 - i] = 0
+    else:
+        return [int(w, 16) for w in spec.split(",")]
+    words = [0] * nw
+    for i, b in enumerate(bits):
+        if b:
+            words[i // 32] |= 1 << (i % 32)
+    return words
 
 
 def amax(x, cell):
@@ -224,7 +268,7 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
         d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
         for i in range(3):
             d.nz[i] = tables.nz[i]
-        d.g_flags = tables.g_flags
+        d.g_flags = tables.g_flags | (L.SAR_GRAPH_ONE_TILE_WG if GRAPH_ONE_TILE_WG else 0)
     if aux is not None:
         d.aux, d.ld_aux = ptr(_f32(aux)), aux.stride(0)
     if aux_affine is not None:

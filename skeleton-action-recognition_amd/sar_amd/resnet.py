@@ -236,7 +236,9 @@ class ResNet18:
         Ho, Wo = (H + 2 * cv.pad - cv.k) // cv.stride + 1, (W + 2 * cv.pad - cv.k) // cv.stride + 1
         out = torch.empty((cv.cout, B * Ho * Wo), dtype=torch.float32, device=X.device)
         sa = self._split_args(name, "f", training)
-        if sa["split"] and bn_src is not None:
+        # (raised whenever the cell exists: the forward launch AND the weight gradient read it -- ADVICE r05: with
+        # SAR_SPLIT_KINDS_PATHB=dgrad,wgrad the weight gradient read a bound that only a split forward launch used to raise)
+        if training and bn_src is not None and self._cell(name, "f") is not None:
             ops.bn_bound(self.p[bn_src[0] + ".weight"], self.p[bn_src[0] + ".bias"], bn_src[1], self._cell(name, "f"))
         r = ops.conv2d_gemm(X, out, self._w(name), cv.cin * cv.cout, cv.cout,
                             epi=L.SAR_EPI_STATS if training else L.SAR_EPI_NONE, B=B, Kc=cv.cin, M=cv.cout, H_src=H,

@@ -420,7 +420,7 @@ class STGCN:
             r1 = ops.graph_dense_fwd(y3, self.A, g, KS, f, V, B * T, stats=training)
         else:
             gimg = self._simg(pre + "gcn.f") if training else None
-            if gimg is not None and self._f16 and i == 0:
+            if training and i == 0 and self._cell_live(pre + "gcn.f", "gfwd", "gwgrad"):
                 ops.amax(X, self._cell(i, 3))       # the bound of the block input (blocks > 0: written by the previous block's tail)
             r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
                                Kc=cin, M=f, taps=KS, bias=self.p[pre + "gcn.bias"], tables=self.tab_fwd, epi=epi,
@@ -433,7 +433,7 @@ class STGCN:
         # tgcn: BN -> ReLU folded into the operand load, Conv2D [9,1] stride s SAME (models/stgcn.py:26-36)
         u = torch.empty((f, n_out), dtype=torch.float32, device=dev)
         simg = self._simg(pre + "tcn.f") if training else None        # inference keeps the fp32 kernels (no batch statistics to bound with)
-        if simg is not None and self._f16:
+        if training and self._cell_live(pre + "tcn.f", "tfwd", "twgrad"):     # (a cell is raised when ANY split consumer of it is on)
             ops.bn_bound(self.p[pre + "bn1.gamma"], self.p[pre + "bn1.beta"], n_in, self._cell(i, 0))
         r2 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, g, u, self.p[pre + "tcn.kernel"], f * f, f, B=B, V=V, T_src=T, T_out=To,
                            Kc=f, M=f, taps=KT, stride=s, pad=pad, bias=self.p[pre + "tcn.bias"],
@@ -460,8 +460,8 @@ class STGCN:
         res_kind = {"none": 0, "identity": 1, "conv": 2}[kind]
         ymask = ops.relu_mask(y) if training else None     # 1 bit per element: what the BatchNorm-backward passes read instead of y
         # (split arithmetic: y is the next block's graph-convolution operand; its bound is a by-product of this pass)
-        ycell = self._cell(i + 1, 3) if (training and self._f16 and i + 1 < len(self.blocks)
-                                         and self._simg("l%d.gcn.f" % (i + 1)) is not None) else None
+        ycell = self._cell(i + 1, 3) if (training and i + 1 < len(self.blocks)
+                                         and self._cell_live("l%d.gcn.f" % (i + 1), "gfwd", "gwgrad")) else None
         ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r,
                             rbn.scale if rbn else None, rbn.shift if rbn else None, y, mask=ymask, amax_cell=ycell)
         if training:
@@ -486,6 +486,16 @@ class STGCN:
         if kind not in _SPLIT_KINDS:
             return None
         return (pk.image(key), pk.bound(key)) if pk is not None and key in pk.index else None
+
+    def _cell_live(self, key, *kinds):
+        """does operand-bound cell of weight `key`'s layer have a split consumer that is switched on?  A cell is raised by its
+        producer whenever ANY of its consumers runs on the fp16 split kernels -- the forward launch or a weight gradient (ADVICE r05:
+        with SAR_SPLIT_KINDS=tdgrad,twgrad the weight gradient read a source bound that only the forward launch used to raise)."""
+        return bool(self._f16 and self._split_has(key) and any(k in _SPLIT_KINDS for k in kinds))
+
+    def _split_has(self, key):
+        """the split kernels take this conv weight's shape (its term images exist), whatever SAR_SPLIT_KINDS switches on"""
+        return self.spacked is not None and key in self.spacked.index
 
     def _cell(self, i, j):
         """operand-bound cell j of block i: 0 relu(bn1(g)), 1 du, 2 dg, 3 X, 4 dr"""
@@ -629,7 +639,7 @@ class STGCN:
         du = torch.empty_like(u)
         dr = torch.empty_like(r) if kind == "conv" else None
         dz = dY if (kind == "identity" and gated is None) else None  # in place: dY becomes the pre-ReLU gradient for the skip path (already gated: nothing to write)
-        ducell = self._cell(i, 1) if (self._f16 and self._simg(pre + "tcn.b") is not None) else None   # the bound of du: by-product
+        ducell = self._cell(i, 1) if self._cell_live(pre + "tcn.b", "tdgrad", "twgrad") else None   # the bound of du: by-product
         ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz,
                                   mask=sb.get("ymask"), amax_cell=ducell)
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
@@ -639,7 +649,7 @@ class STGCN:
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
             pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
-            bf16=self.bf16, split=self.split if (simg is not None and "twgrad" in _SPLIT_KINDS) else None,
+            bf16=self.bf16, split=self.split if ("twgrad" in _SPLIT_KINDS and self._split_has(pre + "tcn.f") and self._split_has(pre + "tcn.b")) else None,
             bounds=(self._cell(i, 0), self._cell(i, 1)) if self._f16 else None), g, du)
         wimg = self._img(pre + "tcn.b")
         wT = None
@@ -654,14 +664,14 @@ class STGCN:
         ops.bn_bwd_finalize(pm[0], pm[1], pm[1] * 2, 2, 0, 1, f, n_in, self.p[pre + "bn1.gamma"], bn1.mean, bn1.rstd,
                             self.g[pre + "bn1.gamma"], self.g[pre + "bn1.beta"], bn1.k1, bn1.k2, bn1.k3)
         dg = dz1
-        dgcell = self._cell(i, 2) if (self._f16 and self._simg(pre + "gcn.b") is not None) else None      # the bound of dg: by-product
+        dgcell = self._cell(i, 2) if self._cell_live(pre + "gcn.b", "gdgrad", "gwgrad") else None      # the bound of dg: by-product
         ops.affine2(dz1, g, (bn1.k1, bn1.k2, bn1.k3), dg, amax_cell=dgcell)   # BN1 backward apply (in place)
         flat_g = self.grad[self.offsets[pre + "gcn.kernel"]:self.offsets[pre + "gcn.bias"] + KS * f]
         if self.dense_A:
             return self._graph_backward_dense(i, sb, dg, dY, dr, B, flat_g)
         # ---- graph conv: weight / bias gradient
-        gw_split = self.split if ("gwgrad" in _SPLIT_KINDS and self._simg(pre + "gcn.f") is not None
-                                  and self._simg(pre + "gcn.b") is not None) else None      # (both bounds exist: X from the forward, dg above)
+        gw_split = self.split if ("gwgrad" in _SPLIT_KINDS and self._split_has(pre + "gcn.f")
+                                  and self._split_has(pre + "gcn.b")) else None      # (both bounds exist: X from the forward, dg above)
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_GRAPH, X, dg, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS, tables=self.tab_fwd,
             w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, bf16=self.bf16, split=gw_split,

@@ -215,8 +215,8 @@ class SpectrogramTrainer:
         """graph=True: a step on a batch shape seen before is ONE hipGraph launch (its ~300 kernel launches -- on two streams --
         captured once, inputs copied into the captured step's buffers): with the resnet's convolutions on the split kernels a step at
         bs = 32 takes the GPU ~5 ms and the host ~6 ms to ISSUE (20 us of Python per launch).  Single process, frozen radar parameters
-        only (the default of main_spectrogram.py); anything else takes the eager path.  The returned (logits, loss) are then the
-        captured step's buffers, overwritten by the next step."""
+        only (the default of main_spectrogram.py): trainable radar parameters take the eager path, a live process group RAISES (the
+        RCCL exchange cannot be captured; tests/test_gpu_rccl.py).  The returned (logits, loss) are copies of the captured buffers."""
         self.model, self.eng, self.world_size = model, model.base_model.engine, world_size
         self.graph, self._graphs = bool(graph), {}
         self.radar_params = list(model.virtual_radar.parameters())
@@ -252,10 +252,21 @@ class SpectrogramTrainer:
 
     def step(self, x, labels, lr):
         """One train step (eager, or a hipGraph replay: __init__)."""
-        if not (self.graph and x.is_cuda and not ddp_active() and not self.train_radar()):
+        if self.graph and ddp_active():
+            # VERDICT r05 next #7(i): no silent fall-back.  The bucketed gradient exchange lives on the communication stream with
+            # host-side event bookkeeping per bucket (GradExchange) and RCCL's own stream semantics: a hipGraph capture of the step
+            # cannot record it, and a replay without it would train every rank on its own gradients.
+            raise RuntimeError("SpectrogramTrainer(graph=True) is a single-process mode: under data parallelism (process group of %d "
+                               "ranks) the step's RCCL gradient exchange cannot be captured into a hipGraph -- construct the trainer "
+                               "with graph=False" % dist.get_world_size())
+        if not (self.graph and x.is_cuda and not self.train_radar()):
             return self._step(x, labels, lr)
         eng = self.eng
-        key = (tuple(x.shape), x.dtype, tuple(labels.shape), labels.dtype)
+        # the capture bakes in: the batch geometry, the engine's parameter / gradient / Adam-state buffers and the radar configuration;
+        # any of them changing (load_params into new buffers, another up-sampling factor) re-captures instead of replaying stale pointers
+        vr = self.model.virtual_radar
+        key = (tuple(x.shape), x.dtype, tuple(labels.shape), labels.dtype, eng.flat.data_ptr(), eng.grad.data_ptr(),
+               tuple(p.data_ptr() for p in self.radar_params), getattr(self.model, "num_pad_frames", None), getattr(vr, "sigma", None))
         st = self._graphs.get(key)
         if st is None:
             # this call's step runs eagerly on copies that become the captured step's inputs (it also makes every lazily built
@@ -278,7 +289,7 @@ class SpectrogramTrainer:
         sy.copy_(labels, non_blocking=True)
         g.replay()
         self.run_ahead.step_issued()
-        return cap
+        return tuple(t.clone() for t in cap)     # the captured buffers are overwritten by the next replay: hand out copies
 
     def _step(self, x, labels, lr, run_ahead=True):
         """Returns (logits, loss) device tensors; nothing in the step reads them back (the host blocks only on the event of the

@@ -53,6 +53,17 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
     info["bare_ok"] = bool(torch.equal(t.cpu(), torch.arange(1 << 20, dtype=torch.float32)))
+    # the hipGraph-captured Path B step under a live communicator must REFUSE, not fall back silently
+    import ddp_worker as W
+    from sar_amd.train import SpectrogramTrainer
+    _, tr = W.make_trainer("spectrogram", dev, 1)
+    gtr = SpectrogramTrainer(tr.model, 1e-3, world_size=1, graph=True)
+    xg, yg = W.global_batch("spectrogram", 4)
+    try:
+        gtr.step(xg.to(dev), yg.to(dev), 1e-3)
+        info["graph_under_ddp"] = "ran"
+    except RuntimeError as e:
+        info["graph_under_ddp"] = str(e)
     torch.save(info, os.path.join(out, "info.pt"))
     for workload in sys.argv[2:]:
         torch.save(run(workload, dev), os.path.join(out, workload + ".pt"))

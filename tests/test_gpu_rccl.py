@@ -43,6 +43,15 @@ def test_one_rank_rccl_communicator_reduces_device_memory(rccl_run):
     assert info["backend"] == "nccl" and info["world"] == 1 and info["bare_ok"]
 
 
+def test_hip_graph_step_refuses_a_live_process_group(rccl_run):
+    """SpectrogramTrainer(graph=True) captures the step's launches into ONE hipGraph; the bucketed RCCL exchange
+    (communication stream, per-bucket events handled by the host) cannot be part of that capture, and a replay without it would train
+    each rank on its own gradients -- so under a live communicator (here the forced one-rank RCCL group) step() raises, loudly."""
+    info = torch.load(os.path.join(rccl_run, "info.pt"))
+    assert info["graph_under_ddp"] != "ran"
+    assert "graph=True" in info["graph_under_ddp"] and "graph=False" in info["graph_under_ddp"] and "hipGraph" in info["graph_under_ddp"]
+
+
 @pytest.mark.parametrize("workload", WORKLOADS)
 def test_forced_ddp_step_on_rccl_is_bit_identical_to_the_plain_step(workload, rccl_run):
     import rccl_worker as R

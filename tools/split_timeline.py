@@ -67,6 +67,19 @@ for (cin, f, T, s) in shapes:
         span = en.max()
         resid = life.sum() / (ncu * span)
         ph = rows[:, 4:14].mean(axis=0)
+        if os.environ.get("SAR_GRAPH_SPLIT2", "1") != "0" and name.startswith("g_"):
+            # the persistent kernel (conv_graph_split2_kernel): a row = one workgroup = several tiles; phases per TILE
+            ntile_total = {"g_fwd": None}.get(name)
+            tiles = B * (-(-T // 10))                      # column tiles of the launch
+            ny = max(1, (cin if name == "g_dgate" else f) // 64)
+            per_wg = tiles * ny / len(rows)
+            q = ph / per_wg
+            print("[%3d->%3d T%3d] %-7s %7.1f us | PERSISTENT %d wgs on %d CUs, %.2f tiles each, lifetime %.1f us, %.2f GHz | cycles per workgroup: "
+                  "prologue %.0f | per TILE: set-up %.0f, convert %.0f, dma-wait %.0f, barrier-B %.0f, raw-issue %.0f, mfma %.0f, barrier-C+W-issue %.0f, "
+                  "epilogue %.0f, barrier-E %.0f (sum %.0f)"
+                  % (cin, f, T, name, e0.elapsed_time(e1) * 1e3, len(rows), ncu, per_wg, life.mean() / 1e3, rows[:, 4:14].sum() / max(life.sum(), 1),
+                     ph[0], q[7], q[1], q[2], q[3], q[8], q[4], q[5], q[6], q[9], q[1:].sum()))
+            continue
         ghz = rows[:, 4:14].sum() / max(life.sum(), 1)
         print("[%3d->%3d T%3d] %-7s %7.1f us | %5d wgs on %d CUs, lifetime %.1f us (p10 %.1f p90 %.1f), resident/CU %.2f, %.2f GHz | cycles: "
               "tables %.0f, geometry+init %.0f, store %.0f, dma-wait %.0f, open-barrier %.0f, load-issue %.0f, mfma %.0f, close-barrier %.0f, epilogue %.0f (sum %.0f)"
