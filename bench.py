@@ -36,6 +36,7 @@ PEAK_FP64_VALU_TFLOPS = 78.6       # MI355X: packed-free fp64 vector FMA, half t
 FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<", "conv_gemm_cn8_dma_kernel<"),
                  "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",), "pathB_f32_split": ("conv2d_split_kernel<",),
                  "f32_split": ("conv_gemm_split_kernel<",), "f32_split_bf16x6": ("conv_gemm_split_kernel<",)}
+PROFILE_CLOCK = {}   # mode -> the clock the dominant family held in the newest committed profile (GRBM_GUI_ACTIVE pass), or None
 BOX = {}        # the box calibration of this process (sar_amd/box.py), filled by main() before the first leg
 
 # What the fields of the line mean (the line itself carries numbers and identifiers of at most 120 characters; DESIGN.md sections 4 and 7
@@ -47,6 +48,7 @@ LEGEND = {
     "roofline.timing": "in_step = HIP events inside the timed step; +wgrad_stream = weight gradients overlap on a second stream (inflates it)",
     "roofline.isolated": "the same family over 3 untimed steps with the side stream off: kernel quality without overlap",
     "roofline.traffic": "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of the build named in traffic_src",
+    "roofline.clock_ghz": "shader clock held under the dominant family: GRBM_GUI_ACTIVE / 8 XCDs / dispatch time, own PMC pass of the same build",
     "box": "sar_amd/box.py: dense v_mfma loops (f32 32x32x2, f16/bf16 32x32x16; ~125 ms each, held clock = s_memtime/s_memrealtime) + 1 GiB float4 copy",
     "peaks": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TF, fp16/bf16 MFMA 2500 TF dense, HBM 8000 GB/s",
     "f32_split": "fp32 storage, statistics, epilogues, optimizer and parity tolerances; every GEMM product = 3 exact fp16-term products (f16x3a)",
@@ -75,6 +77,7 @@ def measured_traffic(mode="fp32"):
     names = [r.get("kernel", "") for r in d.get("kernels", [])]
     if not any(n.startswith(FAMILY_PREFIX[mode]) for n in names):
         return None, None
+    PROFILE_CLOCK[mode] = d.get("dominant_family_clock_ghz")
     return d.get("dominant_family_hbm_bytes_per_launch"), "%s @ %s" % (os.path.basename(files[-1]), d.get("commit", "commit not recorded"))
 
 
@@ -386,7 +389,8 @@ def stgcn_leg(args, mfma, steps, warmup, warm_seconds, rank, world, dev, isolate
                 "bf16": "ST-GCN bf16 (CN8)", "bf16_operands": "ST-GCN bf16-operand"}[mfma]
         overl = eng._side is not None
         common = {"timing": "in_step" + ("+wgrad_stream" if overl else ""), "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
-                  "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "traffic": traffic, "traffic_src": traffic_src}
+                  "algorithmic_bytes_per_launch": int(by / max(calls, 1)), "traffic": traffic, "traffic_src": traffic_src,
+                  "clock_ghz": PROFILE_CLOCK.get(mfma)}      # held under this family in the profiled build's GRBM_GUI_ACTIVE pass (traffic_src)
         if split:
             # fp32 results on the fp16 / bf16 matrix pipe: the roof is that pipe's, priced on the MFMA FLOPs the kernels EXECUTE
             # (products per fp32 product x the 10 tap slots per 9 taps) -- never against the fp32 MFMA peak
@@ -537,7 +541,8 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
                        "global_batch": bs * world, "parallelism": "dp%d" % world, "hip_graph_step": bool(use_graph)},
             "final_loss": round(float(loss.item()), 5),
         }
-        common = {"timing": "in_step+wgrad_stream", "traffic": traffic, "traffic_src": traffic_src}
+        common = {"timing": "in_step+wgrad_stream", "traffic": traffic, "traffic_src": traffic_src,
+                  "clock_ghz": PROFILE_CLOCK.get("pathB_f32_split" if split else "pathB") if not pad else None}
         if not split:
             out["roofline"] = {"bound": "mfma", "kernel": "conv2d_gemm_kernel 3x3 fwd+dgrad+wgrad", "achieved": round(achieved, 2),
                                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),

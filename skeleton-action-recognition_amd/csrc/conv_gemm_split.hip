@@ -1330,8 +1330,9 @@ extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void
   SAR_REQUIRE(d->B > 0 && d->V > 0 && d->T_src > 0 && d->T_out > 0 && d->Kc > 0 && d->M > 0, "sar_conv_gemm_split: bad sizes");
   const int tr = split_tr(*d);
   if (tr < 0) {
-    sar_set_error("sar_conv_gemm_split: built for the 9-tap temporal convolution at V = 25, stride 1 / 2, 8 <= Kc <= 256, M %% 8 == 0 "
-                  "(mode %d, taps %d, V %d, stride %d, Kc %d, M %d): use sar_conv_gemm_f32",
+    sar_set_error("sar_conv_gemm_split: built for the 9-tap temporal convolution at V = 25, stride 1 / 2, 8 <= Kc <= 256, M %% 8 == 0, and "
+                  "for the graph convolution at V = 25, taps 3, T_src == T_out, 16 <= Kc <= 256, Kc %% 16 == 0, M %% 8 == 0, no prologue, "
+                  "SAR_GRAPH_FEW_DENSE tables with <= 16 non-trivial lists (mode %d, taps %d, V %d, stride %d, Kc %d, M %d): use sar_conv_gemm_f32",
                   d->mode, d->taps, d->V, d->stride, d->Kc, d->M);
     return SAR_E_UNSUP;
   }

@@ -44,18 +44,37 @@ def pmc(sub, counter):
     return agg
 
 
+def held_clock():
+    """{kernel: median GHz} from the GRBM_GUI_ACTIVE pass (tools/profile_round.sh step 3): counter / 8 XCDs / dispatch duration, over the
+    dispatches of at least 20 us (shorter ones are dominated by the counter's start / stop granularity)"""
+    cc = newest(os.path.join(P, "clock", "*", "*counter_collection.csv"))
+    kt = newest(os.path.join(P, "clock", "*", "*kernel_trace.csv"))
+    if not cc or not kt:
+        return {}
+    span = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt[0]))}
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(cc[0])):
+        if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
+            continue
+        ns = span.get(r["Dispatch_Id"])
+        if ns and ns >= 20000:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) / 8.0 / ns)
+    return {k: round(sorted(v)[len(v) // 2], 3) for k, v in agg.items()}
+
+
 stats = newest(os.path.join(P, "trace", "*", "*kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(OUT, "%s_bench_kernel_stats.csv" % tag))
 dur = {}
 for r in csv.DictReader(open(stats)):
     dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]), float(r["Percentage"]))
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+CLOCK = held_clock()
 rows = []
 for k, (calls, avg_ns, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
     f = fetch[k][1] / fetch[k][0] if fetch[k][0] else None
     w = write[k][1] / write[k][0] if write[k][0] else None
     hbm = (2 * f + w) * 1024 if f is not None and w is not None else None
-    rows.append({"kernel": k, "calls": calls, "avg_us": round(avg_ns / 1e3, 2), "pct_time": pct,
+    rows.append({"kernel": k, "calls": calls, "avg_us": round(avg_ns / 1e3, 2), "pct_time": pct, "clock_ghz": CLOCK.get(k),
                  "fetch_kib_raw": None if f is None else round(f, 1), "write_kib": None if w is None else round(w, 1),
                  "hbm_bytes_per_launch": None if hbm is None else int(hbm),
                  "hbm_gbps": None if hbm is None else round(hbm / avg_ns, 1)})
@@ -103,6 +122,9 @@ summary = {
     "dominant_family_launches": calls,
     "dominant_family_avg_us": round(sum(r["avg_us"] * r["calls"] for r in fam) / calls, 2),
     "dominant_family_hbm_bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["calls"] for r in fam) / calls),
+    # the clock the chip held under the dominant family (launch-weighted mean of the per-kernel medians; None without the clock pass)
+    "dominant_family_clock_ghz": (round(sum(r["clock_ghz"] * r["calls"] for r in fam if r["clock_ghz"]) / max(1, sum(r["calls"] for r in fam if r["clock_ghz"])), 3)
+                                  if any(r["clock_ghz"] for r in fam) else None),
     "steps_in_trace": nsteps,
     "total_kernel_ms_per_step": round(sum(r["avg_us"] * r["calls"] for r in step_rows) / (1e3 * nsteps), 3),
     "setup_kernel_ms_excluded": round(sum(r["avg_us"] * r["calls"] for r in rows if not r["per_step"]) / 1e3, 3),
