@@ -4,9 +4,19 @@
 #pragma once
 // (the including unit has <type_traits> and sar_common.h in scope)
 
+// (-DSAR_G2_ABLATE builds, tools/g2_ablate.sh: desc.reserved0 bit 0 drops the output stores, bit 1 the partial sums)
+#ifdef SAR_G2_ABLATE
+#define EPI_ABLATE_STORES &&!(d.reserved0 & 1)
+#define EPI_ABLATE_STATS &&!(d.reserved0 & 2)
+#else
+#define EPI_ABLATE_STORES
+#define EPI_ABLATE_STATS
+#endif
 // ---- epilogue (as conv_gemm.hip): mask / add, store, BatchNorm partial sums.  Every wave is past its last MFMA phase
 // and the closing barrier: the transpose area aliases the operand image.
-template <int MS, int NS, int WN, int BM>
+// EPIF >= 0: only that epilogue is compiled in (a kernel instantiated per epilogue: the gated variant's 160 operand registers no
+// longer set the register count of the launches that only store and sum)
+template <int MS, int NS, int WN, int BM, int EPIF = -1>
 __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, int tile, int wm, int wn, int m0,
                                            const bool (&colok)[NS], const int64_t (&coln)[NS], f32x16 (&acc)[MS][NS],
                                            float4* rowp, float* smem, const int64_t* colna = nullptr) {   // colna: the aux tensor's own column index (default: coln)
@@ -127,16 +137,16 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
               s1 += val;
               s2 = fmaf(val, ux[ns][r8] - ap.z, s2);
             }
-            if (grp_ok)
+            if (grp_ok EPI_ABLATE_STORES)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ro, vo_out[ns],
                                                     (ms * 32 + (r & 3) + 8 * (r >> 2)) * so_out, 0);
           }
-          if (stats) {
+          if (stats EPI_ABLATE_STATS) {
             P[(2 * r8) * 65 + lane] = s1;
             P[(2 * r8 + 1) * 65 + lane] = s2;
           }
         }
-        if (stats) {
+        if (stats EPI_ABLATE_STATS) {
           __builtin_amdgcn_wave_barrier();
           const int q = lane & 15, sub = (lane >> 4) & 1;
           const float* pr = P + q * 65 + hi * 32 + sub * 16;
@@ -153,6 +163,10 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
     }
   };
   (void)stats;
+  if constexpr (EPIF >= 0) {
+    fast_epilogue(std::integral_constant<int, EPIF>());
+    return;
+  }
   switch (d.epi) {   // M % 8 == 0 is a precondition of this kernel (checked by the host)
     case SAR_EPI_STATS: fast_epilogue(std::integral_constant<int, SAR_EPI_STATS>()); break;
     case SAR_EPI_MASK: fast_epilogue(std::integral_constant<int, SAR_EPI_MASK>()); break;

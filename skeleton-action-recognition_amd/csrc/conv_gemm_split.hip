@@ -216,7 +216,15 @@ struct ConvKS {
   int FT, TPS, RW, nparts, ntiles, ny;
   const unsigned* src_bound;   // fp16 arithmetics: bits of an upper bound of |pro(src)| / of |W| (device memory)
   const unsigned* w_bound;
+  int ablate;        // -DSAR_G2_ABLATE builds only (tools/g2_ablate.sh): phases of conv_graph_split2_kernel switched off by SAR_G2_ABLATE_BITS
 };
+// Ablation build of the persistent graph kernel: bit 0 no raw DMA after the first two stages, 1 no regular conversion, 2 no virtual-joint
+// conversion, 3 no MFMA, 4 no weight DMA after the first, 5 no epilogue.  Results are then WRONG; only the launch time is read.
+#ifdef SAR_G2_ABLATE
+#define G2_ON(bit) (!(k.ablate & (1 << (bit))))
+#else
+#define G2_ON(bit) true
+#endif
 
 // TR: 0 forward; 1 data gradient, stride 1; 3 data gradient, stride 2, parity-split column map (conv_gemm.hip).  WIDE: the
 // staged window of a stride-2 forward tile (27 frames) instead of 18.
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
 //   raw(g) was issued behind B(g-2) and waited for by its issuing wave in front of B(g-1): visible to every wave behind C(g-1).
 // The epilogue's transpose area aliases Sl only (W DMA of the next tile's first stage is in flight during the epilogue); a barrier
 // E separates it from the next tile's first convert.
-template <int AR>
+template <int AR, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS k) {
   constexpr int NTA = ar_nta(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR);
   static_assert(AR == AR_H3A, "built for the engine's arithmetic (one accumulator, scaled fp16 terms)");
@@ -1065,6 +1073,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
       // ---- convert raw(ring) -> the term image
       {
         const float* raw = rawl + ring * (KC16 * RAWP);
+        if (G2_ON(1))
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float v[8];
@@ -1078,7 +1087,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
 #pragma unroll
           for (int t = 0; t < NTB; ++t) Sl[(t * 2 + h) * SC + tid] = u[t];
         }
-        if (vact) {   // z = sum_j wt_j x_j: the fp32 kernel's chain (conv_gemm.hip), then the split
+        if (vact && G2_ON(2)) {   // z = sum_j wt_j x_j: the fp32 kernel's chain (conv_gemm.hip), then the split
           float v[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -1099,9 +1108,10 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
       SPLIT_TL(2);   // DMA wait
       __syncthreads();   // B: the term image and the weight pieces are visible; every wave is done with raw(ring)
       SPLIT_TL(3);
-      issue_raw(ring);   // two stages ahead
+      if (G2_ON(0)) issue_raw(ring);   // two stages ahead
       SPLIT_TL(8);   // raw DMA issue
       SAR_LDS_SKEW();
+      if (G2_ON(3))
 #pragma unroll
       for (int tp = 0; tp < 3; ++tp) {
         uint4 a[NTA][MS], bq[NTB][NS];
@@ -1128,8 +1138,10 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
       __syncthreads();   // C: every wave is done with the term image and the weight pieces
       ring ^= 1;
       // the next stage's weights: this tile's next channel groups, or the next tile's first
-      if (s_ + 1 < nst) issue_w_dma(2 * (s_ + 1));
-      else if (tile + tstep < k.ntiles) issue_w_dma(0);
+      if (G2_ON(4)) {
+        if (s_ + 1 < nst) issue_w_dma(2 * (s_ + 1));
+        else if (tile + tstep < k.ntiles) issue_w_dma(0);
+      }
       SPLIT_TL(5);   // closing barrier + W DMA issue
     }
 
@@ -1146,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
           acc[ms][ns][r] = colok[ns] ? v : 0.f;
         }
       }
-    epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp_e, smem);
+    if (G2_ON(5)) epilogue_b<MS, NS, WN, BM, EPI>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp_e, smem);
     SPLIT_TL(6);   // epilogue
     __syncthreads();   // E: the transpose area (inside Sl) is free again
     SPLIT_TL(9);
@@ -1220,6 +1232,14 @@ int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned
   k.wp = wp;
   k.src_bound = src_bound;
   k.w_bound = w_bound;
+  k.ablate = 0;
+#ifdef SAR_G2_ABLATE
+  {
+    const char* e = getenv("SAR_G2_ABLATE_BITS");
+    k.ablate = e ? atoi(e) : 0;
+    k.d.reserved0 = k.ablate >> 6;      // bits 6 / 7: conv_epi_f32.h drops the output stores / the partial sums
+  }
+#endif
   geometry_s(d, tr, k);
   const dim3 grid(((k.ntiles * k.ny + 7) / 8) * 8), block(256);
   if (tr == 4) {
@@ -1227,7 +1247,14 @@ int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned
       if ((graph_split_v2() == 1 || (graph_split_v2() == 2 && d.epi != SAR_EPI_STATS)) && !(d.g_flags & SAR_GRAPH_ONE_TILE_WG)) {   // persistent workgroups, two per CU (SAR_GRAPH_SPLIT2=0 / SAR_GRAPH_ONE_TILE_WG: the one-tile-per-workgroup kernel of round 5)
         const int per = 8 * k.ny;
         const int g2 = (2 * device_cus()) / per * per;
-        hipLaunchKernelGGL((conv_graph_split2_kernel<AR>), dim3(g2 > 0 ? g2 : per), block, 0, st, k);
+        const dim3 grid2(g2 > 0 ? g2 : per);
+        switch (d.epi) {   // one instantiation per epilogue (conv_epi_f32.h: EPIF)
+          case SAR_EPI_STATS: hipLaunchKernelGGL((conv_graph_split2_kernel<AR, SAR_EPI_STATS>), grid2, block, 0, st, k); break;
+          case SAR_EPI_MASK: hipLaunchKernelGGL((conv_graph_split2_kernel<AR, SAR_EPI_MASK>), grid2, block, 0, st, k); break;
+          case SAR_EPI_ADD: hipLaunchKernelGGL((conv_graph_split2_kernel<AR, SAR_EPI_ADD>), grid2, block, 0, st, k); break;
+          case SAR_EPI_ADD_GATE: hipLaunchKernelGGL((conv_graph_split2_kernel<AR, SAR_EPI_ADD_GATE>), grid2, block, 0, st, k); break;
+          default: hipLaunchKernelGGL((conv_graph_split2_kernel<AR, SAR_EPI_NONE>), grid2, block, 0, st, k); break;
+        }
         return 0;
       }
     }
