@@ -16,11 +16,17 @@
 // and the closing barrier: the transpose area aliases the operand image.
 // EPIF >= 0: only that epilogue is compiled in (a kernel instantiated per epilogue: the gated variant's 160 operand registers no
 // longer set the register count of the launches that only store and sum)
-template <int MS, int NS, int WN, int BM, int EPIF = -1>
+// LEAN: half as many rounds' aux operands requested together (gate: one round = 48 registers instead of 96; mask: two rounds = 32
+// instead of 64) -- for a kernel whose epilogue must fit beside a large persistent state (conv_graph_split3_kernel)
+template <int MS, int NS, int WN, int BM, int EPIF = -1, bool LEAN = false>
 __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, int tile, int wm, int wn, int m0,
                                            const bool (&colok)[NS], const int64_t (&coln)[NS], f32x16 (&acc)[MS][NS],
-                                           float4* rowp, float* smem, const int64_t* colna = nullptr) {   // colna: the aux tensor's own column index (default: coln)
-  const int tid = threadIdx.x;
+                                           float4* rowp, float* smem, const int64_t* colna = nullptr,    // colna: the aux tensor's own column index (default: coln)
+                                           int team_tid0 = 0, bool rowp_ready = false) {
+  // team_tid0 / rowp_ready: a kernel whose epilogue runs on a SUBSET of its waves (conv_graph_split3_kernel: the four consumer waves,
+  // threads team_tid0 .. team_tid0 + 255) passes the team's first thread -- the transpose areas and the row-parameter fill are indexed
+  // by the thread's position in the team -- and fills rowp itself once per workgroup (rowp_ready: no fill, no barrier in here)
+  const int tid = threadIdx.x - team_tid0;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;
   const int part = tile * WN + wn;
@@ -30,7 +36,7 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
     constexpr bool gate = EPI == SAR_EPI_ADD_GATE;   // out = gate(acc + aux), sums of the gated values (include/sar_hip.h; conv_gemm.hip)
     constexpr bool stats = EPI == SAR_EPI_STATS || EPI == SAR_EPI_MASK || gate;
     constexpr bool has_aux = EPI == SAR_EPI_MASK || EPI == SAR_EPI_ADD || gate;
-    if (EPI == SAR_EPI_MASK || gate) {
+    if ((EPI == SAR_EPI_MASK || gate) && !rowp_ready) {
       if (tid < BM) {
         const int row = m0 + tid;
         float4 ap = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -81,7 +87,7 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
     // round = 8 accumulator registers = half a 32-row block -- are requested before the first one is processed (gate: two rounds at a
     // time): one exposed memory round trip per workgroup (gate: two) instead of one per round (tools/split_timeline.sh: the MASK epilogue took 27 000 cycles of a 90 000-cycle
     // 64-channel workgroup against 10 000 for STATS; the gated one 31 000).
-    constexpr int NRB = gate ? 2 : 2 * MS;   // rounds requested together (gate: three operands per value -- 96 registers per pair of rounds)
+    constexpr int NRB = (gate ? 2 : 2 * MS) / (LEAN ? 2 : 1);   // rounds requested together (gate: three operands per value -- 96 registers per pair of rounds)
     float axb[NRB][NS][8], uxb[gate ? NRB : 1][NS][8];
     unsigned gmb[gate ? NRB : 1][NS][8];
     auto load_round = [&](int ms, int rb, float (&ax)[NS][8], float (&ux)[NS][8], unsigned (&gm)[NS][8]) {

@@ -67,6 +67,25 @@ for (cin, f, T, s) in shapes:
         span = en.max()
         resid = life.sum() / (ncu * span)
         ph = rows[:, 4:14].mean(axis=0)
+        if os.environ.get("SAR_GRAPH_SPLIT3", "0") == "1" and name.startswith("g_"):
+            # producer / consumer kernel (conv_graph_split3_kernel): two rows per workgroup (row[14] = role)
+            tiles = B * (-(-T // 10))
+            ny = max(1, (cin if name == "g_dgate" else f) // 64)
+            for role, label in ((0, "PRODUCERS"), (1, "CONSUMERS")):
+                rr = rows[rows[:, 14] == role]
+                per_wg = tiles * ny / len(rr)
+                q = rr[:, 4:14].mean(axis=0) / per_wg
+                lf = (rr[:, 1] - rr[:, 0]) * 10.0
+                ghz_r = rr[:, 4:14].sum() / max(lf.sum(), 1)
+                if role == 0:
+                    print("[%3d->%3d T%3d] %-7s %7.1f us | %s %d wgs, %.2f tiles each, %.2f GHz | per TILE: barrier wait %.0f, DMA issue %.0f, convert %.0f, "
+                          "DMA wait %.0f, epilogue-slot wait %.0f (sum %.0f) | prologue per wg %.0f"
+                          % (cin, f, T, name, e0.elapsed_time(e1) * 1e3, label, len(rr), per_wg, ghz_r, q[3], q[8], q[1], q[2], q[6], q[1:].sum(), rr[:, 4].mean()))
+                else:
+                    print("[%3d->%3d T%3d] %-7s %7.1f us | %s %d wgs, %.2f tiles each, %.2f GHz | per TILE: set-up %.0f, barrier wait %.0f, k-steps %.0f, "
+                          "epilogue-slot barrier %.0f, epilogue %.0f (sum %.0f)"
+                          % (cin, f, T, name, e0.elapsed_time(e1) * 1e3, label, len(rr), per_wg, ghz_r, q[7], q[3], q[4], q[5], q[6], q[1:].sum()))
+            continue
         if os.environ.get("SAR_GRAPH_SPLIT2", "1") != "0" and name.startswith("g_"):
             # the persistent kernel (conv_graph_split2_kernel): a row = one workgroup = several tiles; phases per TILE
             ntile_total = {"g_fwd": None}.get(name)
