@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
   constexpr int CJ = NS, ZCOL = 256 * CJ, SCOLS = ZCOL + 1;   // staged elements 0 .. 256 CJ - 1, then the always-zero column
   constexpr int NBUF = DEEP ? 2 : 1;
   constexpr int WPIECES = NTA * TAPS, WPB = WPIECES * 64, ZSLOT = NBUF * WPB;   // weight pieces of 64 units per buffer, then the zero slot
+  constexpr int NTA_LDS = nta_lds(AR);   // images of the weights that are moved to / read from LDS
   constexpr int WU = ZSLOT + 64, SUB = NTB * SCOLS, SU = NBUF * SUB;
   constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area aliases the image
   constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int p = wave + 4 * i;   // wave-uniform
-      if (p < WPIECES)
+      if (p < NTA_LDS * TAPS)   // (f16x3a: the third weight image is formed in registers: split_terms.h third_image)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + buf * WPB + p * 64), 16, wvo, (p * k.G + g) * d.M * 16, 0, 0);
     }
   };
@@ -220,9 +221,13 @@ __global__ __launch_bounds__(256, DEEP ? ((NS == 1 && AR == AR_H3A) ? 2 : 1) : (
     constexpr bool last = q == 4;
     const bool dead = last && hi;   // this lane's half of the last k-step has no tap
 #pragma unroll
-    for (int t = 0; t < NTA; ++t)
+    for (int t = 0; t < NTA_LDS; ++t)
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[dead ? ZSLOT + l31 + ms * 32 : buf * WPB + t * (TAPS * 64) + abase + q * 128 + ms * 32];
+    if constexpr (NTA_LDS < NTA) {
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[NTA - 1][ms] = third_image(a[0][ms]);
+    }
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       constexpr int t0 = 2 * q, t1 = 2 * q + 1;   // tap (kh, kw) = unit offset kh Wq + kw
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_dgrad_
     return kh * 3 + kw;
   };
   auto issue_w_dma = [&](int g16) {
-    const int np = NTA * ntap * 2;   // pieces of this class (wave-uniform)
+    const int np = nta_lds(AR) * ntap * 2;   // pieces of this class (wave-uniform; f16x3a: the third weight image is formed in registers)
     for (int p = wave; p < np; p += 4) {
       const int t = p / (ntap * 2), r = p - t * (ntap * 2), s = r >> 1, h = r & 1;
       const int g = 2 * g16 + h;
@@ -613,9 +618,13 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv2d_split_dgrad_
       const int dr = (py && ir == 0) ? 1 : 0, dc = (px && ic == 0) ? 1 : 0;
       uint4 a[NTA][MS], bq[NTB];
 #pragma unroll
-      for (int t = 0; t < NTA; ++t)
+      for (int t = 0; t < nta_lds(AR); ++t)
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[((t * 4 + s) * 2 + hi) * 64 + l31 + ms * 32];
+      if constexpr (nta_lds(AR) < NTA) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) a[NTA - 1][ms] = third_image(a[0][ms]);
+      }
       const int bo = boff[0] + dr * Wq + dc;
 #pragma unroll
       for (int t = 0; t < NTB; ++t) bq[t] = Sl[(t * 2 + hi) * SCOLS + bo];

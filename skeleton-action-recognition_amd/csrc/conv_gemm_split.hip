@@ -237,6 +237,10 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
   constexpr int ZCOL = WIDE ? 27 * V : 18 * V, SCOLS = ZCOL + 1;
   constexpr int CJ = (ZCOL + 255) / 256;
   constexpr int WPIECES = NTA * TAPS, ZSLOT = WPIECES * 64;   // weight pieces of 64 units, then the zero slot
+  // f16x3a: the third image of the weights (w0 2^-11) is neither moved nor read -- every fragment of it is four v_pk_mul_f16 on the
+  // fragment of w0 (an exact power-of-two scaling with the fp16 rounding the pack kernel applies): a third of the weight DMA pieces
+  // and a fifth of the k-steps' LDS reads less (round 6; bit-identical results)
+  constexpr int NTA_LDS = nta_lds(AR), WPIECES_DMA = NTA_LDS * TAPS;
   constexpr int WU = ZSLOT + 64, SU = NTB * SCOLS;
   constexpr int PAREA_U = 4 * 16 * 65 / 4;   // the epilogue's transpose area aliases the image
   constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int p = wave + 4 * i;   // wave-uniform
-      if (p < WPIECES)
+      if (p < WPIECES_DMA)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + p * 64), 16, wvo, (p * k.G + g) * d.M * 16, 0, 0);
     }
   };
@@ -427,9 +431,13 @@ __global__ __launch_bounds__(256, (WIDE || ar_two_acc(AR)) ? 2 : 3) void conv_ge
     int ao = abase + q * ASTEP;
     const bool dead = last && last_half && hi;   // this lane's half of the k-step has no tap
 #pragma unroll
-    for (int t = 0; t < NTA; ++t)
+    for (int t = 0; t < NTA_LDS; ++t)
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[dead ? ZSLOT + l31 + ms * 32 : t * (TAPS * 64) + ao + ms * 32];
+    if constexpr (NTA_LDS < NTA) {   // f16x3a: the third weight image is w0 2^-11 -- formed here, exactly as the pack kernel rounds it
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a[NTA - 1][ms] = third_image(a[0][ms]);
+    }
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       const int bo = dead ? ZCOL : boff[ns] + q * bstep[ns];

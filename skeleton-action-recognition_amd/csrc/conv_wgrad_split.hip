@@ -139,6 +139,16 @@ __device__ __forceinline__ unsigned pk_f16(float x, float y) {
   p[1] = (_Float16)y;
   return *reinterpret_cast<unsigned*>(&p);
 }
+// f16x3a: the conditioned operand's third image is (first image) x 2^-11.  It is neither written to LDS nor read: a fragment of it is four
+// v_pk_mul_f16 on the fragment of the first image -- an exact power-of-two scaling with the same fp16 rounding split2 applies -- so a
+// third of the stager's LDS stores, one conversion per element pair and a third of the k-steps' operand reads are gone (round 6;
+// bit-identical results).  ntl<AR>() = images that live in LDS.
+template <int AR> constexpr int ntl() { return AR == AR_H3A ? ar_nta(AR) - 1 : ar_nta(AR); }
+__device__ __forceinline__ u32x4 third_image(const u32x4& a0) {
+  const f16x8 w0 = *reinterpret_cast<const f16x8*>(&a0);
+  const f16x8 w2 = w0 * (_Float16)(1.f / H3_LO);
+  return *reinterpret_cast<const u32x4*>(&w2);
+}
 // two adjacent (already scaled) values -> one dword per term.  WSIDE: the conditioned operand's images (src), else dout's
 template <int AR, bool WSIDE>
 __device__ __forceinline__ void split2(float x, float y, unsigned (&w)[WSIDE ? ar_nta(AR) : ar_ntb(AR)]) {
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
         split2<AR, true>(v0, v1, w);
         if (col < RS) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * ROWS + row) * RS + col]) = w[t];
+          for (int t = 0; t < ntl<AR>(); ++t) *reinterpret_cast<unsigned*>(&Hs[(t * ROWS + row) * RS + col]) = w[t];
         }
       }
     }
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
     auto load_tap = [&](unsigned a_ks, int t, unsigned (&w)[NT][5]) {
       const int e = tap_elem(t);
 #pragma unroll
-      for (int tm = 0; tm < NT; ++tm) {
+      for (int tm = 0; tm < ntl<AR>(); ++tm) {
         lds_u32 p = (lds_u32)(uintptr_t)(a_ks + tm * (ROWS * RS * 2) + (e & ~1) * 2);
 #pragma unroll
         for (int i = 0; i < 4 + (e & 1); ++i) w[tm][i] = p[i];
@@ -428,13 +438,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradKS 
             const int e = tap_elem(t);
             u32x4 aq[NT];
 #pragma unroll
-            for (int tm = 0; tm < NT; ++tm) {
+            for (int tm = 0; tm < ntl<AR>(); ++tm) {
               const unsigned (&w)[5] = fw[t % 3][tm];
               if ((e & 1) == 0) aq[tm] = u32x4{w[0], w[1], w[2], w[3]};
               else
                 aq[tm] = u32x4{__builtin_amdgcn_alignbyte(w[1], w[0], 2), __builtin_amdgcn_alignbyte(w[2], w[1], 2),
                                __builtin_amdgcn_alignbyte(w[3], w[2], 2), __builtin_amdgcn_alignbyte(w[4], w[3], 2)};
             }
+            if constexpr (ntl<AR>() < NT) aq[NT - 1] = third_image(aq[0]);
 #pragma unroll
             for (int p = 0; p < NPROD; ++p) {
               const int i = ar_pi(AR, p), j = ar_pj(AR, p);
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
         split2<AR, true>(z[0], z[1], w);
         if (2 * lane < RS) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Zs[((kk * NT + t) * CB + row) * RS + 2 * lane]) = w[t];
+          for (int t = 0; t < ntl<AR>(); ++t) *reinterpret_cast<unsigned*>(&Zs[((kk * NT + t) * CB + row) * RS + 2 * lane]) = w[t];
         }
       }
     }
@@ -672,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
         unsigned w[NT];
         split2<AR, true>(ar_f16(AR) ? xr[q][0] * sa : xr[q][0], ar_f16(AR) ? xr[q][1] * sa : xr[q][1], w);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Zs[(t * CB + wave + 4 * q) * RS + 2 * lane]) = w[t];
+        for (int t = 0; t < ntl<AR>(); ++t) *reinterpret_cast<unsigned*>(&Zs[(t * CB + wave + 4 * q) * RS + 2 * lane]) = w[t];
       }
     }
     } else {
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
             split2<AR, true>(z[0], z[1], w);
             if (2 * lane < RS) {
 #pragma unroll
-              for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Zs[((kk * NT + t) * CB + row) * RS + 2 * lane]) = w[t];
+              for (int t = 0; t < ntl<AR>(); ++t) *reinterpret_cast<unsigned*>(&Zs[((kk * NT + t) * CB + row) * RS + 2 * lane]) = w[t];
             }
           }
         }
@@ -772,7 +783,8 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
           for (int kk = 0; kk < 3; ++kk) {
             u32x4 aq[NT];
 #pragma unroll
-            for (int tm = 0; tm < NT; ++tm) aq[tm] = *(lds_u128)(uintptr_t)(a_ks + (kk * NT + tm) * (CB * RS * 2));
+            for (int tm = 0; tm < ntl<AR>(); ++tm) aq[tm] = *(lds_u128)(uintptr_t)(a_ks + (kk * NT + tm) * (CB * RS * 2));
+            if constexpr (ntl<AR>() < NT) aq[NT - 1] = third_image(aq[0]);
 #pragma unroll
             for (int p = 0; p < NPROD; ++p) {
               const int i = ar_pi(AR, p), j = ar_pj(AR, p);
@@ -922,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
       unsigned w[NT];
       split2<AR, true>(v0, v1, w);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
+      for (int t = 0; t < ntl<AR>(); ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB + row) * RS + col]) = w[t];
     }
   };
 
@@ -1000,7 +1012,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
             const unsigned a_t = a_ks + (unsigned)(st * (RING_FP * 2));
             u32x4 aq[NT];
 #pragma unroll
-            for (int tm = 0; tm < NT; ++tm) aq[tm] = *(lds_u128)(uintptr_t)(a_t + tm * (CB * RS * 2));
+            for (int tm = 0; tm < ntl<AR>(); ++tm) aq[tm] = *(lds_u128)(uintptr_t)(a_t + tm * (CB * RS * 2));
+            if constexpr (ntl<AR>() < NT) aq[NT - 1] = third_image(aq[0]);
 #pragma unroll
             for (int p = 0; p < NPROD; ++p) {
               const int i = ar_pi(AR, p), j = ar_pj(AR, p);

@@ -49,6 +49,16 @@ __device__ __forceinline__ unsigned pk_f16(float x, float y) {
   return *reinterpret_cast<unsigned*>(&p);
 }
 
+// f16x3a: the conditioned operand's third image is (first image) x 2^-11.  The kernels neither move it to LDS nor read it: a fragment of
+// it is four v_pk_mul_f16 on the fragment of the first image -- an exact power-of-two scaling with the fp16 rounding the pack kernel
+// applies -- which removes a third of the weight DMA pieces and a fifth of the k-steps' LDS reads (round 6; bit-identical results).
+constexpr int nta_lds(int ar) { return ar == AR_H3A ? ar_nta(ar) - 1 : ar_nta(ar); }
+__device__ __forceinline__ uint4 third_image(const uint4& a0) {
+  const f16x8 w0 = *reinterpret_cast<const f16x8*>(&a0);
+  const f16x8 w2 = w0 * (_Float16)(1.f / H3_LO);
+  return *reinterpret_cast<const uint4*>(&w2);
+}
+
 // 8 consecutive-channel values of one row / column -> the term units (k-innermost: element j of a unit = channel j).  WSIDE: the
 // W-side (well-conditioned) operand's images, else the source side's.
 template <int AR, bool WSIDE>
