@@ -115,6 +115,11 @@ enum { SAR_EPI_NONE = 0, SAR_EPI_STATS = 1, SAR_EPI_MASK = 2, SAR_EPI_ADD = 3,
 /* g_flags (sar_conv_gemm_split, GRAPH, SAR_SPLIT_F16X3A): take the one-tile-per-workgroup kernel of round 5 instead of the persistent
  * LDS-DMA kernel (bit-identical results; kept for A/B measurements and as the cross-check of tests/test_gpu_split.py) */
 #define SAR_GRAPH_ONE_TILE_WG 16
+/* g_flags (GRAPH, epilogues SAR_EPI_ADD / SAR_EPI_ADD_GATE): `aux` holds EVEN output frames only -- [M][ld_aux] with column
+ * (b * Ta + t / 2) * V + v for even t, Ta = (T_out + 1) / 2; odd output frames add nothing.  The skip gradient that reaches a block
+ * through its strided 1x1 residual convolution (models/stgcn.py:47-56, stride 2) is non-zero on even frames only: the engines
+ * compute it as a dense 1x1 product on the To frames and never materialise (or re-read) the zeros. */
+#define SAR_GRAPH_AUX_EVEN_FRAMES 32
 typedef struct sar_conv_desc {
   int32_t mode;        /* SAR_CONV_* */
   int32_t transposed;  /* TEMPORAL only */

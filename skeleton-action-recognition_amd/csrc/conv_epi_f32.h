@@ -64,7 +64,8 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
-      vo_aux[ns] = colok[ns] ? (unsigned)(((colna ? colna[ns] : coln[ns]) + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+      // (colna < 0: this column has no aux element -- SAR_GRAPH_AUX_EVEN_FRAMES on an odd frame: the rejected load returns 0)
+      vo_aux[ns] = (colok[ns] && (!colna || colna[ns] >= 0)) ? (unsigned)(((colna ? colna[ns] : coln[ns]) + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
     }
     const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);
     // SAR_EPI_ADD_GATE: aux2 [M][ld_aux2] fp32 and its gate bytes [M][ld_aux2 / 4] (bit j of byte i = column 4 i + j)

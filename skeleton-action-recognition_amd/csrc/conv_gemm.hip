@@ -145,6 +145,8 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
   // ---- per-lane column geometry (fixed for the whole kernel)
   bool colok[NS];
   int64_t coln[NS];  // output column index n
+  int64_t colna[NS]; // the aux tensor's column: coln, or (SAR_GRAPH_AUX_EVEN_FRAMES) the even-frame index / -1 on an odd frame
+  const bool aux_even = MODE == SAR_CONV_GRAPH && (d.g_flags & SAR_GRAPH_AUX_EVEN_FRAMES) != 0;
   int off[JT][NS];             // TEMPORAL: LDS column offset per tap slot
   unsigned vmask[NS];          // TEMPORAL TR==2: tap validity bits
   int goff[3][NS][NZMAX];      // GRAPH: LDS column offset of each gather entry
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
     // exactly 0, so the epilogue needs no column predicate for the BatchNorm sums
     if (!colok[ns]) fo = par;
     coln[ns] = ((int64_t)b * d.T_out + (t0 + fo)) * V + v;
+    colna[ns] = aux_even ? (((t0 + fo) & 1) ? -1 : ((int64_t)b * ((d.T_out + 1) >> 1) + ((t0 + fo) >> 1)) * V + v) : coln[ns];
     vmask[ns] = 0;
     if (MODE == SAR_CONV_TEMPORAL) {
 #pragma unroll
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {   // off-tile columns: an offset the range check rejects
       vo_out[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_out) * 4) : 0x80000000u;
-      vo_aux[ns] = colok[ns] ? (unsigned)((coln[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;
+      vo_aux[ns] = (colok[ns] && colna[ns] >= 0) ? (unsigned)((colna[ns] + 4 * hi * d.ld_aux) * 4) : 0x80000000u;   // (rejected: 0)
     }
     const int so_out = (int)(d.ld_out * 4), so_aux = (int)(d.ld_aux * 4);   // bytes per row
     // SAR_EPI_ADD_GATE: aux2 [M][ld_aux2] fp32 and its gate bytes [M][ld_aux2 / 4] (bit j of byte i = column 4 i + j, the layout
@@ -660,12 +663,12 @@ __global__ __launch_bounds__(256, (SAR_OCC3 && TR != 2) ? 3 : 2) void conv_gemm_
             s1 += val;
             s2 = fmaf(val, val, s2);
           } else if (d.epi == SAR_EPI_MASK) {
-            const float ax = d.aux[(int64_t)row * d.ld_aux + coln[ns]];
+            const float ax = colna[ns] >= 0 ? d.aux[(int64_t)row * d.ld_aux + colna[ns]] : 0.f;
             val = (fmaf(ax, asc, ash) > 0.f) ? val : 0.f;
             s1 += val;
             s2 = fmaf(val, ax - amu, s2);
           } else if (d.epi == SAR_EPI_ADD) {
-            val += d.aux[(int64_t)row * d.ld_aux + coln[ns]];
+            val += colna[ns] >= 0 ? d.aux[(int64_t)row * d.ld_aux + colna[ns]] : 0.f;
           }
           d.out[(int64_t)row * d.ld_out + coln[ns]] = val;
         }
@@ -757,7 +760,9 @@ int validate(const sar_conv_desc* d) {
   if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD_GATE)
     SAR_REQUIRE(d->partials, "sar_conv_gemm: partials required");
   if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD || d->epi == SAR_EPI_ADD_GATE)
-    SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm: aux required");
+    SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * (aux_even_frames(*d) ? (d->T_out + 1) / 2 : d->T_out) * d->V, "sar_conv_gemm: aux required");
+  SAR_REQUIRE(!aux_even_frames(*d) || (d->mode == SAR_CONV_GRAPH && (d->epi == SAR_EPI_ADD || d->epi == SAR_EPI_ADD_GATE)),
+              "sar_conv_gemm: SAR_GRAPH_AUX_EVEN_FRAMES goes with the GRAPH operator and the ADD / ADD_GATE epilogues");
   if (d->epi == SAR_EPI_ADD_GATE) {   // fp32: aux2 is [M][ld_aux2] floats, aux_mask [M][ld_aux2 / 4] bytes (one bit per column)
     SAR_REQUIRE(d->mode == SAR_CONV_GRAPH && (d->M & 7) == 0, "sar_conv_gemm: SAR_EPI_ADD_GATE is built for the graph data gradient with M %% 8 == 0");
     SAR_REQUIRE(d->aux2 && d->aux_mask && d->ld_aux2 >= (int64_t)d->B * d->T_out * d->V && (d->ld_aux2 & 3) == 0 && d->ld_aux2 < (1 << 22),

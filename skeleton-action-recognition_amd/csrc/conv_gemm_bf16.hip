@@ -619,6 +619,7 @@ extern "C" int sar_conv_gemm_bf16(const sar_conv_desc* d, void* workspace, sar_s
   SAR_REQUIRE(d->src && d->out, "sar_conv_gemm_bf16: null src/out");   /* W == NULL: workspace is already packed */
   if (d->mode == SAR_CONV_GRAPH) {
     SAR_REQUIRE(d->taps == 3 && d->T_src == d->T_out, "sar_conv_gemm_bf16: graph mode needs 3 adjacency slices and keeps T");
+    SAR_REQUIRE(!(d->g_flags & SAR_GRAPH_AUX_EVEN_FRAMES), "sar_conv_gemm_bf16: SAR_GRAPH_AUX_EVEN_FRAMES is built for sar_conv_gemm_f32 / sar_conv_gemm_split");
     SAR_REQUIRE(d->g_idx && d->g_wt, "sar_conv_gemm_bf16: graph gather tables required");
     SAR_REQUIRE(!d->bias || d->g_colsum, "sar_conv_gemm_bf16: graph bias needs g_colsum");
     for (int i = 0; i < 3; ++i)

@@ -626,7 +626,8 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
 
   // ---- per-lane column geometry and the three slices' operand columns
   bool colok[NS];
-  int64_t coln[NS];
+  int64_t coln[NS], colna[NS];   // colna: the aux tensor's column (SAR_GRAPH_AUX_EVEN_FRAMES: even frames only, -1 on odd ones)
+  const bool aux_even = (d.g_flags & SAR_GRAPH_AUX_EVEN_FRAMES) != 0;
   float gcs[3][NS];
   int baddr[3][NS];
 #pragma unroll
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
     const int pv = colok[ns] ? p : 0;
     coln[ns] = ((int64_t)b * d.T_out + t0) * V + pv;
     const int fo = pv / V, v = pv - fo * V;
+    colna[ns] = aux_even ? (((t0 + fo) & 1) ? -1 : ((int64_t)b * ((d.T_out + 1) >> 1) + ((t0 + fo) >> 1)) * V + v) : coln[ns];
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {
       gcs[tp][ns] = (d.g_colsum && colok[ns]) ? d.g_colsum[tp * V + v] : 0.f;
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
       }
     __syncthreads();   // every wave has read its bias rows: the gated epilogue rewrites rowp
   }
-  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc[0], rowp, smem);
+  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc[0], rowp, smem, colna);
   SPLIT_TL(6);
   SPLIT_TL_END(w);
 }
@@ -978,6 +980,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
   const bool nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.w_bound);
   const float sa = __builtin_ldexpf(1.f, ea);
   const float c0 = nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + ew));
+  const bool aux_even = (d.g_flags & SAR_GRAPH_AUX_EVEN_FRAMES) != 0;
 
   // ---- the virtual joints of the stager: thread = (virtual column, channel half); gathers inside the raw tile
   const int vt = tid >> 1, vh = tid & 1;
@@ -1058,12 +1061,15 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
     const int nfr = (t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0;
     const int ncols = nfr * V;
     bool colok[NS];
-    int64_t coln[NS];
+    int64_t coln[NS], colna[NS];
     int baddr[3][NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       colok[ns] = pcol[ns] < ncols;
-      coln[ns] = ((int64_t)b * d.T_out + t0) * V + (colok[ns] ? pcol[ns] : 0);
+      const int pv = colok[ns] ? pcol[ns] : 0;
+      coln[ns] = ((int64_t)b * d.T_out + t0) * V + pv;
+      const int fo = pv / V;
+      colna[ns] = aux_even ? (((t0 + fo) & 1) ? -1 : ((int64_t)b * ((d.T_out + 1) >> 1) + ((t0 + fo) >> 1)) * V + (pv - fo * V)) : coln[ns];
 #pragma unroll
       for (int tp = 0; tp < 3; ++tp) baddr[tp][ns] = colok[ns] ? baddr_full[tp][ns] : ZCOL + hi * SC;
     }
@@ -1166,7 +1172,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
           acc[ms][ns][r] = colok[ns] ? v : 0.f;
         }
       }
-    if (G2_ON(5)) epilogue_b<MS, NS, WN, BM, EPI>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp_e, smem);
+    if (G2_ON(5)) epilogue_b<MS, NS, WN, BM, EPI>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp_e, smem, colna);
     SPLIT_TL(6);   // epilogue
     __syncthreads();   // E: the transpose area (inside Sl) is free again
     SPLIT_TL(9);
@@ -1389,7 +1395,9 @@ extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void
   if (d->epi == SAR_EPI_STATS || d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD_GATE)
     SAR_REQUIRE(d->partials, "sar_conv_gemm_split: partials required");
   if (d->epi == SAR_EPI_MASK || d->epi == SAR_EPI_ADD || d->epi == SAR_EPI_ADD_GATE)
-    SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * d->T_out * d->V, "sar_conv_gemm_split: aux required");
+    SAR_REQUIRE(d->aux && d->ld_aux >= (int64_t)d->B * (aux_even_frames(*d) ? (d->T_out + 1) / 2 : d->T_out) * d->V, "sar_conv_gemm_split: aux required");
+  SAR_REQUIRE(!aux_even_frames(*d) || (d->mode == SAR_CONV_GRAPH && (d->epi == SAR_EPI_ADD || d->epi == SAR_EPI_ADD_GATE)),
+              "sar_conv_gemm_split: SAR_GRAPH_AUX_EVEN_FRAMES goes with the GRAPH operator and the ADD / ADD_GATE epilogues");
   if (d->epi == SAR_EPI_ADD_GATE)
     SAR_REQUIRE(tr == 4 && d->aux2 && d->aux_mask && (d->ld_aux2 & 3) == 0 && d->ld_aux2 >= (int64_t)d->B * d->T_out * d->V &&
                 d->ld_aux2 < (1 << 22), "sar_conv_gemm_split: SAR_EPI_ADD_GATE is the graph data gradient's, with aux2 / aux_mask, ld_aux2 %% 4 == 0");

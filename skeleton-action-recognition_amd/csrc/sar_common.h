@@ -32,6 +32,8 @@ struct sar_context {
     }                                                                 \
   } while (0)
 
+inline bool aux_even_frames(const sar_conv_desc& d) { return d.mode == SAR_CONV_GRAPH && (d.g_flags & SAR_GRAPH_AUX_EVEN_FRAMES) != 0; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // MFMA 32x32x2 f32 fragment maps (cdna_hip_programming.md section 3):

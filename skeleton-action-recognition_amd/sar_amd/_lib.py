@@ -17,6 +17,7 @@ SAR_GRAPH_FEW_DENSE = 4
 SAR_GRAPH_SLICE0_IDENTITY = 8
 SAR_GRAPH_FEW_DENSE_SHIFT = 8
 SAR_GRAPH_ONE_TILE_WG = 16
+SAR_GRAPH_AUX_EVEN_FRAMES = 32
 SAR_C2D_AUX_EVEN_PIXELS = 1
 SAR_SPLIT = {"bf16x1": 1, "bf16x3": 3, "bf16x6": 6, "bf16x9": 9, "f16x3": 103, "f16x3s": 104, "f16x3a": 105}   # include/sar_hip.h SAR_SPLIT_*
 

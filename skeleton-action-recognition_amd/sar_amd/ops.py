@@ -232,7 +232,7 @@ def _src_bound_single(src, pro):
 def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0,
               transposed=False, bias=None, pro=None, pro_relu=False, tables=None, epi=L.SAR_EPI_NONE, aux=None,
               aux_affine=None, aux_mean=None, bf16=False, packed=None, partials_out=None, aux2=None, aux_mask=None,
-              split="default", bounds=None):
+              split="default", bounds=None, aux_even_frames=False):
     """Launch sar_conv_gemm_f32 -- or, with bf16=True, sar_conv_gemm_bf16 (M % 8 == 0, Kc >= 16: bf16
     MFMA operands, fp32 everything else; other shapes stay on the fp32 kernel); or, with split="bf16x6", the fp32-accurate
     split arithmetic on the bf16 / fp16 matrix pipe (sar_conv_gemm_split; `packed` = the PackedSplitWeights image or None = pack
@@ -268,7 +268,10 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
         d.g_idx, d.g_wt, d.g_colsum = ptr(tables.idx), ptr(tables.wt), ptr(tables.colsum)
         for i in range(3):
             d.nz[i] = tables.nz[i]
-        d.g_flags = tables.g_flags | (L.SAR_GRAPH_ONE_TILE_WG if GRAPH_ONE_TILE_WG else 0)
+        # aux_even_frames: `aux` holds the even output frames only (include/sar_hip.h SAR_GRAPH_AUX_EVEN_FRAMES: the skip gradient through a
+        # stride-2 residual convolution, computed compactly)
+        d.g_flags = (tables.g_flags | (L.SAR_GRAPH_ONE_TILE_WG if GRAPH_ONE_TILE_WG else 0)
+                     | (L.SAR_GRAPH_AUX_EVEN_FRAMES if aux_even_frames else 0))
     if aux is not None:
         d.aux, d.ld_aux = ptr(_f32(aux)), aux.stride(0)
     if aux_affine is not None:

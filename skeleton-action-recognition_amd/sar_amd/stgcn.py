@@ -32,6 +32,10 @@ _FUSE_TAIL_F32 = __import__("os").environ.get("SAR_F32_FUSE_TAIL", "1") == "1"  
 DEFAULT_MFMA = __import__("os").environ.get("SAR_MFMA", "fp32")
 SPLIT_ARITH = {"f32_split": "f16x3a", "f32_split_bf16x6": "bf16x6"}      # engine mode -> arithmetic of csrc/conv_gemm_split.hip
 # A/B switch: which kernel families of a split engine take the split kernels (default all that are built)
+# the skip gradient of a conv-residual block as its even frames only: "fp32" (default) = the fp32-arithmetic engine, where it measured
+# +0.4 % (58.70 -> 58.47 ms, interleaved); "1" = the split engines too (single stream -0.29 ms, two streams 34.34 -> 34.44 ms: not taken);
+# "0" = never (gpurun_out/compact_skip_ab*.txt)
+_COMPACT_SKIP = __import__("os").environ.get("SAR_COMPACT_SKIP", "fp32")
 _SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS", "tfwd,tdgrad,twgrad,gfwd,gdgrad,gwgrad").split(","))
 # (filters, stride, residual) -- models/stgcn.py:113-123
 BLOCKS = [(64, 1, False), (64, 1, True), (64, 1, True), (64, 1, True), (128, 2, True), (128, 1, True), (128, 1, True),
@@ -685,16 +689,17 @@ class STGCN:
             gT = self._wT[o:o + KS * f * cin]                             # [k][f][c]
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
+        even = kind == "conv" and aux is not None and self._compact_skip(s, T)      # dXres holds the even frames only
         sgimg = self._simg(pre + "gcn.b")
         if below is not None and aux is not None:
             # dX = gate_{i-1}(W^T dg . A^T + skip gradient) and block i - 1's BatchNorm-backward sums in one epilogue
             bn2b = self.bn["l%d.bn2" % (i - 1)]
             pm = ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
                                tables=self.tab_bwd, epi=L.SAR_EPI_ADD_GATE, aux=aux, aux2=below["u"], aux_mask=below["ymask"],
-                               aux_mean=bn2b.mean, **self._split_args(sgimg, self._cell(i, 2), None))
+                               aux_mean=bn2b.mean, aux_even_frames=even, **self._split_args(sgimg, self._cell(i, 2), None))
             return dX, pm
         ops.conv_gemm(L.SAR_CONV_GRAPH, dg, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=KS,
-                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux,
+                      tables=self.tab_bwd, epi=L.SAR_EPI_ADD if aux is not None else L.SAR_EPI_NONE, aux=aux, aux_even_frames=even,
                       **self._split_args(sgimg, self._cell(i, 2), gimg))
         return (dX, None) if fused_call else dX
 
@@ -716,10 +721,25 @@ class STGCN:
         elif rimg is None:             # engines without the batched re-layout (ST-GIN)
             rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
             ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
+        if self._compact_skip(s, T):
+            # the gradient through a stride-2 1x1 convolution is non-zero on EVEN input frames only: a dense 1x1 product over the To
+            # frames (half the matrix work of the strided data gradient, half the bytes written), added by the graph data gradient's
+            # epilogue on even frames (SAR_GRAPH_AUX_EVEN_FRAMES) -- the zeros are neither written nor read back
+            dXc = torch.empty((cin, B * To * V), dtype=torch.float32, device=dev)
+            ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXc, rT, 0, cin, B=B, V=V, T_src=To, T_out=To, Kc=f, M=cin, taps=1, stride=1, pad=0,
+                          split=None)
+            return dXc
         dXres = torch.empty((cin, B * T * V), dtype=torch.float32, device=dev)
         ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
                       stride=s, pad=0, transposed=True, bf16=self.bf16, packed=rimg)
         return dXres
+
+    def _compact_skip(self, s, T):
+        """the skip gradient of a conv-residual block as its even frames only (SAR_COMPACT_SKIP=0: the strided data gradient over all
+        T frames): fp32-storage engines with gather tables and fp32 / split arithmetic"""
+        on = _COMPACT_SKIP == "1" or (_COMPACT_SKIP == "fp32" and not self.split)
+        return (on and s == 2 and not self.bf16 and not getattr(self, "cn8", False)
+                and not self.dense_A and type(self)._block_backward is STGCN._block_backward)
 
     def _graph_backward_dense(self, i, sb, dg, dY, dr, B, flat_g):
         """Backward of Conv2D(3F, 1x1) -> einsum with the trainable adjacency (models/gcn.py:229-237): dy3 = dg . A^T per

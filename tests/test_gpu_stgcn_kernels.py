@@ -169,6 +169,44 @@ def test_graph_data_gradient_gated_epilogue_f32(dev, B, cin, f, T):
     assert rel_err(part[:, 0], s1) < 1e-6 and rel_err(part[:, 1], s2) < 1e-6
 
 
+@pytest.mark.parametrize("B,cin,f,T", [(2, 64, 128, 12), (3, 128, 256, 9), (2, 64, 128, 300), (1, 3, 64, 7), (5, 64, 128, 33)])
+def test_graph_data_gradient_adds_an_even_frame_skip_gradient(dev, B, cin, f, T):
+    """SAR_GRAPH_AUX_EVEN_FRAMES (include/sar_hip.h): `aux` holds the EVEN output frames only -- the skip gradient through a stride-2
+    1x1 residual convolution (models/stgcn.py:47-56), which the engines compute as a dense product over the To frames.  The result
+    must equal, bit for bit, the plain SAR_EPI_ADD / SAR_EPI_ADD_GATE launch fed with the zero-interleaved tensor (odd T, ragged
+    tiles, the 3-channel generic epilogue, both arithmetics through tests/conftest.py)."""
+    from sar_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(5 * cin + f + T)
+    n, Ta = B * T * 25, (T + 1) // 2
+    kernel = torch.randn(1, 1, cin, 3 * f, generator=g) * 0.1
+    dout = torch.randn(f, n, generator=g).to(dev)
+    compact = torch.randn(cin, B * Ta * 25, generator=g)
+    full = torch.zeros(cin, B, T, 25)
+    full[:, :, 0::2] = compact.view(cin, B, Ta, 25)
+    full = full.reshape(cin, n).to(dev)
+    compact = compact.to(dev)
+    gT = torch.empty((3 * f, cin), device=dev)
+    ops.transpose(kernel.to(dev).contiguous(), gT, 1, cin, 3 * f)
+    args = dict(B=B, V=25, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=_tables(dev, True))
+    want, got = torch.empty((cin, n), device=dev), torch.full((cin, n), float("nan"), device=dev)
+    ops.conv_gemm(L.SAR_CONV_GRAPH, dout, want, gT, f * cin, cin, epi=L.SAR_EPI_ADD, aux=full, **args)
+    ops.conv_gemm(L.SAR_CONV_GRAPH, dout, got, gT, f * cin, cin, epi=L.SAR_EPI_ADD, aux=compact, aux_even_frames=True, **args)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    if cin % 8 == 0 and n % 4 == 0:
+        u = torch.randn(cin, n, generator=g).to(dev)
+        mean = (0.1 * torch.randn(cin, generator=g)).to(dev)
+        keep = (torch.rand(cin, n, generator=g) > 0.4).to(dev)
+        mask = (keep.view(cin, n // 4, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], device=dev, dtype=torch.int32)).sum(dim=2).to(torch.uint8).contiguous()
+        want2, got2 = torch.empty((cin, n), device=dev), torch.full((cin, n), float("nan"), device=dev)
+        p1 = ops.conv_gemm(L.SAR_CONV_GRAPH, dout, want2, gT, f * cin, cin, epi=L.SAR_EPI_ADD_GATE, aux=full, aux2=u, aux_mask=mask,
+                           aux_mean=mean, **args)
+        p2 = ops.conv_gemm(L.SAR_CONV_GRAPH, dout, got2, gT, f * cin, cin, epi=L.SAR_EPI_ADD_GATE, aux=compact, aux2=u, aux_mask=mask,
+                           aux_mean=mean, aux_even_frames=True, **args)
+        torch.cuda.synchronize()
+        assert torch.equal(got2, want2) and torch.equal(p1[0], p2[0])
+
+
 @pytest.mark.parametrize("B,f,T,s", [(2, 64, 13, 1), (2, 64, 14, 2), (2, 128, 9, 2), (1, 256, 7, 1), (2, 64, 11, 2), (4, 256, 75, 1), (3, 128, 150, 2),
                                      (2, 72, 11, 1), (1, 200, 9, 2), (2, 44, 12, 2)])
 def test_temporal_conv_gradients(dev, B, f, T, s):
