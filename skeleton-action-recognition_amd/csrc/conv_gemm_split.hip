@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(256, 2) void conv_graph_split2_kernel(const ConvKS 
           acc[ms][ns][r] = colok[ns] ? v : 0.f;
         }
       }
-    if (G2_ON(5)) epilogue_b<MS, NS, WN, BM, EPI>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp_e, smem, colna);
+    if (G2_ON(5)) epilogue_b<MS, NS, WN, BM, EPI, true>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp_e, smem, colna);
     SPLIT_TL(6);   // epilogue
     __syncthreads();   // E: the transpose area (inside Sl) is free again
     SPLIT_TL(9);

@@ -121,6 +121,7 @@ class PackedSplitWeights(PackedWeights):
         return self.amax[i:i + 1]
 
 
+_WGRADS_SLOTS = int(os.environ.get("SAR_WGRAD_SPLIT_SLOTS", "512"))   # workgroups of a split weight-gradient launch (default: two per CU)
 _side_streams = {}
 GRAPH_ONE_TILE_WG = False     # tests / A-B: the round-5 graph kernel of the split arithmetic (include/sar_hip.h: SAR_GRAPH_ONE_TILE_WG)
 SIDE_CU_MASK_DEFAULT = "off"
@@ -348,9 +349,9 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
         sp_blocks = lib.sar_conv_wgrad_split_blocks(C.byref(d), L.SAR_SPLIT[split], C.byref(wk), C.byref(kt))
         if sp_blocks > 0:
             bf16 = False
-            if nsplit is None:      # one round of the 512 resident workgroups (two per CU)
+            if nsplit is None:      # one round of the 512 resident workgroups (two per CU); SAR_WGRAD_SPLIT_SLOTS: experiment
                 ntiles = B * ((T_out * V + kt.value - 1) // kt.value)
-                nsplit = max(1, min(ntiles, 512 // sp_blocks)) * wk.value
+                nsplit = max(1, min(ntiles, _WGRADS_SLOTS // sp_blocks)) * wk.value
             else:
                 nsplit = (nsplit + wk.value - 1) // wk.value * wk.value
     split = split if sp_blocks > 0 else None

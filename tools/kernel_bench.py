@@ -68,6 +68,9 @@ def main():
             flat_g = torch.empty(cin * 3 * f + 3 * f, device=dev)
             flat_t = torch.empty(9 * f * f + f, device=dev)
             U = U * 1e-5      # gradient-like magnitudes
+            gmask = (torch.randint(0, 256, (max(cin, 8), n_in // 4), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+                     if n_in % 4 == 0 else None)
+            gmean = 0.1 * rn(cin)
             sp = a.split
             kw = {k_: dict(split=None) for k_ in ("gf", "gb", "tf", "tb", "tw", "gw")}
             if sp:
@@ -98,6 +101,10 @@ def main():
                 "gcn_dgrad": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_gemm(
                     L.SAR_CONV_GRAPH, G, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tb_,
                     epi=L.SAR_EPI_ADD, aux=X, bf16=a.bf16, **kw["gb"])),
+                # the gated data gradient (SAR_EPI_ADD_GATE): what 7 of the 9 graph data gradients of a train step are
+                "gcn_dgate": (2.0 * f * cin * 3 * n_in, lambda: ops.conv_gemm(
+                    L.SAR_CONV_GRAPH, G, dX, gT, f * cin, cin, B=B, V=V, T_src=T, T_out=T, Kc=f, M=cin, taps=3, tables=tb_,
+                    epi=L.SAR_EPI_ADD_GATE, aux=X, aux2=X, aux_mask=gmask, aux_mean=gmean, bf16=a.bf16, **kw["gb"])),
                 "tconv_wgrad": (2.0 * f * f * 9 * n_out, lambda: ops.conv_wgrad(
                     L.SAR_CONV_TEMPORAL, G, U, flat_t, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=9, stride=s, pad=pad,
                     pro=None if NOPRO else (sc, sh), pro_relu=not NOPRO, w_stride_tap=f * f, w_stride_c=f, wsize=9 * f * f, bsize=f, bf16=a.bf16,
@@ -108,6 +115,8 @@ def main():
             }
             for name, (flops, fn) in cases.items():
                 if only and name not in only:
+                    continue
+                if name == "gcn_dgate" and (not only or cin % 8 or gmask is None):      # on request only; M % 8 == 0
                     continue
                 ms = timeit(fn, a.reps)
                 tf = flops / (ms * 1e-3) / 1e12
