@@ -41,7 +41,15 @@ struct WgradKS {     // kernel argument (the same definition in every part)
   float invH2;
   const unsigned* src_bound;
   const unsigned* dout_bound;
+  int ablate;        // -DSAR_GW_ABLATE builds only (tools/gw_ablate.sh): phases of graph_wgrad_split_kernel switched off by SAR_GW_ABLATE_BITS
 };
+// bit 0: no gathered slices (1, 2), 1: no slice-0 images, 2: dout fragments not converted (zeros), 3: no MFMA, 4: no slab stores.  Results are
+// then WRONG; only the launch time is read.
+#ifdef SAR_GW_ABLATE
+#define GW_ON(bit) (!(k.ablate & (1 << (bit))))
+#else
+#define GW_ON(bit) true
+#endif
 
 namespace {
 
@@ -653,6 +661,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
     }
     __syncthreads();   // the raw tile is complete
     // ---- slices 1 and 2: gathered from the raw tile (a wave builds the rows it staged; the barrier above covers all rows)
+    if (GW_ON(0))
 #pragma unroll 1
     for (int q = 0; q < 8; ++q) {
       const int row = wave + 4 * q;
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
       }
     }
     __syncthreads();   // every wave has gathered from the raw tile: its area becomes slice 0's images
-    if (2 * lane < RS) {
+    if (2 * lane < RS && GW_ON(1)) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         unsigned w[NT];
@@ -772,8 +781,8 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-              unsigned w[NTB];
-              split2<AR, false>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
+              unsigned w[NTB] = {};
+              if (GW_ON(2)) split2<AR, false>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
 #pragma unroll
               for (int t = 0; t < NTB; ++t) bw[mb][t][p] = w[t];
             }
@@ -785,6 +794,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
 #pragma unroll
             for (int tm = 0; tm < ntl<AR>(); ++tm) aq[tm] = *(lds_u128)(uintptr_t)(a_ks + (kk * NT + tm) * (CB * RS * 2));
             if constexpr (ntl<AR>() < NT) aq[NT - 1] = third_image(aq[0]);
+            if (GW_ON(3))
 #pragma unroll
             for (int p = 0; p < NPROD; ++p) {
               const int i = ar_pi(AR, p), j = ar_pj(AR, p);
@@ -815,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_split_kernel(const WgradKS
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = c0 + mfma_row(r, hi);
-        if (c < d.Kc && m < d.M) slab[(int64_t)kk * d.w_stride_tap + (int64_t)c * d.w_stride_c + m] = acc[kk][mb][r] * unscale;
+        if (c < d.Kc && m < d.M && GW_ON(4)) slab[(int64_t)kk * d.w_stride_tap + (int64_t)c * d.w_stride_c + m] = acc[kk][mb][r] * unscale;
       }
       if (do_bias) {
         const float t = bsum[kk][mb] + __shfl_xor(bsum[kk][mb], 32);
@@ -1081,6 +1091,13 @@ int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, cons
   k.d = d;
   k.src_bound = sb;
   k.dout_bound = db;
+  k.ablate = 0;
+#ifdef SAR_GW_ABLATE
+  {
+    const char* e = getenv("SAR_GW_ABLATE_BITS");
+    k.ablate = e ? atoi(e) : 0;
+  }
+#endif
   if (d.mode == SAR_CONV_GRAPH) {
     k.TPS = (d.T_out + GFT - 1) / GFT;
     k.ntiles = d.B * k.TPS;
@@ -1243,6 +1260,7 @@ extern "C" int sar_conv2d_wgrad_split(const sar_conv2d_desc* d, int arith, const
   SAR_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "sar_conv2d_wgrad_split: pro_scale/pro_shift mismatch");
   SAR_REQUIRE(arith != AR_H3A || (src_bound && dout_bound), "sar_conv2d_wgrad_split: the fp16 arithmetic needs the operand bounds");
   WgradKS k;
+  k.ablate = 0;
   k.d = sar_wgrad_desc{};
   k.d.mode = SAR_CONV_TEMPORAL;
   k.d.B = 1, k.d.V = VJ, k.d.T_src = 1, k.d.T_out = 1;
