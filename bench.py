@@ -35,6 +35,7 @@ PEAK_FP64_VALU_TFLOPS = 78.6       # MI355X: packed-free fp64 vector FMA, half t
 
 FAMILY_PREFIX = {"fp32": ("conv_gemm_kernel<1, ",), "bf16": ("conv_gemm_cn8_kernel<", "conv_gemm_cn8_db_kernel<", "conv_gemm_cn8_dma_kernel<"),
                  "bf16_operands": ("conv_gemm_bf16_kernel<",), "pathB": ("conv2d_gemm_kernel",), "pathB_f32_split": ("conv2d_split_kernel<",),
+                 "pathB_pad250": ("conv2d_gemm_kernel",),
                  "f32_split": ("conv_gemm_split_kernel<",), "f32_split_bf16x6": ("conv_gemm_split_kernel<",)}
 PROFILE_CLOCK = {}   # mode -> the clock the dominant family held in the newest committed profile (GRBM_GUI_ACTIVE pass), or None
 BOX = {}        # the box calibration of this process (sar_amd/box.py), filled by main() before the first leg
@@ -67,6 +68,7 @@ def measured_traffic(mode="fp32"):
     are not this mode's kernel family is refused (None)."""
     import glob
     pat = {"pathB": "r[0-9][0-9]_pathB_kernel_summary.json", "bf16": "r[0-9][0-9]_bf16_kernel_summary.json",
+           "pathB_pad250": "r[0-9][0-9]_pathB_pad250_kernel_summary.json",
            "f32_split": "r[0-9][0-9]_f32split_kernel_summary.json", "f32_split_bf16x6": "r[0-9][0-9]_f32split_bf16x6_kernel_summary.json",
            "pathB_f32_split": "r[0-9][0-9]_pathB_f32split_kernel_summary.json",
            "bf16_operands": "r[0-9][0-9]_bf16_operands_kernel_summary.json"}.get(mode, "r[0-9][0-9]_kernel_summary.json")
@@ -130,7 +132,7 @@ def cpu_baseline(batch=64, fallback_clips=8, budget_s=80.0, classes=60):
         t0 = time.time()
         one(x, y)
         dt, n = time.time() - t0, 1
-        clips, what = batch, "2 warm-up steps on %d clips + 1 timed full-batch step" % fallback_clips
+        clips, what = batch, "2 warm-up steps on %d clips + 1 timed step" % fallback_clips
     else:
         t0 = time.time()
         n = 0
@@ -138,10 +140,9 @@ def cpu_baseline(batch=64, fallback_clips=8, budget_s=80.0, classes=60):
             one(xs, ys)
             n += 1
         dt = time.time() - t0
-        clips, what = fallback_clips, "FALLBACK (a bs=%d step would exceed the %d s budget): %d timed steps" % (batch, budget_s, n)
+        clips, what = fallback_clips, "FALLBACK (bs=%d would exceed %d s): %d timed steps" % (batch, budget_s, n)
     return {"value": round(clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
-            "sample": "%s of fwd+bwd+SGD on a %d-clip (3,300,25,2) fp32 batch, torch CPU ops, %d threads"
-                      % (what, clips, cores)}
+            "sample": "%s, fwd+bwd+SGD, %d-clip fp32 batch, torch CPU ops, %d threads" % (what, clips, cores)}
 
 
 def cpu_baseline_spectrogram(sample_clips, budget_s=12.0, num_pad_frames=0):
@@ -182,9 +183,8 @@ def cpu_baseline_spectrogram(sample_clips, budget_s=12.0, num_pad_frames=0):
             break
     dt = time.time() - t0
     return {"value": round(sample_clips * n / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
-            "sample": "%d timed steps of %sVirtualRadar + resnet18 fwd+bwd+Adam on %d (3,300,25,2) clips, numpy / scipy / torch CPU "
-                      "ops, %d threads" % (n, "the loader's x%d up-sampling + " % num_pad_frames if num_pad_frames else "",
-                                           sample_clips, cores)}
+            "sample": "%d timed steps, %sVirtualRadar + resnet18 fwd+bwd+Adam, %d clips, numpy/scipy/torch CPU ops, %d threads"
+                      % (n, "x%d up-sampling + " % num_pad_frames if num_pad_frames else "", sample_clips, cores)}
 
 
 def launch_ranks(n):
@@ -526,7 +526,8 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
         calls = sum(summ[k]["calls"] for k in fam)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         value = bs * world * steps / dt
-        traffic, traffic_src = measured_traffic("pathB_f32_split" if split else "pathB") if not pad else (None, None)
+        tmode = ("pathB_f32_split" if split else "pathB") if not pad else (None if split else "pathB_pad250")   # (no profile set of the split pad250 leg)
+        traffic, traffic_src = measured_traffic(tmode) if tmode else (None, None)
         nprod = 6 if mfma.endswith("bf16x6") else 3
         front = "VirtualRadar%s" % (" (x%d up-sampling)" % pad if pad else "")
         net = "resnet18 f32_split (%s)" % ("bf16x6" if nprod == 6 else "f16x3a") if split else "resnet18 fp32"
@@ -542,7 +543,7 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
             "final_loss": round(float(loss.item()), 5),
         }
         common = {"timing": "in_step+wgrad_stream", "traffic": traffic, "traffic_src": traffic_src,
-                  "clock_ghz": PROFILE_CLOCK.get("pathB_f32_split" if split else "pathB") if not pad else None}
+                  "clock_ghz": PROFILE_CLOCK.get(tmode) if tmode else None}
         if not split:
             out["roofline"] = {"bound": "mfma", "kernel": "conv2d_gemm_kernel 3x3 fwd+dgrad+wgrad", "achieved": round(achieved, 2),
                                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
