@@ -182,4 +182,3 @@ __device__ __forceinline__ void epilogue_b(const sar_conv_desc& d, int nparts, i
     default: fast_epilogue(std::integral_constant<int, SAR_EPI_NONE>()); break;
   }
 }
-
