@@ -254,6 +254,17 @@ int sar_conv_wgrad_f32(const sar_wgrad_desc* d, sar_stream_t s);
 int sar_conv_wgrad_bf16(const sar_wgrad_desc* d, sar_stream_t s);
 /* out[i] = sum_s slab[s*slab_stride + i] (i < n), summed in split order. */
 int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_stride, int64_t n, float* out, sar_stream_t s);
+/* The same reduction for a BATCH of weight gradients in ONE launch (round 6: a train step reduced its 20-22 slab sets by as many
+ * launches behind their weight-gradient kernels -- 3-4 % of the fp32-storage steps, tools/skip_probe.py): items = DEVICE table,
+ * every out[i] is summed exactly as sar_slab_reduce_f32 sums it (bit-identical); max_n = the largest n of the batch.  The engines
+ * issue one call per gradient bucket (main_gnn.py:234,239: the slice's all-reduce follows it). */
+typedef struct sar_slab_item {
+  const float* slab;        /* [nsplit][slab_stride] */
+  float* out;               /* [n] */
+  int64_t slab_stride, n;
+  int32_t nsplit, reserved;
+} sar_slab_item;
+int sar_slab_reduce_batch_f32(const sar_slab_item* items, int nitems, int64_t max_n, sar_stream_t s);
 /* The weight / bias gradient of the same operator in the split arithmetics SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A
  * (csrc/conv_wgrad_split.hip; SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A): same descriptor and slab contract as sar_conv_wgrad_f32 (slabs reduced by sar_slab_reduce_f32),
  * src_bound / dout_bound = bound cells of pro(src) / dout for the fp16 arithmetic.  Built for the 9-tap TEMPORAL operator at

@@ -787,6 +787,33 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   if (g == 0 && i < n) out[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// the same sums for a batch of slab sets: blockIdx.y = item (device table), blockIdx.x = 64 outputs of it; per element the
+// additions of slab_reduce_kernel in the same order (bit-identical)
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const sar_slab_item* __restrict__ items) {
+  __shared__ float part[4][64];
+  const sar_slab_item it = items[blockIdx.y];
+  if ((int64_t)blockIdx.x * 64 >= it.n) return;   // uniform
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int nsplit = it.nsplit;
+  const int64_t slab_stride = it.slab_stride;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < it.n) {
+    const float* p = it.slab + i;
+    int k = g;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += p[(int64_t)k * slab_stride];
+      s1 += p[(int64_t)(k + 4) * slab_stride];
+      s2 += p[(int64_t)(k + 8) * slab_stride];
+      s3 += p[(int64_t)(k + 12) * slab_stride];
+    }
+    for (; k < nsplit; k += 4) s0 += p[(int64_t)k * slab_stride];
+  }
+  part[g][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && i < it.n) it.out[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 size_t lds_bytes(const sar_wgrad_desc& d, const WgradK& k, int BF, int CT) {
   size_t lds = sizeof(float) * ((size_t)BF * k.DP + (size_t)CT * k.SP);
   if (d.mode == SAR_CONV_GRAPH) lds += sizeof(float) * (4 + (size_t)d.V * 28);   // packed gather rows (ROW <= 28)
@@ -1041,5 +1068,14 @@ extern "C" int sar_slab_reduce_f32(const float* slab, int nsplit, int64_t slab_s
   SAR_REQUIRE(blocks < (1ll << 31), "sar_slab_reduce: n too large");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), slab, nsplit, slab_stride, n, out);
   SAR_LAUNCH_CHECK("sar_slab_reduce_f32");
+  return 0;
+}
+
+extern "C" int sar_slab_reduce_batch_f32(const sar_slab_item* items, int nitems, int64_t max_n, sar_stream_t s) {
+  SAR_REQUIRE(items && nitems >= 1 && nitems <= 65535 && max_n > 0, "sar_slab_reduce_batch: bad arguments");
+  const int64_t blocks = (max_n + 63) / 64;
+  SAR_REQUIRE(blocks < (1ll << 31), "sar_slab_reduce_batch: n too large");
+  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3((unsigned)blocks, (unsigned)nitems), dim3(256), 0, as_stream(s), items);
+  SAR_LAUNCH_CHECK("sar_slab_reduce_batch_f32");
   return 0;
 }

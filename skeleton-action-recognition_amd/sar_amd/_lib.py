@@ -101,6 +101,7 @@ SIGNATURES = {
     "sar_conv_wgrad_f32": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_conv_wgrad_bf16": (_i, [C.POINTER(WgradDesc), _fp]),
     "sar_slab_reduce_f32": (_i, [_fp, _i, _i64, _i64, _fp, _fp]),
+    "sar_slab_reduce_batch_f32": (_i, [_fp, _i, _i64, _fp]),
     "sar_bn_finalize_f32": (_i, [_fp, _i, _i, _d, _f, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sar_bn_eval_affine_f32": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _fp]),
     "sar_bn_bwd_finalize_f32": (_i, [_fp, _i, _i64, _i64, _i, _i, _i, _i, _d, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -321,8 +321,55 @@ _WGRAD9_SLOTS = int(__import__("os").environ.get("SAR_WGRAD9_SLOTS", "1024"))   
 _WGRADG_SLOTS = int(__import__("os").environ.get("SAR_WGRADG_SLOTS", "512"))       # ... of the graph ones
 
 
+# SAR_SLAB_BATCH=0: every weight gradient reduces its slabs by its own launch again (A/B switch)
+SLAB_BATCH = __import__("os").environ.get("SAR_SLAB_BATCH", "1") == "1"
+# when an engine flushes its batch: "end" = at the end of backward (and before a bucket goes to the all-reduce), "bucket" = at every
+# bucket boundary also without a data-parallel callback, "block" = behind every block
+SLAB_FLUSH = __import__("os").environ.get("SAR_SLAB_FLUSH", "end")
+
+
+class SlabBatch:
+    """The partial slabs of the weight gradients of a backward pass, summed by ONE launch per flush() (sar_slab_reduce_batch_f32:
+    per element the additions of sar_slab_reduce_f32 in the same order -- bit-identical) instead of one launch behind every
+    weight-gradient kernel: a step had 20-22 of them, 3-4 % of the fp32-storage steps (tools/skip_probe.py).  The slab buffers are
+    owned here and re-used every step (key = the destination slice of the flat gradient buffer), so a flush of the same items finds
+    its device table in the cache.  Everything -- weight-gradient kernels and flush() -- must be issued on ONE stream (the engines'
+    weight-gradient stream); an engine flushes before a gradient bucket is handed to the all-reduce and at the end of backward."""
+
+    ITEM = [("slab", "<u8"), ("out", "<u8"), ("stride", "<i8"), ("n", "<i8"), ("nsplit", "<i4"), ("reserved", "<i4")]
+
+    def __init__(self):
+        self._slabs, self._pending, self._tables = {}, [], {}
+
+    def slab(self, out, nsplit, n):
+        """the (nsplit, n) slab buffer of the weight gradient that ends in out[0:n]"""
+        key = (out.data_ptr(), nsplit, n)
+        t = self._slabs.get(key)
+        if t is None:
+            t = self._slabs[key] = torch.empty((nsplit, n), dtype=torch.float32, device=out.device)
+        return t
+
+    def add(self, slab, nsplit, n, out):
+        assert out.numel() >= n and out.is_contiguous() and slab.stride(0) >= n
+        self._pending.append((slab.data_ptr(), out.data_ptr(), slab.stride(0), n, nsplit, 0))
+        self._device = slab.device
+
+    def flush(self):
+        if not self._pending:
+            return
+        key, self._pending = tuple(self._pending), []
+        ent = self._tables.get(key)
+        if ent is None:
+            import numpy as np
+            tab = np.array(list(key), dtype=np.dtype(self.ITEM, align=True))
+            assert tab.dtype.itemsize == 40          # sizeof(sar_slab_item)
+            ent = self._tables[key] = (torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self._device), max(it[3] for it in key))
+        check(L.load().sar_slab_reduce_batch_f32(ptr(ent[0]), len(key), ent[1], stream_ptr()), "sar_slab_reduce_batch_f32")
+
+
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
-               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, bf16=False, split="default", bounds=None):
+               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, bf16=False, split="default", bounds=None,
+               slabs=None):
     """dW (and dbias, stored right behind it) -> dW_out[0 : wsize+bsize] (flat float32 view).  bf16=True routes the
     9-tap temporal operator (V = 25; stride 1, or stride 2 with the even-T SAME padding 3) to sar_conv_wgrad_bf16 (bf16 MFMA operands, fp32 accumulation and bias
     sums); every other shape stays on the fp32 kernel."""
@@ -380,7 +427,10 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
         nsplit = max(1, min(ntiles, (target + wgs - 1) // wgs))
     d.nsplit = nsplit
     d.w_stride_tap, d.w_stride_c, d.wsize, d.bsize = w_stride_tap, w_stride_c, wsize, bsize
-    slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
+    assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
+    # slabs (SlabBatch): the slabs are summed by the batch's next flush() instead of by a launch of their own
+    slab = (slabs.slab(dW_out, nsplit, wsize + bsize) if slabs is not None
+            else torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device))
     d.slab = ptr(slab)
     tag = "wgrad_graph" if mode == L.SAR_CONV_GRAPH else "wgrad_temporal%d" % taps
     if split:
@@ -397,7 +447,9 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
             check(lib.sar_conv_wgrad_bf16(C.byref(d), stream_ptr()), "sar_conv_wgrad_bf16")
         else:
             check(lib.sar_conv_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv_wgrad_f32")
-    assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
+    if slabs is not None:
+        slabs.add(slab, nsplit, wsize + bsize, dW_out)
+        return
     check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, wsize + bsize, wsize + bsize, ptr(dW_out), stream_ptr()),
           "sar_slab_reduce_f32")
 
@@ -811,7 +863,7 @@ def conv2d_gemm(src, out, W, w_stride_tap, w_stride_c, *, epi=L.SAR_EPI_NONE, au
 _C2D_WG_SLOTS = int(__import__("os").environ.get("SAR_C2D_WG_SLOTS", "512"))
 
 
-def conv2d_wgrad(src, dout, dW_tcm, *, split="default", bounds=None, **geo):
+def conv2d_wgrad(src, dout, dW_tcm, *, split="default", bounds=None, slabs=None, **geo):
     """dW in (tap, c, m) layout -> dW_tcm (flat, taps*Kc*M floats): sar_conv2d_wgrad_f32 -- or, with split="f16x3a" / "bf16x6" on 3x3 /
     stride 1 / pad 1 at image widths 8 / 16 / 32 / 64, sar_conv2d_wgrad_split (fp32 results on the fp16 / bf16 matrix pipe; bounds =
     (src_bound, dout_bound) cells, None = computed here by device kernels).  Slabs are summed in slab order either way."""
@@ -837,7 +889,7 @@ def conv2d_wgrad(src, dout, dW_tcm, *, split="default", bounds=None, **geo):
         groups = max(1, min(ntiles, (_C2D_WG_SLOTS + wgs - 1) // wgs))      # one round of the resident workgroups (2 per CU)
         nsplit = groups * wk.value
         d.nsplit = nsplit
-        slab = torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
+        slab = slabs.slab(dW_tcm, nsplit, n) if slabs is not None else torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
         d.slab = ptr(slab)
         sb, db = bounds if bounds is not None else (None, None)
         if split.startswith("f16"):
@@ -847,18 +899,24 @@ def conv2d_wgrad(src, dout, dW_tcm, *, split="default", bounds=None, **geo):
                 db = _src_bound_single(dout, None)
         with profiler.region("conv2d_wgrad_3x3_split" + _shape_tag(geo), flops):
             check(lib.sar_conv2d_wgrad_split(C.byref(d), L.SAR_SPLIT[split], ptr(sb), ptr(db), stream_ptr()), "sar_conv2d_wgrad_split")
-        check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")
+        if slabs is not None:
+            slabs.add(slab, nsplit, n, dW_tcm)
+        else:
+            check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")
         return
     wgs = ((geo["M"] + 63) // 64) * max(1, (geo["Kc"] + 31) // 32)
     # one round of the 512 resident workgroups (2 per CU): measured 22 % faster than 768 / 1024 in isolation (the kernels do not
     # fit 3 per CU, so a larger grid runs a second, partly filled round)
     nsplit = max(1, min(geo["B"] * max(1, geo["H_out"] // 2), (_C2D_WG_SLOTS + wgs - 1) // wgs))
     d.nsplit = nsplit
-    slab = torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
+    slab = slabs.slab(dW_tcm, nsplit, n) if slabs is not None else torch.empty((nsplit, n), dtype=torch.float32, device=src.device)
     d.slab = ptr(slab)
     with profiler.region("conv2d_wgrad_%dx%d" % (geo["KH"], geo["KW"]) + _shape_tag(geo), flops):
         check(lib.sar_conv2d_wgrad_f32(C.byref(d), stream_ptr()), "sar_conv2d_wgrad_f32")
-    check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")
+    if slabs is not None:
+        slabs.add(slab, nsplit, n, dW_tcm)
+    else:
+        check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, n, n, ptr(dW_tcm), stream_ptr()), "sar_slab_reduce_f32")
 
 
 def permute3(inp, out, d0, d1, d2, s0, s1, s2):

@@ -99,8 +99,9 @@ _WGRAD_SLOTS = int(__import__("os").environ.get("SAR_WGRAD8_SLOTS", "512"))
 
 
 def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stride=1, pad=0, pro=None, pro_relu=False,
-               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None):
-    """sar_conv_wgrad_cn8 + sar_slab_reduce_f32: dW (and dbias right behind it) -> dW_out[0 : wsize + bsize] (flat fp32)."""
+               tables=None, w_stride_tap, w_stride_c, wsize, bsize, nsplit=None, slabs=None):
+    """sar_conv_wgrad_cn8 + sar_slab_reduce_f32: dW (and dbias right behind it) -> dW_out[0 : wsize + bsize] (flat fp32).
+    slabs (ops.SlabBatch): the slabs are summed by the batch's next flush() instead of by a launch of their own."""
     lib = L.load()
     d = WgradDesc()
     d.mode, d.B, d.V, d.T_src, d.T_out, d.Kc, d.M = mode, B, V, T_src, T_out, Kc, M
@@ -124,12 +125,16 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
             d.nz[i] = tables.nz[i]
         ident = int(getattr(tables, "slice0_identity", False))
     d.w_stride_tap, d.w_stride_c, d.wsize, d.bsize = w_stride_tap, w_stride_c, wsize, bsize
-    slab = torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device)
+    assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
+    slab = (slabs.slab(dW_out, nsplit, wsize + bsize) if slabs is not None
+            else torch.empty((nsplit, wsize + bsize), dtype=torch.float32, device=src.device))
     d.slab = ptr(slab)
     tag = ("wgrad_graph" if mode == L.SAR_CONV_GRAPH else "wgrad_temporal%d" % taps) + "_cn8"
     with profiler.region(tag, 2.0 * M * Kc * taps * B * T_out * V, 2.0 * (Kc * B * T_src * V + M * B * T_out * V)):
         check(lib.sar_conv_wgrad_cn8(C.byref(d), ident, stream_ptr()), "sar_conv_wgrad_cn8")
-    assert dW_out.numel() >= wsize + bsize and dW_out.is_contiguous()
+    if slabs is not None:
+        slabs.add(slab, nsplit, wsize + bsize, dW_out)
+        return
     check(lib.sar_slab_reduce_f32(ptr(slab), nsplit, wsize + bsize, wsize + bsize, ptr(dW_out), stream_ptr()),
           "sar_slab_reduce_f32")
 

@@ -35,6 +35,9 @@ class _Conv:
         self.taps = k * k
 
 
+SLAB_BATCH_PATHB = __import__("os").environ.get("SAR_SLAB_BATCH_PATHB", "0") == "1"
+
+
 class ResNet18:
     def __init__(self, num_classes=60, num_filters=64, device="cuda", seed=0, mfma=None):
         L.load()
@@ -93,6 +96,11 @@ class ResNet18:
         import os
         self._side = (ops.shared_side_stream(dev) if dev.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1"
                       else None)
+        # one slab reduction per gradient bucket (ops.SlabBatch) -- OFF here: at bs = 32 the per-gradient reductions hide beside the
+        # main chain, a batched one lands on the tail of backward (interleaved, profiles/r06_slab_batch_ab.txt: 4.62 -> 4.74 ms in
+        # the split arithmetic, 6.40 -> 6.44 / 6.33 at the end / per stage in fp32); SAR_SLAB_BATCH_PATHB=1 turns it on
+        self._slabs = ops.SlabBatch() if (ops.SLAB_BATCH and SLAB_BATCH_PATHB) else None
+        self._slab_flush = ops.SLAB_FLUSH
         # side streams of the launches that fan out (stride-2 data gradients): owned by this engine, not by the library
         with torch.cuda.device(dev):
             self._ctx = L.Context() if dev.type == "cuda" else None
@@ -319,7 +327,7 @@ class ResNet18:
 
         def run():
             ops.conv2d_wgrad(X, dout, self.grad[o:o + n], B=B, Kc=cv.cin, M=cv.cout, H_src=H, W_src=W, H_out=Ho, W_out=Wo, KH=cv.k,
-                             KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None, **sa)
+                             KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro, pro_relu=pro is not None, slabs=self._slabs, **sa)
         if self._side is None:
             run()
         else:       # ordered after everything issued so far; X / dout must outlive the side stream's use
@@ -328,6 +336,17 @@ class ResNet18:
                 run()
             X.record_stream(self._side)
             dout.record_stream(self._side)
+
+    def _flush_slabs(self):
+        """the slabs of every weight gradient issued since the last flush are summed by ONE launch on the weight-gradient stream
+        (ops.SlabBatch): before a bucket is handed to the all-reduce and at the end of backward()"""
+        if self._slabs is None:
+            return
+        if self._side is None:
+            self._slabs.flush()
+        else:
+            with torch.cuda.stream(self._side):
+                self._slabs.flush()
 
     def _conv_dgrad(self, name, dout, B, H, W, Ho, Wo, **epi):
         """gradient w.r.t. the conv's input (H, W) from dout at (Ho, Wo)."""
@@ -351,6 +370,7 @@ class ResNet18:
         slice's all-reduce as soon as the events have completed -- the main stream goes on with the earlier layers."""
         bk = self._buckets[bi]
         events = []
+        self._flush_slabs()
         if self._side is not None:
             ev = torch.cuda.Event()
             ev.record(self._side)
@@ -421,6 +441,8 @@ class ResNet18:
             dY, _ = self._conv_dgrad(pre + "conv1", dz1, B, H, W, Ho, Wo, epi=L.SAR_EPI_ADD, aux=aux, aux_even_pixels=even)
             if bucket_cb is not None and pre.endswith(".0.") and pre[5] in "432":   # first block of layer 4 / 3 / 2: that stage is done
                 self._bucket_done({"4": 0, "3": 1, "2": 2}[pre[5]], bucket_cb)
+            elif bucket_cb is None and (self._slab_flush == "block" or (self._slab_flush == "bucket" and pre.endswith(".0.") and pre[5] in "432")):
+                self._flush_slabs()  # (experiment switch SAR_SLAB_FLUSH)
         # stem: maxpool + relu + bn backward, then the 7x7 weight gradient (the image needs no gradient)
         bn0 = self.bn["bn1"]
         c0 = sv["c0"]
@@ -434,6 +456,7 @@ class ResNet18:
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
         else:
+            self._flush_slabs()
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
         dx = None

@@ -110,6 +110,8 @@ class STGCN:
         # the main chain)
         self._side = (ops.shared_side_stream(self.device, int(os.environ.get("SAR_WGRAD_PRIO", "0")))
                       if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1" else None)
+        self._slabs = ops.SlabBatch() if ops.SLAB_BATCH else None     # one slab reduction per gradient bucket (ops.SlabBatch)
+        self._slab_flush = ops.SLAB_FLUSH
         self.motion = bool(motion)   # motion stream (data_gen/gen_motion_data.py:24-27) of the joint / bone data, on the fly
         self.bone_parent = None
         if bone_pairs is not None:
@@ -278,6 +280,7 @@ class STGCN:
         main stream.  cb(bi, flat slice, events) may start the slice's all-reduce once the events have completed."""
         _, lo, hi = self._buckets[bi]
         events = []
+        self._flush_slabs()
         if self._side is not None:
             ev = torch.cuda.Event()
             ev.record(self._side)
@@ -287,11 +290,26 @@ class STGCN:
         events.append(ev)
         cb(bi, self.grad[lo:hi], events)
 
+    def _flush_slabs(self):
+        """the slabs of every weight gradient issued since the last flush are summed by ONE launch on the weight-gradient stream
+        (ops.SlabBatch): before a bucket is handed to the all-reduce and at the end of backward()"""
+        slabs = getattr(self, "_slabs", None)
+        if slabs is None:
+            return
+        if self._side is None:
+            slabs.flush()
+        else:
+            with torch.cuda.stream(self._side):
+                slabs.flush()
+
     def _buckets_after_block(self, i, cb):
         if cb is not None:
             for bi, (blk, _, _) in enumerate(self._buckets):
                 if blk == i:
                     self._bucket_done(bi, cb)
+        elif getattr(self, "_slabs", None) is not None and (
+                self._slab_flush == "block" or (self._slab_flush == "bucket" and any(blk == i for blk, _, _ in self._buckets))):
+            self._flush_slabs()      # (experiment switch SAR_SLAB_FLUSH: more, smaller slab reductions than one at the end of backward)
 
     def _finish_backward(self, cb):
         """common tail of backward(): nothing deferred is left behind, the side stream is joined, the remaining buckets go"""
@@ -299,6 +317,7 @@ class STGCN:
             self._flush_deferred()
         if cb is not None:
             self._buckets_after_block(-1, cb)
+        self._flush_slabs()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)      # every weight gradient is in self.grad
         self._saved = None
@@ -654,7 +673,7 @@ class STGCN:
             L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
             pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=wt.numel(), bsize=f,
             bf16=self.bf16, split=self.split if ("twgrad" in _SPLIT_KINDS and self._split_has(pre + "tcn.f") and self._split_has(pre + "tcn.b")) else None,
-            bounds=(self._cell(i, 0), self._cell(i, 1)) if self._f16 else None), g, du)
+            bounds=(self._cell(i, 0), self._cell(i, 1)) if self._f16 else None, slabs=self._slabs), g, du)
         wimg = self._img(pre + "tcn.b")
         wT = None
         if wimg is None:
@@ -679,7 +698,7 @@ class STGCN:
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_GRAPH, X, dg, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS, tables=self.tab_fwd,
             w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, bf16=self.bf16, split=gw_split,
-            bounds=(self._cell(i, 3), self._cell(i, 2)) if self._f16 else None), X, dg)
+            bounds=(self._cell(i, 3), self._cell(i, 2)) if self._f16 else None, slabs=self._slabs), X, dg)
         dXres = self._residual_backward(i, sb, dr, B)
         # ---- graph conv data gradient (+ skip-path gradient)
         gimg = self._img(pre + "gcn.b")
@@ -712,7 +731,7 @@ class STGCN:
         flat_r = self.grad[self.offsets[pre + "res.kernel"]:self.offsets[pre + "res.bias"] + f]
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, X, dr, flat_r, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
-            w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f), X, dr)
+            w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f, slabs=self._slabs), X, dr)
         rimg = self._img(pre + "res.b")
         rT = None
         if rimg is None and pre + "res" in self._wT_off:
@@ -753,7 +772,7 @@ class STGCN:
             ops.graph_dense_dA(y3, dg, self._dA_layers[i], KS, f, V, B * T)
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, X, dy3, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=KS * f, taps=1, stride=1, pad=0,
-            w_stride_tap=0, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f), X, dy3)
+            w_stride_tap=0, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, slabs=self._slabs), X, dy3)
         dXres = self._residual_backward(i, sb, dr, B)
         o = self._wT_off[pre + "gcn"]
         gT = self._wT[o:o + KS * f * cin]

@@ -175,7 +175,7 @@ def _block_backward(eng, i, sb, dY, B, gated=None, below=None):
     flat_w = eng.grad[eng.offsets[pre + "tcn.kernel"]:eng.offsets[pre + "tcn.bias"] + f]
     eng._off_critical_path(lambda: ops8.conv_wgrad(
         L.SAR_CONV_TEMPORAL, g, du, flat_w, B=B, V=V, T_src=T, T_out=To, Kc=f, M=f, taps=KT, stride=s, pad=pad,
-        pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=KT * f * f, bsize=f), g, du)
+        pro=(bn1.scale, bn1.shift), pro_relu=True, w_stride_tap=f * f, w_stride_c=f, wsize=KT * f * f, bsize=f, slabs=eng._slabs), g, du)
     dz1 = ops8.empty(f, n_in, dev)
     pm = ops8.conv_gemm(L.SAR_CONV_TEMPORAL, du, dz1, img(pre + "tcn.b"), B=B, V=V, T_src=To, T_out=T, Kc=f, M=f, taps=KT,
                         stride=s, pad=pad, transposed=True, epi=L.SAR_EPI_MASK, aux=g, aux_affine=(bn1.scale, bn1.shift),
@@ -188,14 +188,14 @@ def _block_backward(eng, i, sb, dY, B, gated=None, below=None):
     flat_g = eng.grad[eng.offsets[pre + "gcn.kernel"]:eng.offsets[pre + "gcn.bias"] + KS * f]
     eng._off_critical_path(lambda: ops8.conv_wgrad(
         L.SAR_CONV_GRAPH, X, dg, flat_g, B=B, V=V, T_src=T, T_out=T, Kc=cin, M=f, taps=KS, tables=eng.tab_fwd,
-        w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f), X, dg)
+        w_stride_tap=f, w_stride_c=KS * f, wsize=cin * KS * f, bsize=KS * f, slabs=eng._slabs), X, dg)
     # ---- residual conv branch
     dXres = None
     if conv:
         flat_r = eng.grad[eng.offsets[pre + "res.kernel"]:eng.offsets[pre + "res.bias"] + f]
         eng._off_critical_path(lambda: ops8.conv_wgrad(
             L.SAR_CONV_TEMPORAL, X, dr, flat_r, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
-            w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f), X, dr)
+            w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f, slabs=eng._slabs), X, dr)
         dXres = ops8.empty(cin, n_in, dev)
         ops8.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, img(pre + "res.b"), B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
                        stride=s, pad=0, transposed=True)
