@@ -99,13 +99,16 @@ def test_resnet_gradients_are_bit_identical_with_one_slab_reduction_per_bucket(d
     from sar_amd import ops
     from sar_amd.resnet import ResNet18
 
+    from sar_amd import resnet
+
     def grads(batch, with_buckets):
-        old = ops.SLAB_BATCH
-        ops.SLAB_BATCH = batch
+        old = (ops.SLAB_BATCH, resnet.SLAB_BATCH_PATHB)       # (the resnet keeps its per-gradient reductions by default: measured)
+        ops.SLAB_BATCH = resnet.SLAB_BATCH_PATHB = batch
         try:
             net = ResNet18(num_classes=10, device=dev, seed=5, mfma=mfma)
         finally:
-            ops.SLAB_BATCH = old
+            ops.SLAB_BATCH, resnet.SLAB_BATCH_PATHB = old
+        assert (net._slabs is not None) == batch
         g = torch.Generator(device=dev).manual_seed(2)
         x = torch.randn((4, 1, 64, 64), generator=g, device=dev)
         y = torch.tensor([1, 3, 5, 7], device=dev)
