@@ -40,19 +40,27 @@ def main():
             old = [getattr(m, a) for m, a in targets]
             for (m, a), x in zip(targets, vs):
                 setattr(m, a, x)
-            try:
-                step, bs = make_step(leg, dev)
+            try:                      # the switch holds while the engine is built, warmed and (below) timed: construction-time and
+                step, bs = make_step(leg, dev)    # call-time switches alike
+                for k in range(6):
+                    step(k)
             finally:
                 for (m, a), x in zip(targets, old):
                     setattr(m, a, x)
-            for k in range(6):
-                step(k)
             engines.append(step)
         res = [[] for _ in values]
         for _ in range(rounds):
             for j, step in enumerate(engines):
-                timed(step, 3)
-                res[j].append(timed(step, steps))
+                vs = values[j] if len(names) > 1 else (values[j],)
+                old = [getattr(m, a) for m, a in targets]
+                for (m, a), x in zip(targets, vs):
+                    setattr(m, a, x)
+                try:
+                    timed(step, 3)
+                    res[j].append(timed(step, steps))
+                finally:
+                    for (m, a), x in zip(targets, old):
+                        setattr(m, a, x)
         base = min(res[-1])
         for v, r in zip(values, res):
             print("%-16s %s=%-16s %s ms/step  (best %.3f, %+.2f %% vs last, %.0f clips/s)" % (
