@@ -970,8 +970,145 @@ __global__ __launch_bounds__(256, KC <= 3 ? 3 : 2) void graph_wgrad_small_kernel
   }
 }
 
+// Round 6: the same reduction with FOUR consecutive columns per lane (tools/leftover_bench.py: the kernel above moves its 257 MB at
+// 0.8 TB/s -- 313 us against an HBM time of 43 -- because an iteration has 2 KB per wave in flight and exposes a full memory round
+// trip): dout rows are read as 16-byte pieces (1 KB per wave instruction, 8 KB per wave and iteration in flight), the z values of
+// the lane's four columns are built from the same gather tables (per-column frame / joint: a column quad may straddle a frame),
+// accumulators and lane tree as above.  Needs 16-byte aligned dout rows and ncol % 4 == 0 (else the kernel above); two waves per SIMD.
+template <int KC>
+__global__ __launch_bounds__(256, 2) void graph_wgrad_small4_kernel(const sar_wgrad_desc d, int ncol, int cols_per_split) {
+  constexpr int MW = 8;            // output channels per wave
+  constexpr int NZV = 3 * KC + 3;  // values per column: z_k[c] (k-major) and colsum_k
+  constexpr int XS = 256 + 64;     // <= 256 columns + one frame of slack (V <= 32)
+  __shared__ int4 t_idx[3 * 32];   // gather tables [k][w] -> 4 entries (weights of unused entries are 0: no branches in the builder)
+  __shared__ float4 t_wt[3 * 32];
+  __shared__ float t_cs[3 * 32];
+  __shared__ float xs[KC][XS];                                       // the src frames of the iteration's columns
+  __shared__ __attribute__((aligned(16))) float zs[NZV][256];        // the iteration's z / colsum values, one row per value
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x, m0 = blockIdx.y * 4 * MW + wave * MW;
+  const int V = d.V;
+  const bool do_bias = d.bsize > 0;
+  if (tid < 3 * V) {
+    const int k = tid / V;
+    int4 ix = *reinterpret_cast<const int4*>(d.g_idx + tid * 4);
+    float4 wt = *reinterpret_cast<const float4*>(d.g_wt + tid * 4);
+    const int nzk = d.nz[k];
+    if (nzk < 1) wt.x = 0.f, ix.x = 0;
+    if (nzk < 2) wt.y = 0.f, ix.y = 0;
+    if (nzk < 3) wt.z = 0.f, ix.z = 0;
+    if (nzk < 4) wt.w = 0.f, ix.w = 0;
+    const int w = tid - k * V;
+    t_idx[k * 32 + w] = ix;
+    t_wt[k * 32 + w] = wt;
+    t_cs[k * 32 + w] = (do_bias && d.g_colsum) ? d.g_colsum[tid] : 0.f;
+  }
+  const int col_lo = split * cols_per_split;   // multiples of 256
+  const int col_hi = (col_lo + cols_per_split < ncol) ? col_lo + cols_per_split : ncol;
+  float acc[MW][NZV];
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NZV; ++j) acc[i][j] = 0.f;
+  // software pipeline: the dout quads and the src frames of iteration i + 1 are requested during iteration i
+  float4 dvn[MW];
+  float xr[KC][2];
+  auto request_dout = [&](int c0) {
+    const int col = c0 + 4 * lane;
+    const bool live = col < col_hi;          // col_hi % 4 == 0: a quad is live or dead as a whole
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+      dvn[i] = (live && m0 + i < d.M) ? *reinterpret_cast<const float4*>(d.dout + (int64_t)(m0 + i) * d.ld_dout + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto request_src = [&](int c0) {
+    const int f_lo = c0 / V;
+    const int c_last = (c0 + 255 < ncol ? c0 + 255 : ncol - 1);
+    const int nst = (c_last / V - f_lo + 1) * V;   // whole frames: every gather of a live column lies inside
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        xr[c][q] = (c < d.Kc && tid + 256 * q < nst) ? d.src[(int64_t)c * d.ld_src + (int64_t)f_lo * V + tid + 256 * q] : 0.f;
+  };
+  if (col_lo < col_hi) {
+    request_src(col_lo);
+    request_dout(col_lo);
+  }
+  for (int c0 = col_lo; c0 < col_hi; c0 += 256) {
+    const int f_lo = c0 / V;
+    const bool more = c0 + 256 < col_hi;   // uniform
+    __syncthreads();   // (A) every wave has consumed zs / xs of the previous iteration (and the tables are written)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (tid + 256 * q < XS)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) xs[c][tid + 256 * q] = xr[c][q];
+    __syncthreads();     // (B) xs complete
+    if (more) request_src(c0 + 256);
+    {   // thread = column c0 + tid: its NZV values, branch-free (an unused entry has weight 0 and index 0)
+      const int ce = c0 + tid;
+      const bool lv = ce < col_hi;
+      const int cq = lv ? ce : c0;
+      const int fr = cq / V, w = cq - fr * V;
+      const int fo = (fr - f_lo) * V;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int4 ix = t_idx[k * 32 + w];
+        float4 wt = t_wt[k * 32 + w];
+        if (!lv) wt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          float zz = wt.x * xs[c][fo + ix.x];
+          zz = fmaf(wt.y, xs[c][fo + ix.y], zz);
+          zz = fmaf(wt.z, xs[c][fo + ix.z], zz);
+          zz = fmaf(wt.w, xs[c][fo + ix.w], zz);
+          zs[k * KC + c][tid] = zz;
+        }
+        zs[3 * KC + k][tid] = lv ? t_cs[k * 32 + w] : 0.f;
+      }
+    }
+    __syncthreads();     // (C) zs complete
+    float4 dv[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) dv[i] = dvn[i];
+    if (more) request_dout(c0 + 256);
+#pragma unroll
+    for (int j = 0; j < NZV; ++j) {
+      const float4 zq = *reinterpret_cast<const float4*>(&zs[j][4 * lane]);
+#pragma unroll
+      for (int i = 0; i < MW; ++i)
+        acc[i][j] = fmaf(zq.w, dv[i].w, fmaf(zq.z, dv[i].z, fmaf(zq.y, dv[i].y, fmaf(zq.x, dv[i].x, acc[i][j]))));
+    }
+  }
+  float* slab = d.slab + (int64_t)split * (d.wsize + d.bsize);
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int m = m0 + i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float t = wave_sum_dpp(acc[i][k * KC + c]);
+        if (lane == 0 && m < d.M && c < d.Kc) slab[k * d.w_stride_tap + c * d.w_stride_c + m] = t;
+      }
+      if (do_bias) {   // uniform
+        const float t = wave_sum_dpp(acc[i][3 * KC + k]);
+        if (lane == 0 && m < d.M) slab[d.wsize + (int64_t)k * d.M + m] = t;
+      }
+    }
+  }
+}
+
 int launch_graph_small(const sar_wgrad_desc& d, hipStream_t st) {
   const int ncol = d.B * d.T_out * d.V;
+  static const bool quad = [] { const char* e = getenv("SAR_WGRAD_SMALL4"); return !(e && e[0] == '0'); }();
+  if (quad && d.V <= 32 && ncol % 4 == 0 && d.ld_dout % 4 == 0 && ((uintptr_t)d.dout & 15) == 0) {   // (V <= 32: an iteration's frames fit the staging buffer)
+    const int cps4 = ((ncol + d.nsplit - 1) / d.nsplit + 255) / 256 * 256;   // whole 256-column chunks per slab
+    dim3 grid4(d.nsplit, (d.M + 31) / 32);
+    if (d.Kc <= 3) hipLaunchKernelGGL(graph_wgrad_small4_kernel<3>, grid4, dim3(256), 0, st, d, ncol, cps4);
+    else hipLaunchKernelGGL(graph_wgrad_small4_kernel<4>, grid4, dim3(256), 0, st, d, ncol, cps4);
+    return 0;
+  }
   const int cps = ((ncol + d.nsplit - 1) / d.nsplit + 63) / 64 * 64;   // whole 64-column chunks per slab
   dim3 grid(d.nsplit, (d.M + 31) / 32);
   if (d.Kc <= 3) hipLaunchKernelGGL(graph_wgrad_small_kernel<3>, grid, dim3(256), 0, st, d, ncol, cps);

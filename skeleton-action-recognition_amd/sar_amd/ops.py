@@ -321,6 +321,9 @@ _WGRAD9_SLOTS = int(__import__("os").environ.get("SAR_WGRAD9_SLOTS", "1024"))   
 _WGRADG_SLOTS = int(__import__("os").environ.get("SAR_WGRADG_SLOTS", "512"))       # ... of the graph ones
 
 
+# columns per workgroup of the first layer's streaming weight gradient (graph_wgrad_small4_kernel: 256-column iterations)
+_WGRAD_SMALL_COLS = int(__import__("os").environ.get("SAR_WGRAD_SMALL_COLS", "4096"))
+
 # SAR_SLAB_BATCH=0: every weight gradient reduces its slabs by its own launch again (A/B switch)
 SLAB_BATCH = __import__("os").environ.get("SAR_SLAB_BATCH", "1") == "1"
 # when an engine flushes its batch: "end" = at the end of backward (and before a bucket goes to the all-reduce), "bucket" = at every
@@ -413,7 +416,7 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     if nsplit is None and mode == L.SAR_CONV_GRAPH and Kc <= 4 and pro is None:
         # streaming kernel of the 3-channel first layer (conv_wgrad.hip: graph_wgrad_small_kernel): ~8 chunks of 64 columns per
         # workgroup (its loop is latency-bound: many short workgroups, not few long ones)
-        nsplit = max(1, min(4096, (B * T_out * V + 511) // 512))
+        nsplit = max(1, min(4096, (B * T_out * V + _WGRAD_SMALL_COLS - 1) // _WGRAD_SMALL_COLS))
     if nsplit is None:
         ft = max(2, min((128 // V) & ~1, (T_out + 1) & ~1))
         bf = 64
