@@ -199,7 +199,10 @@ int sar_pack_weights_bf16_batch(const float* base, const sar_pack_item* items, i
  * gradient) at V = 25, taps = 3, T_src == T_out, 16 <= Kc <= 256 with Kc % 16 == 0, M % 8 == 0, no folded prologue, gather tables
  * flagged SAR_GRAPH_FEW_DENSE with at most 16 non-trivial lists, in SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A only (F16X3A: two kernels
  * with bit-identical results -- persistent workgroups with the raw source by LDS-DMA for the data gradients, one tile per
- * workgroup for the forward launches; SAR_GRAPH_ONE_TILE_WG forces the latter).  Anything else returns SAR_E_UNSUP
+ * workgroup for the forward launches; SAR_GRAPH_ONE_TILE_WG forces the latter); and (iii, round 6) the 1-tap TEMPORAL operator -- the
+ * strided 1x1 residual convolution of models/stgcn.py:47-54, and, with W^T, the dense 1x1 product of its data gradient -- in its
+ * forward form (transposed = 0) at V = 25, stride 1 / 2, pad 0, Kc >= 16, M % 8 == 0, no folded prologue, epilogues NONE / STATS /
+ * MASK / ADD, in SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A only.  Anything else returns SAR_E_UNSUP
  * (sar_conv_gemm_split_nparts too): the caller keeps sar_conv_gemm_f32 for it.  `packed` = the weight term images written by
  * sar_pack_weights_split_batch (same items as sar_pack_weights_bf16_batch, but G = ceil(Kc / 8), and an item occupies
  * sar_conv_gemm_split_workspace_bytes / 16 units = terms * taps * G * M); item_amax[nitems] receives each item's amax bits (fp16

@@ -836,6 +836,202 @@ __global__ __launch_bounds__(256, AR == AR_H3A ? 3 : 2) void conv_graph_split_ke
   SPLIT_TL_END(w);
 }
 
+// ---- The 1-tap TEMPORAL operator (the strided 1x1 residual convolution of models/stgcn.py:47-54 and the dense 1x1 products of its
+// data gradient) in the split arithmetics -- round 6, VERDICT r05 next #1c ("fp32 leftovers").  These launches are memory-bound
+// (<= 16 GFLOP for ~0.4-0.5 GB) but on the fp32 matrix pipe their matrix time alone (50 / 100 us at 64 -> 128 / 128 -> 256 channels)
+// exceeded their HBM time (tools/leftover_bench.py: 163 / 241 us forward, 146 / 219 us dense data gradient).
+//   out[m, (b, t, v)] = sum_c W[c][m] src[c, (b, t stride, v)] (+ bias[m]) ; epilogue NONE / STATS / MASK / ADD   (no folded prologue)
+// The graph kernel's skeleton with ONE slice and no gather: tile 64 x 256 (10 output frames), 4 waves side by side, stage = 32
+// source channels = two k-steps of 16 (lanes 0-31 channels 0-7, lanes 32-63 channels 8-15 of the k-step), weights by LDS-DMA
+// ([term][group][64 rows] pieces), the source split by the stager (thread = output column; its source column is the same joint of
+// frame t * stride: a stride-2 launch reads every other 100-byte frame), single image, two barriers per stage.
+template <int AR>
+__global__ __launch_bounds__(256, 3) void conv_tap1_split_kernel(const ConvKS k) {
+  constexpr int NTA = ar_nta(AR), NTL = nta_lds(AR), NTB = ar_ntb(AR), NPROD = ar_nprod(AR);
+  static_assert(!ar_two_acc(AR), "one accumulator set");
+  constexpr bool SCALED = ar_f16(AR);
+  constexpr int BM = 64, MS = 2, NS = 2, WN = 4, KCS = 32, NG = KCS / 8;
+  constexpr int ZCOL = 256, SC = ZCOL + 1;
+  constexpr int WPIECES = NTL * NG, WU = WPIECES * 64, SU = NTB * NG * SC;   // weight pieces [term][group][64 rows]; source [term][group][column]
+  constexpr int PAREA_U = 4 * 16 * 65 / 4;
+  constexpr int IMG_U = (WU + SU) > PAREA_U ? (WU + SU) : PAREA_U;
+  constexpr int PPW = (WPIECES + 3) / 4;
+  __shared__ uint4 smem_u[IMG_U + BM];
+  uint4* Wl = smem_u;
+  uint4* Sl = smem_u + WU;
+  float* smem = reinterpret_cast<float*>(smem_u);
+  float4* rowp = reinterpret_cast<float4*>(smem_u + IMG_U);
+  const sar_conv_desc& d = k.d;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave;
+  const int ny = k.ny, nwork = k.ntiles * ny;
+  int w = blockIdx.x;
+  {
+    const int per = (nwork + 7) / 8;
+    const int xcd = w & 7, slot = w >> 3;
+    w = xcd * per + slot;
+    if (w >= nwork || slot >= per) return;
+  }
+  const int tile = w / ny;
+  const int b = tile / k.TPS;
+  const int t0 = (tile - b * k.TPS) * k.FT;
+  const int m0 = (w - tile * ny) * BM;
+  const int V = d.V;
+  const int nfr = (t0 + k.FT <= d.T_out) ? k.FT : d.T_out - t0;   // live frames of this tile
+  const int ncols = nfr * V;
+
+  // the bias row is requested here and stored behind the first operand requests
+  float bias_v = 0.f;
+  if (tid < BM && d.bias && m0 + tid < d.M) bias_v = d.bias[m0 + tid];
+
+  bool colok[NS];
+  int64_t coln[NS];
+  int bcol[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int p = (wn * NS + ns) * 32 + l31;
+    colok[ns] = p < ncols;
+    coln[ns] = ((int64_t)b * d.T_out + t0) * V + (colok[ns] ? p : 0);
+    bcol[ns] = colok[ns] ? p : ZCOL;
+  }
+
+  int ea = 0, ew = 0;
+  bool nonfin = false;   // an operand bound holds Inf / NaN bits: every output of the launch is NaN (split_scale.h)
+  if (SCALED) {
+    ea = scale_exp(*k.src_bound);
+    ew = scale_exp(*k.w_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.w_bound);
+  }
+  const float sa = __builtin_ldexpf(1.f, ea);
+  f32x16 acc[MS][NS];
+
+  // ---- source staging: thread = output column tid of the tile; its source column is joint v of frame (t0 + fo) * stride of
+  // sequence b; the descriptor spans exactly the sequence row (a dead thread's offset is rejected: 0)
+  const int seq_len = d.T_src * V;
+  const float* src_b = d.src + (int64_t)b * seq_len;
+  int svo;
+  {
+    const int fo = tid / V, v = tid - fo * V;
+    svo = tid < ncols ? (((t0 + fo) * d.stride) * V + v) * 4 : 0x7fffffff;
+  }
+  float sreg[NG][8];
+  auto issue_s_loads = [&](int c0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + 8 * g + q;
+        const int cg = c < d.Kc ? c : 0;   // wave-uniform (masked in store_s)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src_b + (int64_t)cg * d.ld_src), 0, (unsigned)seq_len * 4u, 0x00020000);
+        sreg[g][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, svo, 0, 0));
+      }
+  };
+  auto store_s = [&](int c0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float x = SCALED ? sreg[g][q] * sa : sreg[g][q];
+        v[q] = (tid < ncols && c0 + 8 * g + q < d.Kc) ? x : 0.f;
+      }
+      uint4 u[NTB];
+      split8<AR, false>(v, u, 1.f);
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) Sl[(t * NG + g) * SC + tid] = u[t];
+    }
+  };
+  // weight pieces by LDS-DMA: piece p = term * NG + group = 64 rows of channel group g0 + group of term image `term`
+  const unsigned wbytes = (unsigned)((int64_t)NTA * k.G * d.M * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)k.wp, 0, wbytes, 0x00020000);
+  const unsigned wvo = (m0 + lane) < d.M ? (unsigned)((m0 + lane) * 16) : 0x80000000u;
+  auto issue_w_dma = [&](int g0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + 4 * i;   // wave-uniform
+      if (p < WPIECES) {
+        const int t = p / NG, g = g0 + (p - t * NG);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wl + p * 64), 16, g < k.G ? wvo : 0x80000000u, (t * k.G + g) * d.M * 16, 0, 0);
+      }
+    }
+  };
+
+  issue_s_loads(0);
+  issue_w_dma(0);
+  asm volatile("" ::: "memory");
+  if (tid < BM) rowp[tid] = make_float4(bias_v, 0.f, 0.f, 0.f);
+  if (tid < NTB * NG) Sl[tid * SC + ZCOL] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+
+  // Happens-before of the single image: as conv_graph_split_kernel (store_s / DMA behind the closing barrier, the opening barrier
+  // behind every wave's ds_writes and vmcnt(0)); rowp / the zero column are written in front of the first opening barrier
+  const int nst = (d.Kc + KCS - 1) / KCS;
+  for (int s_ = 0; s_ < nst; ++s_) {
+    store_s(s_ * KCS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // opening
+    if (s_ + 1 < nst) issue_s_loads((s_ + 1) * KCS);
+    SAR_LDS_SKEW();
+#pragma unroll
+    for (int kk = 0; kk < NG / 2; ++kk) {
+      uint4 a[NTA][MS], bq[NTB][NS];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) a[t][ms] = Wl[(t * NG + 2 * kk + hi) * 64 + ms * 32 + l31];
+      if constexpr (NTL < NTA)
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) a[NTA - 1][ms] = third_image(a[0][ms]);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) bq[t][ns] = Sl[(t * NG + 2 * kk + hi) * SC + bcol[ns]];
+#pragma unroll
+      for (int p = 0; p < NPROD; ++p) {
+        const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            if (ar_f16(AR))
+              acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8*>(&a[i][ms]),
+                                                                   *reinterpret_cast<f16x8*>(&bq[j][ns]), acc[ms][ns], 0, 0, 0);
+            else
+              acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a[i][ms]),
+                                                                    *reinterpret_cast<bf16x8*>(&bq[j][ns]), acc[ms][ns], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();   // closing
+    if (s_ + 1 < nst) issue_w_dma(NG * (s_ + 1));
+  }
+
+  {
+    const float c0 = SCALED ? (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + ew))) : 1.f;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 bp = rowp[ms * 32 + mfma_row(r, hi)];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const float v = fmaf(acc[ms][ns][r], c0, bp.x);
+          acc[ms][ns][r] = colok[ns] ? v : 0.f;
+        }
+      }
+    __syncthreads();   // every wave has read its bias rows: the MASK epilogue rewrites rowp
+  }
+  epilogue_b<MS, NS, WN, BM>(d, k.nparts, tile, 0, wn, m0, colok, coln, acc, rowp, smem);
+}
+
 // ---- The same contraction as conv_graph_split_kernel -- BIT-IDENTICAL results: same term images, same products in the same order,
 // same epilogue, same partial-sum layout -- rebuilt around what the per-workgroup timelines of round 5 showed
 // (profiles/r05_f32split_timelines.txt: a 64-channel forward workgroup lived 45 000 cycles for 7 300 cycles of matrix work and the
@@ -1190,7 +1386,7 @@ int geometry_s(const sar_conv_desc& d, int tr, ConvKS& k) {
   } else if (k.FT > d.T_out) k.FT = d.T_out;
   k.TPS = (d.T_out + k.FT - 1) / k.FT;
   int nf;
-  if (tr == 4) nf = k.FT;
+  if (tr == 4 || tr == 5) nf = k.FT;
   else if (tr == 0) nf = (k.FT - 1) * d.stride + TAPS;
   else if (tr == 1) nf = k.FT + TAPS - 1;
   else nf = (k.FT - 1 + TAPS - 1) / 2 + 2;
@@ -1210,6 +1406,11 @@ int split_tr(const sar_conv_desc& d) {
     if (!(d.g_flags & SAR_GRAPH_FEW_DENSE) || ndense > 16) return -1;
     if (d.Kc < 16 || d.Kc > 256 || (d.Kc & 15) || (d.M & 7)) return -1;
     return 4;
+  }
+  if (d.mode == SAR_CONV_TEMPORAL && d.taps == 1) {   // conv_tap1_split_kernel (5): forward form only (a dense data gradient is a forward launch with W^T)
+    if (d.V != VJ || d.transposed || d.pad != 0 || d.pro_scale || (d.stride != 1 && d.stride != 2)) return -1;
+    if (d.Kc < 16 || (d.M & 7) || d.T_src < (d.T_out - 1) * d.stride + 1) return -1;
+    return 5;
   }
   if (d.mode != SAR_CONV_TEMPORAL || d.taps != 9 || d.V != VJ) return -1;
   if (d.Kc < 8 || d.Kc > 256 || (d.M & 7)) return -1;
@@ -1273,6 +1474,9 @@ int launch_split(const sar_conv_desc& d, int tr, const uint4* wp, const unsigned
       }
     }
     if constexpr (AR == AR_B6 || AR == AR_H3A) hipLaunchKernelGGL((conv_graph_split_kernel<AR>), grid, block, 0, st, k);
+    else return SAR_E_UNSUP;
+  } else if (tr == 5) {
+    if constexpr (AR == AR_B6 || AR == AR_H3A) hipLaunchKernelGGL((conv_tap1_split_kernel<AR>), grid, block, 0, st, k);
     else return SAR_E_UNSUP;
   } else if (tr == 0 && d.stride == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 0>), grid, block, 0, st, k);
   else if (tr == 0) hipLaunchKernelGGL((conv_gemm_split_kernel<0, AR, 1>), grid, block, 0, st, k);
@@ -1373,7 +1577,8 @@ extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void
   if (tr < 0) {
     sar_set_error("sar_conv_gemm_split: built for the 9-tap temporal convolution at V = 25, stride 1 / 2, 8 <= Kc <= 256, M %% 8 == 0, and "
                   "for the graph convolution at V = 25, taps 3, T_src == T_out, 16 <= Kc <= 256, Kc %% 16 == 0, M %% 8 == 0, no prologue, "
-                  "SAR_GRAPH_FEW_DENSE tables with <= 16 non-trivial lists (mode %d, taps %d, V %d, stride %d, Kc %d, M %d): use sar_conv_gemm_f32",
+                  "SAR_GRAPH_FEW_DENSE tables with <= 16 non-trivial lists, and for the 1-tap temporal operator at V = 25, forward form, stride 1 / 2, "
+                  "pad 0, Kc >= 16, no prologue (mode %d, taps %d, V %d, stride %d, Kc %d, M %d): use sar_conv_gemm_f32",
                   d->mode, d->taps, d->V, d->stride, d->Kc, d->M);
     return SAR_E_UNSUP;
   }
@@ -1383,6 +1588,7 @@ extern "C" int sar_conv_gemm_split(const sar_conv_desc* d, int arith, const void
     SAR_REQUIRE(arith == AR_B6 || arith == AR_H3A, "sar_conv_gemm_split: the graph kernel is built for bf16x6 / f16x3a");
   } else {
     SAR_REQUIRE(d->stride >= 1 && d->pad >= 0 && d->pad <= 8, "sar_conv_gemm_split: bad stride/pad");
+    if (tr == 5) SAR_REQUIRE(arith == AR_B6 || arith == AR_H3A, "sar_conv_gemm_split: the 1-tap kernel is built for bf16x6 / f16x3a");
   }
   SAR_REQUIRE(d->src && d->out, "sar_conv_gemm_split: null src/out");
   SAR_REQUIRE(d->ld_src >= (int64_t)d->B * d->T_src * d->V && d->ld_out >= (int64_t)d->B * d->T_out * d->V,

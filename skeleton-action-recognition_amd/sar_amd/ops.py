@@ -203,11 +203,17 @@ def affine_bound(scale, shift, src_cell, cell):
 DEFAULT_SPLIT = None
 
 
-def split_applicable(mode, V, Kc, M, taps, stride, tables=None, pro=None):
+TAP1_SPLIT = __import__("os").environ.get("SAR_TAP1_SPLIT", "1") == "1"      # the 1-tap temporal operator on conv_tap1_split_kernel (A/B switch)
+
+
+def split_applicable(mode, V, Kc, M, taps, stride, tables=None, pro=None, transposed=False, pad=0):
     """shapes csrc/conv_gemm_split.hip is built for (the others stay on the fp32 kernels)"""
     if mode == L.SAR_CONV_GRAPH:       # read-gather graph kernel: few non-trivial gather lists, no folded prologue, 16-channel stages
         return (taps == 3 and V == 25 and 16 <= Kc <= 256 and Kc % 16 == 0 and M % 8 == 0 and pro is None and tables is not None
                 and bool(tables.g_flags & L.SAR_GRAPH_FEW_DENSE) and tables.n_dense_lists <= 16)
+    if mode == L.SAR_CONV_TEMPORAL and taps == 1:      # 1x1 (residual) convolution, forward form: conv_tap1_split_kernel (bf16x6 / f16x3a)
+        return (TAP1_SPLIT and V == 25 and Kc >= 16 and M % 8 == 0 and stride in (1, 2) and pad == 0 and pro is None
+                and not transposed)
     return mode == L.SAR_CONV_TEMPORAL and taps == 9 and V == 25 and 8 <= Kc <= 256 and M % 8 == 0 and stride in (1, 2)
 
 
@@ -242,9 +248,9 @@ def conv_gemm(mode, src, out, W, w_stride_tap, w_stride_c, *, B, V, T_src, T_out
     lib = L.load()
     if split == "default":
         split = DEFAULT_SPLIT
-    split = split if (split and split_applicable(mode, V, Kc, M, taps, stride, tables, pro)
+    split = split if (split and split_applicable(mode, V, Kc, M, taps, stride, tables, pro, transposed, pad)
                       and (epi != L.SAR_EPI_ADD_GATE or mode == L.SAR_CONV_GRAPH)) else None
-    if split and mode == L.SAR_CONV_GRAPH and split not in ("bf16x6", "f16x3a"):
+    if split and (mode == L.SAR_CONV_GRAPH or taps == 1) and split not in ("bf16x6", "f16x3a"):
         split = None
     if split:
         bf16 = False

@@ -36,7 +36,7 @@ SPLIT_ARITH = {"f32_split": "f16x3a", "f32_split_bf16x6": "bf16x6"}      # engin
 # +0.4 % (58.70 -> 58.47 ms, interleaved); "1" = the split engines too (single stream -0.29 ms, two streams 34.34 -> 34.44 ms: not taken);
 # "0" = never (gpurun_out/compact_skip_ab*.txt)
 _COMPACT_SKIP = __import__("os").environ.get("SAR_COMPACT_SKIP", "fp32")
-_SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS", "tfwd,tdgrad,twgrad,gfwd,gdgrad,gwgrad").split(","))
+_SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS", "tfwd,tdgrad,twgrad,gfwd,gdgrad,gwgrad,rfwd,rdgrad").split(","))
 # (filters, stride, residual) -- models/stgcn.py:113-123
 BLOCKS = [(64, 1, False), (64, 1, True), (64, 1, True), (64, 1, True), (128, 2, True), (128, 1, True), (128, 1, True),
           (256, 2, True), (256, 1, True), (256, 1, True)]
@@ -211,6 +211,13 @@ class STGCN:
                     pk.add(pre + "gcn.f", og, f, KS * f, 1, KS, cin, f)          # (k, c, m) = kernel[c][k*F + m]
                 if ops.split_applicable(L.SAR_CONV_GRAPH, num_node, f, cin, KS, 1, self.tab_bwd):
                     pk.add(pre + "gcn.b", og, f, 1, KS * f, KS, f, cin)          # (k, c', m') = kernel[m'][k*F + c']
+                if self.kinds[i] == "conv" and self.split in ("f16x3a", "bf16x6"):
+                    # the strided 1x1 residual convolution and the dense 1x1 product of its data gradient (conv_tap1_split_kernel, round 6)
+                    orr = self.offsets[pre + "res.kernel"]
+                    if ops.split_applicable(L.SAR_CONV_TEMPORAL, num_node, cin, f, 1, s_):
+                        pk.add(pre + "res.f", orr, 0, f, 1, 1, cin, f)           # (0, c, m) = kernel[c][m]
+                    if s_ == 2 and ops.split_applicable(L.SAR_CONV_TEMPORAL, num_node, f, cin, 1, 1):
+                        pk.add(pre + "res.b", orr, 0, 1, f, 1, f, cin)           # (0, c', m') = kernel[m'][c']
                 cin = f
                 if ops.split_applicable(L.SAR_CONV_TEMPORAL, num_node, f, f, KT, s_):
                     pk.add(pre + "tcn.f", ot, f * f, f, 1, KT, f, f)             # (tap, c, m) = kernel[tap][c][m]
@@ -471,9 +478,10 @@ class STGCN:
         rbn = None
         if kind == "conv":  # models/stgcn.py:47-56
             r = torch.empty((f, n_out), dtype=torch.float32, device=dev)
+            rsimg = self._simg(pre + "res.f") if training else None     # split arithmetic: X's bound is cell 3 (raised by the block below)
             r3 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, X, r, self.p[pre + "res.kernel"], 0, f, B=B, V=V, T_src=T, T_out=To,
-                               Kc=cin, M=f, taps=1, stride=s, pad=0, bias=self.p[pre + "res.bias"], epi=epi, bf16=self.bf16,
-                               packed=self._img(pre + "res.f"))
+                               Kc=cin, M=f, taps=1, stride=s, pad=0, bias=self.p[pre + "res.bias"], epi=epi,
+                               **self._split_args(rsimg, self._cell(i, 3), self._img(pre + "res.f")))
             if training:
                 self._bn_forward_stats(pre + "res_bn", r3[0], r3[1], n_out, True, True)
             else:
@@ -484,7 +492,8 @@ class STGCN:
         ymask = ops.relu_mask(y) if training else None     # 1 bit per element: what the BatchNorm-backward passes read instead of y
         # (split arithmetic: y is the next block's graph-convolution operand; its bound is a by-product of this pass)
         ycell = self._cell(i + 1, 3) if (training and i + 1 < len(self.blocks)
-                                         and self._cell_live("l%d.gcn.f" % (i + 1), "gfwd", "gwgrad")) else None
+                                         and (self._cell_live("l%d.gcn.f" % (i + 1), "gfwd", "gwgrad")
+                                              or self._cell_live("l%d.res.f" % (i + 1), "rfwd"))) else None
         ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r,
                             rbn.scale if rbn else None, rbn.shift if rbn else None, y, mask=ymask, amax_cell=ycell)
         if training:
@@ -505,7 +514,7 @@ class STGCN:
     def _simg(self, key):
         """(term images, w_bound cell) of a conv weight in split mode, else None"""
         pk = self.spacked
-        kind = {"tcn.f": "tfwd", "tcn.b": "tdgrad", "gcn.f": "gfwd", "gcn.b": "gdgrad"}[key.split(".", 1)[1]]
+        kind = {"tcn.f": "tfwd", "tcn.b": "tdgrad", "gcn.f": "gfwd", "gcn.b": "gdgrad", "res.f": "rfwd", "res.b": "rdgrad"}[key.split(".", 1)[1]]
         if kind not in _SPLIT_KINDS:
             return None
         return (pk.image(key), pk.bound(key)) if pk is not None and key in pk.index else None
@@ -708,7 +717,7 @@ class STGCN:
             gT = self._wT[o:o + KS * f * cin]                             # [k][f][c]
         dX = torch.empty((cin, n_in), dtype=torch.float32, device=dev)
         aux = dY if kind == "identity" else dXres
-        even = kind == "conv" and aux is not None and self._compact_skip(s, T)      # dXres holds the even frames only
+        even = kind == "conv" and aux is not None and self._compact_skip(s, T, i)   # dXres holds the even frames only
         sgimg = self._simg(pre + "gcn.b")
         if below is not None and aux is not None:
             # dX = gate_{i-1}(W^T dg . A^T + skip gradient) and block i - 1's BatchNorm-backward sums in one epilogue
@@ -740,23 +749,28 @@ class STGCN:
         elif rimg is None:             # engines without the batched re-layout (ST-GIN)
             rT = torch.empty((f, cin), dtype=torch.float32, device=dev)
             ops.transpose(self.p[pre + "res.kernel"], rT, 1, cin, f)
-        if self._compact_skip(s, T):
+        if self._compact_skip(s, T, i):
             # the gradient through a stride-2 1x1 convolution is non-zero on EVEN input frames only: a dense 1x1 product over the To
             # frames (half the matrix work of the strided data gradient, half the bytes written), added by the graph data gradient's
             # epilogue on even frames (SAR_GRAPH_AUX_EVEN_FRAMES) -- the zeros are neither written nor read back
             dXc = torch.empty((cin, B * To * V), dtype=torch.float32, device=dev)
+            rb = self._simg(pre + "res.b")
+            if rb is not None and self._f16:
+                ops.amax(dr, self._cell(i, 4))                   # the bound of dr (one pass over a To-frame tensor)
             ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXc, rT, 0, cin, B=B, V=V, T_src=To, T_out=To, Kc=f, M=cin, taps=1, stride=1, pad=0,
-                          split=None)
+                          **self._split_args(rb, self._cell(i, 4), None))
             return dXc
         dXres = torch.empty((cin, B * T * V), dtype=torch.float32, device=dev)
         ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
                       stride=s, pad=0, transposed=True, bf16=self.bf16, packed=rimg)
         return dXres
 
-    def _compact_skip(self, s, T):
+    def _compact_skip(self, s, T, i=None):
         """the skip gradient of a conv-residual block as its even frames only (SAR_COMPACT_SKIP=0: the strided data gradient over all
-        T frames): fp32-storage engines with gather tables and fp32 / split arithmetic"""
-        on = _COMPACT_SKIP == "1" or (_COMPACT_SKIP == "fp32" and not self.split)
+        T frames): fp32-storage engines with gather tables and fp32 / split arithmetic.  Default ("fp32"): the fp32 engine, and the
+        blocks of a split engine whose dense 1x1 product runs on conv_tap1_split_kernel (round 6)"""
+        on = _COMPACT_SKIP == "1" or (_COMPACT_SKIP == "fp32" and (not self.split or (
+            i is not None and self._simg("l%d.res.b" % i) is not None)))
         return (on and s == 2 and not self.bf16 and not getattr(self, "cn8", False)
                 and not self.dense_A and type(self)._block_backward is STGCN._block_backward)
 

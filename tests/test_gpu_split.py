@@ -227,6 +227,52 @@ def test_a_diverged_step_is_visible_in_the_split_engine(dev):
 
 
 @pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2), (3, 64, 128, 300, 2), (2, 256, 128, 75, 1),
+                                         (1, 48, 72, 23, 2), (2, 16, 200, 31, 1), (1, 72, 40, 10, 2), (4, 128, 64, 150, 1)])
+def test_one_tap_temporal_operator_on_the_split_kernel(dev, arith, B, cin, f, T, s):
+    """conv_tap1_split_kernel (round 6): the strided 1x1 residual convolution forward with bias and BatchNorm partial sums, and the
+    dense 1x1 product of its data gradient with the ADD / MASK epilogues -- ragged channel counts (not multiples of 32 / 64), tiles
+    that end inside a sequence, T > one tile, gradient-like magnitudes; the launch must have taken the split kernel"""
+    import torch.nn.functional as F
+    from sar_amd import ops, _lib as L
+    assert ops.split_applicable(L.SAR_CONV_TEMPORAL, 25, cin, f, 1, s, None, None, False, 0)
+    g = torch.Generator().manual_seed(cin * 7 + f + T)
+    x = torch.randn(B, cin, T, 25, generator=g)
+    kernel = torch.randn(1, 1, cin, f, generator=g) * 0.1
+    bias = torch.randn(f, generator=g) * 0.1
+    ref = F.conv2d(x.double(), O.hwio_to_oihw(kernel.double()), bias.double(), stride=(s, 1))
+    To = ref.shape[2]
+    out = torch.empty((f, B * To * 25), device=dev)
+    r = ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), out, kernel.to(dev), 0, f, B=B, V=25, T_src=T, T_out=To, Kc=cin, M=f,
+                      taps=1, stride=s, pad=0, bias=bias.to(dev), epi=L.SAR_EPI_STATS, split=arith)
+    torch.cuda.synchronize()
+    assert rel_err(from_cn(out.cpu(), B, To, 25), ref) < TOL
+    part = r[0].cpu().double().sum(dim=1)
+    assert rel_err(part[:, 0], ref.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(part[:, 1], (ref * ref).sum(dim=(0, 2, 3))) < TOL
+    # the dense data gradient (forward form with W^T) of a gradient-like dout, added to a skip gradient / masked by a source
+    dr = torch.randn(B, f, To, 25, generator=g) * 3e-6
+    dr[0, f // 2, To // 2, 7] = 1e-2                       # an outlier 3 000 x the typical magnitude
+    skip = torch.randn(B, cin, To, 25, generator=g) * 1e-5
+    want = torch.einsum("bfty,cf->bcty", dr.double(), kernel[0, 0].double())
+    rT = kernel[0, 0].t().contiguous().to(dev)           # [f][cin]
+    dx = torch.empty((cin, B * To * 25), device=dev)
+    if cin % 8 == 0:
+        ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(dr).to(dev), dx, rT, 0, cin, B=B, V=25, T_src=To, T_out=To, Kc=f, M=cin, taps=1,
+                      stride=1, pad=0, epi=L.SAR_EPI_ADD, aux=to_cn(skip).to(dev), split=arith)
+        torch.cuda.synchronize()
+        assert rel_err(from_cn(dx.cpu(), B, To, 25), want + skip.double()) < TOL
+        src = torch.randn(B, cin, To, 25, generator=g)
+        sc, sh = 1 + 0.1 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
+        pm = ops.conv_gemm(L.SAR_CONV_TEMPORAL, to_cn(dr).to(dev), dx, rT, 0, cin, B=B, V=25, T_src=To, T_out=To, Kc=f, M=cin, taps=1,
+                           stride=1, pad=0, epi=L.SAR_EPI_MASK, aux=to_cn(src).to(dev), aux_affine=(sc.to(dev), sh.to(dev)), split=arith)
+        torch.cuda.synchronize()
+        keep = (src.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)) > 0
+        assert rel_err(from_cn(dx.cpu(), B, To, 25), want * keep) < TOL
+        assert rel_err(pm[0].cpu().double().sum(dim=1)[:, 0], (want * keep).sum(dim=(0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("transpose", [False, True])
 def test_graph_conv_with_sums_beyond_the_source_bound(dev, arith, transpose):
     """the transposed NTU lists hold sums of four joints with weight 1: the gathered value reaches 4x the source's amax (the first
@@ -371,18 +417,23 @@ def test_split_engines_match_the_float64_oracle(dev, mode):
 def test_f32_split_trains_a_learnable_task_like_fp32(dev):
     """long-horizon behaviour (VERDICT r05 next #1d; the 1 200-step record is profiles/r06_f32split_training_curve.txt, written by
     tools/split_curve.py): 400 Nesterov-SGD steps of the full 10-block model on the learnable task of tests/test_gpu_bf16_training.py,
-    fp32 and f32_split engines from the same weights on the same data stream.  SGD at this rate separates ANY two runs after a few
-    steps -- the fp32 engine restarted from weights one ulp away ends 0.023 / 0.003 from itself (loss / top-1 over the last 50
-    steps) -- so the bound is that yardstick with a margin, far inside the bf16 engine's 7.5 % / 0.03."""
+    fp32 and f32_split engines from the same weights on the same data stream -- and, as the YARDSTICK, the fp32 engine once more from
+    weights ONE ulp away.  SGD at this rate separates ANY two runs after a few steps: at 400 steps the two fp32 runs end 0.02-0.07 /
+    0.00-0.04 apart (loss / top-1 over the last 50 steps; 0.003 / 0.003 at 1 200 steps), differently on every change of a summation
+    order anywhere in the step (a fixed 5 % band around ONE fp32 run failed on exactly that in round 6).  So the split engine must
+    end inside the band the two fp32 runs span, widened by 1.5 x their distance and a small absolute margin -- far inside the bf16
+    engine's 7.5 % / 0.03 when the fp32 runs agree, and no tighter than fp32 is with itself when they do not."""
     import test_gpu_bf16_training as TT
     from sar_amd.stgcn import STGCN
     classes, steps, bs = 10, 400, 32
     batch = TT._task(dev, classes)
     p = O.init_params(classes, seed=7, dtype=torch.float64)
+    p_ulp = {k: (torch.nextafter(v.float(), torch.full_like(v.float(), float("inf"))).double() if v.is_floating_point() else v)
+             for k, v in p.items()}
     res = {}
-    for mode in ("fp32", "f32_split"):
+    for name, mode, params in (("fp32", "fp32", p), ("f32_split", "f32_split", p), ("fp32+1ulp", "fp32", p_ulp)):
         eng = STGCN(num_classes=classes, device=dev, mfma=mode)
-        eng.load_params(p)
+        eng.load_params(params)
         losses, correct = [], []
         for s in range(steps):
             x, y = batch(bs, s)
@@ -391,13 +442,17 @@ def test_f32_split_trains_a_learnable_task_like_fp32(dev):
             losses.append(loss.reshape(()))
             correct.append((logits.argmax(1) == y).float().mean())
         losses, correct = torch.stack(losses).cpu(), torch.stack(correct).cpu()
-        assert torch.isfinite(losses).all(), mode
-        res[mode] = (losses[0].item(), losses[-50:].mean().item(), correct[-50:].mean().item())
-    (f0, fl, fa), (s0, sl, sa) = res["fp32"], res["f32_split"]
-    print("learnable task, %d steps: fp32 loss %.4f -> %.4f top-1 %.3f | f32_split %.4f -> %.4f top-1 %.3f" % (steps, f0, fl, fa, s0, sl, sa))
+        assert torch.isfinite(losses).all(), name
+        res[name] = (losses[0].item(), losses[-50:].mean().item(), correct[-50:].mean().item())
+        del eng
+    (f0, fl, fa), (s0, sl, sa), (c0, cl, ca) = res["fp32"], res["f32_split"], res["fp32+1ulp"]
+    print("learnable task, %d steps: fp32 loss %.4f -> %.4f top-1 %.3f | f32_split %.4f -> %.4f top-1 %.3f | fp32 + 1 ulp %.4f -> %.4f top-1 %.3f"
+          % (steps, f0, fl, fa, s0, sl, sa, c0, cl, ca))
     assert abs(s0 - f0) <= 1e-4 * abs(f0), "the first step's loss (same weights, same batch) is the parity tolerance's business"
-    assert fl < 0.5 * f0 and fa > 0.6 and fl > 0.5, res
-    assert abs(sl - fl) <= 0.05 * fl and abs(sa - fa) <= 0.03, res
+    for l_, a_ in ((fl, fa), (cl, ca), (sl, sa)):
+        assert l_ < 0.5 * f0 and a_ > 0.6 and l_ > 0.5, res            # every run learns the task down to its irreducible error
+    assert abs(sl - 0.5 * (fl + cl)) <= 1.5 * abs(fl - cl) + 0.03 * fl, res
+    assert abs(sa - 0.5 * (fa + ca)) <= 1.5 * abs(fa - ca) + 0.02, res
 
 
 # ---------------------------------------------------------------------------------------------- Path B: csrc/conv2d_split.hip

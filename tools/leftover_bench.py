@@ -66,6 +66,17 @@ def main():
         case("res data gradient " + tag + " (compact)", 4.0 * (f * n_out + cin * n_out), lambda: ops.conv_gemm(
             L.SAR_CONV_TEMPORAL, dr, dXc, rT, 0, cin, B=B, V=V, T_src=To, T_out=To, Kc=f, M=cin, taps=1, stride=1, pad=0,
             split=None))
+        # the same launches on conv_tap1_split_kernel (f16x3a; term images and bounds prepared outside the timed launches)
+        imf = ops._pack_split_single(W, 0, f, 1, cin, f, "f16x3a")
+        imb = ops._pack_split_single(rT, 0, cin, 1, f, cin, "f16x3a")
+        bX, bD = ops._src_bound_single(X, None), ops._src_bound_single(dr, None)
+        case("res forward " + tag + " (STATS) f16x3a", 4.0 * (cin * n_in + f * n_out), lambda: ops.conv_gemm(
+            L.SAR_CONV_TEMPORAL, X, r, W, 0, f, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=2, pad=0, bias=bias,
+            epi=L.SAR_EPI_STATS, split="f16x3a", packed=imf[0], bounds=(bX, imf[1])))
+        case("res data gradient " + tag + " (compact) f16x3a", 4.0 * (f * n_out + cin * n_out), lambda: ops.conv_gemm(
+            L.SAR_CONV_TEMPORAL, dr, dXc, rT, 0, cin, B=B, V=V, T_src=To, T_out=To, Kc=f, M=cin, taps=1, stride=1, pad=0,
+            split="f16x3a", packed=imb[0], bounds=(bD, imb[1])))
+        case("amax pass over dr " + tag, 4.0 * f * n_out, lambda: ops.amax(dr, bD))
         case("res weight gradient " + tag, 4.0 * (cin * n_in + f * n_out), lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, X, dr, flat, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=2, pad=0, w_stride_tap=0,
             w_stride_c=f, wsize=cin * f, bsize=f, split=None))
