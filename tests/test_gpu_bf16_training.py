@@ -52,14 +52,22 @@ def _task(dev, classes=10, T=64, seed=0):
 
 
 def test_bf16_trains_a_learnable_task_like_fp32(dev):
+    """400 Nesterov-SGD steps of the full model on the learnable task above: fp32, bf16 storage and -- the YARDSTICK -- the fp32 engine
+    once more from weights ONE ulp away.  SGD at this rate separates any two runs after a few steps; at 400 steps two fp32 runs end
+    0.02-0.07 / 0.00-0.04 apart (loss / top-1 over the last 50 steps), differently on every change of a summation order anywhere in
+    the step (round 6: a fixed band around ONE fp32 run failed on the first layer's new weight-gradient kernel).  The bf16 engine
+    must end inside the band the two fp32 runs span, widened by 1.5 x their distance and the margin measured for bf16 storage
+    (5 % of the loss, 0.02 top-1: fp32 1.204 / 0.748, bf16 1.263 / 0.734, tools/bf16_curve.py)."""
     from sar_amd.stgcn import STGCN
     classes, steps, bs = 10, 400, 32
     batch = _task(dev, classes)
     p = O.init_params(classes, seed=7, dtype=torch.float64)
+    p_ulp = {k: (torch.nextafter(v.float(), torch.full_like(v.float(), float("inf"))).double() if v.is_floating_point() else v)
+             for k, v in p.items()}
     res = {}
-    for mode in ("fp32", "bf16"):
+    for name, mode, params in (("fp32", "fp32", p), ("bf16", "bf16", p), ("fp32+1ulp", "fp32", p_ulp)):
         eng = STGCN(num_classes=classes, device=dev, mfma=mode)
-        eng.load_params(p)
+        eng.load_params(params)
         losses, correct = [], []
         for s in range(steps):
             x, y = batch(bs, s)
@@ -69,14 +77,16 @@ def test_bf16_trains_a_learnable_task_like_fp32(dev):
             losses.append(loss.reshape(()))
             correct.append((logits.argmax(1) == y).float().mean())
         losses, correct = torch.stack(losses).cpu(), torch.stack(correct).cpu()
-        res[mode] = (losses[:10].mean().item(), losses[-50:].mean().item(), correct[-50:].mean().item())
-    (f0, fl, fa), (b0, bl, ba) = res["fp32"], res["bf16"]
-    print("learnable task, %d steps: fp32 loss %.4f -> %.4f top-1 %.3f | bf16 loss %.4f -> %.4f top-1 %.3f" % (steps, f0, fl, fa, b0, bl, ba))
-    assert fl < 0.5 * f0 and fa > 0.6, "the task must be learnable: %s" % (res,)
-    assert 0.5 < fl, "an irreducible error must remain, or the comparison says nothing"
-    # measured: fp32 1.204 / 0.748, bf16 1.263 / 0.734 (bf16_operands 1.211 / 0.746, tools/bf16_curve.py): 4.9 % / 0.014
-    assert abs(bl - fl) <= 0.075 * fl, res
-    assert abs(ba - fa) <= 0.03, res
+        res[name] = (losses[:10].mean().item(), losses[-50:].mean().item(), correct[-50:].mean().item())
+        del eng
+    (f0, fl, fa), (b0, bl, ba), (c0, cl, ca) = res["fp32"], res["bf16"], res["fp32+1ulp"]
+    print("learnable task, %d steps: fp32 loss %.4f -> %.4f top-1 %.3f | bf16 loss %.4f -> %.4f top-1 %.3f | fp32 + 1 ulp %.4f -> %.4f top-1 %.3f"
+          % (steps, f0, fl, fa, b0, bl, ba, c0, cl, ca))
+    for l_, a_ in ((fl, fa), (cl, ca), (bl, ba)):
+        assert l_ < 0.5 * f0 and a_ > 0.6, "the task must be learnable: %s" % (res,)
+        assert 0.5 < l_, "an irreducible error must remain, or the comparison says nothing"
+    assert abs(bl - 0.5 * (fl + cl)) <= 1.5 * abs(fl - cl) + 0.05 * fl, res
+    assert abs(ba - 0.5 * (fa + ca)) <= 1.5 * abs(fa - ca) + 0.02, res
 
 
 def test_engine_gradient_is_the_gradient_of_the_bf16_storage_network(dev):
