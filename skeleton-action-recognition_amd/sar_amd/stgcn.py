@@ -68,6 +68,7 @@ class _BN:
 class STGCN:
     # split arithmetic (mfma="f32_split*"): off unless __init__ turns it on (subclasses with their own __init__ -- ST-GIN -- are fp32)
     mfma, split, spacked, _cells = "fp32", None, None, None
+    _slabs, _slab_flush = None, "end"     # (ops.SlabBatch of the weight gradients: set by __init__; ST-GIN keeps its per-gradient reductions)
 
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
                  blocks=None, motion=False, mfma=None, trainable_adjacency=False):
