@@ -370,8 +370,8 @@ int sar_bn_add_relu_fwd_mask_amax_f32(const float* u, const float* scale, const 
 int sar_bn_add_relu_bwd_apply_mask_amax_f32(const float* dy, const void* mask, const float* u, const float* r,
                                             const float* k1, const float* k2, const float* k3,
                                             const float* rk1, const float* rk2, const float* rk3,
-                                            float* du, float* dr, float* dz_out, uint32_t* amax_du, int C, int64_t n, int64_t ld,
-                                            sar_stream_t s);
+                                            float* du, float* dr, float* dz_out, uint32_t* amax_du, uint32_t* amax_dr, int C, int64_t n,
+                                            int64_t ld, sar_stream_t s);   /* amax_dr (may be NULL): the same for dr -- the operand of the residual branch's dense 1x1 data gradient (round 6) */
 int sar_affine2_amax_f32(const float* a, const float* b, const float* k1, const float* k2, const float* k3,
                          float* out, uint32_t* amax_out, int C, int64_t n, int64_t ld, sar_stream_t s);
 /* generic row-affine: out = k1[c]*a + k2[c]*b + k3[c]  (BN backward apply: dg from dz1 and g) */

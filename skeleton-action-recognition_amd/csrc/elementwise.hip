@@ -477,12 +477,13 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ u, const float* __restrict__ r,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3, const float* __restrict__ rk1,
     const float* __restrict__ rk2, const float* __restrict__ rk3, float* du, float* dr, float* dz_out, int64_t n,
-    int64_t ldm, const unsigned char* __restrict__ mask = nullptr, unsigned* __restrict__ amax = nullptr) {
+    int64_t ldm, const unsigned char* __restrict__ mask = nullptr, unsigned* __restrict__ amax = nullptr,
+    unsigned* __restrict__ amax_r = nullptr) {
   const int c = blockIdx.y;
   const int64_t base = (int64_t)c * ldm;
   const float a1 = k1[c], a2 = k2[c], a3 = k3[c];
   const float b1 = dr ? rk1[c] : 0.f, b2 = dr ? rk2[c] : 0.f, b3 = dr ? rk3[c] : 0.f;
-  unsigned am = 0u;
+  unsigned am = 0u, amr = 0u;
   for (int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * TPB * VEC) {
     float g[VEC], yv[VEC], uv[VEC], rv[VEC], o1[VEC], o2[VEC], o3[VEC];
     ld<VEC>(dy + base + i, g);
@@ -502,13 +503,20 @@ __global__ __launch_bounds__(TPB) void bn_add_relu_bwd_apply_kernel(
       o3[j] = dz;
       o1[j] = fmaf(a1, dz, fmaf(a2, uv[j], a3));
       if (amax) am = amax_bits(am, o1[j]);   // uniform
-      if (dr) o2[j] = fmaf(b1, dz, fmaf(b2, rv[j], b3));
+      if (dr) {
+        o2[j] = fmaf(b1, dz, fmaf(b2, rv[j], b3));
+        if (amax_r) amr = amax_bits(amr, o2[j]);   // uniform
+      }
     }
     st<VEC>(du + base + i, o1);
     if (dr) st<VEC>(dr + base + i, o2);
     if (dz_out) st<VEC>(dz_out + base + i, o3);
   }
   if (amax) block_amax(am, amax);
+  if (amax_r && dr) {
+    __syncthreads();   // block_amax's LDS words are re-used
+    block_amax(amr, amax_r);
+  }
 }
 
 template <int VEC>
@@ -880,7 +888,7 @@ extern "C" int sar_bn_add_relu_bwd_reduce_mask_f32(const float* dy, const void* 
 static int bn_add_relu_bwd_apply_mask_impl(const float* dy, const void* mask, const float* u, const float* r,
                                            const float* k1, const float* k2, const float* k3, const float* rk1,
                                            const float* rk2, const float* rk3, float* du, float* dr, float* dz_out, uint32_t* amax,
-                                           int C, int64_t n, int64_t ldm, sar_stream_t s) {
+                                           int C, int64_t n, int64_t ldm, sar_stream_t s, uint32_t* amax_r = nullptr) {
   SAR_REQUIRE(dy && mask && u && k1 && k2 && k3 && du && C > 0 && n > 0 && ldm >= n, "sar_bn_add_relu_bwd_apply_mask: bad arguments");
   SAR_REQUIRE(!dr || (r && rk1 && rk2 && rk3), "sar_bn_add_relu_bwd_apply_mask: residual arguments");
   if (!vec4_ok(n, ldm, {dy, u, r, du, dr, dz_out})) {
@@ -888,7 +896,7 @@ static int bn_add_relu_bwd_apply_mask_impl(const float* dy, const void* mask, co
     return SAR_E_UNSUP;
   }
   hipLaunchKernelGGL(bn_add_relu_bwd_apply_kernel<4>, dim3(row_blocks(n, 4), C), dim3(TPB), 0, as_stream(s), dy, (const float*)nullptr,
-                     u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, n, ldm, (const unsigned char*)mask, amax);
+                     u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, n, ldm, (const unsigned char*)mask, amax, amax_r);
   SAR_LAUNCH_CHECK("sar_bn_add_relu_bwd_apply_mask_f32");
   return 0;
 }
@@ -901,9 +909,10 @@ extern "C" int sar_bn_add_relu_bwd_apply_mask_f32(const float* dy, const void* m
 extern "C" int sar_bn_add_relu_bwd_apply_mask_amax_f32(const float* dy, const void* mask, const float* u, const float* r,
                                                        const float* k1, const float* k2, const float* k3, const float* rk1,
                                                        const float* rk2, const float* rk3, float* du, float* dr, float* dz_out,
-                                                       uint32_t* amax_du, int C, int64_t n, int64_t ldm, sar_stream_t s) {
+                                                       uint32_t* amax_du, uint32_t* amax_dr, int C, int64_t n, int64_t ldm, sar_stream_t s) {
   SAR_REQUIRE(amax_du != nullptr, "sar_bn_add_relu_bwd_apply_mask_amax: null cell");
-  return bn_add_relu_bwd_apply_mask_impl(dy, mask, u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, amax_du, C, n, ldm, s);
+  SAR_REQUIRE(!amax_dr || dr, "sar_bn_add_relu_bwd_apply_mask_amax: amax_dr without dr");
+  return bn_add_relu_bwd_apply_mask_impl(dy, mask, u, r, k1, k2, k3, rk1, rk2, rk3, du, dr, dz_out, amax_du, C, n, ldm, s, amax_dr);
 }
 
 extern "C" int sar_bn_add_relu_bwd_reduce_f32(const float* dy, const float* y, const float* u, const float* r,

@@ -118,7 +118,7 @@ SIGNATURES = {
     "sar_affine2_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_affine2_amax_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
     "sar_bn_add_relu_fwd_mask_amax_f32": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i64, _fp]),
-    "sar_bn_add_relu_bwd_apply_mask_amax_f32": (_i, [_fp] * 14 + [_i, _i64, _i64, _fp]),
+    "sar_bn_add_relu_bwd_apply_mask_amax_f32": (_i, [_fp] * 15 + [_i, _i64, _i64, _fp]),
     "sar_pool_fwd_f32": (_i, [_fp, _i64, _i, _i, _i, _i, _fp, _fp]),
     "sar_fc_fwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "sar_softmax_ce_f32": (_i, [_fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),

@@ -586,19 +586,24 @@ def bn_add_relu_bwd_reduce(dy, y, u, r, mu=None, mr=None, tail=None, mask=None):
     return partials, nparts
 
 
-def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask=None, amax_cell=None):
-    """amax_cell: the bound cell of du (split arithmetic), see bn_add_relu_fwd"""
+def bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask=None, amax_cell=None, amax_dr_cell=None):
+    """amax_cell: the bound cell of du (split arithmetic), see bn_add_relu_fwd; amax_dr_cell: the same for dr (the operand of the
+    residual branch's dense 1x1 data gradient)"""
     Cc, n = u.shape
     rk = rk or (None, None, None)
     if mask is not None and amax_cell is not None:
         check(L.load().sar_bn_add_relu_bwd_apply_mask_amax_f32(ptr(dy), ptr(mask), ptr(u), ptr(r), ptr(k[0]), ptr(k[1]), ptr(k[2]),
                                                                ptr(rk[0]), ptr(rk[1]), ptr(rk[2]), ptr(du), ptr(dr), ptr(dz_out),
-                                                               ptr(amax_cell), Cc, n, u.stride(0), stream_ptr()),
+                                                               ptr(amax_cell), ptr(amax_dr_cell if dr is not None else None),
+                                                               Cc, n, u.stride(0), stream_ptr()),
               "sar_bn_add_relu_bwd_apply_mask_amax_f32")
         return
-    if amax_cell is not None:
+    if amax_cell is not None or amax_dr_cell is not None:
         bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz_out, mask)
-        amax(du, amax_cell)
+        if amax_cell is not None:
+            amax(du, amax_cell)
+        if amax_dr_cell is not None and dr is not None:
+            amax(dr, amax_dr_cell)
         return
     if mask is not None:
         check(L.load().sar_bn_add_relu_bwd_apply_mask_f32(ptr(dy), ptr(mask), ptr(u), ptr(r), ptr(k[0]), ptr(k[1]), ptr(k[2]),

@@ -673,8 +673,11 @@ class STGCN:
         dr = torch.empty_like(r) if kind == "conv" else None
         dz = dY if (kind == "identity" and gated is None) else None  # in place: dY becomes the pre-ReLU gradient for the skip path (already gated: nothing to write)
         ducell = self._cell(i, 1) if self._cell_live(pre + "tcn.b", "tdgrad", "twgrad") else None   # the bound of du: by-product
+        # (the bound of dr: operand of the residual branch's dense 1x1 data gradient on conv_tap1_split_kernel; by-product too)
+        drcell = self._cell(i, 4) if (kind == "conv" and self._f16 and self._simg(pre + "res.b") is not None
+                                      and self._compact_skip(s, T, i)) else None
         ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz,
-                                  mask=sb.get("ymask"), amax_cell=ducell)
+                                  mask=sb.get("ymask"), amax_cell=ducell, amax_dr_cell=drcell)
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
         wt = self.g[pre + "tcn.kernel"]
         flat_w = self.grad[self.offsets[pre + "tcn.kernel"]:self.offsets[pre + "tcn.bias"] + f]
@@ -756,8 +759,6 @@ class STGCN:
             # epilogue on even frames (SAR_GRAPH_AUX_EVEN_FRAMES) -- the zeros are neither written nor read back
             dXc = torch.empty((cin, B * To * V), dtype=torch.float32, device=dev)
             rb = self._simg(pre + "res.b")
-            if rb is not None and self._f16:
-                ops.amax(dr, self._cell(i, 4))                   # the bound of dr (one pass over a To-frame tensor)
             ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXc, rT, 0, cin, B=B, V=V, T_src=To, T_out=To, Kc=f, M=cin, taps=1, stride=1, pad=0,
                           **self._split_args(rb, self._cell(i, 4), None))
             return dXc

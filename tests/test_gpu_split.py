@@ -226,6 +226,33 @@ def test_a_diverged_step_is_visible_in_the_split_engine(dev):
         assert not torch.isfinite(eng.g["l0.gcn.kernel"]).all().item(), mode
 
 
+def test_block_tail_backward_raises_the_bounds_of_du_and_dr(dev):
+    """sar_bn_add_relu_bwd_apply_mask_amax_f32 raises amax_du AND (round 6) amax_dr to the largest magnitude it wrote -- what a
+    separate sar_amax_f32 pass over each tensor gives -- and the outputs do not depend on the cells being asked for"""
+    from sar_amd import ops
+    g = torch.Generator().manual_seed(5)
+    C, n = 24, 4000
+    dy, u, r = (torch.randn(C, n, generator=g).to(dev) for _ in range(3))
+    y = torch.randn(C, n, generator=g).to(dev)
+    mask = ops.relu_mask(y)
+    ops.bn_add_relu_fwd(u, torch.ones(C, device=dev), torch.zeros(C, device=dev), 0, None, None, None, y, mask=mask)
+    k = [torch.randn(C, generator=g).to(dev) for _ in range(3)]
+    rk = [torch.randn(C, generator=g).to(dev) * 3 for _ in range(3)]
+    du, dr, dz = (torch.empty(C, n, device=dev) for _ in range(3))
+    cells = torch.zeros(2, dtype=torch.int32, device=dev)
+    ops.bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du, dr, dz, mask=mask, amax_cell=cells[0:1], amax_dr_cell=cells[1:2])
+    du2, dr2, dz2 = (torch.empty(C, n, device=dev) for _ in range(3))
+    ops.bn_add_relu_bwd_apply(dy, y, u, r, k, rk, du2, dr2, dz2, mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(du, du2) and torch.equal(dr, dr2) and torch.equal(dz, dz2)
+    assert cells[0].item() == _bits(du.abs().max().item()) and cells[1].item() == _bits(dr.abs().max().item())
+    assert cells[0].item() != cells[1].item()
+    only_du = torch.zeros(1, dtype=torch.int32, device=dev)       # no residual branch: the second cell is not touched
+    ops.bn_add_relu_bwd_apply(dy, y, u, None, k, None, du2, None, None, mask=mask, amax_cell=only_du, amax_dr_cell=cells[1:2])
+    torch.cuda.synchronize()
+    assert only_du.item() == _bits(du2.abs().max().item()) and cells[1].item() == _bits(dr.abs().max().item())
+
+
 @pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("B,cin,f,T,s", [(2, 64, 128, 13, 2), (2, 128, 256, 10, 2), (3, 64, 128, 300, 2), (2, 256, 128, 75, 1),
                                          (1, 48, 72, 23, 2), (2, 16, 200, 31, 1), (1, 72, 40, 10, 2), (4, 128, 64, 150, 1)])
