@@ -355,6 +355,10 @@ class SlabBatch:
         key = (out.data_ptr(), nsplit, n)
         t = self._slabs.get(key)
         if t is None:
+            if len(self._slabs) >= 512:      # a caller that keeps changing its batch geometry: do not grow without bound
+                assert not self._pending, "SlabBatch: slab buffers would be dropped with reductions pending"
+                self._slabs.clear()
+                self._tables.clear()
             t = self._slabs[key] = torch.empty((nsplit, n), dtype=torch.float32, device=out.device)
         return t
 

@@ -1,5 +1,11 @@
-import sys, os
-sys.path.insert(0, "/root/repo/skeleton-action-recognition_amd"); sys.path.insert(0, "/root/repo")
+"""Per-region table of one leg's train step (sar_amd.profiler regions: calls and ms per step, in-step timings with the weight-gradient
+stream on): which arithmetic each GEMM family of the step actually took.   python tools/step_regions.py [fp32|bf16|f32_split]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "skeleton-action-recognition_amd"))
+sys.path.insert(0, ROOT)
 import torch
 from sar_amd import profiler
 from sar_amd.stgcn import STGCN
