@@ -151,6 +151,17 @@ def shared_side_stream(device, priority=0):
     return st
 
 
+def shared_aux_stream(device):
+    """ONE further stream per (device, host thread) for the branch launches an engine forks off its main chain (the resnet's
+    down-sampling branch, SAR_PATHB_DS_STREAM): shared for the reason shared_side_stream gives"""
+    import threading
+    key = (torch.device(device).index or 0, threading.get_ident(), "aux")
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def side_stream_cu_mask(device):
     """the CU mask of the weight-gradient stream as a list of 32-bit words, or None = every CU.  SAR_SIDE_CU_MASK:
     'off' | 'skip:<n>' (every n-th CU left to the main chain) | 'first:<k>' / 'last:<k>' (k contiguous CUs left out) | hex words"""

@@ -36,6 +36,14 @@ class _Conv:
 
 
 SLAB_BATCH_PATHB = __import__("os").environ.get("SAR_SLAB_BATCH_PATHB", "0") == "1"
+# Fork / join of what does not depend on the main chain (round 6; SAR_PATHB_DS_STREAM=0: everything on the main stream again).  At bs = 32
+# a step is a serial chain of ~150 launches of 4-50 us: the down-sampling branch of the three stride-2 blocks (1x1 convolution + its
+# BatchNorm finalisation forward; its backward finalisation and the dense 1x1 product of its data gradient backward), the nine Samuelson
+# bound cells and -- through prepack(), called by the trainer in front of the radar front-end -- the step's weight images run on a third
+# stream and are joined where their results are needed.  Same launches, same order per tensor: bit-identical
+# (tests/test_gpu_slab_batch.py); interleaved processes (tools/ab_pathb2.sh, profiles/r06_pathB_fork_ab.txt): fp32 4 976 -> 5 222 clips/s
+# (+4.9 %), f32_split 7 098 -> 7 386 (+4.1 %)
+DS_STREAM = __import__("os").environ.get("SAR_PATHB_DS_STREAM", "1") == "1"
 
 
 class ResNet18:
@@ -101,6 +109,9 @@ class ResNet18:
         # the split arithmetic, 6.40 -> 6.44 / 6.33 at the end / per stage in fp32); SAR_SLAB_BATCH_PATHB=1 turns it on
         self._slabs = ops.SlabBatch() if (ops.SLAB_BATCH and SLAB_BATCH_PATHB) else None
         self._slab_flush = ops.SLAB_FLUSH
+        self._aux = ops.shared_aux_stream(dev) if (DS_STREAM and dev.type == "cuda") else None
+        self._bounds_forked = False
+        self._prepacked = None
         # side streams of the launches that fan out (stride-2 data gradients): owned by this engine, not by the library
         with torch.cuda.device(dev):
             self._ctx = L.Context() if dev.type == "cuda" else None
@@ -185,6 +196,7 @@ class ResNet18:
                 self.p[k].zero_()
 
     def load_params(self, params):
+        self._prepacked = None           # images issued by prepack() would be those of the old weights
         for k, v in params.items():
             if k in self.p:
                 self.p[k].copy_(v.to(torch.float32).reshape(self.shapes[k]))
@@ -217,6 +229,17 @@ class ResNet18:
                 self._wb_ready = torch.cuda.Event()
                 self._wb_ready.record(self._side)
 
+    def prepack(self, training=True):
+        """The coming step's weight images (term images and amax cells of the split arithmetic, the data-gradient layouts) issued NOW
+        on the third stream, so that they run beside whatever the caller issues next on the main stream -- the radar front-end, which
+        does not read the resnet's weights (sar_amd/train.py).  forward() then joins instead of packing.  No-op without the stream."""
+        if self._aux is None or self._prepacked is not None:
+            return
+        self._aux.wait_stream(torch.cuda.current_stream())      # behind the optimizer step that produced self.flat
+        with torch.cuda.stream(self._aux):
+            self._pack(training)
+        self._prepacked = bool(training)
+
     def _w(self, name, bwd=False):
         if bwd:
             o, n = self._woff[name]
@@ -237,22 +260,43 @@ class ResNet18:
         return dict(split=self.split, packed=self.spacked.image((name, kind)),
                     bounds=(self._cell(name, kind), self.spacked.bound((name, kind))))
 
-    def _conv_fwd(self, name, X, B, H, W, training, pro=None, bn_src=None):
+    def _conv_fwd(self, name, X, B, H, W, training, pro=None, bn_src=None, out=None):
         """bn_src: (BatchNorm name, sample count) of the folded prologue -- the source bound of the split kernels is then the Samuelson
         bound of that train-mode BatchNorm (no pass over the data); without a prologue the producer of X has raised the cell."""
         cv = self.convs[name]
         Ho, Wo = (H + 2 * cv.pad - cv.k) // cv.stride + 1, (W + 2 * cv.pad - cv.k) // cv.stride + 1
-        out = torch.empty((cv.cout, B * Ho * Wo), dtype=torch.float32, device=X.device)
+        if out is None:
+            out = torch.empty((cv.cout, B * Ho * Wo), dtype=torch.float32, device=X.device)
+        assert out.shape == (cv.cout, B * Ho * Wo)
         sa = self._split_args(name, "f", training)
         # (raised whenever the cell exists: the forward launch AND the weight gradient read it -- ADVICE r05: with
         # SAR_SPLIT_KINDS_PATHB=dgrad,wgrad the weight gradient read a bound that only a split forward launch used to raise)
-        if training and bn_src is not None and self._cell(name, "f") is not None:
+        if training and bn_src is not None and self._cell(name, "f") is not None and not self._bounds_forked:
             ops.bn_bound(self.p[bn_src[0] + ".weight"], self.p[bn_src[0] + ".bias"], bn_src[1], self._cell(name, "f"))
         r = ops.conv2d_gemm(X, out, self._w(name), cv.cin * cv.cout, cv.cout,
                             epi=L.SAR_EPI_STATS if training else L.SAR_EPI_NONE, B=B, Kc=cv.cin, M=cv.cout, H_src=H,
                             W_src=W, H_out=Ho, W_out=Wo, KH=cv.k, KW=cv.k, stride=cv.stride, pad=cv.pad, pro=pro,
                             pro_relu=pro is not None, **sa)
         return out, r, Ho, Wo
+
+    def _all_bn_bounds(self, B, H, W):
+        """the Samuelson bound cells of a training step -- the stem's (source of the first block) and every block's bn1 (folded into
+        conv2's operand) -- from the geometry alone: what forward() raises layer by layer when they are not forked"""
+        def osz(n, cv):
+            return (n + 2 * cv.pad - cv.k) // cv.stride + 1
+        cv = self.convs["conv1"]
+        H1, W1 = osz(H, cv), osz(W, cv)
+        first = self._cell(self.blocks[0][0] + "conv1", "f")
+        if first is not None:
+            ops.bn_bound(self.p["bn1.weight"], self.p["bn1.bias"], B * H1 * W1, first)
+        Hc, Wc = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        for pre, inpl, planes, stride, ds in self.blocks:
+            c1 = self.convs[pre + "conv1"]
+            Ho, Wo = osz(Hc, c1), osz(Wc, c1)
+            cell = self._cell(pre + "conv2", "f")
+            if cell is not None:
+                ops.bn_bound(self.p[pre + "bn1.weight"], self.p[pre + "bn1.bias"], B * Ho * Wo, cell)
+            Hc, Wc = Ho, Wo
 
     def _bn_stats(self, name, r, count, training):
         b = self.bn[name]
@@ -271,7 +315,19 @@ class ResNet18:
         x = x.contiguous()
         B, _, H, W = x.shape
         dev = x.device
-        self._pack(training)
+        if self._prepacked is not None and self._prepacked == bool(training):      # prepack(): issued on the third stream by the trainer
+            torch.cuda.current_stream().wait_stream(self._aux)
+        else:
+            self._pack(training)
+        self._prepacked = None
+        self._bounds_forked = False
+        if training and self._aux is not None and self._cells is not None:
+            # every Samuelson bound of the step (they depend on gamma / beta and the sample counts only) on the third stream, beside
+            # the stem: nine 4-us launches off the serial chain; joined in front of the first block
+            self._aux.wait_stream(torch.cuda.current_stream())      # behind the zeroing of the cells
+            with torch.cuda.stream(self._aux):
+                self._all_bn_bounds(B, H, W)
+            self._bounds_forked = True
         X0 = x.view(1, B * H * W)
         c0, r, H1, W1 = self._conv_fwd("conv1", X0, B, H, W, training)
         bn0 = self._bn_stats("bn1", r, B * H1 * W1, training)
@@ -282,19 +338,33 @@ class ResNet18:
             keep["conv1"], keep["pool"] = c0, h
         saved = dict(x0=X0, c0=c0, B=B, H=H, W=W, H1=H1, W1=W1, H2=H2, W2=W2, blocks=[])
         Hc, Wc = H2, W2
-        if training and self._cell(self.blocks[0][0] + "conv1", "f") is not None:
+        if self._bounds_forked:
+            torch.cuda.current_stream().wait_stream(self._aux)
+        elif training and self._cell(self.blocks[0][0] + "conv1", "f") is not None:
             # the stem tail is max-pool(relu(bn1(c0))): bounded by bn1's Samuelson bound
             ops.bn_bound(self.p["bn1.weight"], self.p["bn1.bias"], B * H1 * W1, self._cell(self.blocks[0][0] + "conv1", "f"))
         for bi_, (pre, inpl, planes, stride, ds) in enumerate(self.blocks):
+            dsc = bd = None
+            forked = ds and self._aux is not None
+            if forked:       # the down-sampling branch on the third stream; its output lives in main-stream memory
+                cd = self.convs[pre + "downsample.0"]
+                Hd, Wd = (Hc + 2 * cd.pad - cd.k) // cd.stride + 1, (Wc + 2 * cd.pad - cd.k) // cd.stride + 1
+                dsc = torch.empty((cd.cout, B * Hd * Wd), dtype=torch.float32, device=dev)
+                self._aux.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._aux):
+                    _, rd, _, _ = self._conv_fwd(pre + "downsample.0", h, B, Hc, Wc, training, out=dsc)
+                    bd = self._bn_stats(pre + "downsample.1", rd, B * Hd * Wd, training)
+                h.record_stream(self._aux)
             c1, r1, Ho, Wo = self._conv_fwd(pre + "conv1", h, B, Hc, Wc, training)
             b1 = self._bn_stats(pre + "bn1", r1, B * Ho * Wo, training)
             c2, r2, _, _ = self._conv_fwd(pre + "conv2", c1, B, Ho, Wo, training, pro=(b1.scale, b1.shift),
                                           bn_src=(pre + "bn1", B * Ho * Wo))
             b2 = self._bn_stats(pre + "bn2", r2, B * Ho * Wo, training)
-            dsc = bd = None
-            if ds:
+            if ds and not forked:
                 dsc, rd, _, _ = self._conv_fwd(pre + "downsample.0", h, B, Hc, Wc, training)
                 bd = self._bn_stats(pre + "downsample.1", rd, B * Ho * Wo, training)
+            if forked:
+                torch.cuda.current_stream().wait_stream(self._aux)
             y = torch.empty_like(c2)
             ymask = ops.relu_mask(y) if training else None  # 1 bit per element: what the BatchNorm-backward passes read instead of y
             nxt = self.blocks[bi_ + 1][0] + "conv1" if bi_ + 1 < len(self.blocks) else None
@@ -411,13 +481,23 @@ class ResNet18:
                 ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None, tail=tail)
             else:
                 part, nparts = ops.bn_add_relu_bwd_reduce(dY, y, c2, dsc, b2.mean, bd.mean if ds else None, mask=sb.get("ymask"))
+                if ds and self._aux is not None:     # the two finalisations read the same partial sums: side by side
+                    self._aux.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._aux):
+                        self._bn_bwd(pre + "downsample.1", part, nparts, nparts * 4, 4, 2, n_out)
+                    part.record_stream(self._aux)
                 self._bn_bwd(pre + "bn2", part, nparts, nparts * 4, 4, 1, n_out)
-                if ds:
+                if ds and self._aux is not None:
+                    torch.cuda.current_stream().wait_stream(self._aux)
+                elif ds:
                     self._bn_bwd(pre + "downsample.1", part, nparts, nparts * 4, 4, 2, n_out)
             dc2 = torch.empty_like(c2)
             ddsc = torch.empty_like(dsc) if ds else None
             ops.bn_add_relu_bwd_apply(dY, y, c2, dsc, (b2.k1, b2.k2, b2.k3), rk, dc2, ddsc, None if ds else dY, mask=sb.get("ymask"),
                                       amax_cell=self._cell(pre + "conv2", "b"))      # bound of dc2 for conv2's split data gradient
+            if ds and self._aux is not None:
+                ddsc_ready = torch.cuda.Event()
+                ddsc_ready.record(torch.cuda.current_stream())
             # conv2 (input = relu(bn1(c1)), folded)
             self._conv_wgrad(pre + "conv2", c1, dc2, B, Ho, Wo, Ho, Wo, pro=(b1.scale, b1.shift))
             dz1, pm = self._conv_dgrad(pre + "conv2", dc2, B, Ho, Wo, Ho, Wo, epi=L.SAR_EPI_MASK, aux=c1,
@@ -433,8 +513,16 @@ class ResNet18:
                     # the 1x1 / stride 2 data gradient is non-zero at the even pixels only: computed at the small resolution
                     # (a plain stride-1 product) and added there by the parity-class launches of conv1's data gradient
                     aux = torch.empty((cd.cin, B * Ho * Wo), dtype=torch.float32, device=dev)
-                    ops.conv2d_gemm(ddsc, aux, self._w(pre + "downsample.0", True), cd.cout * cd.cin, cd.cin, B=B, Kc=cd.cout,
-                                    M=cd.cin, H_src=Ho, W_src=Wo, H_out=Ho, W_out=Wo, KH=1, KW=1, stride=1, pad=0, transposed=True)
+                    if self._aux is not None:     # forked: ddsc has been ready since the apply pass; joined in front of conv1's data gradient
+                        self._aux.wait_event(ddsc_ready)
+                        with torch.cuda.stream(self._aux):
+                            ops.conv2d_gemm(ddsc, aux, self._w(pre + "downsample.0", True), cd.cout * cd.cin, cd.cin, B=B, Kc=cd.cout,
+                                            M=cd.cin, H_src=Ho, W_src=Wo, H_out=Ho, W_out=Wo, KH=1, KW=1, stride=1, pad=0, transposed=True)
+                        ddsc.record_stream(self._aux)
+                        torch.cuda.current_stream().wait_stream(self._aux)
+                    else:
+                        ops.conv2d_gemm(ddsc, aux, self._w(pre + "downsample.0", True), cd.cout * cd.cin, cd.cin, B=B, Kc=cd.cout,
+                                        M=cd.cin, H_src=Ho, W_src=Wo, H_out=Ho, W_out=Wo, KH=1, KW=1, stride=1, pad=0, transposed=True)
                     even = True
                 else:
                     aux, _ = self._conv_dgrad(pre + "downsample.0", ddsc, B, H, W, Ho, Wo)
@@ -484,6 +572,7 @@ class ResNet18:
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         """torch.optim.Adam(lr) (main_spectrogram.py:106) over the flat buffers."""
+        self._prepacked = None
         self.step_dev += 1.0
         if getattr(self, "_lr_host", None) != float(lr):      # one launch less per step while the schedule holds the rate
             self.lr_dev.fill_(float(lr))

@@ -313,6 +313,8 @@ class SpectrogramTrainer:
             self.exchange.submit(flat, events)
 
         kw = dict(grad_scale=1.0 / world, bucket_cb=on_bucket) if ddp else {}
+        if hasattr(eng, "prepack"):
+            eng.prepack(True)            # the resnet's weight images beside the radar front-end (sar_amd/resnet.py: SAR_PATHB_DS_STREAM)
         with torch.set_grad_enabled(train_radar):
             img = model.spectrogram(x)
         if train_radar:                                  # the image depends on trainable radar parameters

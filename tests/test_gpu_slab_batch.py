@@ -131,3 +131,37 @@ def test_resnet_gradients_are_bit_identical_with_one_slab_reduction_per_bucket(d
             assert torch.isfinite(ga).all() and ga.abs().max().item() > 0
             assert torch.equal(ga, gb)
         assert len(sa) == len(sb) and all(torch.equal(u, v) for u, v in zip(sa, sb))
+
+
+@pytest.mark.parametrize("mfma", ["fp32", "f32_split"])
+def test_resnet_with_the_down_sampling_branch_on_its_own_stream_is_bit_identical(dev, mfma):
+    """SAR_PATHB_DS_STREAM (sar_amd/resnet.py: DS_STREAM): the 1x1 down-sampling convolution + its BatchNorm finalisation (forward) and the
+    dense 1x1 product of its data gradient (backward) forked onto a third stream -- same launches, same order per tensor: logits,
+    loss and every gradient bit for bit, over repeated steps (moving statistics included)"""
+    from sar_amd import resnet
+    from sar_amd.resnet import ResNet18
+
+    def run(forked):
+        old = resnet.DS_STREAM
+        resnet.DS_STREAM = forked
+        try:
+            net = ResNet18(num_classes=10, device=dev, seed=5, mfma=mfma)
+        finally:
+            resnet.DS_STREAM = old
+        assert (net._aux is not None) == forked
+        g = torch.Generator(device=dev).manual_seed(2)
+        x = torch.randn((4, 1, 64, 64), generator=g, device=dev)
+        y = torch.tensor([1, 3, 5, 7], device=dev)
+        out = []
+        for _ in range(3):
+            logits, loss = net.loss_and_grad(x, y)[:2]
+            out.append((logits.clone(), loss.clone(), net.grad.clone()))
+        torch.cuda.synchronize()
+        stats = torch.cat([b.moving_mean for b in net.bn.values()] + [b.moving_var for b in net.bn.values()])
+        return out, stats
+    a, sa = run(True)
+    b, sb = run(False)
+    for (la, lsa, ga), (lb, lsb, gb) in zip(a, b):
+        assert torch.equal(la, lb) and torch.equal(lsa, lsb) and torch.equal(ga, gb)
+        assert torch.isfinite(ga).all() and ga.abs().max().item() > 0
+    assert torch.equal(sa, sb)
