@@ -151,11 +151,12 @@ def shared_side_stream(device, priority=0):
     return st
 
 
-def shared_aux_stream(device):
-    """ONE further stream per (device, host thread) for the branch launches an engine forks off its main chain (the resnet's
-    down-sampling branch, SAR_PATHB_DS_STREAM): shared for the reason shared_side_stream gives"""
+def shared_aux_stream(device, tag="aux"):
+    """ONE further stream per (device, host thread, tag) for the branch launches an engine forks off its main chain (the resnet's
+    down-sampling branch and weight images: "aux"; the radar front-end of a resident batch: "front"; SAR_PATHB_DS_STREAM): shared for
+    the reason shared_side_stream gives"""
     import threading
-    key = (torch.device(device).index or 0, threading.get_ident(), "aux")
+    key = (torch.device(device).index or 0, threading.get_ident(), tag)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)

@@ -315,19 +315,21 @@ class ResNet18:
         x = x.contiguous()
         B, _, H, W = x.shape
         dev = x.device
-        if self._prepacked is not None and self._prepacked == bool(training):      # prepack(): issued on the third stream by the trainer
-            torch.cuda.current_stream().wait_stream(self._aux)
-        else:
+        # prepack(): the weight images were issued on the third stream by the trainer.  The stem (an fp32 7x7 kernel on the stored
+        # weights) needs none of them: they are joined in front of the first block, so the pack runs beside the stem
+        join_aux = self._prepacked is not None and self._prepacked == bool(training)
+        if not join_aux:
             self._pack(training)
         self._prepacked = None
         self._bounds_forked = False
         if training and self._aux is not None and self._cells is not None:
             # every Samuelson bound of the step (they depend on gamma / beta and the sample counts only) on the third stream, beside
             # the stem: nine 4-us launches off the serial chain; joined in front of the first block
-            self._aux.wait_stream(torch.cuda.current_stream())      # behind the zeroing of the cells
+            if not join_aux:
+                self._aux.wait_stream(torch.cuda.current_stream())  # behind the zeroing of the cells (prepacked: zeroed on that stream)
             with torch.cuda.stream(self._aux):
                 self._all_bn_bounds(B, H, W)
-            self._bounds_forked = True
+            self._bounds_forked = join_aux = True
         X0 = x.view(1, B * H * W)
         c0, r, H1, W1 = self._conv_fwd("conv1", X0, B, H, W, training)
         bn0 = self._bn_stats("bn1", r, B * H1 * W1, training)
@@ -338,8 +340,10 @@ class ResNet18:
             keep["conv1"], keep["pool"] = c0, h
         saved = dict(x0=X0, c0=c0, B=B, H=H, W=W, H1=H1, W1=W1, H2=H2, W2=W2, blocks=[])
         Hc, Wc = H2, W2
-        if self._bounds_forked:
+        if join_aux:
             torch.cuda.current_stream().wait_stream(self._aux)
+        if self._bounds_forked:
+            pass
         elif training and self._cell(self.blocks[0][0] + "conv1", "f") is not None:
             # the stem tail is max-pool(relu(bn1(c0))): bounded by bn1's Samuelson bound
             ops.bn_bound(self.p["bn1.weight"], self.p["bn1.bias"], B * H1 * W1, self._cell(self.blocks[0][0] + "conv1", "f"))
