@@ -480,8 +480,8 @@ def spectrogram_leg(args, steps, warmup, warm_seconds, rank, world, dev, instrum
     batches = [synthetic_clips(bs, dev, seed=1000 * rank + i, num_classes=args.classes) for i in range(4)]
     leg = Leg(world, dev)
 
-    def step(i):     # (the synthetic batches are resident in HBM: the radar front-end may pipeline with the previous step, sar_amd/train.py)
-        return trainer.step(*batches[i % 4], 1e-3, resident=True)[1]
+    def step(i):
+        return trainer.step(*batches[i % 4], 1e-3)[1]
 
     for i in range(warmup):
         step(i)

@@ -203,7 +203,6 @@ class parallel_batches:
                     cur.wait_event(ev)
                     x.record_stream(cur)
                     y.record_stream(cur)
-                    x._sar_ready = ev      # (SpectrogramTrainer: the radar front-end may wait for THIS instead of for the current stream)
                     yield x, y
                 pending = nxt
         finally:

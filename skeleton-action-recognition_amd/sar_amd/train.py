@@ -204,9 +204,6 @@ class Trainer:
         return logits, loss
 
 
-FRONT_STREAM = __import__("os").environ.get("SAR_PATHB_FRONT_STREAM", "1") == "1"    # SpectrogramTrainer: the radar front-end of a resident batch on its own stream (A/B switch)
-
-
 class SpectrogramTrainer:
     """Train step of main_spectrogram.py:124-189 on the HIP engines: VirtualRadar -> spectrogram image -> resnet18
     forward / backward (mean CrossEntropyLoss) -> ONE all-reduce of the flat resnet gradient buffer and ONE of the
@@ -253,10 +250,8 @@ class SpectrogramTrainer:
             o += p.numel()
         return self._radar_bucket
 
-    def step(self, x, labels, lr, resident=False):
-        """One train step (eager, or a hipGraph replay: __init__).  resident=True: the caller guarantees that x is complete in device
-        memory and is not being written by any stream (a batch kept on the device, a synthetic one) -- its radar front-end may then
-        start beside the previous step's tail (_step); a batch of sar_amd/data.py's loaders carries its copy event and needs no flag."""
+    def step(self, x, labels, lr):
+        """One train step (eager, or a hipGraph replay: __init__)."""
         if self.graph and ddp_active():
             # VERDICT r05 next #7(i): no silent fall-back.  The bucketed gradient exchange lives on the communication stream with
             # host-side event bookkeeping per bucket (GradExchange) and RCCL's own stream semantics: a hipGraph capture of the step
@@ -265,7 +260,7 @@ class SpectrogramTrainer:
                                "ranks) the step's RCCL gradient exchange cannot be captured into a hipGraph -- construct the trainer "
                                "with graph=False" % dist.get_world_size())
         if not (self.graph and x.is_cuda and not self.train_radar()):
-            return self._step(x, labels, lr, resident=resident)
+            return self._step(x, labels, lr)
         eng = self.eng
         # the capture bakes in: the batch geometry, the engine's parameter / gradient / Adam-state buffers and the radar configuration;
         # any of them changing (load_params into new buffers, another up-sampling factor) re-captures instead of replaying stale pointers
@@ -296,7 +291,7 @@ class SpectrogramTrainer:
         self.run_ahead.step_issued()
         return tuple(t.clone() for t in cap)     # the captured buffers are overwritten by the next replay: hand out copies
 
-    def _step(self, x, labels, lr, run_ahead=True, resident=False):
+    def _step(self, x, labels, lr, run_ahead=True):
         """Returns (logits, loss) device tensors; nothing in the step reads them back (the host blocks only on the event of the
         step before the previous one: RunAhead).  Under data parallelism every gradient is
         produced already divided by the world size (the loss scale), the flat resnet gradient buffer is exchanged in four
@@ -320,25 +315,10 @@ class SpectrogramTrainer:
         kw = dict(grad_scale=1.0 / world, bucket_cb=on_bucket) if ddp else {}
         if hasattr(eng, "prepack"):
             eng.prepack(True)            # the resnet's weight images beside the radar front-end / the stem (sar_amd/resnet.py: SAR_PATHB_DS_STREAM)
-        ready = getattr(x, "_sar_ready", None)      # the loader's copy event of this batch (sar_amd/data.py), if it came from there
-        if (FRONT_STREAM and getattr(eng, "_aux", None) is not None and not train_radar and x.is_cuda and (resident or ready is not None)
-                and not torch.cuda.is_current_stream_capturing()):
-            # The radar front-end of a batch that is COMPLETE in device memory reads neither the resnet's weights nor (frozen: the
-            # default of main_spectrogram.py) anything the previous step wrote: on its own stream it does not queue behind that
-            # step's backward tail and optimizer but runs beside them -- the steps of a training loop pipeline by one front-end.
-            # The main chain joins it in front of the stem.  Same kernels on the same inputs: bit-identical.
-            from . import ops
-            front, main = ops.shared_aux_stream(x.device, "front"), torch.cuda.current_stream()
-            if ready is not None:
-                front.wait_event(ready)
-            with torch.cuda.stream(front), torch.no_grad():
-                img = model.spectrogram(x)
-            x.record_stream(front)
-            main.wait_stream(front)
-            img.record_stream(main)
-        else:
-            with torch.set_grad_enabled(train_radar):
-                img = model.spectrogram(x)
+        # (Measured and removed, profiles/r06_pathB_fork_ab.txt: the radar front-end of a resident batch on a stream of its own, so
+        # that it runs beside the previous step's backward tail -- bit-identical, and SLOWER: 5 225 -> 5 131 / 7 400 -> 7 150 clips/s.)
+        with torch.set_grad_enabled(train_radar):
+            img = model.spectrogram(x)
         if train_radar:                                  # the image depends on trainable radar parameters
             bucket = self._radar_grad_bucket()
             logits, loss, dimg = eng.loss_and_grad(img.detach(), labels, need_dx=True, **kw)

@@ -256,11 +256,11 @@ def test_graph_captured_train_step_equals_the_eager_step(dev):
         assert torch.equal(a, b)
 
 
-def test_pipelined_front_end_of_a_resident_batch_is_bit_identical(dev, arith_mode):
-    """SpectrogramTrainer.step(..., resident=True) (round 6): the radar front-end of a batch that is complete in device memory runs on
-    its own stream beside the previous step's tail, the weight images beside the stem, the down-sampling branch beside the main chain
-    (sar_amd/resnet.py: DS_STREAM) -- the same kernels on the same inputs: parameters, Adam state and every step's loss bit for bit
-    with the serial schedule (DS_STREAM off, resident=False), over steps with changing inputs and a changing learning rate."""
+def test_forked_train_step_equals_the_serial_step(dev, arith_mode):
+    """SpectrogramTrainer.step with sar_amd/resnet.py's DS_STREAM (round 6): the weight images issued beside the radar front-end and
+    joined in front of the first block (beside the stem), the Samuelson cells and the down-sampling branch beside the main chain --
+    the same kernels on the same inputs: parameters, Adam state and every step's loss bit for bit with the serial schedule, over
+    steps with changing inputs and a changing learning rate."""
     from sar_amd import resnet
     from sar_amd.train import SpectrogramTrainer, synthetic_clips
     from models.resnet import Model
@@ -275,11 +275,10 @@ def test_pipelined_front_end_of_a_resident_batch_is_bit_identical(dev, arith_mod
         eng = model.base_model.engine
         assert (eng._aux is not None) == forked
         tr = SpectrogramTrainer(model, 1e-3, world_size=1)
-        batches = [synthetic_clips(4, dev, seed=i) for i in range(6)]
-        torch.cuda.synchronize()                      # resident: complete in device memory
         losses = []
-        for i, (x, y) in enumerate(batches):
-            _, loss = tr.step(x, y, 1e-3 if i < 3 else 5e-4, resident=forked)
+        for i in range(6):
+            x, y = synthetic_clips(4, dev, seed=i)
+            _, loss = tr.step(x, y, 1e-3 if i < 3 else 5e-4)
             losses.append(loss.clone())
         torch.cuda.synchronize()
         outs.append((eng.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone(), torch.stack(losses)))
