@@ -389,6 +389,8 @@ int sar_fc_fwd_f32(const float* feat, const float* W /* [C][K] */, const float* 
  * loss_sum[0] receives sum_i loss_i * inv_global_batch (written, not accumulated). */
 int sar_softmax_ce_f32(const float* logits, const int64_t* labels, int N, int K, float inv_global_batch,
                        float* loss_sum, float* dlogits, float* probs /* may be NULL */, sar_stream_t s);
+/* dW[c][k] = sum_n feat[n][c] dlogits[n][k], dbias[k] = sum_n dlogits[n][k], dfeat = dlogits W^T.  dW and dbias may both be NULL (only
+ * dfeat, the launch on the backward chain), or dfeat (only the parameter gradients: they feed nothing but the optimizer). */
 int sar_fc_bwd_f32(const float* feat, const float* W, const float* dlogits, int N, int C, int K,
                    float* dW, float* dbias, float* dfeat, sar_stream_t s);
 /* dy[c,(b,tv)] = dfeat[b/Mp][c] / (Mp*TV) */

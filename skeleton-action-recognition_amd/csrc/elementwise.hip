@@ -1020,9 +1020,12 @@ extern "C" int sar_softmax_ce_f32(const float* logits, const int64_t* labels, in
 
 extern "C" int sar_fc_bwd_f32(const float* feat, const float* W, const float* dlogits, int N, int C, int K, float* dW,
                               float* dbias, float* dfeat, sar_stream_t s) {
-  SAR_REQUIRE(feat && W && dlogits && dW && dbias && dfeat && N > 0 && C > 0 && K > 0, "sar_fc_bwd: bad arguments");
-  hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(C + 1), dim3(128), 0, as_stream(s), feat, dlogits, N, C, K, dW, dbias);
-  hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(N), dim3(256), 0, as_stream(s), W, dlogits, C, K, dfeat);
+  // (round 6) dW == dbias == NULL: only the feature gradient (the launch on the backward chain); dfeat == NULL: only dW / dbias (they
+  // feed nothing but the optimizer: an engine may issue them on another stream)
+  SAR_REQUIRE(feat && W && dlogits && N > 0 && C > 0 && K > 0 && ((dW != nullptr) == (dbias != nullptr)) && (dW || dfeat),
+              "sar_fc_bwd: bad arguments");
+  if (dW) hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(C + 1), dim3(128), 0, as_stream(s), feat, dlogits, N, C, K, dW, dbias);
+  if (dfeat) hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(N), dim3(256), 0, as_stream(s), W, dlogits, C, K, dfeat);
   SAR_LAUNCH_CHECK("sar_fc_bwd_f32");
   return 0;
 }

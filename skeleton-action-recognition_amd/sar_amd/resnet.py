@@ -466,8 +466,21 @@ class ResNet18:
             self._wb_ready = None
         dwt = torch.empty_like(sv["wt"])
         dfeat = torch.empty_like(sv["feat"])
-        ops.fc_bwd(sv["feat"], sv["wt"], dlogits.contiguous(), dwt, self.g["fc.bias"], dfeat)
-        ops.transpose(dwt, self.g["fc.weight"], 1, self.c_last, self.num_classes)
+        dlogits = dlogits.contiguous()
+        if self._aux is not None and bucket_cb is None:
+            # the classifier's parameter gradients feed nothing but the optimizer: beside the chain (joined at the end of backward);
+            # under data parallelism they belong to the first bucket, whose events are recorded on the main stream: serial there
+            self._aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._aux):
+                ops.fc_bwd(sv["feat"], sv["wt"], dlogits, dwt, self.g["fc.bias"], None)
+                ops.transpose(dwt, self.g["fc.weight"], 1, self.c_last, self.num_classes)
+            dwt.record_stream(self._aux)
+            dlogits.record_stream(self._aux)
+            ops.fc_bwd(sv["feat"], sv["wt"], dlogits, None, None, dfeat)
+            self._fc_forked = True
+        else:
+            ops.fc_bwd(sv["feat"], sv["wt"], dlogits, dwt, self.g["fc.bias"], dfeat)
+            ops.transpose(dwt, self.g["fc.weight"], 1, self.c_last, self.num_classes)
         dY = torch.empty((self.c_last, B * sv["Hl"] * sv["Wl"]), dtype=torch.float32, device=dev)
         ops.pool_bwd(dfeat, B, sv["Hl"] * sv["Wl"], 1, dY)
         nblk = len(self.blocks)
@@ -551,6 +564,9 @@ class ResNet18:
             self._flush_slabs()
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
+        if getattr(self, "_fc_forked", False):
+            torch.cuda.current_stream().wait_stream(self._aux)
+            self._fc_forked = False
         dx = None
         if need_dx:
             cv = self.convs["conv1"]
