@@ -272,7 +272,9 @@ int sar_slab_reduce_batch_f32(const sar_slab_item* items, int nitems, int64_t ma
  * (csrc/conv_wgrad_split.hip; SAR_SPLIT_BF16X6 / SAR_SPLIT_F16X3A): same descriptor and slab contract as sar_conv_wgrad_f32 (slabs reduced by sar_slab_reduce_f32),
  * src_bound / dout_bound = bound cells of pro(src) / dout for the fp16 arithmetic.  Built for the 9-tap TEMPORAL operator at
  * V = 25, stride 1 or stride 2 with pad 3 and T_src = 2 T_out, 8 <= Kc <= 256, and for the GRAPH operator at V = 25, 16 <= Kc <= 256
- * without a folded prologue; other shapes: SAR_E_UNSUP (keep sar_conv_wgrad_f32).  nsplit must be a multiple of the wk
+ * without a folded prologue, and (round 6) for the 1-tap TEMPORAL operator (the residual 1x1 convolution's weight / bias gradient) at
+ * V = 25, pad 0, T_src = stride T_out, Kc >= 16, no folded prologue (wk 1; tiles of 128 flat positions, 64 x 128-channel blocks);
+ * other shapes: SAR_E_UNSUP (keep sar_conv_wgrad_f32).  nsplit must be a multiple of the wk
  * that sar_conv_wgrad_split_blocks reports -- TEMPORAL: 1, or 2 at M <= 64 (two wave pairs of a workgroup split a tile's k-steps and
  * write two slabs); GRAPH: 1 at M >= 256, 2 at M = 128, 4 at M <= 64 (the waves that do not own an M block split the k-steps);
  * that query returns the weight blocks per slab group (or SAR_E_UNSUP) and the positions per tile: a launch has

@@ -1057,6 +1057,163 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_ring_kernel(const WgradKS k
   }
 }
 
+// ---- The 1-tap TEMPORAL weight gradient (the strided 1x1 residual convolution, models/stgcn.py:47-54) in the split arithmetics -- round 6:
+// the last fp32 GEMM launch of the split engine's step besides the 3-channel layer (tools/leftover_bench.py: 176 / 271 us alone at
+// 64 -> 128 / 128 -> 256 channels for 82 us of HBM time; 15.7 GFLOP are 100 us of fp32 matrix time).
+//   dW[c][m] = sum_n src[c, s(n)] dout[m, n],  dbias[m] = sum_n dout[m, n];   n = (b, t, v) flat,  s(n) = n + (stride - 1) V floor(n / V)
+// (T_src == stride T_out: the source frame of flat output frame f is frame stride f of the flat source).  Without taps a tile is just
+// KT1 consecutive flat positions: workgroup = 64 src channels x 128 dout channels, the src tile through LDS ([term][64 rows][KT1] 2-byte
+// elements, converted by the stager: a lane owns two adjacent positions of a row, their sources are adjacent unless a frame ends between
+// them), wave w owns dout channels 32 w .. 32 w + 31 of the block: its dout fragments come straight from global memory, two k-steps
+// ahead, and are summed for the bias gradient and converted in registers (conv_wgrad_split_kernel).  Two barriers per tile.
+constexpr int KT1 = 128, KS1 = KT1 / 16, RS1 = KT1 + 8, CB1 = 64;   // row stride 272 bytes: 16-byte fragment reads of 32 rows hit distinct banks
+template <int AR>
+__global__ __launch_bounds__(256, 3) void wgrad_tap1_split_kernel(const WgradKS k) {
+  constexpr int NT = ar_nta(AR), NTL = ntl<AR>(), NTB = ar_ntb(AR), NPROD = ar_nprod(AR), V = VJ;
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[NTL * CB1 * RS1];
+  const sar_wgrad_desc& d = k.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  int sg, by, bz;
+  {
+    const int nyz = k.gy * k.gz, nwork = d.nsplit * nyz;
+    const int per = (nwork + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int w = xcd * per + slot;
+    if (slot >= per || w >= nwork) return;
+    sg = w / nyz;
+    const int yz = w - sg * nyz;
+    bz = yz / k.gy;
+    by = yz - bz * k.gy;
+  }
+  const int m0 = by * 128 + wave * 32, c0 = bz * CB1;
+  int ea = 0, eb = 0;
+  bool nonfin = false;
+  if (ar_f16(AR)) {
+    ea = scale_exp(*k.src_bound);
+    eb = scale_exp(*k.dout_bound);
+    nonfin = bound_nonfinite(*k.src_bound) || bound_nonfinite(*k.dout_bound);
+  }
+  const float sa = __builtin_ldexpf(1.f, ea), sb = __builtin_ldexpf(1.f, eb);
+  const int64_t npos = (int64_t)d.B * d.T_out * V;          // flat output positions
+  const int ntl_ = k.ntiles;                                 // ceil(npos / KT1)
+  const int tps = (ntl_ + d.nsplit - 1) / d.nsplit;
+  const int tile_lo = sg * tps;
+  const int tile_hi = (tile_lo + tps < ntl_) ? tile_lo + tps : ntl_;
+  const int smul = (d.stride - 1) * V;
+  const unsigned src_bytes = (unsigned)((int64_t)d.B * d.T_src * V * 4);   // one row of the flat source (< 2^32: checked by the host)
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ms][r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = d.bsize > 0 && bz == 0;   // uniform
+  constexpr unsigned REJECT = 0xf0000000u;
+  const int64_t dbytes = (int64_t)d.M * d.ld_dout * 4;
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.dout, 0, (unsigned)(dbytes < (int64_t)REJECT ? dbytes : (int64_t)REJECT), 0x00020000);
+  const bool mrow_ok = (m0 + l31) < d.M;
+  const unsigned drow = (unsigned)(((int64_t)(mrow_ok ? m0 + l31 : 0) * d.ld_dout) * 4);
+  // stager: thread -> (position pair 2 (tid & 63), rows (tid >> 6) + 4 q, q < 16)
+  const int sp = 2 * (tid & 63), sr0 = tid >> 6;
+  typedef const u32x4 __attribute__((address_space(3))) * lds_u128;
+  const unsigned a_base = (unsigned)(uintptr_t)Hs + (unsigned)((l31 * RS1 + 8 * hi) * 2);
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int64_t n0 = (int64_t)tile * KT1;
+    const int nlive = (int)((npos - n0 < KT1) ? npos - n0 : KT1);
+    // the dout fragments of the first two k-steps, requested in front of the stager
+    auto load_dout = [&](int ks, u32x4 (&raw)[2]) {
+      const int pos = 16 * ks + 8 * hi;
+      const unsigned vo = (mrow_ok && pos < nlive) ? drow + (unsigned)((n0 + pos) * 4) : REJECT;
+      raw[0] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 0, 0);
+      raw[1] = __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 16, 0);
+    };
+    u32x4 raw[3][2];
+    load_dout(0, raw[0]);
+    load_dout(1, raw[1]);
+    {   // src tile: 64 rows x KT1 positions, two adjacent positions per lane
+      const int64_t na = n0 + sp, nb = na + 1;
+      const int64_t sa_ = na + (int64_t)smul * (na / V), sb_ = nb + (int64_t)smul * (nb / V);
+      const bool la = sp < nlive, lb = sp + 1 < nlive;
+      float x[16][2];
+      const unsigned oa = la ? (unsigned)(sa_ * 4) : 0x7fffffffu, ob = lb ? (unsigned)(sb_ * 4) : 0x7fffffffu;   // dead positions: rejected -> 0
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int c = c0 + sr0 + 4 * q;   // wave-uniform: the row is a scalar descriptor (buffer loads: no FLAT loads beside the LDS traffic)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(d.src + (int64_t)(c < d.Kc ? c : 0) * d.ld_src), 0,
+                                                                            c < d.Kc ? src_bytes : 0u, 0x00020000);
+        x[q][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, oa, 0, 0));
+        x[q][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ob, 0, 0));
+      }
+      __syncthreads();   // closing: every wave has read its last fragment of the previous tile
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        unsigned w[NT];
+        split2<AR, true>(ar_f16(AR) ? x[q][0] * sa : x[q][0], ar_f16(AR) ? x[q][1] * sa : x[q][1], w);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) *reinterpret_cast<unsigned*>(&Hs[(t * CB1 + sr0 + 4 * q) * RS1 + sp]) = w[t];
+      }
+    }
+    __syncthreads();     // opening: the images are complete
+    SAR_LDS_SKEW();
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      if (ks + 2 < KS1) load_dout(ks + 2, raw[(ks + 2) % 3]);
+      const int nv = nlive - (16 * ks + 8 * hi);
+      float dv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dv[j] = __uint_as_float(raw[ks % 3][j >> 2][j & 3]);
+        dv[j] = j < nv ? dv[j] : 0.f;
+      }
+      if (do_bias) bsum += ((dv[0] + dv[1]) + (dv[2] + dv[3])) + ((dv[4] + dv[5]) + (dv[6] + dv[7]));
+      unsigned bw[NTB][4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        unsigned w[NTB];
+        split2<AR, false>(dv[2 * p] * sb, dv[2 * p + 1] * sb, w);
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) bw[t][p] = w[t];
+      }
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        u32x4 aq[NT];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) aq[t] = *(lds_u128)(uintptr_t)(a_base + (unsigned)(((t * CB1 + ms * 32) * RS1 + 16 * ks) * 2));
+        if constexpr (NTL < NT) aq[NT - 1] = third_image(aq[0]);
+#pragma unroll
+        for (int p = 0; p < NPROD; ++p) {
+          const int i = ar_pi(AR, p), j = ar_pj(AR, p);
+          const u32x4 bq = u32x4{bw[j][0], bw[j][1], bw[j][2], bw[j][3]};
+          if (ar_f16(AR))
+            acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&aq[i]), *reinterpret_cast<const f16x8*>(&bq), acc[ms], 0, 0, 0);
+          else
+            acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&aq[i]), *reinterpret_cast<const bf16x8*>(&bq), acc[ms], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* slab = d.slab + (int64_t)sg * (d.wsize + d.bsize);
+  const float unscale = (nonfin ? __uint_as_float(0x7fc00000u) : __builtin_ldexpf(1.f, -(ea + eb)));
+  const int m = m0 + l31;
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + ms * 32 + mfma_row(r, hi);
+      if (c < d.Kc && m < d.M) slab[(int64_t)c * d.w_stride_c + m] = acc[ms][r] * unscale;
+    }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32);
+    if (hi == 0 && m < d.M) slab[d.wsize + m] = bsum;
+  }
+}
+
 // SAR_WGRAD_RING=0: the first design (flat window, conv_wgrad_split_kernel) for the stride-1 temporal weight gradient (A/B runs)
 bool wgrad_ring_on() {
   static const bool on = [] { const char* e = getenv("SAR_WGRAD_RING"); return !e || atoi(e) != 0; }();
@@ -1071,6 +1228,11 @@ int wgrad_split_wk(const sar_wgrad_desc& d, int arith) {
     for (int i = 0; i < 3; ++i)
       if (d.nz[i] < 1 || d.nz[i] > 4) return 0;
     return d.M > 128 ? 1 : (d.M > 64 ? 2 : 4);
+  }
+  if (d.mode == SAR_CONV_TEMPORAL && d.taps == 1) {   // wgrad_tap1_split_kernel (wk 1): no prologue, pad 0, whole strides
+    if (d.V != VJ || d.pad != 0 || d.pro_scale || d.stride < 1 || d.T_src != d.stride * d.T_out || d.Kc < 16) return 0;
+    if ((int64_t)d.B * d.T_src * d.V >= (1ll << 30)) return 0;
+    return 1;
   }
   if (d.mode != SAR_CONV_TEMPORAL || d.taps != TAPS || d.V != VJ) return 0;
   if (!((d.stride == 1 && d.T_src == d.T_out) || (d.stride == 2 && d.pad == 3 && d.T_src == 2 * d.T_out))) return 0;
@@ -1109,6 +1271,16 @@ int launch_wgrad_split(const sar_wgrad_desc& d, int wk, const unsigned* sb, cons
     if (d.nz[0] == 1 && d.nz[1] == 1) s0id ? launch_graph_wgrad_split<AR, 1, 1, 4, true>(k, wk, grid, st) : launch_graph_wgrad_split<AR, 1, 1, 4, false>(k, wk, grid, st);
     else if (d.nz[0] == 1 && d.nz[2] == 1) s0id ? launch_graph_wgrad_split<AR, 1, 4, 1, true>(k, wk, grid, st) : launch_graph_wgrad_split<AR, 1, 4, 1, false>(k, wk, grid, st);
     else launch_graph_wgrad_split<AR, 4, 4, 4, false>(k, wk, grid, st);
+    return 0;
+  }
+  if (d.taps == 1) {
+    const int64_t npos = (int64_t)d.B * d.T_out * d.V;
+    k.TPS = 0;
+    k.ntiles = (int)((npos + KT1 - 1) / KT1);
+    k.gy = (d.M + 127) / 128;
+    k.gz = (d.Kc + CB1 - 1) / CB1;
+    const int nwork1 = d.nsplit * k.gy * k.gz;
+    hipLaunchKernelGGL((wgrad_tap1_split_kernel<AR>), dim3(((nwork1 + 7) / 8) * 8), dim3(256), 0, st, k);
     return 0;
   }
   const int seq = d.T_out * d.V;
@@ -1161,6 +1333,10 @@ extern "C" int sar_conv_wgrad_split_blocks(const sar_wgrad_desc* d, int arith, i
     if (tile_positions) *tile_positions = GKP;
     return ((d->M + 256 / wk - 1) / (256 / wk)) * ((d->Kc + CB - 1) / CB);
   }
+  if (d->taps == 1) {
+    if (tile_positions) *tile_positions = KT1;
+    return ((d->M + 127) / 128) * ((d->Kc + CB1 - 1) / CB1);
+  }
   if (tile_positions) *tile_positions = wgrad_ring_on() ? (d->stride == 2 ? 2 : RING_TF) * VJ : (d->stride == 2 ? Cfg<AR_H3A, 1>::KT : Cfg<AR_H3A, 0>::KT);
   return ((d->M + 128 / wk - 1) / (128 / wk)) * ((d->Kc + CB - 1) / CB);
 }
@@ -1171,7 +1347,8 @@ extern "C" int sar_conv_wgrad_split(const sar_wgrad_desc* d, int arith, const ui
   const int wk = wgrad_split_wk(*d, arith);
   if (!wk) {
     sar_set_error("sar_conv_wgrad_split: built for the 9-tap temporal convolution at V = 25, stride 1 (or 2 with pad 3, even T), 8 <= Kc <= 256 and the graph "
-                  "convolution at V = 25, 16 <= Kc <= 256 without a folded prologue, in the arithmetics bf16x6 / f16x3a (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
+                  "convolution at V = 25, 16 <= Kc <= 256 without a folded prologue, and the 1-tap temporal convolution at V = 25, pad 0, T_src = stride T_out, Kc >= 16, no prologue, "
+                  "in the arithmetics bf16x6 / f16x3a (mode %d, taps %d, V %d, stride %d, Kc %d, arith %d): use sar_conv_wgrad_f32",
                   d->mode, d->taps, d->V, d->stride, d->Kc, arith);
     return SAR_E_UNSUP;
   }

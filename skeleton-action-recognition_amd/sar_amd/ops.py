@@ -415,6 +415,8 @@ def conv_wgrad(mode, src, dout, dW_out, *, B, V, T_src, T_out, Kc, M, taps, stri
     # dout_bound) cells for the fp16 arithmetic, None = computed here by device kernels); other shapes stay on the fp32 kernel
     if split == "default":
         split = DEFAULT_SPLIT
+    if taps == 1 and mode == L.SAR_CONV_TEMPORAL and not TAP1_SPLIT:
+        split = None
     sp_blocks = 0
     if split in ("bf16x6", "f16x3a"):
         wk, kt = C.c_int(0), C.c_int(0)

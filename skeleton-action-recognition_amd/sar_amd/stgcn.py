@@ -36,7 +36,7 @@ SPLIT_ARITH = {"f32_split": "f16x3a", "f32_split_bf16x6": "bf16x6"}      # engin
 # +0.4 % (58.70 -> 58.47 ms, interleaved); "1" = the split engines too (single stream -0.29 ms, two streams 34.34 -> 34.44 ms: not taken);
 # "0" = never (gpurun_out/compact_skip_ab*.txt)
 _COMPACT_SKIP = __import__("os").environ.get("SAR_COMPACT_SKIP", "fp32")
-_SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS", "tfwd,tdgrad,twgrad,gfwd,gdgrad,gwgrad,rfwd,rdgrad").split(","))
+_SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS", "tfwd,tdgrad,twgrad,gfwd,gdgrad,gwgrad,rfwd,rdgrad,rwgrad").split(","))
 # (filters, stride, residual) -- models/stgcn.py:113-123
 BLOCKS = [(64, 1, False), (64, 1, True), (64, 1, True), (64, 1, True), (128, 2, True), (128, 1, True), (128, 1, True),
           (256, 2, True), (256, 1, True), (256, 1, True)]
@@ -494,7 +494,7 @@ class STGCN:
         # (split arithmetic: y is the next block's graph-convolution operand; its bound is a by-product of this pass)
         ycell = self._cell(i + 1, 3) if (training and i + 1 < len(self.blocks)
                                          and (self._cell_live("l%d.gcn.f" % (i + 1), "gfwd", "gwgrad")
-                                              or self._cell_live("l%d.res.f" % (i + 1), "rfwd"))) else None
+                                              or self._cell_live("l%d.res.f" % (i + 1), "rfwd", "rwgrad"))) else None
         ops.bn_add_relu_fwd(u, bn2.scale, bn2.shift, res_kind, X if kind == "identity" else r,
                             rbn.scale if rbn else None, rbn.shift if rbn else None, y, mask=ymask, amax_cell=ycell)
         if training:
@@ -674,8 +674,8 @@ class STGCN:
         dz = dY if (kind == "identity" and gated is None) else None  # in place: dY becomes the pre-ReLU gradient for the skip path (already gated: nothing to write)
         ducell = self._cell(i, 1) if self._cell_live(pre + "tcn.b", "tdgrad", "twgrad") else None   # the bound of du: by-product
         # (the bound of dr: operand of the residual branch's dense 1x1 data gradient on conv_tap1_split_kernel; by-product too)
-        drcell = self._cell(i, 4) if (kind == "conv" and self._f16 and self._simg(pre + "res.b") is not None
-                                      and self._compact_skip(s, T, i)) else None
+        drcell = self._cell(i, 4) if (kind == "conv" and self._f16 and (
+            (self._simg(pre + "res.b") is not None and self._compact_skip(s, T, i)) or self._res_wgrad_split(pre))) else None
         ops.bn_add_relu_bwd_apply(dY, y, u, r if kind == "conv" else None, (bn2.k1, bn2.k2, bn2.k3), rk, du, dr, dz,
                                   mask=sb.get("ymask"), amax_cell=ducell, amax_dr_cell=drcell)
         # ---- temporal conv: weight / bias gradient, then data gradient fused with ReLU-mask + BN1 reductions
@@ -742,9 +742,11 @@ class STGCN:
         V, dev, pre = self.V, dr.device, "l%d." % i
         X, T, To, cin, f, s = sb["X"], sb["T"], sb["To"], sb["cin"], sb["f"], sb["s"]
         flat_r = self.grad[self.offsets[pre + "res.kernel"]:self.offsets[pre + "res.bias"] + f]
+        rw_split = self._res_wgrad_split(pre) and T == s * To      # wgrad_tap1_split_kernel: bounds = X's cell 3, dr's cell 4
         self._off_critical_path(lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, X, dr, flat_r, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=s, pad=0,
-            w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f, slabs=self._slabs), X, dr)
+            w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f, slabs=self._slabs, split=self.split if rw_split else None,
+            bounds=(self._cell(i, 3), self._cell(i, 4)) if (rw_split and self._f16) else None), X, dr)
         rimg = self._img(pre + "res.b")
         rT = None
         if rimg is None and pre + "res" in self._wT_off:
@@ -766,6 +768,11 @@ class STGCN:
         ops.conv_gemm(L.SAR_CONV_TEMPORAL, dr, dXres, rT, 0, cin, B=B, V=V, T_src=To, T_out=T, Kc=f, M=cin, taps=1,
                       stride=s, pad=0, transposed=True, bf16=self.bf16, packed=rimg)
         return dXres
+
+    def _res_wgrad_split(self, pre):
+        """the residual 1x1 convolution's weight gradient on wgrad_tap1_split_kernel: the layer has its forward term images (the same
+        shape test) and the kind is switched on"""
+        return bool(self.split in ("f16x3a", "bf16x6") and "rwgrad" in _SPLIT_KINDS and ops.TAP1_SPLIT and self._split_has(pre + "res.f"))
 
     def _compact_skip(self, s, T, i=None):
         """the skip gradient of a conv-residual block as its even frames only (SAR_COMPACT_SKIP=0: the strided data gradient over all

@@ -280,6 +280,17 @@ def test_one_tap_temporal_operator_on_the_split_kernel(dev, arith, B, cin, f, T,
     # the dense data gradient (forward form with W^T) of a gradient-like dout, added to a skip gradient / masked by a source
     dr = torch.randn(B, f, To, 25, generator=g) * 3e-6
     dr[0, f // 2, To // 2, 7] = 1e-2                       # an outlier 3 000 x the typical magnitude
+    # the weight / bias gradient (wgrad_tap1_split_kernel where T_src == stride T_out, else the fp32 kernel): dW[c][m] = sum x dr
+    xs = x[:, :, ::s][:, :, :To].double()
+    gk = torch.einsum("bcty,bfty->cf", xs, dr.double())
+    gb = dr.double().sum(dim=(0, 2, 3))
+    flat = torch.zeros(cin * f + f, device=dev)
+    for nsplit in (None, 3):
+        ops.conv_wgrad(L.SAR_CONV_TEMPORAL, to_cn(x).to(dev), to_cn(dr).to(dev), flat, B=B, V=25, T_src=T, T_out=To, Kc=cin, M=f, taps=1,
+                       stride=s, pad=0, w_stride_tap=0, w_stride_c=f, wsize=cin * f, bsize=f, split=arith, nsplit=nsplit)
+        torch.cuda.synchronize()
+        assert rel_err(flat[:cin * f].cpu().view(cin, f), gk) < TOL, nsplit
+        assert rel_err(flat[cin * f:].cpu(), gb) < TOL, nsplit
     skip = torch.randn(B, cin, To, 25, generator=g) * 1e-5
     want = torch.einsum("bfty,cf->bcty", dr.double(), kernel[0, 0].double())
     rT = kernel[0, 0].t().contiguous().to(dev)           # [f][cin]

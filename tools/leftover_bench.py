@@ -76,7 +76,9 @@ def main():
         case("res data gradient " + tag + " (compact) f16x3a", 4.0 * (f * n_out + cin * n_out), lambda: ops.conv_gemm(
             L.SAR_CONV_TEMPORAL, dr, dXc, rT, 0, cin, B=B, V=V, T_src=To, T_out=To, Kc=f, M=cin, taps=1, stride=1, pad=0,
             split="f16x3a", packed=imb[0], bounds=(bD, imb[1])))
-        case("amax pass over dr " + tag, 4.0 * f * n_out, lambda: ops.amax(dr, bD))
+        case("res weight gradient " + tag + " f16x3a", 4.0 * (cin * n_in + f * n_out), lambda: ops.conv_wgrad(
+            L.SAR_CONV_TEMPORAL, X, dr, flat, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=2, pad=0, w_stride_tap=0,
+            w_stride_c=f, wsize=cin * f, bsize=f, split="f16x3a", bounds=(bX, bD)))
         case("res weight gradient " + tag, 4.0 * (cin * n_in + f * n_out), lambda: ops.conv_wgrad(
             L.SAR_CONV_TEMPORAL, X, dr, flat, B=B, V=V, T_src=T, T_out=To, Kc=cin, M=f, taps=1, stride=2, pad=0, w_stride_tap=0,
             w_stride_c=f, wsize=cin * f, bsize=f, split=None))
