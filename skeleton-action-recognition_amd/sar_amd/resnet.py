@@ -44,6 +44,11 @@ SLAB_BATCH_PATHB = __import__("os").environ.get("SAR_SLAB_BATCH_PATHB", "0") == 
 # (tests/test_gpu_slab_batch.py); interleaved processes (tools/ab_pathb2.sh, profiles/r06_pathB_fork_ab.txt): fp32 4 976 -> 5 222 clips/s
 # (+4.9 %), f32_split 7 098 -> 7 386 (+4.1 %)
 DS_STREAM = __import__("os").environ.get("SAR_PATHB_DS_STREAM", "1") == "1"
+# The BatchNorm-backward finalisation of a block tail (bn2 and the down-sampling BN) in the reduce kernel's last workgroup per channel
+# (ops.BN_TAIL) instead of one or two launches behind it.  One bench.py process per entry (profiles/r06_pathB_fork_ab.txt):
+# fp32 5 214 -> 5 220 clips/s (neutral), f32_split 7 208 -> 7 330 (+1.7 %): on for the split arithmetic ("split"; "1" / "0": always / never;
+# SAR_BN_TAIL=1 still turns it on everywhere)
+BN_TAIL_PATHB = __import__("os").environ.get("SAR_BN_TAIL_PATHB", "split")
 
 
 class ResNet18:
@@ -491,7 +496,7 @@ class ResNet18:
             b1, b2 = self.bn[pre + "bn1"], self.bn[pre + "bn2"]
             bd = self.bn.get(pre + "downsample.1")
             rk = (bd.k1, bd.k2, bd.k3) if ds else None
-            if ops.BN_TAIL:   # the reduce kernel's last workgroup per channel finalises bn2 (and the downsample BN)
+            if ops.BN_TAIL or BN_TAIL_PATHB == "1" or (BN_TAIL_PATHB == "split" and self.split):   # the reduce kernel's last workgroup per channel finalises bn2 (and the downsample BN)
                 n2, nd = pre + "bn2", pre + "downsample.1"
                 tail = ops.make_bn_tail(dY.device, n_out, self.p[n2 + ".weight"], b2, self.g[n2 + ".weight"], self.g[n2 + ".bias"],
                                         *((self.p[nd + ".weight"], bd, self.g[nd + ".weight"], self.g[nd + ".bias"]) if ds else ()))
