@@ -35,6 +35,11 @@ SPLIT_ARITH = {"f32_split": "f16x3a", "f32_split_bf16x6": "bf16x6"}      # engin
 # the skip gradient of a conv-residual block as its even frames only: "fp32" (default) = the fp32-arithmetic engine, where it measured
 # +0.4 % (58.70 -> 58.47 ms, interleaved); "1" = the split engines too (single stream -0.29 ms, two streams 34.34 -> 34.44 ms: not taken);
 # "0" = never (gpurun_out/compact_skip_ab*.txt)
+# SAR_STGCN_AUX_STREAM=0: the split engine's term images, the zeroing of its bound cells and its Samuelson cells on the main stream again
+# instead of on a third stream beside the data_bn stage and the first layer (round 6, as sar_amd/resnet.py; bit-identical).  One bench.py
+# process per entry (gpurun_out/stgcn_aux_ab.txt): f32_split 1 929 -> 1 936 clips/s (+0.3 %); the bf16 engine's single pack launch
+# forked the same way: 5 497 -> 5 466 (-0.5 %), not forked
+AUX_STREAM = __import__("os").environ.get("SAR_STGCN_AUX_STREAM", "1") == "1"
 _COMPACT_SKIP = __import__("os").environ.get("SAR_COMPACT_SKIP", "fp32")
 _SPLIT_KINDS = set(__import__("os").environ.get("SAR_SPLIT_KINDS", "tfwd,tdgrad,twgrad,gfwd,gdgrad,gwgrad,rfwd,rdgrad,rwgrad").split(","))
 # (filters, stride, residual) -- models/stgcn.py:113-123
@@ -69,6 +74,7 @@ class STGCN:
     # split arithmetic (mfma="f32_split*"): off unless __init__ turns it on (subclasses with their own __init__ -- ST-GIN -- are fp32)
     mfma, split, spacked, _cells = "fp32", None, None, None
     _slabs, _slab_flush = None, "end"     # (ops.SlabBatch of the weight gradients: set by __init__; ST-GIN keeps its per-gradient reductions)
+    _aux, _aux_pending, _bounds_forked = None, False, False     # (third stream: set by __init__; engines with their own __init__ have none)
 
     def __init__(self, num_classes=60, in_channels=3, num_node=25, A=None, device="cuda", seed=0, bone_pairs=None,
                  blocks=None, motion=False, mfma=None, trainable_adjacency=False):
@@ -113,6 +119,7 @@ class STGCN:
                       if self.device.type == "cuda" and os.environ.get("SAR_WGRAD_STREAM", "1") == "1" else None)
         self._slabs = ops.SlabBatch() if ops.SLAB_BATCH else None     # one slab reduction per gradient bucket (ops.SlabBatch)
         self._slab_flush = ops.SLAB_FLUSH
+        self._aux = ops.shared_aux_stream(self.device) if (AUX_STREAM and self.device.type == "cuda" and type(self) is STGCN) else None
         self.motion = bool(motion)   # motion stream (data_gen/gen_motion_data.py:24-27) of the joint / bone data, on the fly
         self.bone_parent = None
         if bone_pairs is not None:
@@ -403,9 +410,24 @@ class STGCN:
         saved = {"x": x, "N": N, "M": M, "T": T, "blocks": [], "training": training}
         if self.packed is not None:
             self.packed.refresh(self.flat)       # the parameters may have changed since the last step
+        self._bounds_forked = False
         if self.spacked is not None and training:
-            self.spacked.refresh(self.flat)
-            self._cells.zero_()
+            if self._aux is not None:
+                # term images, bound cells and the Samuelson cells (functions of gamma / beta and the sample counts) beside the data_bn
+                # stage and the 3-channel layer: joined in front of the first launch that reads an image or a cell (_join_aux)
+                self._aux.wait_stream(torch.cuda.current_stream())      # behind the optimizer step that produced self.flat
+                with torch.cuda.stream(self._aux):
+                    self.spacked.refresh(self.flat)
+                    self._cells.zero_()
+                    Tb = T
+                    for bi_, (f_, s_, _r) in enumerate(self.blocks):
+                        if self._cell_live("l%d.tcn.f" % bi_, "tfwd", "twgrad"):
+                            ops.bn_bound(self.p["l%d.bn1.gamma" % bi_], self.p["l%d.bn1.beta" % bi_], B * Tb * V, self._cell(bi_, 0))
+                        Tb = same_pad(Tb, KT, s_)[0]
+                self._aux_pending = self._bounds_forked = True
+            else:
+                self.spacked.refresh(self.flat)
+                self._cells.zero_()
         # ---- data_bn (models/stgcn.py:142-147)
         nch = V * Cin
         if training:
@@ -451,6 +473,8 @@ class STGCN:
             r1 = ops.graph_dense_fwd(y3, self.A, g, KS, f, V, B * T, stats=training)
         else:
             gimg = self._simg(pre + "gcn.f") if training else None
+            if gimg is not None or (training and self._cell_live(pre + "gcn.f", "gfwd", "gwgrad")):
+                self._join_aux()                    # first reader of a term image / first writer of a cell on the main chain
             if training and i == 0 and self._cell_live(pre + "gcn.f", "gfwd", "gwgrad"):
                 ops.amax(X, self._cell(i, 3))       # the bound of the block input (blocks > 0: written by the previous block's tail)
             r1 = ops.conv_gemm(L.SAR_CONV_GRAPH, X, g, self.p[pre + "gcn.kernel"], f, KS * f, B=B, V=V, T_src=T, T_out=T,
@@ -464,7 +488,8 @@ class STGCN:
         # tgcn: BN -> ReLU folded into the operand load, Conv2D [9,1] stride s SAME (models/stgcn.py:26-36)
         u = torch.empty((f, n_out), dtype=torch.float32, device=dev)
         simg = self._simg(pre + "tcn.f") if training else None        # inference keeps the fp32 kernels (no batch statistics to bound with)
-        if training and self._cell_live(pre + "tcn.f", "tfwd", "twgrad"):     # (a cell is raised when ANY split consumer of it is on)
+        self._join_aux()           # (the 3-channel layer's graph convolution above reads neither images nor cells: the fork ends here)
+        if training and self._cell_live(pre + "tcn.f", "tfwd", "twgrad") and not self._bounds_forked:     # (a cell is raised when ANY split consumer of it is on)
             ops.bn_bound(self.p[pre + "bn1.gamma"], self.p[pre + "bn1.beta"], n_in, self._cell(i, 0))
         r2 = ops.conv_gemm(L.SAR_CONV_TEMPORAL, g, u, self.p[pre + "tcn.kernel"], f * f, f, B=B, V=V, T_src=T, T_out=To,
                            Kc=f, M=f, taps=KT, stride=s, pad=pad, bias=self.p[pre + "tcn.bias"],
@@ -502,6 +527,12 @@ class STGCN:
         if keep is not None:
             keep[pre + "g"], keep[pre + "u"], keep[pre + "y"] = g, u, y
         return y, To
+
+    def _join_aux(self):
+        """the main chain waits for what forward() forked onto the third stream (once per step)"""
+        if self._aux_pending:
+            torch.cuda.current_stream().wait_stream(self._aux)
+            self._aux_pending = False
 
     def _img(self, key):
         """packed bf16 operand image of a conv weight (bf16 mode), else None"""

@@ -165,3 +165,34 @@ def test_resnet_with_the_down_sampling_branch_on_its_own_stream_is_bit_identical
         assert torch.equal(la, lb) and torch.equal(lsa, lsb) and torch.equal(ga, gb)
         assert torch.isfinite(ga).all() and ga.abs().max().item() > 0
     assert torch.equal(sa, sb)
+
+
+@pytest.mark.parametrize("mfma", ["f32_split", "f32_split_bf16x6"])
+def test_stgcn_with_its_weight_images_on_the_third_stream_is_bit_identical(dev, mfma):
+    """sar_amd/stgcn.py: AUX_STREAM -- the split engine's term images, the zeroing of its bound cells and its Samuelson cells issued on a
+    third stream beside the data_bn stage and the first layer, joined in front of their first reader: logits, losses and gradients
+    bit for bit with the serial schedule over repeated steps.  (The bf16 engine's one pack launch measured SLOWER forked: not forked.)"""
+    from sar_amd import stgcn
+    from sar_amd.stgcn import STGCN
+    from sar_amd.train import synthetic_clips
+    blocks = [(64, 1, False), (64, 1, True), (128, 2, True), (128, 1, True)]
+
+    def run(forked):
+        old = stgcn.AUX_STREAM
+        stgcn.AUX_STREAM = forked
+        try:
+            eng = STGCN(num_classes=10, device=dev, blocks=blocks, mfma=mfma, seed=3)
+        finally:
+            stgcn.AUX_STREAM = old
+        assert (eng._aux is not None) == forked
+        out = []
+        for i in range(3):
+            x, y = synthetic_clips(4, dev, seed=20 + i, num_classes=10, T=40)
+            logits, loss = eng.loss_and_grad(x, y)
+            out.append((logits.clone(), loss.clone(), eng.grad.clone()))
+            eng.sgd_step(0.05)
+        torch.cuda.synchronize()
+        return out
+    for (la, lsa, ga), (lb, lsb, gb) in zip(run(True), run(False)):
+        assert torch.equal(la, lb) and torch.equal(lsa, lsb) and torch.equal(ga, gb)
+        assert torch.isfinite(ga).all() and ga.abs().max().item() > 0
