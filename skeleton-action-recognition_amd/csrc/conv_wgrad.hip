@@ -1102,7 +1102,8 @@ __global__ __launch_bounds__(256, 2) void graph_wgrad_small4_kernel(const sar_wg
 int launch_graph_small(const sar_wgrad_desc& d, hipStream_t st) {
   const int ncol = d.B * d.T_out * d.V;
   static const bool quad = [] { const char* e = getenv("SAR_WGRAD_SMALL4"); return !(e && e[0] == '0'); }();
-  if (quad && d.V <= 32 && ncol % 4 == 0 && d.ld_dout % 4 == 0 && ((uintptr_t)d.dout & 15) == 0) {   // (V <= 32: an iteration's frames fit the staging buffer)
+  if (quad && d.V <= 32 && ncol % 4 == 0 && d.ld_dout % 4 == 0 && ((uintptr_t)d.dout & 15) == 0 &&
+      (((uintptr_t)d.g_idx | (uintptr_t)d.g_wt) & 15) == 0) {   // (V <= 32: an iteration's frames fit the staging buffer; tables read as 16-byte entries)
     const int cps4 = ((ncol + d.nsplit - 1) / d.nsplit + 255) / 256 * 256;   // whole 256-column chunks per slab
     dim3 grid4(d.nsplit, (d.M + 31) / 32);
     if (d.Kc <= 3) hipLaunchKernelGGL(graph_wgrad_small4_kernel<3>, grid4, dim3(256), 0, st, d, ncol, cps4);
