@@ -37,7 +37,7 @@ SPLIT_ARITH = {"f32_split": "f16x3a", "f32_split_bf16x6": "bf16x6"}      # engin
 # "0" = never (gpurun_out/compact_skip_ab*.txt)
 # SAR_STGCN_AUX_STREAM=0: the split engine's term images, the zeroing of its bound cells and its Samuelson cells on the main stream again
 # instead of on a third stream beside the data_bn stage and the first layer (round 6, as sar_amd/resnet.py; bit-identical).  One bench.py
-# process per entry (gpurun_out/stgcn_aux_ab.txt): f32_split 1 929 -> 1 936 clips/s (+0.3 %); the bf16 engine's single pack launch
+# process per entry (profiles/r06_stgcn_aux_stream_ab.txt): f32_split 1 929 -> 1 936 clips/s (+0.3 %); the bf16 engine's single pack launch
 # forked the same way: 5 497 -> 5 466 (-0.5 %), not forked
 AUX_STREAM = __import__("os").environ.get("SAR_STGCN_AUX_STREAM", "1") == "1"
 _COMPACT_SKIP = __import__("os").environ.get("SAR_COMPACT_SKIP", "fp32")
